@@ -1,0 +1,177 @@
+/* mpcx -- C ABI of the MI355X-native batched MPC solve engine.
+ *
+ * This is the drop-in boundary for ONE path of libmpc++: what sits behind
+ * IOptimizer<sizer>::run (reference include/mpc/IOptimizer.hpp:24-58) for the
+ * linear MPC back-end, i.e. LOptimizer::run + ProblemBuilder
+ * (include/mpc/LMPC/LOptimizer.hpp:189-368, include/mpc/LMPC/ProblemBuilder.hpp),
+ * for a *batch* of independent MPC instances that share one controller set-up.
+ *
+ * Conventions
+ *   - plain C, opaque handle, no C++/torch types in any signature;
+ *   - every matrix argument of a setter is a HOST pointer to column-major
+ *     doubles (Eigen's default layout, reference include/mpc/Types.hpp:42);
+ *   - every pointer inside mpcx_lmpc_batch is a DEVICE pointer (HBM), batch
+ *     arrays are instance-major: x0[b*nx + j];
+ *   - every call returns MPCX_OK (0) or a negative MPCX_E_* code; the per-instance
+ *     outcome of a solve is reported in status[] / solver_status[] / is_feasible[]
+ *     exactly like mpc::Result (Types.hpp:168-182).
+ *   - horizon-slice semantics are the reference's: a slice is the half-open
+ *     step range [start, end); {-1,-1} = whole horizon (Types.hpp:57-82,
+ *     IMPC.hpp:244-283).  Replicate-along-horizon setters follow LMPC.hpp.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_OK              0
+#define MPCX_E_INVALID      -1   /* bad argument / dimension / slice            */
+#define MPCX_E_UNSUPPORTED  -2   /* dimension outside what the kernels cover    */
+#define MPCX_E_DEVICE       -3   /* HIP runtime error                           */
+#define MPCX_E_NUMERIC      -4   /* set-up factorisation failed                 */
+#define MPCX_E_STATE        -5   /* call order (e.g. solve before a model)      */
+
+/* mpc::ResultStatus (Types.hpp:87-94) */
+#define MPCX_STATUS_SUCCESS        0
+#define MPCX_STATUS_MAX_ITERATION  1
+#define MPCX_STATUS_INFEASIBLE     2
+#define MPCX_STATUS_ERROR          3
+#define MPCX_STATUS_UNKNOWN        4
+
+/* solver_status: OSQP v0.6.3 status_val codes, which is what LOptimizer stores
+ * in Result::solver_status (LOptimizer.hpp:342) */
+#define MPCX_SOLVER_SOLVED               1
+#define MPCX_SOLVER_SOLVED_INACCURATE    2
+#define MPCX_SOLVER_MAX_ITER_REACHED    -2
+#define MPCX_SOLVER_PRIMAL_INFEASIBLE   -3
+#define MPCX_SOLVER_NON_CVX             -7
+#define MPCX_SOLVER_UNSOLVED           -10
+
+/* Dimensions: the run-time twin of MPCSize (reference include/mpc/Dim.hpp). */
+typedef struct mpcx_dims {
+    int nx, nu, ndu, ny, ph, ch;
+} mpcx_dims;
+
+/* POD mirror of mpc::LParameters (Types.hpp:99-114,146-161). */
+typedef struct mpcx_lparams {
+    int    maximum_iteration;   /* default 100 */
+    double time_limit;          /* accepted, ignored (no wall clock inside a kernel) */
+    int    enable_warm_start;   /* default 0 */
+    double alpha;               /* 1.6  */
+    double rho;                 /* 1e-6; used as the uniform ADMM step only when adaptive_rho == 0 */
+    double eps_rel, eps_abs;    /* 1e-4 */
+    double eps_prim_inf, eps_dual_inf;  /* 1e-3 */
+    int    verbose;
+    int    adaptive_rho;        /* 1: step sizes from the model's dual Hessian diagonal */
+    int    polish;              /* 1: finish on the exact active-set solution, as OSQP's polish   */
+} mpcx_lparams;
+
+typedef struct mpcx_lmpc *mpcx_lmpc_t;
+
+/* How a per-solve reference / exogenous-input array is laid out in HBM. */
+#define MPCX_REF_SHARED        0  /* use the matrix given to the host setter (LMPC::setReferences) */
+#define MPCX_REF_PER_INSTANCE  1  /* [B x n]      one vector per instance, constant along horizon  */
+#define MPCX_REF_PER_STEP      2  /* [B x ph x n] full matrix per instance (column k = step k)     */
+
+/* One batched LOptimizer::run.  All pointers are device pointers; optional
+ * outputs may be NULL.  Replaces LOptimizer::run(x0,u0) (LOptimizer.hpp:189). */
+typedef struct mpcx_lmpc_batch {
+    int batch;
+    const double *x0;              /* [B x nx]  measured state                                  */
+    const double *u0;              /* [B x nu]  last applied input (lastU)                       */
+    const double *yref;  int yref_mode;    /* output reference   (ny)  */
+    const double *uref;  int uref_mode;    /* input reference    (nu)  */
+    const double *duref; int duref_mode;   /* delta-u reference  (nu)  */
+    const double *dmeas; int dmeas_mode;   /* exogenous inputs   (ndu) */
+    /* Result<nu> as structure-of-arrays */
+    double *cmd;                   /* [B x nu]  required: optimal first input, Result::cmd       */
+    double *cost;                  /* [B]       0.5 z'Pz + q'z of the reference QP               */
+    int32_t *status;               /* [B]       MPCX_STATUS_*                                    */
+    int32_t *solver_status;        /* [B]       MPCX_SOLVER_*                                    */
+    int32_t *is_feasible;          /* [B]                                                        */
+    int32_t *iterations;           /* [B]       ADMM iterations spent                            */
+    /* active set at the returned point, reference row numbering of A/l/u
+     * (ProblemBuilder.hpp:814-822), one bit per row, [B x active_words] words */
+    uint32_t *active_lower;
+    uint32_t *active_upper;
+    /* OptSequence (Types.hpp:184-198): row i = horizon step i, instance-major
+     * [B x (ph+1) x n], row-major inside an instance */
+    double *seq_state;
+    double *seq_output;
+    double *seq_input;
+} mpcx_lmpc_batch;
+
+/* ---- lifetime (replaces LMPC::onSetup / new LOptimizer, LMPC.hpp:728-735) ---- */
+int mpcx_lmpc_create(const mpcx_dims *dims, int device, mpcx_lmpc_t *out);
+int mpcx_lmpc_destroy(mpcx_lmpc_t h);
+void mpcx_lparams_default(mpcx_lparams *p);
+const char *mpcx_last_error(void);
+
+/* ---- controller set-up: names and semantics of LMPC.hpp ---------------------- */
+/* LMPC::setStateSpaceModel (LMPC.hpp:493) */
+int mpcx_lmpc_set_state_space_model(mpcx_lmpc_t h, const double *A, const double *B, const double *C);
+/* LMPC::setDisturbances (LMPC.hpp:518) */
+int mpcx_lmpc_set_disturbances(mpcx_lmpc_t h, const double *Bd, const double *Dd);
+/* LMPC::setObjectiveWeights matrix form (LMPC.hpp:306) / vector+slice form (LMPC.hpp:436) */
+int mpcx_lmpc_set_objective_weights(mpcx_lmpc_t h, const double *OW, const double *UW, const double *DUW);
+int mpcx_lmpc_set_objective_weights_slice(mpcx_lmpc_t h, const double *ow, const double *uw, const double *duw,
+                                          int start, int end);
+/* LMPC::setStateBounds / setInputBounds / setOutputBounds (LMPC.hpp:111-292) */
+int mpcx_lmpc_set_state_bounds(mpcx_lmpc_t h, const double *xmin, const double *xmax);
+int mpcx_lmpc_set_state_bounds_slice(mpcx_lmpc_t h, const double *xmin, const double *xmax, int start, int end);
+int mpcx_lmpc_set_input_bounds(mpcx_lmpc_t h, const double *umin, const double *umax);
+int mpcx_lmpc_set_input_bounds_slice(mpcx_lmpc_t h, const double *umin, const double *umax, int start, int end);
+int mpcx_lmpc_set_output_bounds(mpcx_lmpc_t h, const double *ymin, const double *ymax);
+int mpcx_lmpc_set_output_bounds_slice(mpcx_lmpc_t h, const double *ymin, const double *ymax, int start, int end);
+/* LMPC::setScalarConstraint slice form (LMPC.hpp:355) and index form (LMPC.hpp:409) */
+int mpcx_lmpc_set_scalar_constraint_slice(mpcx_lmpc_t h, double smin, double smax, const double *X, const double *U,
+                                          int start, int end);
+int mpcx_lmpc_set_scalar_constraint_index(mpcx_lmpc_t h, int index, double smin, double smax,
+                                          const double *X, const double *U);
+/* LMPC::setReferences matrix form (LMPC.hpp:596) / vector+slice form (LMPC.hpp:616) */
+int mpcx_lmpc_set_references(mpcx_lmpc_t h, const double *yref, const double *uref, const double *duref);
+int mpcx_lmpc_set_references_slice(mpcx_lmpc_t h, const double *yref, const double *uref, const double *duref,
+                                   int start, int end);
+/* LMPC::setExogenousInputs matrix form (LMPC.hpp:534) / vector+slice form (LMPC.hpp:550) */
+int mpcx_lmpc_set_exogenous_inputs(mpcx_lmpc_t h, const double *dmeas);
+int mpcx_lmpc_set_exogenous_inputs_slice(mpcx_lmpc_t h, const double *dmeas, int start, int end);
+/* LMPC::setOptimizerParameters -> LOptimizer::setParameters (LMPC.hpp:79, LOptimizer.hpp:100) */
+int mpcx_lmpc_set_optimizer_parameters(mpcx_lmpc_t h, const mpcx_lparams *p);
+
+/* ---- the hot path --------------------------------------------------------------- */
+/* Condense the controller into device-resident matrices.  Called implicitly by
+ * the first solve after any setter; exposed so that set-up cost can be paid
+ * (and timed) up front. */
+int mpcx_lmpc_setup(mpcx_lmpc_t h);
+/* Batched LOptimizer::run on `stream` (a hipStream_t, NULL = default stream).
+ * Asynchronous with respect to the host; outputs are valid once the stream
+ * has been synchronised. */
+int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream);
+/* Same launch, timed with HIP events recorded on `stream` around `repeats`
+ * back-to-back launches; returns the mean kernel time in milliseconds. */
+int mpcx_lmpc_time_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms_mean);
+
+/* ---- introspection -------------------------------------------------------------- */
+/* sizes of the reference QP (ProblemBuilder.hpp:70-76) and of the condensed one */
+typedef struct mpcx_lmpc_info {
+    int n_ref, m_ref, neq_ref;     /* reference QP variables / rows / equality rows          */
+    int nz, mg;                    /* condensed: decision variables, general inequality rows */
+    int active_words;              /* uint32 words per instance in active_lower/upper        */
+    int kernel_variant;            /* which template instantiation serves these dimensions   */
+    double flops_setup;            /* algorithmic flops of one set-up                         */
+    double flops_per_admm_iter;    /* algorithmic flops of one ADMM iteration of one instance */
+    double flops_fixed_per_solve;  /* assembly + unconstrained solve + cost, per instance     */
+    double bytes_per_solve;        /* algorithmic HBM bytes per instance (inputs + outputs)   */
+} mpcx_lmpc_info;
+int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info);
+
+const char *mpcx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

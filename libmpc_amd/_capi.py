@@ -1,0 +1,97 @@
+"""ctypes binding of the mpcx C ABI (include/mpcx.h).  Product code: loads
+libmpc_amd/libmpcx.so and fails loudly when it is missing -- there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpcx.so")
+
+OK = 0
+E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_STATE = -1, -2, -3, -4, -5
+STATUS_SUCCESS, STATUS_MAX_ITERATION, STATUS_INFEASIBLE, STATUS_ERROR, STATUS_UNKNOWN = range(5)
+REF_SHARED, REF_PER_INSTANCE, REF_PER_STEP = 0, 1, 2
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ndu", "ny", "ph", "ch")]
+
+
+class LParams(C.Structure):
+    """POD mirror of mpc::LParameters (reference include/mpc/Types.hpp:99-161)."""
+    _fields_ = [("maximum_iteration", C.c_int), ("time_limit", C.c_double), ("enable_warm_start", C.c_int),
+                ("alpha", C.c_double), ("rho", C.c_double), ("eps_rel", C.c_double), ("eps_abs", C.c_double),
+                ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+                ("verbose", C.c_int), ("adaptive_rho", C.c_int), ("polish", C.c_int)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("batch", C.c_int),
+                ("x0", C.c_void_p), ("u0", C.c_void_p),
+                ("yref", C.c_void_p), ("yref_mode", C.c_int),
+                ("uref", C.c_void_p), ("uref_mode", C.c_int),
+                ("duref", C.c_void_p), ("duref_mode", C.c_int),
+                ("dmeas", C.c_void_p), ("dmeas_mode", C.c_int),
+                ("cmd", C.c_void_p), ("cost", C.c_void_p),
+                ("status", C.c_void_p), ("solver_status", C.c_void_p), ("is_feasible", C.c_void_p),
+                ("iterations", C.c_void_p),
+                ("active_lower", C.c_void_p), ("active_upper", C.c_void_p),
+                ("seq_state", C.c_void_p), ("seq_output", C.c_void_p), ("seq_input", C.c_void_p)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_ref", C.c_int), ("m_ref", C.c_int), ("neq_ref", C.c_int), ("nz", C.c_int), ("mg", C.c_int),
+                ("active_words", C.c_int), ("kernel_variant", C.c_int),
+                ("flops_setup", C.c_double), ("flops_per_admm_iter", C.c_double),
+                ("flops_fixed_per_solve", C.c_double), ("bytes_per_solve", C.c_double)]
+
+
+EXPORTS = [
+    "mpcx_lmpc_create", "mpcx_lmpc_destroy", "mpcx_lparams_default", "mpcx_last_error",
+    "mpcx_lmpc_set_state_space_model", "mpcx_lmpc_set_disturbances",
+    "mpcx_lmpc_set_objective_weights", "mpcx_lmpc_set_objective_weights_slice",
+    "mpcx_lmpc_set_state_bounds", "mpcx_lmpc_set_state_bounds_slice",
+    "mpcx_lmpc_set_input_bounds", "mpcx_lmpc_set_input_bounds_slice",
+    "mpcx_lmpc_set_output_bounds", "mpcx_lmpc_set_output_bounds_slice",
+    "mpcx_lmpc_set_scalar_constraint_slice", "mpcx_lmpc_set_scalar_constraint_index",
+    "mpcx_lmpc_set_references", "mpcx_lmpc_set_references_slice",
+    "mpcx_lmpc_set_exogenous_inputs", "mpcx_lmpc_set_exogenous_inputs_slice",
+    "mpcx_lmpc_set_optimizer_parameters", "mpcx_lmpc_setup", "mpcx_lmpc_solve_batch",
+    "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_get_info", "mpcx_version",
+]
+
+_lib = None
+
+
+class MpcxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mpcx error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  libmpc_amd has no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be in the process first so
+        # that libmpcx.so binds to the same HIP runtime instead of loading a second one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mpcx_last_error.restype = C.c_char_p
+        _lib.mpcx_version.restype = C.c_char_p
+        _lib.mpcx_lmpc_set_scalar_constraint_slice.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.mpcx_lmpc_set_scalar_constraint_index.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise MpcxError(rc, lib().mpcx_last_error().decode())
+    return rc

@@ -1,0 +1,67 @@
+// POD views of the device-resident controller handed to the HIP kernels.
+//
+// HBM layout (all doubles, zero padded; every leading dimension is even so a lane
+// can fetch an element pair with one 16-byte load):
+//   H, Kinv : nz columns x ldz rows, column-major (both symmetric)
+//   Gr      : row r of G contiguous   [ldg x ldz]  -> G' v  (lanes own elements of nz)
+//   Gc      : column j of G contiguous [ldz x ldg] -> G x   (lanes own rows of G)
+//   Y       : [ldy x ldy], ldy = ldz + ldg, the dual Hessian N Hinv N' with N = [I; G];
+//             unified index q: box variable e -> q = e, general row r -> q = ldz + r
+// A vector of length n is held by a wavefront as element pairs: lane l owns elements
+// 128*c + 2*l and 128*c + 2*l + 1 for c < CP (CP = ceil(n / 128)).
+#pragma once
+
+#include <cstdint>
+
+namespace mpcx {
+
+constexpr int kMaxActive = 32;          // working-set capacity of the in-kernel polish
+constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
+
+struct LmpcDev {
+    int nx, nu, ndu, ny, ph, ch, nf, nz, mg;
+    int ldz, ldg, ldy;
+    int m_ref, neq_ref, active_words;
+    int has_dist, n_fixed;
+    // solver parameters
+    int max_iter, polish, check_every, polish_rounds0, polish_rounds;
+    double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
+    // per-wave LDS carve (in doubles)
+    int stage_len, arena_len, lds_per_wave;
+    // model, column-major
+    const double *A, *B, *C, *Bd, *Dd;
+    const double *Wy, *Wu, *Wdu;                 // [(ph+1) x ny], [(ph+1) x nu], [ph x nu]; column = internal step
+    const double *yref_s, *uref_s, *duref_s, *dmeas_s;   // shared references [ph x n]
+    // step-0 feasibility rows
+    const double *lo0x, *hi0x, *lo0u, *hi0u, *lo0y, *hi0y, *sX, *sU;
+    double s0lo, s0hi;
+    // condensed QP
+    const double *H, *Kinv, *Gr, *Gc, *Y;
+    const double *lw, *uw, *rho_b;               // [ldz]
+    const double *lg0, *ug0, *rho_g;             // [ldg]
+    const int *g_kind, *g_step, *g_comp, *g_refrow;      // [ldg]
+    const int *f_kind, *f_step, *f_comp; const double *f_lo, *f_hi;   // fixed rows [n_fixed]
+    const int *boxrow_ptr, *boxrow_ref; const double *boxrow_lo, *boxrow_hi;
+    const int *blk;                              // [ph+1]
+};
+
+struct LmpcBatchDev {
+    int batch;
+    const double *x0, *u0;
+    // reference accessors: value(b, k, a) = p[b*bs + k*ks + a]
+    const double *yref; long yref_bs, yref_ks;
+    const double *uref; long uref_bs, uref_ks;
+    const double *duref; long duref_bs, duref_ks;
+    const double *dmeas; long dmeas_bs, dmeas_ks;
+    double *cmd, *cost;
+    int32_t *status, *solver_status, *is_feasible, *iterations;
+    uint32_t *active_lower, *active_upper;
+    double *seq_state, *seq_output, *seq_input;
+};
+
+// implemented in lmpc_kernels.hip
+int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, void *stream);
+int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
+
+}  // namespace mpcx

@@ -1,0 +1,518 @@
+// extern "C" boundary of the batched LMPC engine (include/mpcx.h).
+// Host code only: owns the controller state, runs the one-time condensing, keeps the
+// condensed model resident in HBM, and launches the HIP kernel.  There is no CPU solve
+// path here: without a usable HIP device every solve call fails with MPCX_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcx.h"
+#include "lmpc_device.hpp"
+#include "lmpc_model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+}  // namespace
+
+struct mpcx_lmpc {
+    mpcx::LmpcController ctl;
+    int device = 0;
+    bool host_only = false;
+    bool dirty = true;
+    mpcx::Condensed cond;
+    mpcx::LmpcDev dev{};
+    mpcx::LmpcDev *dev_d = nullptr;     // the same struct, resident in HBM for the kernel
+    std::vector<void *> allocs;
+    explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
+
+    void release()
+    {
+        for (void *p : allocs) (void)hipFree(p);
+        allocs.clear();
+    }
+    template <typename T>
+    const T *up(const std::vector<T> &v, int &rc)
+    {
+        size_t n = v.size() ? v.size() : 1;
+        void *p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { rc = MPCX_E_DEVICE; return nullptr; }
+        allocs.push_back(p);
+        if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) rc = MPCX_E_DEVICE;
+        return static_cast<const T *>(p);
+    }
+};
+
+extern "C" {
+
+const char *mpcx_version(void) { return "mpcx 0.1.0 (gfx950)"; }
+const char *mpcx_last_error(void) { return g_err.c_str(); }
+
+void mpcx_lparams_default(mpcx_lparams *p)
+{
+    // mpc::LParameters defaults, reference include/mpc/Types.hpp:108-114,150-160
+    p->maximum_iteration = 100; p->time_limit = 0; p->enable_warm_start = 0;
+    p->alpha = 1.6; p->rho = 1e-6; p->eps_rel = 1e-4; p->eps_abs = 1e-4;
+    p->eps_prim_inf = 1e-3; p->eps_dual_inf = 1e-3;
+    p->verbose = 0; p->adaptive_rho = 1; p->polish = 1;
+}
+
+int mpcx_lmpc_create(const mpcx_dims *d, int device, mpcx_lmpc_t *out)
+{
+    if (!d || !out) return fail(MPCX_E_INVALID, "null argument");
+    if (d->nx < 1 || d->nu < 1 || d->ny < 1 || d->ndu < 0 || d->ph < 1 || d->ch < 1 || d->ch > d->ph)
+        return fail(MPCX_E_INVALID, "dimensions must satisfy nx,nu,ny,ph >= 1, 1 <= ch <= ph, ndu >= 0");
+    if (d->nx > 64 || d->nu > 64 || d->ny > 64 || d->ndu > 64)
+        return fail(MPCX_E_UNSUPPORTED, "nx, nu, ny, ndu must be <= 64 (one lane per component)");
+    std::unique_ptr<mpcx_lmpc> h(new mpcx_lmpc(*d));
+    h->device = device;
+    h->host_only = device < 0;
+    if (!h->host_only) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n)
+            return fail(MPCX_E_DEVICE, "no such HIP device (the solve path has no CPU fallback)");
+    }
+    *out = h.release();
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_destroy(mpcx_lmpc_t h)
+{
+    if (!h) return MPCX_OK;
+    if (!h->host_only) { (void)hipSetDevice(h->device); h->release(); }
+    delete h;
+    return MPCX_OK;
+}
+
+#define CHECK_H(h) do { if (!(h)) return fail(MPCX_E_INVALID, "null handle"); } while (0)
+
+int mpcx_lmpc_set_state_space_model(mpcx_lmpc_t h, const double *A, const double *B, const double *C)
+{
+    CHECK_H(h);
+    if (!A || !B || !C) return fail(MPCX_E_INVALID, "null matrix");
+    auto &c = h->ctl;
+    std::memcpy(c.A.a.data(), A, sizeof(double) * c.A.a.size());
+    std::memcpy(c.B.a.data(), B, sizeof(double) * c.B.a.size());
+    std::memcpy(c.C.a.data(), C, sizeof(double) * c.C.a.size());
+    c.have_model = true;
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_disturbances(mpcx_lmpc_t h, const double *Bd, const double *Dd)
+{
+    CHECK_H(h);
+    auto &c = h->ctl;
+    if (c.d.ndu > 0) {
+        if (!Bd || !Dd) return fail(MPCX_E_INVALID, "null matrix");
+        std::memcpy(c.Bd.a.data(), Bd, sizeof(double) * c.Bd.a.size());
+        std::memcpy(c.Dd.a.data(), Dd, sizeof(double) * c.Dd.a.size());
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_objective_weights(mpcx_lmpc_t h, const double *OW, const double *UW, const double *DUW)
+{
+    CHECK_H(h);
+    if (!OW || !UW || !DUW) return fail(MPCX_E_INVALID, "null matrix");
+    h->ctl.set_objective(OW, UW, DUW);
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+// Replicate-along-horizon helpers: {-1,-1} goes through the matrix setter, any other
+// valid slice through the per-index setter, exactly as LMPC.hpp does (e.g. :436-481).
+int mpcx_lmpc_set_objective_weights_slice(mpcx_lmpc_t h, const double *ow, const double *uw, const double *duw, int start, int end)
+{
+    CHECK_H(h);
+    if (!ow || !uw || !duw) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    const int ph = c.d.ph;
+    if (start == -1 && end == -1) {
+        std::vector<double> O((size_t)c.d.ny * ph), U((size_t)c.d.nu * ph), D((size_t)c.d.nu * ph);
+        for (int k = 0; k < ph; k++) {
+            std::memcpy(&O[(size_t)k * c.d.ny], ow, sizeof(double) * c.d.ny);
+            std::memcpy(&U[(size_t)k * c.d.nu], uw, sizeof(double) * c.d.nu);
+            std::memcpy(&D[(size_t)k * c.d.nu], duw, sizeof(double) * c.d.nu);
+        }
+        c.set_objective(O.data(), U.data(), D.data());
+    } else {
+        if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+        for (int i = start; i < end; i++) c.set_objective_idx(i, ow, uw, duw);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_state_bounds(mpcx_lmpc_t h, const double *lo, const double *hi)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null matrix");
+    h->ctl.set_state_bounds(lo, hi);
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_state_bounds_slice(mpcx_lmpc_t h, const double *lo, const double *hi, int start, int end)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    if (start == -1 && end == -1) {
+        std::vector<double> L((size_t)c.d.nx * c.d.ph), H((size_t)c.d.nx * c.d.ph);
+        for (int k = 0; k < c.d.ph; k++) {
+            std::memcpy(&L[(size_t)k * c.d.nx], lo, sizeof(double) * c.d.nx);
+            std::memcpy(&H[(size_t)k * c.d.nx], hi, sizeof(double) * c.d.nx);
+        }
+        c.set_state_bounds(L.data(), H.data());
+    } else {
+        if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+        for (int i = start; i < end; i++) c.set_state_bounds_idx(i, lo, hi);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_input_bounds(mpcx_lmpc_t h, const double *lo, const double *hi)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null matrix");
+    h->ctl.set_input_bounds(lo, hi);
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_input_bounds_slice(mpcx_lmpc_t h, const double *lo, const double *hi, int start, int end)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    if (start == -1 && end == -1) {
+        std::vector<double> L((size_t)c.d.nu * c.d.ch), H((size_t)c.d.nu * c.d.ch);
+        for (int k = 0; k < c.d.ch; k++) {
+            std::memcpy(&L[(size_t)k * c.d.nu], lo, sizeof(double) * c.d.nu);
+            std::memcpy(&H[(size_t)k * c.d.nu], hi, sizeof(double) * c.d.nu);
+        }
+        c.set_input_bounds(L.data(), H.data());
+    } else {
+        if (!c.ctrl_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The control horizon slice is out of bounds");
+        for (int i = start; i < end; i++) c.set_input_bounds_idx(i, lo, hi);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_output_bounds(mpcx_lmpc_t h, const double *lo, const double *hi)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null matrix");
+    h->ctl.set_output_bounds(lo, hi);
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_output_bounds_slice(mpcx_lmpc_t h, const double *lo, const double *hi, int start, int end)
+{
+    CHECK_H(h);
+    if (!lo || !hi) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    if (start == -1 && end == -1) {
+        std::vector<double> L((size_t)c.d.ny * c.d.ph), H((size_t)c.d.ny * c.d.ph);
+        for (int k = 0; k < c.d.ph; k++) {
+            std::memcpy(&L[(size_t)k * c.d.ny], lo, sizeof(double) * c.d.ny);
+            std::memcpy(&H[(size_t)k * c.d.ny], hi, sizeof(double) * c.d.ny);
+        }
+        c.set_output_bounds(L.data(), H.data());
+    } else {
+        if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+        for (int i = start; i < end; i++) c.set_output_bounds_idx(i, lo, hi);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_scalar_constraint_slice(mpcx_lmpc_t h, double smin, double smax, const double *X, const double *U, int start, int end)
+{
+    CHECK_H(h);
+    if (!X || !U) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    if (start == -1 && end == -1) {
+        std::vector<double> L(c.d.ph, smin), H(c.d.ph, smax);
+        c.set_scalar_vec(L.data(), H.data(), X, U);
+    } else {
+        if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+        for (int i = start; i < end; i++) c.set_scalar_idx(i, smin, smax, X, U);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_scalar_constraint_index(mpcx_lmpc_t h, int index, double smin, double smax, const double *X, const double *U)
+{
+    CHECK_H(h);
+    if (!X || !U) return fail(MPCX_E_INVALID, "null vector");
+    if (index < 0 || index >= h->ctl.d.ph) return fail(MPCX_E_INVALID, "Horizon index out of bounds");
+    h->ctl.set_scalar_idx(index, smin, smax, X, U);
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_references(mpcx_lmpc_t h, const double *yref, const double *uref, const double *duref)
+{
+    CHECK_H(h);
+    if (!yref || !uref || !duref) return fail(MPCX_E_INVALID, "null matrix");
+    auto &c = h->ctl;
+    std::memcpy(c.yRef.a.data(), yref, sizeof(double) * c.yRef.a.size());
+    std::memcpy(c.uRef.a.data(), uref, sizeof(double) * c.uRef.a.size());
+    std::memcpy(c.duRef.a.data(), duref, sizeof(double) * c.duRef.a.size());
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_references_slice(mpcx_lmpc_t h, const double *yref, const double *uref, const double *duref, int start, int end)
+{
+    CHECK_H(h);
+    if (!yref || !uref || !duref) return fail(MPCX_E_INVALID, "null vector");
+    auto &c = h->ctl;
+    int s = start, e = end;
+    if (start == -1 && end == -1) { s = 0; e = c.d.ph; }
+    else if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+    for (int i = s; i < e; i++) {
+        std::memcpy(c.yRef.col(i), yref, sizeof(double) * c.d.ny);
+        std::memcpy(c.uRef.col(i), uref, sizeof(double) * c.d.nu);
+        std::memcpy(c.duRef.col(i), duref, sizeof(double) * c.d.nu);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_exogenous_inputs(mpcx_lmpc_t h, const double *dmeas)
+{
+    CHECK_H(h);
+    auto &c = h->ctl;
+    if (c.d.ndu > 0) {
+        if (!dmeas) return fail(MPCX_E_INVALID, "null matrix");
+        std::memcpy(c.dMeas.a.data(), dmeas, sizeof(double) * c.dMeas.a.size());
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+int mpcx_lmpc_set_exogenous_inputs_slice(mpcx_lmpc_t h, const double *dmeas, int start, int end)
+{
+    CHECK_H(h);
+    auto &c = h->ctl;
+    int s = start, e = end;
+    if (start == -1 && end == -1) { s = 0; e = c.d.ph; }
+    else if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+    if (c.d.ndu > 0) {
+        if (!dmeas) return fail(MPCX_E_INVALID, "null vector");
+        for (int i = s; i < e; i++) std::memcpy(c.dMeas.col(i), dmeas, sizeof(double) * c.d.ndu);
+    }
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_set_optimizer_parameters(mpcx_lmpc_t h, const mpcx_lparams *p)
+{
+    CHECK_H(h);
+    if (!p) return fail(MPCX_E_INVALID, "null parameters");
+    if (p->maximum_iteration < 0 || !(p->alpha > 0 && p->alpha < 2) || !(p->rho > 0))
+        return fail(MPCX_E_INVALID, "parameters out of range");
+    h->ctl.prm = *p;
+    h->dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_setup(mpcx_lmpc_t h)
+{
+    CHECK_H(h);
+    if (!h->dirty) return MPCX_OK;
+    std::string msg = h->ctl.condense(h->cond);
+    if (!msg.empty()) return fail(msg == "state-space model not set" ? MPCX_E_STATE : MPCX_E_NUMERIC, msg);
+    const auto &c = h->ctl;
+    const auto &o = h->cond;
+    if (mpcx::lmpc_kernel_variant(o.ldz, o.ldg) < 0)
+        return fail(MPCX_E_UNSUPPORTED, "condensed problem larger than 512 variables / rows");
+    mpcx::LmpcDev &D = h->dev;
+    D = mpcx::LmpcDev{};
+    D.nx = c.d.nx; D.nu = c.d.nu; D.ndu = c.d.ndu; D.ny = c.d.ny; D.ph = c.d.ph; D.ch = c.d.ch;
+    D.nf = o.nf; D.nz = o.nz; D.mg = o.mg; D.ldz = o.ldz; D.ldg = o.ldg; D.ldy = o.ldy;
+    D.m_ref = o.m_ref; D.neq_ref = o.neq_ref; D.active_words = o.active_words;
+    D.has_dist = o.has_dist ? 1 : 0;
+    D.n_fixed = (int)o.fixed_rows.size();
+    D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
+    D.check_every = 10; D.polish_rounds0 = 6; D.polish_rounds = 8;
+    D.alpha = c.prm.alpha; D.sigma = 1e-6;
+    D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
+    D.lds_per_wave = mpcx::lmpc_lds_per_wave(D, &D.stage_len, &D.arena_len);
+    D.s0lo = c.sMin[0]; D.s0hi = c.sMax[0];
+    if (h->host_only) { h->dirty = false; return MPCX_OK; }
+
+    if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    h->release();
+    int rc = MPCX_OK;
+    D.A = h->up(c.A.a, rc); D.B = h->up(c.B.a, rc); D.C = h->up(c.C.a, rc);
+    D.Bd = h->up(c.Bd.a, rc); D.Dd = h->up(c.Dd.a, rc);
+    D.Wy = h->up(c.wOutput.a, rc); D.Wu = h->up(c.wU.a, rc); D.Wdu = h->up(c.wDeltaU.a, rc);
+    D.yref_s = h->up(c.yRef.a, rc); D.uref_s = h->up(c.uRef.a, rc);
+    D.duref_s = h->up(c.duRef.a, rc); D.dmeas_s = h->up(c.dMeas.a, rc);
+    {
+        std::vector<double> lo0x(c.d.nx), hi0x(c.d.nx), lo0u(c.d.nu), hi0u(c.d.nu), lo0y(c.d.ny), hi0y(c.d.ny);
+        for (int j = 0; j < c.d.nx; j++) { lo0x[j] = c.minX(j, 0); hi0x[j] = c.maxX(j, 0); }
+        for (int j = 0; j < c.d.nu; j++) { lo0u[j] = c.minU(j, 0); hi0u[j] = c.maxU(j, 0); }
+        for (int j = 0; j < c.d.ny; j++) { lo0y[j] = c.minY(j, 0); hi0y[j] = c.maxY(j, 0); }
+        D.lo0x = h->up(lo0x, rc); D.hi0x = h->up(hi0x, rc); D.lo0u = h->up(lo0u, rc); D.hi0u = h->up(hi0u, rc);
+        D.lo0y = h->up(lo0y, rc); D.hi0y = h->up(hi0y, rc);
+        D.sX = h->up(c.sX, rc); D.sU = h->up(c.sU, rc);
+    }
+    D.H = h->up(o.H, rc); D.Kinv = h->up(o.Kinv, rc); D.Gr = h->up(o.Gr, rc); D.Gc = h->up(o.Gc, rc); D.Y = h->up(o.Y, rc);
+    D.lw = h->up(o.lw, rc); D.uw = h->up(o.uw, rc); D.rho_b = h->up(o.rho_b, rc);
+    D.lg0 = h->up(o.lg0, rc); D.ug0 = h->up(o.ug0, rc); D.rho_g = h->up(o.rho_g, rc);
+    D.g_kind = h->up(o.g_kind, rc); D.g_step = h->up(o.g_step, rc); D.g_comp = h->up(o.g_comp, rc); D.g_refrow = h->up(o.g_refrow, rc);
+    {
+        std::vector<int> fk, fs, fc; std::vector<double> fl, fh;
+        for (auto &r : o.fixed_rows) { fk.push_back(r.kind); fs.push_back(r.step); fc.push_back(r.comp); fl.push_back(r.lo); fh.push_back(r.hi); }
+        D.f_kind = h->up(fk, rc); D.f_step = h->up(fs, rc); D.f_comp = h->up(fc, rc); D.f_lo = h->up(fl, rc); D.f_hi = h->up(fh, rc);
+    }
+    D.boxrow_ptr = h->up(o.boxrow_ptr, rc); D.boxrow_ref = h->up(o.boxrow_ref, rc);
+    D.boxrow_lo = h->up(o.boxrow_lo, rc); D.boxrow_hi = h->up(o.boxrow_hi, rc);
+    D.blk = h->up(o.blk, rc);
+    if (rc != MPCX_OK) return fail(rc, "device upload failed");
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(mpcx::LmpcDev)) != hipSuccess) return fail(MPCX_E_DEVICE, "hipMalloc failed");
+        h->allocs.push_back(p);
+        if (hipMemcpy(p, &D, sizeof(mpcx::LmpcDev), hipMemcpyHostToDevice) != hipSuccess) return fail(MPCX_E_DEVICE, "hipMemcpy failed");
+        h->dev_d = static_cast<mpcx::LmpcDev *>(p);
+    }
+    h->dirty = false;
+    return MPCX_OK;
+}
+
+static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDev &B)
+{
+    const auto &d = h->ctl.d;
+    const auto &D = h->dev;
+    if (b->batch < 0) return fail(MPCX_E_INVALID, "negative batch");
+    if (b->batch > 0 && (!b->x0 || !b->u0 || !b->cmd)) return fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
+    B = mpcx::LmpcBatchDev{};
+    B.batch = b->batch; B.x0 = b->x0; B.u0 = b->u0;
+    auto refsel = [&](const double *p, int mode, const double *shared, int n, const double *&op, long &bs, long &ks) -> bool {
+        if (mode == MPCX_REF_SHARED) { op = shared; bs = 0; ks = n; return true; }
+        if (!p) return false;
+        if (mode == MPCX_REF_PER_INSTANCE) { op = p; bs = n; ks = 0; return true; }
+        if (mode == MPCX_REF_PER_STEP) { op = p; bs = (long)d.ph * n; ks = n; return true; }
+        return false;
+    };
+    if (!refsel(b->yref, b->yref_mode, D.yref_s, d.ny, B.yref, B.yref_bs, B.yref_ks) ||
+        !refsel(b->uref, b->uref_mode, D.uref_s, d.nu, B.uref, B.uref_bs, B.uref_ks) ||
+        !refsel(b->duref, b->duref_mode, D.duref_s, d.nu, B.duref, B.duref_bs, B.duref_ks) ||
+        !refsel(b->dmeas, b->dmeas_mode, D.dmeas_s, d.ndu, B.dmeas, B.dmeas_bs, B.dmeas_ks))
+        return fail(MPCX_E_INVALID, "reference array missing for a non-shared mode, or unknown mode");
+    B.cmd = b->cmd; B.cost = b->cost; B.status = b->status; B.solver_status = b->solver_status;
+    B.is_feasible = b->is_feasible; B.iterations = b->iterations;
+    B.active_lower = b->active_lower; B.active_upper = b->active_upper;
+    B.seq_state = b->seq_state; B.seq_output = b->seq_output; B.seq_input = b->seq_input;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
+{
+    CHECK_H(h);
+    if (!b) return fail(MPCX_E_INVALID, "null batch");
+    if (h->host_only) return fail(MPCX_E_DEVICE, "host-only handle: the solve path needs a HIP device, there is no CPU fallback");
+    int rc = mpcx_lmpc_setup(h);
+    if (rc != MPCX_OK) return rc;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    mpcx::LmpcBatchDev B;
+    rc = make_batch(h, b, B);
+    if (rc != MPCX_OK) return rc;
+    if (b->batch == 0) return MPCX_OK;
+    int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, stream);
+    if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
+    if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_time_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms_mean)
+{
+    CHECK_H(h);
+    if (!b || !ms_mean || repeats < 1) return fail(MPCX_E_INVALID, "bad argument");
+    if (h->host_only) return fail(MPCX_E_DEVICE, "host-only handle");
+    int rc = mpcx_lmpc_setup(h);
+    if (rc != MPCX_OK) return rc;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MPCX_E_DEVICE, "hipEventCreate failed");
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < repeats; i++) {
+        rc = mpcx_lmpc_solve_batch(h, b, stream);
+        if (rc != MPCX_OK) break;
+    }
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_mean = ms / (float)repeats;
+    return rc;
+}
+
+int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info)
+{
+    CHECK_H(h);
+    if (!info) return fail(MPCX_E_INVALID, "null info");
+    int rc = mpcx_lmpc_setup(h);
+    if (rc != MPCX_OK) return rc;
+    const auto &o = h->cond;
+    const auto &d = h->ctl.d;
+    info->n_ref = o.n_ref; info->m_ref = o.m_ref; info->neq_ref = o.neq_ref;
+    info->nz = o.nz; info->mg = o.mg; info->active_words = o.active_words;
+    info->kernel_variant = mpcx::lmpc_kernel_variant(o.ldz, o.ldg);
+    info->flops_setup = o.flops_setup;
+    const double nz = o.nz, mg = o.mg;
+    info->flops_per_admm_iter = 2 * nz * nz + 4 * mg * nz + 12 * nz + 10 * mg;
+    info->flops_fixed_per_solve = 2.0 * d.ph * d.nx * d.nx + 2.0 * (d.ph + 1) * d.ny * d.nx +
+                                  2.0 * d.ph * (d.nx * d.nx + d.ny * d.nx + d.nx * d.nu) +
+                                  2.0 * nz * (nz + mg) + 2.0 * nz * nz;
+    info->bytes_per_solve = 8.0 * (d.nx + d.nu) + 8.0 * d.nu + 8.0 + 16.0;
+    return MPCX_OK;
+}
+
+/* ---- testing aid (not part of the reference-facing surface): copy a condensed array to
+ * the host so that CPU-only tests can check the set-up without a GPU. ------------------ */
+int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap)
+{
+    CHECK_H(h);
+    int rc = mpcx_lmpc_setup(h);
+    if (rc != MPCX_OK) return rc;
+    const auto &o = h->cond;
+    const std::vector<double> *v = nullptr;
+    std::vector<double> tmp;
+    std::string n(name ? name : "");
+    if (n == "H") v = &o.H; else if (n == "Kinv") v = &o.Kinv; else if (n == "Gr") v = &o.Gr;
+    else if (n == "Gc") v = &o.Gc; else if (n == "Y") v = &o.Y; else if (n == "lw") v = &o.lw;
+    else if (n == "uw") v = &o.uw; else if (n == "rho_b") v = &o.rho_b; else if (n == "lg0") v = &o.lg0;
+    else if (n == "ug0") v = &o.ug0; else if (n == "rho_g") v = &o.rho_g;
+    else if (n == "dims") {
+        tmp = {(double)o.nz, (double)o.mg, (double)o.ldz, (double)o.ldg, (double)o.ldy, (double)o.nf,
+               (double)o.n_ref, (double)o.m_ref, (double)o.neq_ref, (double)o.fixed_rows.size(),
+               (double)h->dev.lds_per_wave, (double)(o.h_regularised ? 1 : 0)};
+        v = &tmp;
+    } else if (n == "g_refrow") { tmp.assign(o.g_refrow.begin(), o.g_refrow.end()); v = &tmp; }
+    else if (n == "g_step") { tmp.assign(o.g_step.begin(), o.g_step.end()); v = &tmp; }
+    else if (n == "g_kind") { tmp.assign(o.g_kind.begin(), o.g_kind.end()); v = &tmp; }
+    else if (n == "g_comp") { tmp.assign(o.g_comp.begin(), o.g_comp.end()); v = &tmp; }
+    else return fail(MPCX_E_INVALID, "unknown array name");
+    if (!out) return (int)v->size();
+    if (cap < (int)v->size()) return fail(MPCX_E_INVALID, "buffer too small");
+    std::memcpy(out, v->data(), sizeof(double) * v->size());
+    return (int)v->size();
+}
+
+}  // extern "C"

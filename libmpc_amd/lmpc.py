@@ -1,0 +1,370 @@
+"""Host-side mirror of libmpc++'s linear MPC front-end for the batched MI355X engine.
+
+`LMPC` keeps the method names, argument meaning and return/raise behaviour of
+`mpc::LMPC<>` (reference include/mpc/LMPC.hpp, and its pybind export
+python/pybind_export.cpp:59-123) for the one path this package replaces -- what sits
+behind `optimize()` -- and adds `optimizeBatch()`: B independent instances of the same
+controller solved by one HIP kernel launch through the C ABI in include/mpcx.h.
+
+PyTorch is plumbing here (device buffers and streams), not the product: all numerics
+run in libmpcx.so.  There is no CPU fallback; a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _capi
+from ._capi import LParams, MpcxError, check
+
+inf = float("inf")
+
+
+class HorizonSlice:
+    """Half-open step range [start, end); {-1,-1} = whole horizon (Types.hpp:57-82)."""
+
+    def __init__(self, start, end):
+        self.start, self.end = int(start), int(end)
+
+    @staticmethod
+    def all():
+        return HorizonSlice(-1, -1)
+
+
+def _slice(s):
+    if s is None:
+        return HorizonSlice.all()
+    if isinstance(s, HorizonSlice):
+        return s
+    a, b = s
+    return HorizonSlice(a, b)
+
+
+class ResultStatus:
+    SUCCESS, MAX_ITERATION, INFEASIBLE, ERROR, UNKNOWN = range(5)
+
+
+def LParameters(**kw) -> LParams:
+    """mpc::LParameters with the reference defaults (Types.hpp:146-161)."""
+    p = LParams()
+    _capi.lib().mpcx_lparams_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+@dataclass
+class Result:
+    """mpc::Result<nu> (Types.hpp:168-182)."""
+    solver_status: int = 0
+    is_feasible: bool = False
+    solver_status_msg: str = ""
+    cost: float = 0.0
+    status: int = ResultStatus.UNKNOWN
+    cmd: np.ndarray = field(default_factory=lambda: np.zeros(0))
+
+
+@dataclass
+class OptSequence:
+    """mpc::OptSequence (Types.hpp:184-198): row i = horizon step i."""
+    state: np.ndarray
+    output: np.ndarray
+    input: np.ndarray
+
+
+@dataclass
+class BatchResult:
+    """Result<nu> for B instances as structure-of-arrays of device tensors."""
+    cmd: "object"
+    cost: "object"
+    status: "object"
+    solver_status: "object"
+    is_feasible: "object"
+    iterations: "object"
+    active_lower: "object" = None
+    active_upper: "object" = None
+    seq_state: "object" = None
+    seq_output: "object" = None
+    seq_input: "object" = None
+
+
+def _cm(a, rows, cols):
+    """column-major float64 host copy with a shape check"""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1 and cols == 1:
+        a = a.reshape(rows, 1)
+    if a.shape != (rows, cols):
+        raise ValueError(f"expected shape {(rows, cols)}, got {a.shape}")
+    return np.asfortranarray(a)
+
+
+def _vec(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if a.shape[0] != n:
+        raise ValueError(f"expected length {n}, got {a.shape[0]}")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class LMPC:
+    """Linear MPC controller whose optimize() runs on an MI355X.
+
+    Mirrors mpc::LMPC<Tnx,Tnu,Tndu,Tny,Tph,Tch> with run-time sizes
+    (the reference's MPC_DYNAMIC form, LMPC.hpp:57-62).  `device=-1` builds a
+    host-only handle: setters and the condensing work, any solve raises.
+    """
+
+    def __init__(self, nx, nu, ndu, ny, ph, ch, device=0):
+        self._lib = _capi.lib()
+        self.nx, self.nu, self.ndu, self.ny, self.ph, self.ch = map(int, (nx, nu, ndu, ny, ph, ch))
+        self.device = int(device)
+        d = _capi.Dims(self.nx, self.nu, self.ndu, self.ny, self.ph, self.ch)
+        self._h = C.c_void_p()
+        check(self._lib.mpcx_lmpc_create(C.byref(d), self.device, C.byref(self._h)))
+        self._last = Result(cmd=np.zeros(self.nu))
+        self._seq = OptSequence(np.zeros((self.ph + 1, self.nx)), np.zeros((self.ph + 1, self.ny)),
+                                np.zeros((self.ph + 1, self.nu)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.mpcx_lmpc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- not available on the linear front-end (LMPC.hpp:68-100) -------------------
+    def setDiscretizationSamplingTime(self, ts):
+        raise RuntimeError("Linear MPC supports only discrete time systems")
+
+    def setInputScale(self, scaling):
+        raise RuntimeError("Linear MPC does not support input scaling")
+
+    def setStateScale(self, scaling):
+        raise RuntimeError("Linear MPC does not support state scaling")
+
+    def setLoggerLevel(self, level):
+        return True
+
+    def setLoggerPrefix(self, prefix):
+        return True
+
+    # -- set-up ---------------------------------------------------------------------
+    def _ok(self, rc):
+        if rc == _capi.E_INVALID:
+            return False          # the reference's setters return false on a bad slice
+        check(rc)
+        return True
+
+    def setOptimizerParameters(self, params: LParams):
+        check(self._lib.mpcx_lmpc_set_optimizer_parameters(self._h, C.byref(params)))
+
+    def setStateSpaceModel(self, A, B, Cm):
+        A, B, Cm = _cm(A, self.nx, self.nx), _cm(B, self.nx, self.nu), _cm(Cm, self.ny, self.nx)
+        return self._ok(self._lib.mpcx_lmpc_set_state_space_model(self._h, _p(A), _p(B), _p(Cm)))
+
+    def setDisturbances(self, Bd, Dd):
+        Bd, Dd = _cm(Bd, self.nx, self.ndu), _cm(Dd, self.ny, self.ndu)
+        return self._ok(self._lib.mpcx_lmpc_set_disturbances(self._h, _p(Bd), _p(Dd)))
+
+    def setObjectiveWeights(self, OWeight, UWeight, DeltaUWeight, slice=None):
+        ow = np.asarray(OWeight, dtype=np.float64)
+        if ow.ndim == 2 and slice is None:
+            O, U, D = _cm(OWeight, self.ny, self.ph), _cm(UWeight, self.nu, self.ph), _cm(DeltaUWeight, self.nu, self.ph)
+            return self._ok(self._lib.mpcx_lmpc_set_objective_weights(self._h, _p(O), _p(U), _p(D)))
+        s = _slice(slice)
+        o, u, d = _vec(OWeight, self.ny), _vec(UWeight, self.nu), _vec(DeltaUWeight, self.nu)
+        return self._ok(self._lib.mpcx_lmpc_set_objective_weights_slice(self._h, _p(o), _p(u), _p(d), s.start, s.end))
+
+    def _bounds(self, lo, hi, rows, cols, fmat, fslice, slice):
+        a = np.asarray(lo, dtype=np.float64)
+        if a.ndim == 2 and slice is None:
+            L, H = _cm(lo, rows, cols), _cm(hi, rows, cols)
+            return self._ok(fmat(self._h, _p(L), _p(H)))
+        s = _slice(slice)
+        l, h = _vec(lo, rows), _vec(hi, rows)
+        return self._ok(fslice(self._h, _p(l), _p(h), s.start, s.end))
+
+    def setStateBounds(self, XMin, XMax, slice=None):
+        return self._bounds(XMin, XMax, self.nx, self.ph, self._lib.mpcx_lmpc_set_state_bounds,
+                            self._lib.mpcx_lmpc_set_state_bounds_slice, slice)
+
+    def setInputBounds(self, UMin, UMax, slice=None):
+        return self._bounds(UMin, UMax, self.nu, self.ch, self._lib.mpcx_lmpc_set_input_bounds,
+                            self._lib.mpcx_lmpc_set_input_bounds_slice, slice)
+
+    def setOutputBounds(self, YMin, YMax, slice=None):
+        return self._bounds(YMin, YMax, self.ny, self.ph, self._lib.mpcx_lmpc_set_output_bounds,
+                            self._lib.mpcx_lmpc_set_output_bounds_slice, slice)
+
+    def setScalarConstraint(self, *args):
+        """(min, max, X, U, slice) as LMPC.hpp:355 or (index, min, max, X, U) as LMPC.hpp:409."""
+        if len(args) != 5:
+            raise TypeError("setScalarConstraint takes (min, max, X, U, slice) or (index, min, max, X, U)")
+        if isinstance(args[4], (HorizonSlice, tuple, list)) or args[4] is None:
+            smin, smax, X, U, sl = args
+            s = _slice(sl)
+            X, U = _vec(X, self.nx), _vec(U, self.nu)
+            return self._ok(self._lib.mpcx_lmpc_set_scalar_constraint_slice(
+                self._h, float(smin), float(smax), _p(X), _p(U), s.start, s.end))
+        index, smin, smax, X, U = args
+        X, U = _vec(X, self.nx), _vec(U, self.nu)
+        return self._ok(self._lib.mpcx_lmpc_set_scalar_constraint_index(
+            self._h, int(index), float(smin), float(smax), _p(X), _p(U)))
+
+    def setReferences(self, outRef, cmdRef, deltaCmdRef, slice=None):
+        a = np.asarray(outRef, dtype=np.float64)
+        if a.ndim == 2 and slice is None:
+            Y, U, D = _cm(outRef, self.ny, self.ph), _cm(cmdRef, self.nu, self.ph), _cm(deltaCmdRef, self.nu, self.ph)
+            return self._ok(self._lib.mpcx_lmpc_set_references(self._h, _p(Y), _p(U), _p(D)))
+        s = _slice(slice)
+        y, u, d = _vec(outRef, self.ny), _vec(cmdRef, self.nu), _vec(deltaCmdRef, self.nu)
+        return self._ok(self._lib.mpcx_lmpc_set_references_slice(self._h, _p(y), _p(u), _p(d), s.start, s.end))
+
+    def setExogenousInputs(self, uMeas, slice=None):
+        a = np.asarray(uMeas, dtype=np.float64)
+        if a.ndim == 2 and slice is None:
+            Dm = _cm(uMeas, self.ndu, self.ph)
+            return self._ok(self._lib.mpcx_lmpc_set_exogenous_inputs(self._h, _p(Dm)))
+        s = _slice(slice)
+        d = _vec(uMeas, self.ndu)
+        return self._ok(self._lib.mpcx_lmpc_set_exogenous_inputs_slice(self._h, _p(d), s.start, s.end))
+
+    # -- introspection -----------------------------------------------------------------
+    def setup(self):
+        check(self._lib.mpcx_lmpc_setup(self._h))
+
+    def info(self):
+        i = _capi.Info()
+        check(self._lib.mpcx_lmpc_get_info(self._h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in _capi.Info._fields_}
+
+    def debug_get(self, name):
+        """testing aid: condensed arrays as computed by the host set-up"""
+        f = self._lib.mpcx_lmpc_debug_get
+        n = check(f(self._h, name.encode(), None, 0))
+        out = np.zeros(n)
+        check(f(self._h, name.encode(), _p(out), n))
+        return out
+
+    # -- the hot path ------------------------------------------------------------------
+    def _torch(self):
+        import torch
+        if self.device < 0 or not torch.cuda.is_available():
+            raise MpcxError(_capi.E_DEVICE, "optimize needs an MI355X: libmpc_amd has no CPU solve path")
+        return torch, torch.device("cuda", self.device)
+
+    def _dev(self, torch, dev, a, shape):
+        if a is None:
+            return None
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+        t = t.to(device=dev, dtype=torch.float64).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _ref(self, torch, dev, a, B, n):
+        """classify a per-solve reference: None -> shared, [B,n] -> per instance, [B,ph,n] -> per step"""
+        if a is None:
+            return None, _capi.REF_SHARED
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+        t = t.to(device=dev, dtype=torch.float64).contiguous()
+        if tuple(t.shape) == (B, n):
+            return t, _capi.REF_PER_INSTANCE
+        if tuple(t.shape) == (B, self.ph, n):
+            return t, _capi.REF_PER_STEP
+        raise ValueError(f"reference must be [B,{n}] or [B,{self.ph},{n}], got {tuple(t.shape)}")
+
+    def make_batch(self, x0, u0, yref=None, uref=None, duref=None, dmeas=None,
+                   want_active=False, want_sequence=False):
+        """Allocate outputs and fill the mpcx_lmpc_batch descriptor.  Returns (Batch, BatchResult, keepalive)."""
+        torch, dev = self._torch()
+        x0t = x0 if hasattr(x0, "shape") else np.asarray(x0)
+        B = int(x0t.shape[0])
+        x0 = self._dev(torch, dev, x0, (B, self.nx))
+        u0 = self._dev(torch, dev, u0, (B, self.nu))
+        yr, ym = self._ref(torch, dev, yref, B, self.ny)
+        ur, um = self._ref(torch, dev, uref, B, self.nu)
+        dr, dmo = self._ref(torch, dev, duref, B, self.nu)
+        de, dem = self._ref(torch, dev, dmeas, B, self.ndu)
+        i = self.info()
+        f64, i32 = torch.float64, torch.int32
+        res = BatchResult(
+            cmd=torch.empty((B, self.nu), dtype=f64, device=dev),
+            cost=torch.empty((B,), dtype=f64, device=dev),
+            status=torch.empty((B,), dtype=i32, device=dev),
+            solver_status=torch.empty((B,), dtype=i32, device=dev),
+            is_feasible=torch.empty((B,), dtype=i32, device=dev),
+            iterations=torch.empty((B,), dtype=i32, device=dev))
+        if want_active:
+            res.active_lower = torch.zeros((B, i["active_words"]), dtype=i32, device=dev)
+            res.active_upper = torch.zeros((B, i["active_words"]), dtype=i32, device=dev)
+        if want_sequence:
+            res.seq_state = torch.empty((B, self.ph + 1, self.nx), dtype=f64, device=dev)
+            res.seq_output = torch.empty((B, self.ph + 1, self.ny), dtype=f64, device=dev)
+            res.seq_input = torch.empty((B, self.ph + 1, self.nu), dtype=f64, device=dev)
+
+        def ptr(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        b = _capi.Batch()
+        b.batch = B
+        b.x0, b.u0 = ptr(x0), ptr(u0)
+        b.yref, b.yref_mode = ptr(yr), ym
+        b.uref, b.uref_mode = ptr(ur), um
+        b.duref, b.duref_mode = ptr(dr), dmo
+        b.dmeas, b.dmeas_mode = ptr(de), dem
+        b.cmd, b.cost = ptr(res.cmd), ptr(res.cost)
+        b.status, b.solver_status = ptr(res.status), ptr(res.solver_status)
+        b.is_feasible, b.iterations = ptr(res.is_feasible), ptr(res.iterations)
+        b.active_lower, b.active_upper = ptr(res.active_lower), ptr(res.active_upper)
+        b.seq_state, b.seq_output, b.seq_input = ptr(res.seq_state), ptr(res.seq_output), ptr(res.seq_input)
+        keep = (x0, u0, yr, ur, dr, de)
+        return b, res, keep
+
+    def launch(self, batch, stream=None):
+        """One asynchronous kernel launch for a descriptor built by make_batch()."""
+        torch, _ = self._torch()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(self._lib.mpcx_lmpc_solve_batch(self._h, C.byref(batch), C.c_void_p(s.cuda_stream)))
+
+    def time_launches(self, batch, repeats, stream=None):
+        """Mean kernel time (ms) over `repeats` launches, HIP events on the launch stream."""
+        torch, _ = self._torch()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ms = C.c_float()
+        check(self._lib.mpcx_lmpc_time_solve_batch(self._h, C.byref(batch), C.c_void_p(s.cuda_stream), int(repeats), C.byref(ms)))
+        return ms.value
+
+    def optimizeBatch(self, x0, lastU, yref=None, uref=None, duref=None, dmeas=None,
+                      want_active=False, want_sequence=False, stream=None) -> BatchResult:
+        """B independent LOptimizer::run calls (LOptimizer.hpp:189) in one launch."""
+        b, res, keep = self.make_batch(x0, lastU, yref, uref, duref, dmeas, want_active, want_sequence)
+        self.launch(b, stream)
+        self._keep = keep
+        return res
+
+    def optimize(self, x0, lastU) -> Result:
+        """IMPC::optimize (IMPC.hpp:149-166) for one instance, through the batched path."""
+        r = self.optimizeBatch(np.asarray(x0, dtype=np.float64).reshape(1, self.nx),
+                               np.asarray(lastU, dtype=np.float64).reshape(1, self.nu), want_sequence=True)
+        sst = int(r.solver_status[0].item())
+        self._last = Result(solver_status=sst, is_feasible=bool(r.is_feasible[0].item()), solver_status_msg="",
+                            cost=float(r.cost[0].item()), status=int(r.status[0].item()),
+                            cmd=r.cmd[0].cpu().numpy().copy())
+        self._seq = OptSequence(r.seq_state[0].cpu().numpy().copy(), r.seq_output[0].cpu().numpy().copy(),
+                                r.seq_input[0].cpu().numpy().copy())
+        return self._last
+
+    def getLastResult(self) -> Result:
+        return self._last
+
+    def getOptimalSequence(self) -> OptSequence:
+        return self._seq

@@ -1,0 +1,80 @@
+"""Benchmark / test workloads: the reference's quadrotor controller and the synthetic
+per-instance inputs of SURVEY.md section 8(d).  Data only -- no solver code."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .lmpc import LMPC, LParameters, inf
+
+
+def quadrotor_matrices():
+    """Ad, Bd, Cd of reference examples/quadrotor_ex.cpp:19-48 (numeric data)."""
+    Ad = np.eye(12)
+    for (i, j, v) in [(0, 6, 0.1), (1, 7, 0.1), (2, 8, 0.1),
+                      (3, 0, 0.0488), (3, 6, 0.0016), (3, 9, 0.0992),
+                      (4, 1, -0.0488), (4, 7, -0.0016), (4, 10, 0.0992),
+                      (5, 11, 0.0992),
+                      (9, 0, 0.9734), (9, 6, 0.0488), (9, 9, 0.9846),
+                      (10, 1, -0.9734), (10, 7, -0.0488), (10, 10, 0.9846),
+                      (11, 11, 0.9846)]:
+        Ad[i, j] = v
+    Bd = np.array([
+        [0, -0.0726, 0, 0.0726], [-0.0726, 0, 0.0726, 0], [-0.0152, 0.0152, -0.0152, 0.0152],
+        [0, -0.0006, -0.0000, 0.0006], [0.0006, 0, -0.0006, 0], [0.0106, 0.0106, 0.0106, 0.0106],
+        [0, -1.4512, 0, 1.4512], [-1.4512, 0, 1.4512, 0], [-0.3049, 0.3049, -0.3049, 0.3049],
+        [0, -0.0236, 0, 0.0236], [0.0236, 0, -0.0236, 0], [0.2107, 0.2107, 0.2107, 0.2107]], dtype=float)
+    return Ad, Bd, np.eye(12)
+
+
+def quadrotor_lmpc(ph=20, ch=None, device=0, maximum_iteration=250) -> LMPC:
+    """The controller of examples/quadrotor_ex.cpp:52-93 at horizon ph (=ch by default)."""
+    ch = ph if ch is None else ch
+    c = LMPC(12, 4, 4, 12, ph, ch, device=device)
+    Ad, Bd, Cd = quadrotor_matrices()
+    c.setStateSpaceModel(Ad, Bd, Cd)
+    c.setObjectiveWeights([0, 0, 10, 10, 10, 10, 0, 0, 0, 5, 5, 5], [0.1] * 4, [0] * 4, (0, ph))
+    xmin = [-math.pi / 6, -math.pi / 6, -inf, -inf, -inf, -1] + [-inf] * 6
+    xmax = [math.pi / 6, math.pi / 6] + [inf] * 10
+    u0 = 10.5916
+    c.setStateBounds(xmin, xmax, (0, ph))
+    c.setOutputBounds([-inf] * 12, [inf] * 12, (0, ph))
+    c.setInputBounds([9.6 - u0] * 4, [13 - u0] * 4, (0, ch))
+    yref = np.zeros(12); yref[2] = 1.0
+    c.setReferences(yref, np.zeros(4), np.zeros(4), (0, ph))
+    c.setOptimizerParameters(LParameters(maximum_iteration=maximum_iteration))
+    return c
+
+
+_MASK = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix(state):
+    state = (state + 0x9E3779B97F4A7C15) & _MASK
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    return state, z ^ (z >> 31)
+
+
+def quadrotor_batch(B, first=0):
+    """SplitMix64 inputs (seed 0x6d70632b2b + instance index, doubles = (r>>11)*2^-53):
+    x0[0,1]~U(-.2,.2), x0[2..5]~U(-.5,.5), x0[6..11]~U(-.3,.3), u0~U(-.5,.5)^4,
+    yRef[2]~U(.5,1.5).  Instance 0 is the reference test's exact input."""
+    x0 = np.zeros((B, 12)); u0 = np.zeros((B, 4)); yref = np.zeros((B, 12))
+    for b in range(B):
+        idx = first + b
+        s = (0x6d70632b2b + idx) & _MASK
+        vals = []
+        for _ in range(17):
+            s, r = _splitmix(s)
+            vals.append((r >> 11) * 2.0 ** -53)
+        for j in range(12):
+            w = 0.2 if j < 2 else (0.5 if j < 6 else 0.3)
+            x0[b, j] = -w + 2 * w * vals[j]
+        u0[b] = -0.5 + np.array(vals[12:16])
+        yref[b, 2] = 0.5 + vals[16]
+        if idx == 0:
+            x0[b] = 0; u0[b] = 0; yref[b] = 0; yref[b, 2] = 1.0
+    return x0, u0, yref
