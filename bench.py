@@ -1,0 +1,135 @@
+"""bench.py -- MPC solves/sec on the reference's quadrotor LMPC (N=20), batch 4096 per GPU.
+
+One "step" = one pass of the hot path (batched LOptimizer::run) over one batch of synthetic
+instances already resident in HBM.  N>1: one process per GPU (torch.distributed / RCCL),
+each rank solves its own shard, then one all-gather of u* over xGMI; weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP64_TFLOPS = 78.6      # MI355X FP64 vector == FP64 matrix peak; see DESIGN.md
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from libmpc_amd.distributed import allgather_controls
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+
+    B, ph = args.batch, args.horizon
+    ctl = quadrotor_lmpc(ph, device=local)
+    info = ctl.info()
+    x0, u0, yref = quadrotor_batch(B, first=rank * B)
+    batch, res, keep = ctl.make_batch(x0, u0, yref=yref)
+    stream = torch.cuda.current_stream(local)
+
+    def step():
+        ctl.launch(batch, stream)
+        if world > 1:
+            return allgather_controls(res.cmd)
+        return res.cmd
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-step latency distribution (host-synchronised single steps), outside the timed region
+    lat = []
+    for _ in range(min(50, max(5, args.steps))):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    lat_p50 = float(np.median(lat)) * 1e3
+
+    if rank == 0:
+        # dominant kernel: average launch duration by HIP events on the launch stream
+        kern_ms = ctl.time_launches(batch, max(10, min(args.steps, 100)), stream)
+        torch.cuda.synchronize()
+        iters = res.iterations.cpu().numpy().astype(np.float64)
+        status = res.status.cpu().numpy()
+        flops = float(B * info["flops_fixed_per_solve"] + iters.sum() * info["flops_per_admm_iter"])
+        bytes_alg = float(B) * (8.0 * (12 + 4 + 12) + 8.0 * 4 + 8.0 + 16.0)   # x0,u0,yref in; cmd,cost,4 ints out
+        ach_tf = flops / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                "kernel": "lmpc_solve_kernel<1,1>", "kernel_ms": kern_ms,
+                "algorithmic_flops_per_launch": flops, "mean_admm_iters": float(iters.mean()),
+                "hbm_achieved_GBs": bytes_alg / (kern_ms * 1e-3) / 1e9,
+                "hbm_frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_bytes_per_launch": bytes_alg}
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import quadrotor_oracle
+            o = quadrotor_oracle(ph)
+            probe = o.solve_batch_constref(x0[:32], u0[:32], yref[:32])
+            per = probe["seconds"] / 32
+            n = int(max(32, min(B, args.cpu_seconds / per)))
+            rr = o.solve_batch_constref(x0[:n], u0[:n], yref[:n])
+            ps = np.sort(rr["per_solve_seconds"])
+            cpu = {"value": n / rr["seconds"], "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"first {n} instances of the same batch, one thread, set-up per solve as LOptimizer::run",
+                   "p50_ms": float(ps[len(ps) // 2] * 1e3), "p99_ms": float(ps[int(len(ps) * 0.99) - 1] * 1e3)}
+        total = world * B * args.steps
+        out = {"metric": "MPC solves/sec (whole node), quadrotor LMPC N=%d batch=%d per GPU" % (ph, B),
+               "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "quadrotor_ex.cpp LMPC nx=12 nu=4 ny=12 ph=ch=%d, batch %d per GPU, "
+                                      "SplitMix64 x0/u0/yref (SURVEY 8d), maximum_iteration=250" % (ph, B),
+                          "parallelism": "batch-sharded x%d, all-gather of u*" % world if world > 1 else "single GPU"},
+               "p50_step_latency_ms": lat_p50,
+               "solved_fraction": float((status == 0).mean()),
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,34 +47,24 @@ def quadrotor_lmpc(ph=20, ch=None, device=0, maximum_iteration=250) -> LMPC:
     return c
 
 
-_MASK = 0xFFFFFFFFFFFFFFFF
-
-
-def _splitmix(state):
-    state = (state + 0x9E3779B97F4A7C15) & _MASK
-    z = state
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
-    return state, z ^ (z >> 31)
-
-
 def quadrotor_batch(B, first=0):
     """SplitMix64 inputs (seed 0x6d70632b2b + instance index, doubles = (r>>11)*2^-53):
     x0[0,1]~U(-.2,.2), x0[2..5]~U(-.5,.5), x0[6..11]~U(-.3,.3), u0~U(-.5,.5)^4,
-    yRef[2]~U(.5,1.5).  Instance 0 is the reference test's exact input."""
-    x0 = np.zeros((B, 12)); u0 = np.zeros((B, 4)); yref = np.zeros((B, 12))
-    for b in range(B):
-        idx = first + b
-        s = (0x6d70632b2b + idx) & _MASK
-        vals = []
-        for _ in range(17):
-            s, r = _splitmix(s)
-            vals.append((r >> 11) * 2.0 ** -53)
-        for j in range(12):
-            w = 0.2 if j < 2 else (0.5 if j < 6 else 0.3)
-            x0[b, j] = -w + 2 * w * vals[j]
-        u0[b] = -0.5 + np.array(vals[12:16])
-        yref[b, 2] = 0.5 + vals[16]
-        if idx == 0:
-            x0[b] = 0; u0[b] = 0; yref[b] = 0; yref[b, 2] = 1.0
-    return x0, u0, yref
+    yRef[2]~U(.5,1.5).  Instance 0 is the reference test's exact input
+    (test/LMPC/test_common.cpp:224-228).  Vectorised: draw k of instance i is
+    mix(seed + i + (k+1)*golden) because SplitMix64 advances its state by a constant."""
+    idx = (np.arange(B, dtype=np.uint64) + np.uint64(first))
+    with np.errstate(over="ignore"):
+        st = (np.uint64(0x6d70632b2b) + idx)[:, None] + (np.arange(1, 18, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))[None, :]
+        z = st
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    vals = (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    w = np.array([0.2, 0.2] + [0.5] * 4 + [0.3] * 6)
+    x0 = -w[None, :] + 2 * w[None, :] * vals[:, :12]
+    u0 = -0.5 + vals[:, 12:16]
+    yref = np.zeros((B, 12)); yref[:, 2] = 0.5 + vals[:, 16]
+    if first == 0 and B > 0:
+        x0[0] = 0; u0[0] = 0; yref[0] = 0; yref[0, 2] = 1.0
+    return np.ascontiguousarray(x0), np.ascontiguousarray(u0), yref
