@@ -28,6 +28,7 @@ struct LmpcDev {
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
     // per-wave LDS carve (in doubles)
     int stage_len, arena_len, lds_per_wave;
+    int wsld;                                    // per-instance workspace record (doubles): f | t0 | gt0 | lg | ug | c0, flag
     // model, column-major
     const double *A, *B, *C, *Bd, *Dd;
     const double *Wy, *Wu, *Wdu;                 // [(ph+1) x ny], [(ph+1) x nu], [ph x nu]; column = internal step
@@ -57,11 +58,12 @@ struct LmpcBatchDev {
     int32_t *status, *solver_status, *is_feasible, *iterations;
     uint32_t *active_lower, *active_upper;
     double *seq_state, *seq_output, *seq_input;
+    long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, void *stream);
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 
 }  // namespace mpcx

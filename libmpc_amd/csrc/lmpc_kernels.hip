@@ -1,20 +1,26 @@
-// Batched linear-MPC solve kernel for gfx950 (MI355X): one MPC instance per wavefront.
+// Batched linear-MPC kernels for gfx950 (MI355X).
 //
-// Replaces, for a batch of instances sharing one controller, what the reference does
-// per call in LOptimizer::run (include/mpc/LMPC/LOptimizer.hpp:189-368):
-//   ProblemBuilder::get        (ProblemBuilder.hpp:528-633)  -> phase 1/2: free response
-//                               rollout over the horizon + adjoint pass = linear term and
-//                               constraint offsets of the condensed QP
-//   osqp_setup/osqp_solve      (LOptimizer.hpp:261,284)      -> phase 3/4: ADMM iterations on
-//                               the condensed QP with the shared, pre-inverted ADMM matrix,
-//                               and an active-set polish (OSQP's polish, iterated until the
-//                               KKT conditions verify) on a Schur complement staged in LDS
-//   unpacking                   (LOptimizer.hpp:305-347)     -> phase 5
-// A wavefront owns an instance from load to store; nothing is exchanged between
-// wavefronts, so there is no workgroup barrier anywhere in the kernel.  Vectors live
-// in registers as element pairs (see lmpc_device.hpp); the vector that a mat-vec
-// broadcasts is staged through the wave's LDS slice; the shared matrices stream from
-// L2 with 16-byte loads, coalesced across the wavefront.
+// Replace, for a batch of instances sharing one controller, what the reference does per
+// call in LOptimizer::run (include/mpc/LMPC/LOptimizer.hpp:189-368):
+//
+//   lmpc_assemble_*   ProblemBuilder::get (ProblemBuilder.hpp:528-633): per-instance linear
+//                     term, constraint offsets and cost constant of the condensed QP from
+//                     (x0, lastU, references, exogenous inputs), plus the unconstrained
+//                     optimum.
+//                       _generic  one instance per wavefront, horizon roll-out + adjoint pass
+//                                 (any reference layout, disturbances, per-step references).
+//   lmpc_solve        osqp_setup/osqp_solve (LOptimizer.hpp:261,284) + unpacking (:305-347):
+//                     one instance per wavefront; active-set polish (OSQP's polish, iterated
+//                     until the KKT conditions verify) on a Schur complement staged in LDS,
+//                     with ADMM iterations on the shared pre-inverted ADMM matrix as the
+//                     globalisation step whenever the polish does not verify.
+//
+// A wavefront owns its instance from load to store; nothing is exchanged between
+// wavefronts, so there is no workgroup barrier anywhere.  Per-instance vectors live in
+// registers as element pairs (lmpc_device.hpp); the vector a mat-vec broadcasts is staged
+// through the wave's LDS slice; the shared matrices stream from L2 with 16-byte loads that
+// are coalesced across the wavefront and never predicated (out-of-range lanes re-read
+// element 0), so the compiler keeps many of them in flight.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -27,6 +33,23 @@ namespace mpcx {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+
+// Pointers that come out of the model struct are generic pointers to the compiler, which
+// would emit flat_load (tied to both vmcnt and lgkmcnt, serialising against LDS traffic).
+// Everything they point to lives in HBM: say so.
+#define MPCX_GAS __attribute__((address_space(1)))
+typedef const double MPCX_GAS *gdp;
+typedef const int MPCX_GAS *gip;
+typedef double MPCX_GAS *gdw;
+template <typename T> __device__ __forceinline__ const T MPCX_GAS *gl(const T *p) { return (const T MPCX_GAS *)p; }
+template <typename T> __device__ __forceinline__ T MPCX_GAS *glw(T *p) { return (T MPCX_GAS *)p; }
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 ld2(gdp p) { return *reinterpret_cast<const d2 MPCX_GAS *>(p); }
+__device__ __forceinline__ void st2(gdw p, double a, double b)
+{
+    d2 v; v.x = a; v.y = b;
+    *reinterpret_cast<d2 MPCX_GAS *>(p) = v;
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -46,28 +69,35 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-__device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
-// acc += M[:, 0..ncols) * xs, M column-major with leading dimension ld, rows < R (even)
+// acc += M[:, 0..ncols) * xs.  M column-major, leading dimension ld, R (even) valid rows.
 template <int CP>
-__device__ __forceinline__ void matvec_acc(const double *__restrict__ M, int ld, int R, int ncols,
-                                           const double *xs, double (&acc)[2 * CP], int lane)
+__device__ __forceinline__ void matvec_acc(gdp M, int ld, int R, int ncols, const double *xs,
+                                           double (&acc)[2 * CP], int lane)
 {
-#pragma unroll 4
+    int off[CP];
+    double t[2 * CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        const int e = 128 * c + 2 * lane;
+        off[c] = e < R ? e : 0;
+        t[2 * c] = 0; t[2 * c + 1] = 0;
+    }
+#pragma unroll 8
     for (int j = 0; j < ncols; ++j) {
         const double xj = xs[j];
-        const double *col = M + (size_t)j * ld;
+        gdp col = M + (size_t)j * ld;
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
-            const int e = 128 * c + 2 * lane;
-            if (e < R) {
-                const double2 m = ld2(col + e);
-                acc[2 * c] = fma(m.x, xj, acc[2 * c]);
-                acc[2 * c + 1] = fma(m.y, xj, acc[2 * c + 1]);
-            }
+            const d2 m = ld2(col + off[c]);
+            t[2 * c] = fma(m.x, xj, t[2 * c]);
+            t[2 * c + 1] = fma(m.y, xj, t[2 * c + 1]);
         }
     }
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+        if (128 * c + 2 * lane < R) { acc[2 * c] += t[2 * c]; acc[2 * c + 1] += t[2 * c + 1]; }
 }
 
 template <int CP>
@@ -80,7 +110,7 @@ __device__ __forceinline__ void stage_store(double *xs, const double (&v)[2 * CP
     }
 }
 
-__device__ __forceinline__ double ref_at(const double *p, long bs, long ks, int b, int k, int a)
+__device__ __forceinline__ double ref_at(gdp p, long bs, long ks, int b, int k, int a)
 {
     return p[(size_t)b * bs + (size_t)k * ks + a];
 }
@@ -91,50 +121,58 @@ __device__ __forceinline__ bool violates(double v, double lo, double hi, double 
     return (v < lo - (ea + er * fabs(lo))) || (v > hi + (ea + er * fabs(hi)));
 }
 
+#define GP(field) gl(M.field)
+
+// =====================================================================================
+// assemble, generic form: one instance per wavefront
+// =====================================================================================
 template <int CPZ, int CPG>
-__device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
-                          double *stage, double *nt0, double *arena)
+__device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
+                             double *stage, double *arena, gdw ws)
 {
     constexpr int NZS = 2 * CPZ, NGS = 2 * CPG;
     const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
-    const int nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
-    const double INF = __builtin_huge_val();
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nz = M.nz, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
+    const bool has_dist = M.has_dist != 0;
+    const double ea = M.eps_abs, er = M.eps_rel;
+    const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd);
+    const gdp gdm = gl(Bt.dmeas), gyr = gl(Bt.yref), gur = gl(Bt.uref), gdr = gl(Bt.duref);
 
-    // ------------------------------------------------------------------ phase 0: inputs
     double *xb = arena;                       // free response, (ph+1) x nx
     double *ey = xb + (ph + 1) * nx;          // weighted output error, (ph+1) x ny
     double *pv = ey + (ph + 1) * ny;          // adjoint ping-pong, 2 x nx
     double *u0s = pv + 2 * nx;                // lastU
-    if (lane < nx) xb[lane] = Bt.x0[(size_t)b * nx + lane];
-    if (lane < nu) u0s[lane] = Bt.u0[(size_t)b * nu + lane];
+    if (lane < nx) xb[lane] = gl(Bt.x0)[(size_t)b * nx + lane];
+    if (lane < nu) u0s[lane] = gl(Bt.u0)[(size_t)b * nu + lane];
     wave_sync();
 
-    auto dm = [&](int k, int dd) -> double { return ref_at(Bt.dmeas, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
+    auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
 
+    // step-0 rows involve no decision variable: pure feasibility conditions on (x0, lastU)
     bool bad = false;
-    if (lane < nx) bad |= violates(xb[lane], M.lo0x[lane], M.hi0x[lane], M.eps_abs, M.eps_rel);
-    if (lane < nu) bad |= violates(u0s[lane], M.lo0u[lane], M.hi0u[lane], M.eps_abs, M.eps_rel);
+    if (lane < nx) bad |= violates(xb[lane], GP(lo0x)[lane], GP(hi0x)[lane], ea, er);
+    if (lane < nu) bad |= violates(u0s[lane], GP(lo0u)[lane], GP(hi0u)[lane], ea, er);
     if (lane < ny) {
         double y0 = 0;
-        for (int c = 0; c < nx; ++c) y0 = fma(M.C[lane + c * ny], xb[c], y0);
-        if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) y0 = fma(M.Dd[lane + dd * ny], dm(0, dd), y0);
-        bad |= violates(y0, M.lo0y[lane], M.hi0y[lane], M.eps_abs, M.eps_rel);
+        for (int c = 0; c < nx; ++c) y0 = fma(gC[lane + c * ny], xb[c], y0);
+        if (has_dist) for (int dd = 0; dd < ndu; ++dd) y0 = fma(gDd[lane + dd * ny], dm(0, dd), y0);
+        bad |= violates(y0, GP(lo0y)[lane], GP(hi0y)[lane], ea, er);
     }
     if (lane == 0) {
         double s0 = 0;
-        for (int c = 0; c < nx; ++c) s0 = fma(M.sX[c], xb[c], s0);
-        for (int c = 0; c < nu; ++c) s0 = fma(M.sU[c], u0s[c], s0);
-        bad |= violates(s0, M.s0lo, M.s0hi, M.eps_abs, M.eps_rel);
+        for (int c = 0; c < nx; ++c) s0 = fma(GP(sX)[c], xb[c], s0);
+        for (int c = 0; c < nu; ++c) s0 = fma(GP(sU)[c], u0s[c], s0);
+        bad |= violates(s0, M.s0lo, M.s0hi, ea, er);
     }
 
-    // ------------------------------------------------------------------ phase 1: horizon rollout
+    // horizon roll-out of the free response
     for (int i = 1; i <= ph; ++i) {
         if (lane < nx) {
             const double *xp = xb + (i - 1) * nx;
             double s = 0;
-            for (int c = 0; c < nx; ++c) s = fma(M.A[lane + c * nx], xp[c], s);
-            if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) s = fma(M.Bd[lane + dd * nx], dm(i - 1, dd), s);
+#pragma unroll 4
+            for (int c = 0; c < nx; ++c) s = fma(gA[lane + c * nx], xp[c], s);
+            if (has_dist) for (int dd = 0; dd < ndu; ++dd) s = fma(gBd[lane + dd * nx], dm(i - 1, dd), s);
             xb[i * nx + lane] = s;
         }
         wave_sync();
@@ -143,90 +181,93 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int idx = lane; idx < (ph + 1) * ny; idx += 64) {
         const int i = idx / ny, a = idx - i * ny, k = i > 0 ? i - 1 : 0;
         double cx = 0;
-        for (int c = 0; c < nx; ++c) cx = fma(M.C[a + c * ny], xb[i * nx + c], cx);
-        double r = ref_at(Bt.yref, Bt.yref_bs, Bt.yref_ks, b, k, a);
-        if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) r -= M.Dd[a + dd * ny] * dm(k, dd);
-        const double w = M.Wy[i * ny + a];
+#pragma unroll 4
+        for (int c = 0; c < nx; ++c) cx = fma(gC[a + c * ny], xb[i * nx + c], cx);
+        double r = ref_at(gyr, Bt.yref_bs, Bt.yref_ks, b, k, a);
+        if (has_dist) for (int dd = 0; dd < ndu; ++dd) r -= gDd[a + dd * ny] * dm(k, dd);
+        const double w = GP(Wy)[i * ny + a];
         ey[idx] = w * (cx - r);
         c0 += w * (0.5 * cx * cx - r * cx);
     }
     if (lane < nu) {
         const double u = u0s[lane];
-        c0 += M.Wu[lane] * (0.5 * u * u - ref_at(Bt.uref, Bt.uref_bs, Bt.uref_ks, b, 0, lane) * u);
-        c0 += M.Wdu[lane] * (0.5 * u * u + ref_at(Bt.duref, Bt.duref_bs, Bt.duref_ks, b, 0, lane) * u);
+        c0 += GP(Wu)[lane] * (0.5 * u * u - ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, 0, lane) * u);
+        c0 += GP(Wdu)[lane] * (0.5 * u * u + ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, 0, lane) * u);
     }
     c0 = wave_sum(c0);
 
     // constraint rows: bounds shifted by the free response
-    double lg[NGS], ug[NGS], rg[NGS];
-    bool eqg[NGS];
+    const double INF = __builtin_huge_val();
+    double lg[NGS], ug[NGS];
 #pragma unroll
     for (int s = 0; s < NGS; ++s) {
         const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
-        lg[s] = -INF; ug[s] = INF; rg[s] = 1.0; eqg[s] = false;
+        lg[s] = -INF; ug[s] = INF;
         if (r < ldg) {
-            const int kind = M.g_kind[r], st = M.g_step[r], cp = M.g_comp[r];
+            const int kind = GP(g_kind)[r], st = GP(g_step)[r], cp = GP(g_comp)[r];
             double off;
             if (kind == 0) off = xb[st * nx + cp];
             else if (kind == 1) {
                 off = 0;
-                for (int c = 0; c < nx; ++c) off = fma(M.C[cp + c * ny], xb[st * nx + c], off);
-                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) off = fma(M.Dd[cp + dd * ny], dm(st - 1, dd), off);
+                for (int c = 0; c < nx; ++c) off = fma(gC[cp + c * ny], xb[st * nx + c], off);
+                if (has_dist) for (int dd = 0; dd < ndu; ++dd) off = fma(gDd[cp + dd * ny], dm(st - 1, dd), off);
             } else {
                 off = 0;
-                for (int c = 0; c < nx; ++c) off = fma(M.sX[c], xb[st * nx + c], off);
+                for (int c = 0; c < nx; ++c) off = fma(GP(sX)[c], xb[st * nx + c], off);
             }
-            const double l0 = M.lg0[r], u0 = M.ug0[r];
-            lg[s] = l0 - off; ug[s] = u0 - off; rg[s] = M.rho_g[r];
-            eqg[s] = (l0 == u0);
+            lg[s] = GP(lg0)[r] - off; ug[s] = GP(ug0)[r] - off;
         }
     }
     for (int idx = lane; idx < M.n_fixed; idx += 64) {
-        const int kind = M.f_kind[idx], st = M.f_step[idx], cp = M.f_comp[idx];
+        const int kind = GP(f_kind)[idx], st = GP(f_step)[idx], cp = GP(f_comp)[idx];
         double v = 0;
         if (kind == 0) v = xb[st * nx + cp];
         else if (kind == 1) {
-            for (int c = 0; c < nx; ++c) v = fma(M.C[cp + c * ny], xb[st * nx + c], v);
-            if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) v = fma(M.Dd[cp + dd * ny], dm(st - 1, dd), v);
+            for (int c = 0; c < nx; ++c) v = fma(gC[cp + c * ny], xb[st * nx + c], v);
+            if (has_dist) for (int dd = 0; dd < ndu; ++dd) v = fma(gDd[cp + dd * ny], dm(st - 1, dd), v);
         } else {
-            for (int c = 0; c < nx; ++c) v = fma(M.sX[c], xb[st * nx + c], v);
+            for (int c = 0; c < nx; ++c) v = fma(GP(sX)[c], xb[st * nx + c], v);
         }
-        bad |= violates(v, M.f_lo[idx], M.f_hi[idx], M.eps_abs, M.eps_rel);
+        bad |= violates(v, GP(f_lo)[idx], GP(f_hi)[idx], ea, er);
     }
     const bool infeasible0 = wave_any(bad);
 
-    // ------------------------------------------------------------------ phase 2: adjoint pass -> linear term
+    // adjoint pass -> linear term
     for (int e = lane; e < ldz; e += 64) stage[e] = 0.0;
     if (lane < nx) { pv[lane] = 0.0; pv[nx + lane] = 0.0; }
     wave_sync();
     {
+        const gip gblk = GP(blk);
         int cur = 0;
         for (int i = ph; i >= 1; --i) {
             const double *pin = pv + cur * nx;
             double *pout = pv + (1 - cur) * nx;
             if (lane < nx) {
                 double s = 0;
-                for (int a = 0; a < ny; ++a) s = fma(M.C[a + lane * ny], ey[i * ny + a], s);
-                for (int a = 0; a < nx; ++a) s = fma(M.A[a + lane * nx], pin[a], s);
+#pragma unroll 4
+                for (int a = 0; a < ny; ++a) s = fma(gC[a + lane * ny], ey[i * ny + a], s);
+#pragma unroll 4
+                for (int a = 0; a < nx; ++a) s = fma(gA[a + lane * nx], pin[a], s);
                 pout[lane] = s;
             }
             wave_sync();
             if (lane < nu) {
                 double g = 0;
-                for (int a = 0; a < nx; ++a) g = fma(M.B[a + lane * nx], pout[a], g);
-                g -= M.Wu[i * nu + lane] * ref_at(Bt.uref, Bt.uref_bs, Bt.uref_ks, b, i - 1, lane);
-                stage[M.blk[i] * nu + lane] += g;
+#pragma unroll 4
+                for (int a = 0; a < nx; ++a) g = fma(gB[a + lane * nx], pout[a], g);
+                g -= GP(Wu)[i * nu + lane] * ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, i - 1, lane);
+                stage[gblk[i] * nu + lane] += g;
             }
             cur = 1 - cur;
             wave_sync();
         }
         if (lane < nu) {
             const int j = lane;
-            stage[M.blk[1] * nu + j] -= M.Wdu[j] * (u0s[j] + ref_at(Bt.duref, Bt.duref_bs, Bt.duref_ks, b, 0, j));
+            stage[gblk[1] * nu + j] -= GP(Wdu)[j] * (u0s[j] + ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, 0, j));
             for (int i = 1; i < ph; ++i) {
-                const int bn = M.blk[i + 1], bp = M.blk[i];
+                const int bn = gblk[i + 1], bp = gblk[i];
                 if (bn != bp) {
-                    const double t = -M.Wdu[i * nu + j] * ref_at(Bt.duref, Bt.duref_bs, Bt.duref_ks, b, i - 1, j);
+                    const double t = -GP(Wdu)[i * nu + j] * ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, i - 1, j);
                     stage[bn * nu + j] += t;
                     stage[bp * nu + j] -= t;
                 }
@@ -234,37 +275,116 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         }
         wave_sync();
     }
-    double f[NZS], lw[NZS], uw[NZS], rb[NZS];
-    bool eqb[NZS];
+    double f[NZS], nf_[NZS];
 #pragma unroll
     for (int s = 0; s < NZS; ++s) {
         const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
-        f[s] = 0; lw[s] = -INF; uw[s] = INF; rb[s] = 0; eqb[s] = false;
-        if (e < ldz) {
-            f[s] = stage[e]; lw[s] = M.lw[e]; uw[s] = M.uw[e]; rb[s] = M.rho_b[e];
-            eqb[s] = (lw[s] == uw[s]);
-        }
+        f[s] = e < ldz ? stage[e] : 0.0;
+        nf_[s] = -f[s];
     }
     wave_sync();
+    stage_store<CPZ>(stage, nf_, ldz, lane);
+    wave_sync();
 
-    // ------------------------------------------------------------------ phase 3: unconstrained optimum
-    {
-        double nf_[NZS];
-#pragma unroll
-        for (int s = 0; s < NZS; ++s) nf_[s] = -f[s];
-        stage_store<CPZ>(stage, nf_, ldz, lane);
-        wave_sync();
-    }
+    // unconstrained optimum t0 = -Hinv f and its image under the constraint rows
     double t0[NZS], gt0[NGS];
 #pragma unroll
     for (int s = 0; s < NZS; ++s) t0[s] = 0;
 #pragma unroll
     for (int s = 0; s < NGS; ++s) gt0[s] = 0;
-    matvec_acc<CPZ>(M.Y, ldy, ldz, nz, stage, t0, lane);
-    matvec_acc<CPG>(M.Y + ldz, ldy, ldg, nz, stage, gt0, lane);
+    matvec_acc<CPZ>(GP(Y), ldy, ldz, nz, stage, t0, lane);
+    matvec_acc<CPG>(GP(Y) + ldz, ldy, ldg, nz, stage, gt0, lane);
+
+    // workspace record: f | t0 | gt0 | lg | ug | c0, flag
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {
+        const int e = 128 * c + 2 * lane;
+        if (e < ldz) { st2(ws + e, f[2 * c], f[2 * c + 1]); st2(ws + ldz + e, t0[2 * c], t0[2 * c + 1]); }
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const int r = 128 * c + 2 * lane;
+        if (r < ldg) {
+            st2(ws + ldz + ldz + r, gt0[2 * c], gt0[2 * c + 1]);
+            st2(ws + ldz + ldy + r, lg[2 * c], lg[2 * c + 1]);
+            st2(ws + ldz + ldy + ldg + r, ug[2 * c], ug[2 * c + 1]);
+        }
+    }
+    if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, infeasible0 ? 1.0 : 0.0);
+    wave_sync();
+}
+
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *stage = smem + (size_t)wave * M.lds_per_wave;
+    double *arena = stage + M.stage_len + M.ldy;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+        assemble_one<CPZ, CPG>(M, Bt, b, lane, stage, arena, glw(wsbase) + (size_t)b * M.wsld);
+}
+
+// =====================================================================================
+// solve: one instance per wavefront
+// =====================================================================================
+template <int CPZ, int CPG>
+__device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
+                          double *stage, double *nt0, double *arena, gdp ws)
+{
+    constexpr int NZS = 2 * CPZ, NGS = 2 * CPG;
+    const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
+    const int nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
+    const double INF = __builtin_huge_val();
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const gdp gY = GP(Y);
+
+    long long tstamp[8];
+    int tsi = 0;
+    auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 8) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
+    stamp();
+
+    // ---- load the assembled problem
+    double f[NZS], lw[NZS], uw[NZS], rb[NZS], t0[NZS];
+    bool eqb[NZS];
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {
+        const int e = 128 * c + 2 * lane;
+        const int eo = e < ldz ? e : 0;
+        const d2 vf = ld2(ws + eo), vt = ld2(ws + ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
+        const bool ok = e < ldz;
+        f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
+        t0[2 * c] = ok ? vt.x : 0.0; t0[2 * c + 1] = ok ? vt.y : 0.0;
+        lw[2 * c] = ok ? vl.x : -INF; lw[2 * c + 1] = ok ? vl.y : -INF;
+        uw[2 * c] = ok ? vu.x : INF; uw[2 * c + 1] = ok ? vu.y : INF;
+        rb[2 * c] = ok ? vr.x : 0.0; rb[2 * c + 1] = ok ? vr.y : 0.0;
+    }
+    double lg[NGS], ug[NGS], rg[NGS], gt0[NGS];
+    bool eqg[NGS];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const int r = 128 * c + 2 * lane;
+        const int ro = r < ldg ? r : 0;
+        const d2 vt = ld2(ws + 2 * ldz + ro), vl = ld2(ws + ldz + ldy + ro), vu = ld2(ws + ldz + ldy + ldg + ro), vr = ld2(GP(rho_g) + ro);
+        const d2 l0 = ld2(GP(lg0) + ro), u0 = ld2(GP(ug0) + ro);
+        const bool ok = r < ldg;
+        gt0[2 * c] = ok ? vt.x : 0.0; gt0[2 * c + 1] = ok ? vt.y : 0.0;
+        lg[2 * c] = ok ? vl.x : -INF; lg[2 * c + 1] = ok ? vl.y : -INF;
+        ug[2 * c] = ok ? vu.x : INF; ug[2 * c + 1] = ok ? vu.y : INF;
+        rg[2 * c] = ok ? vr.x : 1.0; rg[2 * c + 1] = ok ? vr.y : 1.0;
+        eqg[2 * c] = ok && (l0.x == u0.x); eqg[2 * c + 1] = ok && (l0.y == u0.y);
+    }
+#pragma unroll
+    for (int s = 0; s < NZS; ++s) eqb[s] = (lw[s] == uw[s]);
+    const d2 tail = ld2(ws + ldz + ldy + 2 * ldg);
+    const double c0 = tail.x;
+    const bool infeasible0 = tail.y != 0.0;
     stage_store<CPZ>(nt0, t0, ldz, lane);
     stage_store<CPG>(nt0 + ldz, gt0, ldg, lane);
     wave_sync();
+    stamp();   // 1: loaded
 
     // ADMM state
     double x[NZS], zb[NZS], yb[NZS], dyb[NZS], zg[NGS], yg[NGS], dyg[NGS];
@@ -294,8 +414,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     double *dg0 = wsb + kMaxActive;                  // original diagonal (pivot scale)
     int *wsidx = reinterpret_cast<int *>(dg0 + kMaxActive);
     double dtol_last = 0;
+    int na_last = 0;
 
-    // -------- active-set polish with repair: returns true when the KKT conditions verify
+    // -------- active-set polish with repair: true when the KKT conditions verify
     auto polish = [&](int rounds) -> bool {
         for (int rd = 0; rd < rounds; ++rd) {
             int na = 0;
@@ -320,12 +441,13 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 na += __popcll(mk);
             }
             if (na > kMaxActive) return false;
+            na_last = na;
             wave_sync();
             int dep_at = -1;
             if (na > 0) {
                 for (int p = lane; p < na * na; p += 64) {
                     const int a = p / na, c = p - a * na;
-                    S[a * kSld + c] = M.Y[(size_t)wsidx[a] * ldy + wsidx[c]];
+                    S[a * kSld + c] = gY[(size_t)wsidx[a] * ldy + wsidx[c]];
                 }
                 if (lane < na) lam[lane] = nt0[wsidx[lane]] - wsb[lane];
                 wave_sync();
@@ -373,24 +495,31 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 wave_sync();
                 continue;
             }
+            // w = t0 - Y[:, A] lambda, all row fetches unpredicated
+            int offz[CPZ], offg[CPG];
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) { const int e = 128 * c + 2 * lane; offz[c] = e < ldz ? e : 0; }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) { const int r = 128 * c + 2 * lane; offg[c] = ldz + (r < ldg ? r : 0); }
 #pragma unroll
             for (int s = 0; s < NZS; ++s) wv[s] = t0[s];
 #pragma unroll
             for (int s = 0; s < NGS; ++s) gw[s] = gt0[s];
             double lmax = 0;
+#pragma unroll 4
             for (int a = 0; a < na; ++a) {
                 const double la = lam[a];
                 lmax = fmax(lmax, fabs(la));
-                const double *row = M.Y + (size_t)wsidx[a] * ldy;
+                const gdp row = gY + (size_t)wsidx[a] * ldy;
 #pragma unroll
                 for (int c = 0; c < CPZ; ++c) {
-                    const int e = 128 * c + 2 * lane;
-                    if (e < ldz) { const double2 m = ld2(row + e); wv[2 * c] = fma(-la, m.x, wv[2 * c]); wv[2 * c + 1] = fma(-la, m.y, wv[2 * c + 1]); }
+                    const d2 m = ld2(row + offz[c]);
+                    wv[2 * c] = fma(-la, m.x, wv[2 * c]); wv[2 * c + 1] = fma(-la, m.y, wv[2 * c + 1]);
                 }
 #pragma unroll
                 for (int c = 0; c < CPG; ++c) {
-                    const int r = 128 * c + 2 * lane;
-                    if (r < ldg) { const double2 m = ld2(row + ldz + r); gw[2 * c] = fma(-la, m.x, gw[2 * c]); gw[2 * c + 1] = fma(-la, m.y, gw[2 * c + 1]); }
+                    const d2 m = ld2(row + offg[c]);
+                    gw[2 * c] = fma(-la, m.x, gw[2 * c]); gw[2 * c + 1] = fma(-la, m.y, gw[2 * c + 1]);
                 }
             }
             const double dtol = 1e-9 * lmax + 1e-300;
@@ -398,6 +527,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             bool changed = false, nanv = false;
 #pragma unroll
             for (int s = 0; s < NZS; ++s) {
+                const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+                if (e >= nz) { wv[s] = 0.0; continue; }
                 nanv |= !(wv[s] == wv[s]);
                 if (actb[s] == 0) {
                     if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; changed = true; }
@@ -409,6 +540,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             }
 #pragma unroll
             for (int s = 0; s < NGS; ++s) {
+                const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+                if (r >= mg) { gw[s] = 0.0; continue; }
                 nanv |= !(gw[s] == gw[s]);
                 if (actg[s] == 0) {
                     if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; changed = true; }
@@ -436,21 +569,21 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         double rhs[NZS];
 #pragma unroll
         for (int s = 0; s < NZS; ++s) rhs[s] = sigma * x[s] - f[s] + (rb[s] * zb[s] - yb[s]);
-        matvec_acc<CPZ>(M.Gr, ldz, ldz, mg, stage, rhs, lane);
+        matvec_acc<CPZ>(GP(Gr), ldz, ldz, mg, stage, rhs, lane);
         wave_sync();
         stage_store<CPZ>(stage, rhs, ldz, lane);
         wave_sync();
         double xt[NZS];
 #pragma unroll
         for (int s = 0; s < NZS; ++s) xt[s] = 0;
-        matvec_acc<CPZ>(M.Kinv, ldz, ldz, nz, stage, xt, lane);
+        matvec_acc<CPZ>(GP(Kinv), ldz, ldz, nz, stage, xt, lane);
         wave_sync();
         stage_store<CPZ>(stage, xt, ldz, lane);
         wave_sync();
         double ztg[NGS];
 #pragma unroll
         for (int s = 0; s < NGS; ++s) ztg[s] = 0;
-        matvec_acc<CPG>(M.Gc, ldg, ldg, nz, stage, ztg, lane);
+        matvec_acc<CPG>(GP(Gc), ldg, ldg, nz, stage, ztg, lane);
         wave_sync();
 #pragma unroll
         for (int s = 0; s < NZS; ++s) {
@@ -499,7 +632,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         if (!(lhs < -M.eps_prim_inf * nrm)) return false;
         stage_store<CPG>(stage, pg, ldg, lane);
         wave_sync();
-        matvec_acc<CPZ>(M.Gr, ldz, ldz, mg, stage, pb, lane);
+        matvec_acc<CPZ>(GP(Gr), ldz, ldz, mg, stage, pb, lane);
         wave_sync();
         double n2 = 0;
 #pragma unroll
@@ -517,12 +650,12 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         for (int s = 0; s < NZS; ++s) { hx[s] = 0; aty[s] = yb[s]; }
         stage_store<CPZ>(stage, x, ldz, lane);
         wave_sync();
-        matvec_acc<CPG>(M.Gc, ldg, ldg, nz, stage, gx, lane);
-        matvec_acc<CPZ>(M.H, ldz, ldz, nz, stage, hx, lane);
+        matvec_acc<CPG>(GP(Gc), ldg, ldg, nz, stage, gx, lane);
+        matvec_acc<CPZ>(GP(H), ldz, ldz, nz, stage, hx, lane);
         wave_sync();
         stage_store<CPG>(stage, yg, ldg, lane);
         wave_sync();
-        matvec_acc<CPZ>(M.Gr, ldz, ldz, mg, stage, aty, lane);
+        matvec_acc<CPZ>(GP(Gr), ldz, ldz, mg, stage, aty, lane);
         wave_sync();
         double pr = 0, pn = 0, dr = 0, dn = 0;
 #pragma unroll
@@ -542,7 +675,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         return 0;
     };
 
-    // ------------------------------------------------------------------ phase 4: solve
+    // ---- solve
     int iters = 0;
     bool solved = false, polished = false, infeasible = infeasible0;
     int solver_status = -10;
@@ -575,8 +708,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     } else {
         solver_status = -3;
     }
+    stamp();   // 2: solved
 
-    // ------------------------------------------------------------------ phase 5: unpack
+    // ---- unpack (LOptimizer.hpp:305-347)
     double w[NZS];
 #pragma unroll
     for (int s = 0; s < NZS; ++s) w[s] = polished ? wv[s] : x[s];
@@ -595,7 +729,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         double hw[NZS];
 #pragma unroll
         for (int s = 0; s < NZS; ++s) hw[s] = 0;
-        matvec_acc<CPZ>(M.H, ldz, ldz, nz, stage, hw, lane);
+        matvec_acc<CPZ>(GP(H), ldz, ldz, nz, stage, hw, lane);
         double j = 0;
 #pragma unroll
         for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + f[s]);
@@ -604,21 +738,21 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 #pragma unroll
     for (int s = 0; s < NZS; ++s) {
         const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
-        if (e < nu) Bt.cmd[(size_t)b * nu + e] = w[s];
+        if (e < nu) glw(Bt.cmd)[(size_t)b * nu + e] = w[s];
     }
     if (lane == 0) {
-        if (Bt.cost) Bt.cost[b] = cost;
-        if (Bt.solver_status) Bt.solver_status[b] = solver_status;
+        if (Bt.cost) glw(Bt.cost)[b] = cost;
+        if (Bt.solver_status) glw(Bt.solver_status)[b] = solver_status;
         if (Bt.status) {
             // LOptimizer.hpp:386-415
             int st = 4;
             if (solver_status == 1 || solver_status == 2) st = 0;
             else if (solver_status == -2) st = 1;
             else if (solver_status == -3) st = 2;
-            Bt.status[b] = st;
+            glw(Bt.status)[b] = st;
         }
-        if (Bt.is_feasible) Bt.is_feasible[b] = (solver_status == 1 || solver_status == 2 || solver_status == -2) ? 1 : 0;
-        if (Bt.iterations) Bt.iterations[b] = iters;
+        if (Bt.is_feasible) glw(Bt.is_feasible)[b] = (solver_status == 1 || solver_status == 2 || solver_status == -2) ? 1 : 0;
+        if (Bt.iterations) glw(Bt.iterations)[b] = iters;
     }
 
     if (Bt.active_lower && Bt.active_upper) {
@@ -643,10 +777,10 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     side = (zb[s] - lw[s] < -yb[s]) ? -1 : ((uw[s] - zb[s] < yb[s]) ? 1 : 0);
                 }
                 if (side == 0) continue;
-                for (int p = M.boxrow_ptr[e]; p < M.boxrow_ptr[e + 1]; ++p) {
-                    const int rr = M.boxrow_ref[p];
-                    if (side < 0 && M.boxrow_lo[p] == lw[s]) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
-                    if (side > 0 && M.boxrow_hi[p] == uw[s]) atomicOr(&bu[rr >> 5], 1u << (rr & 31));
+                for (int p = GP(boxrow_ptr)[e]; p < GP(boxrow_ptr)[e + 1]; ++p) {
+                    const int rr = GP(boxrow_ref)[p];
+                    if (side < 0 && GP(boxrow_lo)[p] == lw[s]) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
+                    if (side > 0 && GP(boxrow_hi)[p] == uw[s]) atomicOr(&bu[rr >> 5], 1u << (rr & 31));
                 }
             }
 #pragma unroll
@@ -663,15 +797,15 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     side = (zg[s] - lg[s] < -yg[s]) ? -1 : ((ug[s] - zg[s] < yg[s]) ? 1 : 0);
                 }
                 if (side == 0) continue;
-                const int rr = M.g_refrow[r];
+                const int rr = GP(g_refrow)[r];
                 if (side < 0) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
                 else atomicOr(&bu[rr >> 5], 1u << (rr & 31));
             }
         }
         wave_sync();
         for (int wd = lane; wd < M.active_words; wd += 64) {
-            Bt.active_lower[(size_t)b * M.active_words + wd] = bl[wd];
-            Bt.active_upper[(size_t)b * M.active_words + wd] = bu[wd];
+            glw(Bt.active_lower)[(size_t)b * M.active_words + wd] = bl[wd];
+            glw(Bt.active_upper)[(size_t)b * M.active_words + wd] = bu[wd];
         }
         wave_sync();
     }
@@ -679,61 +813,68 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     if (Bt.seq_state || Bt.seq_input || Bt.seq_output) {
         // OptSequence (LOptimizer.hpp:305-338): roll the model forward with the optimal inputs
         wave_sync();
+        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas);
+        const gip gblk = GP(blk);
+        auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
         double *xs0 = arena, *xs1 = arena + nx;      // ping-pong state
-        if (lane < nx) xs0[lane] = infeasible ? qnan : Bt.x0[(size_t)b * nx + lane];
+        if (lane < nx) xs0[lane] = infeasible ? qnan : gl(Bt.x0)[(size_t)b * nx + lane];
         wave_sync();
         for (int i = 0; i <= ph; ++i) {
             const double *xc = (i & 1) ? xs1 : xs0;
             double *xn = (i & 1) ? xs0 : xs1;
             const int k = i > 0 ? i - 1 : 0;
-            if (Bt.seq_state && lane < nx) Bt.seq_state[((size_t)b * (ph + 1) + i) * nx + lane] = xc[lane];
+            if (Bt.seq_state && lane < nx) glw(Bt.seq_state)[((size_t)b * (ph + 1) + i) * nx + lane] = xc[lane];
             if (Bt.seq_input && lane < nu) {
                 const int ii = (i + 1 <= ph) ? i + 1 : ph;
-                Bt.seq_input[((size_t)b * (ph + 1) + i) * nu + lane] = stage[M.blk[ii] * nu + lane];
+                glw(Bt.seq_input)[((size_t)b * (ph + 1) + i) * nu + lane] = stage[gblk[ii] * nu + lane];
             }
             if (Bt.seq_output && lane < ny) {
                 double yv = 0;
-                for (int c = 0; c < nx; ++c) yv = fma(M.C[lane + c * ny], xc[c], yv);
-                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) yv = fma(M.Dd[lane + dd * ny], dm(k, dd), yv);
-                Bt.seq_output[((size_t)b * (ph + 1) + i) * ny + lane] = yv;
+                for (int c = 0; c < nx; ++c) yv = fma(gC[lane + c * ny], xc[c], yv);
+                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) yv = fma(gDd[lane + dd * ny], dm(k, dd), yv);
+                glw(Bt.seq_output)[((size_t)b * (ph + 1) + i) * ny + lane] = yv;
             }
             if (i < ph && lane < nx) {
                 double s = 0;
-                for (int c = 0; c < nx; ++c) s = fma(M.A[lane + c * nx], xc[c], s);
-                for (int c = 0; c < nu; ++c) s = fma(M.B[lane + c * nx], stage[M.blk[i + 1] * nu + c], s);
-                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) s = fma(M.Bd[lane + dd * nx], dm(i, dd), s);
+                for (int c = 0; c < nx; ++c) s = fma(gA[lane + c * nx], xc[c], s);
+                for (int c = 0; c < nu; ++c) s = fma(gB[lane + c * nx], stage[gblk[i + 1] * nu + c], s);
+                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) s = fma(gBd[lane + dd * nx], dm(i, dd), s);
                 xn[lane] = s;
             }
             wave_sync();
         }
     }
     wave_sync();
+    stamp();   // 3: unpacked
+    if (Bt.dbg_cycles && lane == 0)
+        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < tsi ? tstamp[k] : 0;
 }
 
 template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, 2) void lmpc_solve_kernel(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt)
+__global__ __launch_bounds__(kWavesPerBlock * 64, 4) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, const double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *ws = smem + (size_t)wave * M.lds_per_wave;
-    double *stage = ws;
+    double *stage = smem + (size_t)wave * M.lds_per_wave;
     double *nt0 = stage + M.stage_len;
     double *arena = nt0 + M.ldy;
     const int wpb = blockDim.x >> 6;
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_one<CPZ, CPG>(M, Bt, b, lane, stage, nt0, arena);
+        solve_one<CPZ, CPG>(M, Bt, b, lane, stage, nt0, arena, gl(wsbase) + (size_t)b * M.wsld);
 }
 
 template <int CPZ, int CPG>
-int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, hipStream_t stream)
+int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
 {
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
     if (lds > 160 * 1024) return -2;
-    auto kern = lmpc_solve_kernel<CPZ, CPG>;
+    auto k1 = lmpc_assemble_generic<CPZ, CPG>;
+    auto k2 = lmpc_solve<CPZ, CPG>;
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         configured = lds;
     }
@@ -741,7 +882,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const int cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b);
+    hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+    hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, (const double *)ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -773,13 +915,13 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len)
     return st + ldy + ar;
 }
 
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, void *stream)
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (lmpc_kernel_variant(m.ldz, m.ldg)) {
-    case 1: return launch_variant<1, 1>(m, m_dev, b, s);
-    case 2: return launch_variant<2, 2>(m, m_dev, b, s);
-    case 4: return launch_variant<4, 4>(m, m_dev, b, s);
+    case 1: return launch_variant<1, 1>(m, m_dev, b, ws, s);
+    case 2: return launch_variant<2, 2>(m, m_dev, b, ws, s);
+    case 4: return launch_variant<4, 4>(m, m_dev, b, ws, s);
     default: return -2;
     }
 }

@@ -35,12 +35,17 @@ struct mpcx_lmpc {
     mpcx::LmpcDev dev{};
     mpcx::LmpcDev *dev_d = nullptr;     // the same struct, resident in HBM for the kernel
     std::vector<void *> allocs;
+    long long *dbg_cycles = nullptr;
+    double *ws = nullptr;               // per-instance workspace between assemble and solve
+    size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
 
     void release()
     {
         for (void *p : allocs) (void)hipFree(p);
         allocs.clear();
+        if (ws) (void)hipFree(ws);
+        ws = nullptr; ws_cap = 0;
     }
     template <typename T>
     const T *up(const std::vector<T> &v, int &rc)
@@ -345,10 +350,11 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.has_dist = o.has_dist ? 1 : 0;
     D.n_fixed = (int)o.fixed_rows.size();
     D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
-    D.check_every = 10; D.polish_rounds0 = 6; D.polish_rounds = 8;
+    D.check_every = 10; D.polish_rounds0 = 30; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
     D.lds_per_wave = mpcx::lmpc_lds_per_wave(D, &D.stage_len, &D.arena_len);
+    D.wsld = D.ldz + D.ldy + 2 * D.ldg + 2;
     D.s0lo = c.sMin[0]; D.s0hi = c.sMax[0];
     if (h->host_only) { h->dirty = false; return MPCX_OK; }
 
@@ -417,6 +423,7 @@ static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDe
     B.is_feasible = b->is_feasible; B.iterations = b->iterations;
     B.active_lower = b->active_lower; B.active_upper = b->active_upper;
     B.seq_state = b->seq_state; B.seq_output = b->seq_output; B.seq_input = b->seq_input;
+    B.dbg_cycles = h->dbg_cycles;
     return MPCX_OK;
 }
 
@@ -432,7 +439,15 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     rc = make_batch(h, b, B);
     if (rc != MPCX_OK) return rc;
     if (b->batch == 0) return MPCX_OK;
-    int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, stream);
+    if ((size_t)b->batch > h->ws_cap) {
+        // grows only when a larger batch than ever before arrives (not capturable in a graph)
+        if (h->ws) (void)hipFree(h->ws);
+        h->ws = nullptr; h->ws_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess)
+            return fail(MPCX_E_DEVICE, "workspace allocation failed");
+        h->ws_cap = (size_t)b->batch;
+    }
+    int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return MPCX_OK;
@@ -481,6 +496,14 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info)
                                   2.0 * d.ph * (d.nx * d.nx + d.ny * d.nx + d.nx * d.nu) +
                                   2.0 * nz * (nz + mg) + 2.0 * nz * nz;
     info->bytes_per_solve = 8.0 * (d.nx + d.nu) + 8.0 * d.nu + 8.0 + 16.0;
+    return MPCX_OK;
+}
+
+/* profiling aid: device buffer [B x 8] of int64 receiving per-phase cycle stamps */
+int mpcx_lmpc_debug_set_cycle_buffer(mpcx_lmpc_t h, void *dev_ptr)
+{
+    CHECK_H(h);
+    h->dbg_cycles = static_cast<long long *>(dev_ptr);
     return MPCX_OK;
 }
 

@@ -1,0 +1,31 @@
+"""Profiling aid: per-phase shader-cycle breakdown of lmpc_solve_kernel (median over instances)."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+
+ph = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+c = quadrotor_lmpc(ph, device=0)
+x0, u0, yref = quadrotor_batch(B)
+buf = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
+c._lib.mpcx_lmpc_debug_set_cycle_buffer(c._h, C.c_void_p(buf.data_ptr()))
+batch, res, keep = c.make_batch(x0, u0, yref=yref)
+for _ in range(3):
+    c.launch(batch)
+torch.cuda.synchronize()
+t = buf.cpu().numpy()
+d = np.diff(t[:, :7], axis=1)
+names = ["rollout", "errors+offsets", "adjoint", "t0 matvec", "solve(polish/admm)", "unpack"]
+print("per-instance wave cycles: median / p90 / max (s_memtime ticks, 100 MHz const clock if readcyclecounter maps to s_memrealtime)")
+for k, n in enumerate(names):
+    print(f"  {n:22s} {np.median(d[:, k]):10.0f} {np.percentile(d[:, k], 90):10.0f} {d[:, k].max():10.0f}")
+tot = t[:, 6] - t[:, 0]
+print("  total                  %10.0f %10.0f %10.0f" % (np.median(tot), np.percentile(tot, 90), tot.max()))
+print("span first start -> last end:", t[:, 6].max() - t[:, 0].min())
+it = res.iterations.cpu().numpy()
+print("iterations hist:", np.unique(it, return_counts=True))
+ms = c.time_launches(batch, 20)
+print("kernel ms", ms)
