@@ -63,7 +63,8 @@ struct LmpcBatchDev {
 
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream);
+// which: bit 0 = assemble, bit 1 = solve (3 = the normal path; single bits are for per-kernel timing)
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which = 3);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 
 }  // namespace mpcx

@@ -33,6 +33,9 @@ namespace mpcx {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+#ifndef MPCX_SOLVE_WAVES
+#define MPCX_SOLVE_WAVES 2
+#endif
 
 // Pointers that come out of the model struct are generic pointers to the compiler, which
 // would emit flat_load (tied to both vmcnt and lgkmcnt, serialising against LDS traffic).
@@ -84,8 +87,30 @@ __device__ __forceinline__ void matvec_acc(gdp M, int ld, int R, int ncols, cons
         off[c] = e < R ? e : 0;
         t[2 * c] = 0; t[2 * c + 1] = 0;
     }
-#pragma unroll 8
-    for (int j = 0; j < ncols; ++j) {
+    // explicit software pipelining: issue a batch of column fetches, then consume them
+    constexpr int U = CP == 1 ? 8 : (CP == 2 ? 4 : 2);
+    int j = 0;
+    for (; j + U <= ncols; j += U) {
+        d2 m[U][CP];
+        double xj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gdp col = M + (size_t)(j + u) * ld;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) m[u][c] = ld2(col + off[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xj[u] = xs[j + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                t[2 * c] = fma(m[u][c].x, xj[u], t[2 * c]);
+                t[2 * c + 1] = fma(m[u][c].y, xj[u], t[2 * c + 1]);
+            }
+        }
+    }
+    for (; j < ncols; ++j) {
         const double xj = xs[j];
         gdp col = M + (size_t)j * ld;
 #pragma unroll
@@ -418,13 +443,19 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 
     // -------- active-set polish with repair: true when the KKT conditions verify
     auto polish = [&](int rounds) -> bool {
+        // working sets already visited in this call (hashed): a repeat means the repair rule is
+        // cycling, which happens on a few instances in a thousand -- hand over to ADMM at once
+        unsigned long long seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int rd = 0; rd < rounds; ++rd) {
             int na = 0;
+            unsigned long long hsh = 0x9E3779B97F4A7C15ull;
 #pragma unroll
             for (int s = 0; s < NZS; ++s) {
                 const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
                 const bool act = actb[s] != 0;
                 const unsigned long long mk = __ballot(act);
+                hsh = (hsh ^ mk) * 0xBF58476D1CE4E5B9ull;
+                hsh = (hsh ^ __ballot(actb[s] > 0)) * 0x94D049BB133111EBull;
                 const int pos = na + __popcll(mk & lt_mask);
                 posb[s] = pos;
                 if (act && pos < kMaxActive) { wsidx[pos] = e; wsb[pos] = actb[s] < 0 ? lw[s] : uw[s]; }
@@ -435,12 +466,22 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
                 const bool act = actg[s] != 0;
                 const unsigned long long mk = __ballot(act);
+                hsh = (hsh ^ mk) * 0xBF58476D1CE4E5B9ull;
+                hsh = (hsh ^ __ballot(actg[s] > 0)) * 0x94D049BB133111EBull;
                 const int pos = na + __popcll(mk & lt_mask);
                 posg[s] = pos;
                 if (act && pos < kMaxActive) { wsidx[pos] = ldz + r; wsb[pos] = actg[s] < 0 ? lg[s] : ug[s]; }
                 na += __popcll(mk);
             }
             if (na > kMaxActive) return false;
+            hsh |= 1ull;
+            bool cyc = false;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cyc |= (seen[q] == hsh);
+            if (cyc) return false;
+#pragma unroll
+            for (int q = 7; q > 0; --q) seen[q] = seen[q - 1];
+            seen[0] = hsh;
             na_last = na;
             wave_sync();
             int dep_at = -1;
@@ -506,36 +547,47 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 #pragma unroll
             for (int s = 0; s < NGS; ++s) gw[s] = gt0[s];
             double lmax = 0;
-#pragma unroll 4
-            for (int a = 0; a < na; ++a) {
-                const double la = lam[a];
-                lmax = fmax(lmax, fabs(la));
-                const gdp row = gY + (size_t)wsidx[a] * ldy;
+            for (int a0 = 0; a0 < na; a0 += 4) {
+                // four working-set rows of Y in flight at a time (rows past na re-read row a0, weight 0)
+                double la[4];
+                d2 mz[4][CPZ], mgv[4][CPG];
 #pragma unroll
-                for (int c = 0; c < CPZ; ++c) {
-                    const d2 m = ld2(row + offz[c]);
-                    wv[2 * c] = fma(-la, m.x, wv[2 * c]); wv[2 * c + 1] = fma(-la, m.y, wv[2 * c + 1]);
+                for (int u = 0; u < 4; ++u) {
+                    const int a = a0 + u < na ? a0 + u : a0;
+                    la[u] = a0 + u < na ? lam[a] : 0.0;
+                    const gdp row = gY + (size_t)wsidx[a] * ldy;
+#pragma unroll
+                    for (int c = 0; c < CPZ; ++c) mz[u][c] = ld2(row + offz[c]);
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) mgv[u][c] = ld2(row + offg[c]);
                 }
 #pragma unroll
-                for (int c = 0; c < CPG; ++c) {
-                    const d2 m = ld2(row + offg[c]);
-                    gw[2 * c] = fma(-la, m.x, gw[2 * c]); gw[2 * c + 1] = fma(-la, m.y, gw[2 * c + 1]);
+                for (int u = 0; u < 4; ++u) {
+                    lmax = fmax(lmax, fabs(la[u]));
+#pragma unroll
+                    for (int c = 0; c < CPZ; ++c) {
+                        wv[2 * c] = fma(-la[u], mz[u][c].x, wv[2 * c]); wv[2 * c + 1] = fma(-la[u], mz[u][c].y, wv[2 * c + 1]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) {
+                        gw[2 * c] = fma(-la[u], mgv[u][c].x, gw[2 * c]); gw[2 * c + 1] = fma(-la[u], mgv[u][c].y, gw[2 * c + 1]);
+                    }
                 }
             }
             const double dtol = 1e-9 * lmax + 1e-300;
             dtol_last = dtol;
-            bool changed = false, nanv = false;
+            // Repair rule: first shed every working-set row whose multiplier has the wrong sign;
+            // only a working set with all signs right is grown by the violated rows.  (Doing both at
+            // once cycles on a few instances in a thousand; this order does not.)
+            bool drop = false, nanv = false;
 #pragma unroll
             for (int s = 0; s < NZS; ++s) {
                 const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
                 if (e >= nz) { wv[s] = 0.0; continue; }
                 nanv |= !(wv[s] == wv[s]);
-                if (actb[s] == 0) {
-                    if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; changed = true; }
-                    else if (wv[s] > uw[s] + ptol * fmax(1.0, fabs(uw[s]))) { actb[s] = 1; changed = true; }
-                } else if (!eqb[s]) {
+                if (actb[s] != 0 && !eqb[s]) {
                     const double l = lam[posb[s]];
-                    if ((actb[s] < 0 && l > dtol) || (actb[s] > 0 && l < -dtol)) { actb[s] = 0; changed = true; }
+                    if ((actb[s] < 0 && l > dtol) || (actb[s] > 0 && l < -dtol)) { actb[s] = 0; drop = true; }
                 }
             }
 #pragma unroll
@@ -543,16 +595,32 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
                 if (r >= mg) { gw[s] = 0.0; continue; }
                 nanv |= !(gw[s] == gw[s]);
-                if (actg[s] == 0) {
-                    if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; changed = true; }
-                    else if (gw[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s]))) { actg[s] = 1; changed = true; }
-                } else if (!eqg[s]) {
+                if (actg[s] != 0 && !eqg[s]) {
                     const double l = lam[posg[s]];
-                    if ((actg[s] < 0 && l > dtol) || (actg[s] > 0 && l < -dtol)) { actg[s] = 0; changed = true; }
+                    if ((actg[s] < 0 && l > dtol) || (actg[s] > 0 && l < -dtol)) { actg[s] = 0; drop = true; }
                 }
             }
+            bool changed = wave_any(drop);
+            if (!changed) {
+                bool add = false;
+#pragma unroll
+                for (int s = 0; s < NZS; ++s) {
+                    if (actb[s] == 0) {
+                        if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; add = true; }
+                        else if (wv[s] > uw[s] + ptol * fmax(1.0, fabs(uw[s]))) { actb[s] = 1; add = true; }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NGS; ++s) {
+                    if (actg[s] == 0) {
+                        if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; add = true; }
+                        else if (gw[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s]))) { actg[s] = 1; add = true; }
+                    }
+                }
+                changed = wave_any(add);
+            }
             if (wave_any(nanv)) return false;
-            if (!wave_any(changed)) return true;
+            if (!changed) return true;
             wave_sync();
         }
         return false;
@@ -851,7 +919,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 }
 
 template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, 4) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, const double *wsbase)
+__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, const double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
@@ -865,7 +933,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void lmpc_solve(const LmpcD
 }
 
 template <int CPZ, int CPG>
-int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
+int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which)
 {
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
     if (lds > 160 * 1024) return -2;
@@ -882,8 +950,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const int cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
-    hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, (const double *)ws);
+    if (which & 1) hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+    if (which & 2) hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, (const double *)ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -915,13 +983,13 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len)
     return st + ldy + ar;
 }
 
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (lmpc_kernel_variant(m.ldz, m.ldg)) {
-    case 1: return launch_variant<1, 1>(m, m_dev, b, ws, s);
-    case 2: return launch_variant<2, 2>(m, m_dev, b, ws, s);
-    case 4: return launch_variant<4, 4>(m, m_dev, b, ws, s);
+    case 1: return launch_variant<1, 1>(m, m_dev, b, ws, s, which);
+    case 2: return launch_variant<2, 2>(m, m_dev, b, ws, s, which);
+    case 4: return launch_variant<4, 4>(m, m_dev, b, ws, s, which);
     default: return -2;
     }
 }

@@ -499,6 +499,33 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info)
     return MPCX_OK;
 }
 
+/* profiling aid: mean time (ms) of the assemble and of the solve kernel, each timed alone with
+ * HIP events on `stream` (the solve kernel re-reads the workspace the assemble kernel left). */
+int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms2)
+{
+    CHECK_H(h);
+    if (!b || !ms2 || repeats < 1 || h->host_only) return fail(MPCX_E_INVALID, "bad argument");
+    int rc = mpcx_lmpc_solve_batch(h, b, stream);      // sizes the workspace, fills it
+    if (rc != MPCX_OK) return rc;
+    mpcx::LmpcBatchDev B;
+    rc = make_batch(h, b, B);
+    if (rc != MPCX_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int which = 1; which <= 2; which++) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ms2[which - 1] = ms / (float)repeats;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MPCX_OK;
+}
+
 /* profiling aid: device buffer [B x 8] of int64 receiving per-phase cycle stamps */
 int mpcx_lmpc_debug_set_cycle_buffer(mpcx_lmpc_t h, void *dev_ptr)
 {

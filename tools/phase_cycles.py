@@ -17,15 +17,18 @@ for _ in range(3):
     c.launch(batch)
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
-d = np.diff(t[:, :7], axis=1)
-names = ["rollout", "errors+offsets", "adjoint", "t0 matvec", "solve(polish/admm)", "unpack"]
+d = np.diff(t[:, :4], axis=1)
+names = ["load workspace", "solve(polish/admm)", "unpack"]
 print("per-instance wave cycles: median / p90 / max (s_memtime ticks, 100 MHz const clock if readcyclecounter maps to s_memrealtime)")
 for k, n in enumerate(names):
     print(f"  {n:22s} {np.median(d[:, k]):10.0f} {np.percentile(d[:, k], 90):10.0f} {d[:, k].max():10.0f}")
-tot = t[:, 6] - t[:, 0]
+tot = t[:, 3] - t[:, 0]
 print("  total                  %10.0f %10.0f %10.0f" % (np.median(tot), np.percentile(tot, 90), tot.max()))
-print("span first start -> last end:", t[:, 6].max() - t[:, 0].min())
+print("span first start -> last end:", t[:, 3].max() - t[:, 0].min())
 it = res.iterations.cpu().numpy()
 print("iterations hist:", np.unique(it, return_counts=True))
 ms = c.time_launches(batch, 20)
-print("kernel ms", ms)
+print("both kernels ms", ms)
+ms2 = (C.c_float * 2)()
+c._lib.mpcx_lmpc_debug_time_kernels(c._h, C.byref(batch), C.c_void_p(torch.cuda.current_stream().cuda_stream), 20, ms2)
+print("assemble ms %.4f  solve ms %.4f" % (ms2[0], ms2[1]))
