@@ -15,7 +15,7 @@
 
 namespace mpcx {
 
-constexpr int kMaxActive = 32;          // working-set capacity of the in-kernel polish
+constexpr int kMaxActive = 24;          // working-set capacity of the in-kernel polish
 constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
 
 struct LmpcDev {
@@ -63,8 +63,9 @@ struct LmpcBatchDev {
 
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
-// which: bit 0 = assemble, bit 1 = solve (3 = the normal path; single bits are for per-kernel timing)
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which = 3);
+// which: bit 0 = assemble, bit 1 = polish-only solve, bit 2 = ADMM fallback (7 = the normal path;
+// single bits are for per-kernel timing)
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which = 7);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 
 }  // namespace mpcx

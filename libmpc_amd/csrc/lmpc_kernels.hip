@@ -355,9 +355,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(con
 // =====================================================================================
 // solve: one instance per wavefront
 // =====================================================================================
-template <int CPZ, int CPG>
+template <int CPZ, int CPG, bool ADMM>
 __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
-                          double *stage, double *nt0, double *arena, gdp ws)
+                          double *stage, double *nt0, double *arena, gdw ws)
 {
     constexpr int NZS = 2 * CPZ, NGS = 2 * CPG;
     const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
@@ -405,7 +405,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int s = 0; s < NZS; ++s) eqb[s] = (lw[s] == uw[s]);
     const d2 tail = ld2(ws + ldz + ldy + 2 * ldg);
     const double c0 = tail.x;
-    const bool infeasible0 = tail.y != 0.0;
+    const bool infeasible0 = tail.y == 1.0;
+    if (ADMM && tail.y == 2.0) return;          // already solved by the polish-only kernel
     stage_store<CPZ>(nt0, t0, ldz, lane);
     stage_store<CPG>(nt0 + ldz, gt0, ldg, lane);
     wave_sync();
@@ -446,6 +447,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         // working sets already visited in this call (hashed): a repeat means the repair rule is
         // cycling, which happens on a few instances in a thousand -- hand over to ADMM at once
         unsigned long long seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool safe = false;       // after a cycle: one exchange per round (most negative multiplier out,
+                                 // else most violated row in), which does not cycle in practice
         for (int rd = 0; rd < rounds; ++rd) {
             int na = 0;
             unsigned long long hsh = 0x9E3779B97F4A7C15ull;
@@ -478,7 +481,12 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             bool cyc = false;
 #pragma unroll
             for (int q = 0; q < 8; ++q) cyc |= (seen[q] == hsh);
-            if (cyc) return false;
+            if (cyc) {
+                if (safe) return false;
+                safe = true;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) seen[q] = 0;
+            }
 #pragma unroll
             for (int q = 7; q > 0; --q) seen[q] = seen[q - 1];
             seen[0] = hsh;
@@ -576,48 +584,120 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             }
             const double dtol = 1e-9 * lmax + 1e-300;
             dtol_last = dtol;
-            // Repair rule: first shed every working-set row whose multiplier has the wrong sign;
-            // only a working set with all signs right is grown by the violated rows.  (Doing both at
-            // once cycles on a few instances in a thousand; this order does not.)
-            bool drop = false, nanv = false;
+            bool nanv = false, changed = false;
 #pragma unroll
             for (int s = 0; s < NZS; ++s) {
                 const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
-                if (e >= nz) { wv[s] = 0.0; continue; }
+                if (e >= nz) wv[s] = 0.0;
                 nanv |= !(wv[s] == wv[s]);
-                if (actb[s] != 0 && !eqb[s]) {
-                    const double l = lam[posb[s]];
-                    if ((actb[s] < 0 && l > dtol) || (actb[s] > 0 && l < -dtol)) { actb[s] = 0; drop = true; }
-                }
             }
 #pragma unroll
             for (int s = 0; s < NGS; ++s) {
                 const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
-                if (r >= mg) { gw[s] = 0.0; continue; }
+                if (r >= mg) gw[s] = 0.0;
                 nanv |= !(gw[s] == gw[s]);
-                if (actg[s] != 0 && !eqg[s]) {
-                    const double l = lam[posg[s]];
-                    if ((actg[s] < 0 && l > dtol) || (actg[s] > 0 && l < -dtol)) { actg[s] = 0; drop = true; }
-                }
             }
-            bool changed = wave_any(drop);
-            if (!changed) {
-                bool add = false;
+            if (!safe) {
+                // Repair rule: first shed every working-set row whose multiplier has the wrong sign;
+                // only a working set with all signs right is grown by the violated rows.
+                bool drop = false;
 #pragma unroll
-                for (int s = 0; s < NZS; ++s) {
-                    if (actb[s] == 0) {
-                        if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; add = true; }
-                        else if (wv[s] > uw[s] + ptol * fmax(1.0, fabs(uw[s]))) { actb[s] = 1; add = true; }
+                for (int s = 0; s < NZS; ++s)
+                    if (actb[s] != 0 && !eqb[s]) {
+                        const double l = lam[posb[s]];
+                        if ((actb[s] < 0 && l > dtol) || (actb[s] > 0 && l < -dtol)) { actb[s] = 0; drop = true; }
+                    }
+#pragma unroll
+                for (int s = 0; s < NGS; ++s)
+                    if (actg[s] != 0 && !eqg[s]) {
+                        const double l = lam[posg[s]];
+                        if ((actg[s] < 0 && l > dtol) || (actg[s] > 0 && l < -dtol)) { actg[s] = 0; drop = true; }
+                    }
+                changed = wave_any(drop);
+                if (!changed) {
+                    bool add = false;
+#pragma unroll
+                    for (int s = 0; s < NZS; ++s)
+                        if (actb[s] == 0) {
+                            if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; add = true; }
+                            else if (wv[s] > uw[s] + ptol * fmax(1.0, fabs(uw[s]))) { actb[s] = 1; add = true; }
+                        }
+#pragma unroll
+                    for (int s = 0; s < NGS; ++s)
+                        if (actg[s] == 0) {
+                            if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; add = true; }
+                            else if (gw[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s]))) { actg[s] = 1; add = true; }
+                        }
+                    changed = wave_any(add);
+                }
+            } else {
+                // single exchange
+                double bestv = 0; int bests = -1;
+#pragma unroll
+                for (int s = 0; s < NZS; ++s)
+                    if (actb[s] != 0 && !eqb[s]) {
+                        const double l = lam[posb[s]];
+                        const double bad = actb[s] < 0 ? l : -l;
+                        if (bad > dtol && bad > bestv) { bestv = bad; bests = s; }
+                    }
+#pragma unroll
+                for (int s = 0; s < NGS; ++s)
+                    if (actg[s] != 0 && !eqg[s]) {
+                        const double l = lam[posg[s]];
+                        const double bad = actg[s] < 0 ? l : -l;
+                        if (bad > dtol && bad > bestv) { bestv = bad; bests = NZS + s; }
+                    }
+                double mx = wave_max(bestv);
+                if (mx > 0) {
+                    const unsigned long long mk = __ballot(bestv == mx && bests >= 0);
+                    if (lane == __ffsll((long long)mk) - 1) {
+#pragma unroll
+                        for (int s = 0; s < NZS; ++s) if (bests == s) actb[s] = 0;
+#pragma unroll
+                        for (int s = 0; s < NGS; ++s) if (bests == NZS + s) actg[s] = 0;
+                    }
+                    changed = true;
+                } else {
+                    int side = 0;
+                    bestv = 0; bests = -1;
+#pragma unroll
+                    for (int s = 0; s < NZS; ++s) {
+                        const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+                        if (actb[s] == 0 && e < nz) {
+                            const double vl = lw[s] - ptol * fmax(1.0, fabs(lw[s])) - wv[s];
+                            const double vu = wv[s] - uw[s] - ptol * fmax(1.0, fabs(uw[s]));
+                            const double v = fmax(vl, vu);
+                            if (v > 0) {
+                                const double nv = v * rsqrt(gY[(size_t)e * ldy + e]);
+                                if (nv > bestv) { bestv = nv; bests = s; side = vl > vu ? -1 : 1; }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < NGS; ++s) {
+                        const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+                        if (actg[s] == 0 && r < mg) {
+                            const double vl = lg[s] - ptol * fmax(1.0, fabs(lg[s])) - gw[s];
+                            const double vu = gw[s] - ug[s] - ptol * fmax(1.0, fabs(ug[s]));
+                            const double v = fmax(vl, vu);
+                            if (v > 0) {
+                                const double nv = v * rsqrt(gY[(size_t)(ldz + r) * ldy + ldz + r]);
+                                if (nv > bestv) { bestv = nv; bests = NZS + s; side = vl > vu ? -1 : 1; }
+                            }
+                        }
+                    }
+                    mx = wave_max(bestv);
+                    if (mx > 0) {
+                        const unsigned long long mk = __ballot(bestv == mx && bests >= 0);
+                        if (lane == __ffsll((long long)mk) - 1) {
+#pragma unroll
+                            for (int s = 0; s < NZS; ++s) if (bests == s) actb[s] = side;
+#pragma unroll
+                            for (int s = 0; s < NGS; ++s) if (bests == NZS + s) actg[s] = side;
+                        }
+                        changed = true;
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < NGS; ++s) {
-                    if (actg[s] == 0) {
-                        if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; add = true; }
-                        else if (gw[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s]))) { actg[s] = 1; add = true; }
-                    }
-                }
-                changed = wave_any(add);
             }
             if (wave_any(nanv)) return false;
             if (!changed) return true;
@@ -748,8 +828,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     bool solved = false, polished = false, infeasible = infeasible0;
     int solver_status = -10;
     if (!infeasible) {
-        if (M.polish) { solved = polish(M.polish_rounds0); polished = solved; }
-        while (!solved && iters < M.max_iter) {
+        if (M.polish && !ADMM) { solved = polish(M.polish_rounds0); polished = solved; }
+        if (!ADMM && !solved) return;                 // left for the fallback kernel (flag stays 0)
+        while (ADMM && !solved && iters < M.max_iter) {
             const int nblk = min(M.check_every, M.max_iter - iters);
             for (int k = 0; k < nblk; ++k) admm_iter();
             iters += nblk;
@@ -913,13 +994,14 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         }
     }
     wave_sync();
+    if (!ADMM && lane == 0) ws[ldz + ldy + 2 * ldg + 1] = 2.0;     // done: the fallback kernel skips it
     stamp();   // 3: unpacked
     if (Bt.dbg_cycles && lane == 0)
         for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < tsi ? tstamp[k] : 0;
 }
 
 template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, const double *wsbase)
+__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
@@ -929,7 +1011,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_so
     double *arena = nt0 + M.ldy;
     const int wpb = blockDim.x >> 6;
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_one<CPZ, CPG>(M, Bt, b, lane, stage, nt0, arena, gl(wsbase) + (size_t)b * M.wsld);
+        solve_one<CPZ, CPG, false>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+}
+
+// Fallback for the instances the polish-only kernel left unsolved (a handful in a thousand, or
+// everything when polish is switched off): ADMM iterations, then polish again.
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *stage = smem + (size_t)wave * M.lds_per_wave;
+    double *nt0 = stage + M.stage_len;
+    double *arena = nt0 + M.ldy;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+        solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
 }
 
 template <int CPZ, int CPG>
@@ -939,10 +1037,12 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (lds > 160 * 1024) return -2;
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
     auto k2 = lmpc_solve<CPZ, CPG>;
+    auto k3 = lmpc_solve_admm<CPZ, CPG>;
     static size_t configured = 0;
     if (lds > configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         configured = lds;
     }
@@ -951,7 +1051,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (which & 1) hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
-    if (which & 2) hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, (const double *)ws);
+    if (which & 2) hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+    if (which & 4) hipLaunchKernelGGL(k3, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

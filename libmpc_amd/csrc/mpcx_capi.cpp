@@ -513,14 +513,14 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int which = 1; which <= 2; which++) {
+    for (int which = 1; which <= 4; which *= 2) {
         (void)hipEventRecord(e0, s);
         for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        ms2[which - 1] = ms / (float)repeats;
+        ms2[which == 1 ? 0 : (which == 2 ? 1 : 2)] = ms / (float)repeats;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MPCX_OK;

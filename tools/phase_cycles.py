@@ -29,6 +29,6 @@ it = res.iterations.cpu().numpy()
 print("iterations hist:", np.unique(it, return_counts=True))
 ms = c.time_launches(batch, 20)
 print("both kernels ms", ms)
-ms2 = (C.c_float * 2)()
+ms2 = (C.c_float * 3)()
 c._lib.mpcx_lmpc_debug_time_kernels(c._h, C.byref(batch), C.c_void_p(torch.cuda.current_stream().cuda_stream), 20, ms2)
-print("assemble ms %.4f  solve ms %.4f" % (ms2[0], ms2[1]))
+print("assemble ms %.4f  polish-solve ms %.4f  admm-fallback ms %.4f" % (ms2[0], ms2[1], ms2[2]))
