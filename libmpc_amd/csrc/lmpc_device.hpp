@@ -15,7 +15,7 @@
 
 namespace mpcx {
 
-constexpr int kMaxActive = 24;          // working-set capacity of the in-kernel polish
+constexpr int kMaxActive = 28;          // working-set capacity of the in-kernel polish
 constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
 
 struct LmpcDev {

@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 #ifndef MPCX_SOLVE_WAVES
-#define MPCX_SOLVE_WAVES 2
+#define MPCX_SOLVE_WAVES 3
 #endif
 
 // Pointers that come out of the model struct are generic pointers to the compiler, which
@@ -72,6 +72,14 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// broadcast lane l's value (l wave-uniform): two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kRegCap = 16;      // working sets up to this size are factored in registers
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // acc += M[:, 0..ncols) * xs.  M column-major, leading dimension ld, R (even) valid rows.
@@ -494,6 +502,74 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             wave_sync();
             int dep_at = -1;
             if (na > 0) {
+                if (na <= kRegCap) {
+                    // ---- Schur complement in registers: lane i owns row i; LDL' with the pivot
+                    // column broadcast by v_readlane (no LDS round trip on the dependent chain)
+                    const int qi = wsidx[lane < na ? lane : 0];
+                    double Sr[kRegCap];
+#pragma unroll
+                    for (int c = 0; c < kRegCap; ++c) {
+                        const int qc = wsidx[c < na ? c : 0];
+                        Sr[c] = gY[(size_t)qi * ldy + qc];
+                    }
+                    double y = nt0[qi] - wsb[lane < na ? lane : 0];
+                    double dgi = 1.0, mydinv = 1.0;
+#pragma unroll
+                    for (int c = 0; c < kRegCap; ++c) if (lane == c) dgi = Sr[c];
+#pragma unroll
+                    for (int k = 0; k < kRegCap; ++k) {
+                        if (k < na && dep_at < 0) {
+                            const double dk = readlane_d(Sr[k], k);
+                            const double d0 = readlane_d(dgi, k);
+                            if (!(dk > 1e-11 * d0)) {
+                                dep_at = k;
+                            } else {
+                                const double rinv = 1.0 / dk;
+                                if (lane == k) mydinv = rinv;
+                                const double lik = Sr[k] * rinv;
+#pragma unroll
+                                for (int j = k + 1; j < kRegCap; ++j) {
+                                    if (j < na) {
+                                        const double tjk = readlane_d(Sr[k], j);
+                                        if (lane >= j) Sr[j] = fma(-lik, tjk, Sr[j]);
+                                    }
+                                }
+                                if (lane > k) Sr[k] = lik;
+                            }
+                        }
+                    }
+                    if (dep_at < 0) {
+#pragma unroll
+                        for (int k = 0; k < kRegCap; ++k) {
+                            if (k < na) {
+                                const double yk = readlane_d(y, k);
+                                if (lane > k) y = fma(-Sr[k], yk, y);
+                            }
+                        }
+                        y *= mydinv;
+                        // transpose L through LDS so that the back-substitution also walks registers
+                        double *T = S;
+#pragma unroll
+                        for (int c = 0; c < kRegCap; ++c)
+                            if (c < lane && lane < na) T[lane * kRegCap + c] = Sr[c];
+                        wave_sync();
+#pragma unroll
+                        for (int k = 0; k < kRegCap; ++k) {
+                            const bool ok = k > lane && k < na;
+                            const double v = T[(ok ? k : 0) * kRegCap + (ok ? lane : 0)];
+                            Sr[k] = ok ? v : 0.0;
+                        }
+#pragma unroll
+                        for (int k = kRegCap - 1; k >= 0; --k) {
+                            if (k < na) {
+                                const double xk = readlane_d(y, k);
+                                if (lane < k) y = fma(-Sr[k], xk, y);
+                            }
+                        }
+                        if (lane < na) lam[lane] = y;
+                        wave_sync();
+                    }
+                } else {
                 for (int p = lane; p < na * na; p += 64) {
                     const int a = p / na, c = p - a * na;
                     S[a * kSld + c] = gY[(size_t)wsidx[a] * ldy + wsidx[c]];
@@ -530,6 +606,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                         if (lane < k) lam[lane] -= S[k * kSld + lane] * lk;
                         wave_sync();
                     }
+                }
                 }
             }
             if (dep_at >= 0) {
