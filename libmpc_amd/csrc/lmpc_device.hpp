@@ -44,6 +44,9 @@ struct LmpcDev {
     const int *f_kind, *f_step, *f_comp; const double *f_lo, *f_hi;   // fixed rows [n_fixed]
     const int *boxrow_ptr, *boxrow_ref; const double *boxrow_lo, *boxrow_hi;
     const int *blk;                              // [ph+1]
+    // stacked maps of the MFMA assemble kernel (see Condensed in lmpc_model.hpp)
+    int kin, nxp, nup, nyp, ione, nz16, mg16, ns, ns16, kq16, rowsA, ldy16;
+    const double *MA0, *MA1, *Ym, *slo, *shi;
 };
 
 struct LmpcBatchDev {
@@ -64,8 +67,10 @@ struct LmpcBatchDev {
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
 // which: bit 0 = assemble, bit 1 = polish-only solve, bit 2 = ADMM fallback (7 = the normal path;
-// single bits are for per-kernel timing)
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which = 7);
+// single bits are for per-kernel timing).  fast_variant: -1 = generic assemble kernel, 0/1 = MFMA
+// assemble kernel with shared / per-instance-constant output reference.
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream,
+                int which = 7, int fast_variant = -1);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 
 }  // namespace mpcx

@@ -360,6 +360,143 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(con
         assemble_one<CPZ, CPG>(M, Bt, b, lane, stage, arena, glw(wsbase) + (size_t)b * M.wsld);
 }
 
+
+// =====================================================================================
+// assemble, MFMA form: 16 instances per workgroup of 4 wavefronts
+// =====================================================================================
+// Everything the generic kernel computes is affine in vin = [x0 | lastU | yref | 1] (the cost
+// constant: a quadratic form), with maps tabulated at set-up.  With 16 instances as the N
+// dimension each step is a small GEMM on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64):
+//     [f ; goff ; feasibility rows ; Qc vin] = MA * vin            (rowsA x kin) (kin x 16)
+//     [t0 ; gt0]                             = (-Y[:, :nz]) * f    (ldy16 x nz16)(nz16 x 16)
+// The D layout of a row tile (lane l, register r: row 4r + (l>>4), column l&15) is exactly the
+// B-operand layout of k-step 4*tile + r, so results chain into the next product without any
+// cross-lane movement: each lane parks its own registers in LDS and reads them back by k index.
+// The four wavefronts of a workgroup split the row tiles and share the operands through LDS.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt,
+                                                           double *wsbase, const int variant)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nx = M.nx, nu = M.nu, ny = M.ny;
+    const int kin4 = M.kin >> 2, nz4 = M.nz16 >> 2;
+    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, nz = M.nz, mg = M.mg;
+    double *Bv = smem;                               // [kin4][64]   vin as MFMA B operands
+    double *Bf = Bv + (size_t)kin4 * 64;             // [nz4][64]    f as MFMA B operands
+    double *c0s = Bf + (size_t)nz4 * 64;             // [16]
+    unsigned *bad = reinterpret_cast<unsigned *>(c0s + 16);   // [16]
+    const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
+    const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
+
+    for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
+        const int bj = b0 + j;
+        const bool live = bj < Bt.batch;
+        const int bc = live ? bj : Bt.batch - 1;
+        // vin operands: k-step kb holds rows 4kb + kq of instance j
+        for (int kb = wave; kb < kin4; kb += 4) {
+            const int k = 4 * kb + kq;
+            double v = 0.0;
+            if (k < M.nxp) { if (k < nx) v = gl(Bt.x0)[(size_t)bc * nx + k]; }
+            else if (k < M.nxp + M.nup) { const int c = k - M.nxp; if (c < nu) v = gl(Bt.u0)[(size_t)bc * nu + c]; }
+            else if (k < M.ione) { const int c = k - M.nxp - M.nup; if (variant && c < ny) v = gl(Bt.yref)[(size_t)bc * Bt.yref_bs + c]; }
+            else if (k == M.ione) v = 1.0;
+            Bv[kb * 64 + lane] = v;
+        }
+        if (threadIdx.x < 16) { c0s[threadIdx.x] = 0.0; bad[threadIdx.x] = 0u; }
+        __syncthreads();
+
+        gdw wsj = glw(wsbase) + (size_t)bc * M.wsld;
+        double c0p = 0.0;
+        bool badl = false;
+        for (int t = wave; t < ntile1; t += 4) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const gdp Mt = MA + 16 * t + j;
+            int kb = 0;
+            for (; kb + 4 <= kin4; kb += 4) {
+                double a[4], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = Mt[(size_t)(4 * (kb + u) + kq) * M.rowsA];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = Bv[(kb + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+            for (; kb < kin4; ++kb)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(size_t)(4 * kb + kq) * M.rowsA], Bv[kb * 64 + lane], acc, 0, 0, 0);
+            if (t < tg) {
+                // linear term: keep as operand for the second product, and file it
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Bf[(4 * t + r) * 64 + lane] = acc[r];
+                    const int row = 16 * t + 4 * r + kq;
+                    if (live && row < ldz) wsj[row] = acc[r];
+                }
+            } else if (t < ts) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (t - tg) + 4 * r + kq;
+                    if (live && row < ldg) {
+                        wsj[ldz + ldy + row] = GP(lg0)[row] - acc[r];
+                        wsj[ldz + ldy + ldg + row] = GP(ug0)[row] - acc[r];
+                    }
+                }
+            } else if (t < tq) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (t - ts) + 4 * r + kq;
+                    if (row < M.ns) badl |= violates(acc[r], GP(slo)[row], GP(shi)[row], M.eps_abs, M.eps_rel);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kb2 = 4 * (t - tq) + r;
+                    if (kb2 < kin4) c0p = fma(0.5 * Bv[kb2 * 64 + lane], acc[r], c0p);
+                }
+            }
+        }
+        // per-instance reductions over the four k-quarters of the wave, then over the waves
+        c0p += __shfl_xor(c0p, 16, 64);
+        c0p += __shfl_xor(c0p, 32, 64);
+        if (kq == 0) atomicAdd(&c0s[j], c0p);
+        if (badl) atomicOr(&bad[j], 1u);
+        __syncthreads();
+
+        const int ntile2 = M.ldy16 >> 4;
+        for (int t = wave; t < ntile2; t += 4) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const gdp Yt = Ym + 16 * t + j;
+            int kb = 0;
+            for (; kb + 4 <= nz4; kb += 4) {
+                double a[4], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = Yt[(size_t)(4 * (kb + u) + kq) * M.ldy16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = Bf[(kb + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+            for (; kb < nz4; ++kb)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * r + kq;
+                if (live && row < ldy) wsj[ldz + row] = acc[r];
+            }
+        }
+        if (threadIdx.x < 16 && b0 + (int)threadIdx.x < Bt.batch) {
+            gdw wst = glw(wsbase) + (size_t)(b0 + threadIdx.x) * M.wsld + ldz + ldy + 2 * ldg;
+            wst[0] = c0s[threadIdx.x];
+            wst[1] = bad[threadIdx.x] ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
+    (void)nz; (void)mg;
+}
+
 // =====================================================================================
 // solve: one instance per wavefront
 // =====================================================================================
@@ -1108,7 +1245,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
 }
 
 template <int CPZ, int CPG>
-int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which)
+int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which, int fast)
 {
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
     if (lds > 160 * 1024) return -2;
@@ -1127,7 +1264,16 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const int cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (which & 1) hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+    if (which & 1) {
+        if (fast >= 0) {
+            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 16 + 8) * sizeof(double);
+            int blocks1 = (b.batch + 15) / 16;
+            if (blocks1 > 4096) blocks1 = 4096;
+            hipLaunchKernelGGL(lmpc_assemble_mfma, dim3(blocks1), dim3(256), lds1, stream, m_dev, b, ws, fast);
+        } else {
+            hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        }
+    }
     if (which & 2) hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
     if (which & 4) hipLaunchKernelGGL(k3, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -1161,13 +1307,13 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len)
     return st + ldy + ar;
 }
 
-int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which)
+int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream, int which, int fast)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (lmpc_kernel_variant(m.ldz, m.ldg)) {
-    case 1: return launch_variant<1, 1>(m, m_dev, b, ws, s, which);
-    case 2: return launch_variant<2, 2>(m, m_dev, b, ws, s, which);
-    case 4: return launch_variant<4, 4>(m, m_dev, b, ws, s, which);
+    case 1: return launch_variant<1, 1>(m, m_dev, b, ws, s, which, fast);
+    case 2: return launch_variant<2, 2>(m, m_dev, b, ws, s, which, fast);
+    case 4: return launch_variant<4, 4>(m, m_dev, b, ws, s, which, fast);
     default: return -2;
     }
 }

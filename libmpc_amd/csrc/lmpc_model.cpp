@@ -405,7 +405,184 @@ std::string LmpcController::condense(Condensed &o) const
         }
     }
     (void)ndu;
+    build_fast_maps(o);
     return std::string();
+}
+
+// Mirrors assemble_one() of lmpc_kernels.hip in host doubles: free-response roll-out, weighted
+// output error, adjoint pass, constraint offsets, feasibility-row values, cost constant.
+void LmpcController::assemble_host(const Condensed &o, const double *x0, const double *u0, const Mat &yR,
+                                   const Mat &uR, const Mat &dR, const Mat &dM, AsmOut &out) const
+{
+    const int nx = d.nx, nu = d.nu, ny = d.ny, ndu = d.ndu, ph = d.ph;
+    std::vector<double> xb((size_t)(ph + 1) * nx), ey((size_t)(ph + 1) * ny);
+    for (int a = 0; a < nx; a++) xb[a] = x0[a];
+    for (int i = 1; i <= ph; i++)
+        for (int a = 0; a < nx; a++) {
+            double s = 0;
+            for (int c = 0; c < nx; c++) s += A(a, c) * xb[(size_t)(i - 1) * nx + c];
+            for (int dd = 0; dd < ndu; dd++) s += Bd(a, dd) * dM(dd, i - 1);
+            xb[(size_t)i * nx + a] = s;
+        }
+    double c0 = 0;
+    for (int i = 0; i <= ph; i++) {
+        const int k = i > 0 ? i - 1 : 0;
+        for (int a = 0; a < ny; a++) {
+            double cx = 0;
+            for (int c = 0; c < nx; c++) cx += C(a, c) * xb[(size_t)i * nx + c];
+            double r = yR(a, k);
+            for (int dd = 0; dd < ndu; dd++) r -= Dd(a, dd) * dM(dd, k);
+            const double w = wOutput(a, i);
+            ey[(size_t)i * ny + a] = w * (cx - r);
+            c0 += w * (0.5 * cx * cx - r * cx);
+        }
+    }
+    for (int j = 0; j < nu; j++) {
+        const double u = u0[j];
+        c0 += wU(j, 0) * (0.5 * u * u - uR(j, 0) * u);
+        c0 += wDeltaU(j, 0) * (0.5 * u * u + dR(j, 0) * u);
+    }
+    out.c0 = c0;
+    auto rowval = [&](int kind, int st, int cp) {
+        double v = 0;
+        if (kind == G_STATE) v = xb[(size_t)st * nx + cp];
+        else if (kind == G_OUTPUT) {
+            for (int c = 0; c < nx; c++) v += C(cp, c) * xb[(size_t)st * nx + c];
+            for (int dd = 0; dd < ndu; dd++) v += Dd(cp, dd) * dM(dd, st > 0 ? st - 1 : 0);
+        } else {
+            for (int c = 0; c < nx; c++) v += sX[c] * xb[(size_t)st * nx + c];
+        }
+        return v;
+    };
+    out.goff.assign(o.mg, 0.0);
+    for (int r = 0; r < o.mg; r++) out.goff[r] = rowval(o.g_kind[r], o.g_step[r], o.g_comp[r]);
+    // feasibility rows: x0, lastU, y0, scalar row 0, then the rows that do not see the inputs
+    out.sval.clear();
+    for (int a = 0; a < nx; a++) out.sval.push_back(x0[a]);
+    for (int j = 0; j < nu; j++) out.sval.push_back(u0[j]);
+    for (int a = 0; a < ny; a++) {
+        double v = 0;
+        for (int c = 0; c < nx; c++) v += C(a, c) * x0[c];
+        for (int dd = 0; dd < ndu; dd++) v += Dd(a, dd) * dM(dd, 0);
+        out.sval.push_back(v);
+    }
+    {
+        double v = 0;
+        for (int c = 0; c < nx; c++) v += sX[c] * x0[c];
+        for (int j = 0; j < nu; j++) v += sU[j] * u0[j];
+        out.sval.push_back(v);
+    }
+    for (auto &fr : o.fixed_rows) out.sval.push_back(rowval(fr.kind, fr.step, fr.comp));
+    // adjoint pass
+    out.f.assign(o.nz, 0.0);
+    std::vector<double> p(nx, 0.0), pn(nx);
+    for (int i = ph; i >= 1; i--) {
+        for (int b = 0; b < nx; b++) {
+            double s = 0;
+            for (int a = 0; a < ny; a++) s += C(a, b) * ey[(size_t)i * ny + a];
+            for (int a = 0; a < nx; a++) s += A(a, b) * p[a];
+            pn[b] = s;
+        }
+        p = pn;
+        for (int j = 0; j < nu; j++) {
+            double g = 0;
+            for (int a = 0; a < nx; a++) g += B(a, j) * p[a];
+            g -= wU(j, i) * uR(j, i - 1);
+            out.f[o.blk[i] * nu + j] += g;
+        }
+    }
+    for (int j = 0; j < nu; j++) {
+        out.f[o.blk[1] * nu + j] -= wDeltaU(j, 0) * (u0[j] + dR(j, 0));
+        for (int i = 1; i < ph; i++) {
+            const int bn = o.blk[i + 1], bp = o.blk[i];
+            if (bn != bp) {
+                const double t = -wDeltaU(j, i) * dR(j, i - 1);
+                out.f[bn * nu + j] += t;
+                out.f[bp * nu + j] -= t;
+            }
+        }
+    }
+}
+
+// Every quantity above is affine (the cost constant: quadratic) in (x0, lastU, yref): probe the
+// host evaluation on unit vectors to tabulate the maps the MFMA assemble kernel multiplies with.
+void LmpcController::build_fast_maps(Condensed &o) const
+{
+    const int nx = d.nx, nu = d.nu, ny = d.ny, ph = d.ph;
+    auto r4 = [](int v) { return (v + 3) / 4 * 4; };
+    auto r16 = [](int v) { return (v + 15) / 16 * 16; };
+    o.nxp = r4(nx); o.nup = r4(nu); o.nyp = r4(ny);
+    o.kin = o.nxp + o.nup + o.nyp + 4;
+    o.ione = o.nxp + o.nup + o.nyp;
+    o.nz16 = r16(o.nz); o.mg16 = r16(std::max(o.mg, 1));
+    o.ns = nx + nu + ny + 1 + (int)o.fixed_rows.size();
+    o.ns16 = r16(o.ns); o.kq16 = r16(o.kin);
+    o.rowsA = o.nz16 + o.mg16 + o.ns16 + o.kq16;
+    o.ldy16 = r16(o.ldy);
+    const int offg = o.nz16, offs = offg + o.mg16, offq = offs + o.ns16;
+
+    o.slo.assign(o.ns16, -kInf); o.shi.assign(o.ns16, kInf);
+    {
+        int q = 0;
+        for (int a = 0; a < nx; a++, q++) { o.slo[q] = minX(a, 0); o.shi[q] = maxX(a, 0); }
+        for (int j = 0; j < nu; j++, q++) { o.slo[q] = minU(j, 0); o.shi[q] = maxU(j, 0); }
+        for (int a = 0; a < ny; a++, q++) { o.slo[q] = minY(a, 0); o.shi[q] = maxY(a, 0); }
+        o.slo[q] = sMin[0]; o.shi[q] = sMax[0]; q++;
+        for (auto &fr : o.fixed_rows) { o.slo[q] = fr.lo; o.shi[q] = fr.hi; q++; }
+    }
+
+    const int nin = nx + nu + ny;              // physical inputs
+    auto col_of = [&](int k) { return k < nx ? k : (k < nx + nu ? o.nxp + (k - nx) : o.nxp + o.nup + (k - nx - nu)); };
+    Mat zero_y(ny, ph);
+    for (int variant = 0; variant < 2; variant++) {
+        std::vector<double> &M = o.MA[variant];
+        M.assign((size_t)o.rowsA * o.kin, 0.0);
+        auto eval = [&](const std::vector<double> &v, AsmOut &out) {
+            Mat yR = variant == 0 ? yRef : zero_y;
+            if (variant == 1)
+                for (int k = 0; k < ph; k++)
+                    for (int a = 0; a < ny; a++) yR(a, k) = v[nx + nu + a];
+            assemble_host(o, v.data(), v.data() + nx, yR, uRef, duRef, dMeas, out);
+        };
+        const int nprobe = variant == 0 ? nx + nu : nin;
+        std::vector<double> v(nin, 0.0);
+        AsmOut base; eval(v, base);
+        auto put = [&](int row, int col, double val) { M[(size_t)col * o.rowsA + row] = val; };
+        for (int r = 0; r < o.nz; r++) put(r, o.ione, base.f[r]);
+        for (int r = 0; r < o.mg; r++) put(offg + r, o.ione, base.goff[r]);
+        for (int r = 0; r < o.ns; r++) put(offs + r, o.ione, base.sval[r]);
+        std::vector<AsmOut> e1(nprobe);
+        std::vector<double> cneg(nprobe);
+        for (int k = 0; k < nprobe; k++) {
+            v.assign(nin, 0.0); v[k] = 1.0; eval(v, e1[k]);
+            AsmOut neg; v[k] = -1.0; eval(v, neg); cneg[k] = neg.c0;
+            const int c = col_of(k);
+            for (int r = 0; r < o.nz; r++) put(r, c, e1[k].f[r] - base.f[r]);
+            for (int r = 0; r < o.mg; r++) put(offg + r, c, e1[k].goff[r] - base.goff[r]);
+            for (int r = 0; r < o.ns; r++) put(offs + r, c, e1[k].sval[r] - base.sval[r]);
+        }
+        // quadratic form of the cost constant: 0.5 [v;1]' Qc [v;1]
+        const double c = base.c0;
+        put(offq + o.ione, o.ione, 2.0 * c);
+        for (int k = 0; k < nprobe; k++) {
+            const double gp = e1[k].c0 - c, gm = cneg[k] - c;      // 0.5 A_kk +- b_k
+            const double akk = gp + gm, bk = 0.5 * (gp - gm);
+            const int ck = col_of(k);
+            put(offq + ck, ck, akk);
+            put(offq + ck, o.ione, bk); put(offq + o.ione, ck, bk);
+            for (int m = 0; m < k; m++) {
+                v.assign(nin, 0.0); v[k] = 1.0; v[m] = 1.0;
+                AsmOut both; eval(v, both);
+                const double akm = both.c0 - e1[k].c0 - e1[m].c0 + c;
+                const int cm = col_of(m);
+                put(offq + ck, cm, akm); put(offq + cm, ck, akm);
+            }
+        }
+    }
+    // -Y[:, 0:nz] in tile-padded layout
+    o.Ym.assign((size_t)o.ldy16 * o.nz16, 0.0);
+    for (int q = 0; q < o.nz; q++)
+        for (int r = 0; r < o.ldy; r++) o.Ym[(size_t)q * o.ldy16 + r] = -o.Y[(size_t)q * o.ldy + r];
 }
 
 }  // namespace mpcx

@@ -66,6 +66,21 @@ struct Condensed {
     std::vector<double> boxrow_lo, boxrow_hi;
     std::vector<int> blk;                        // [ph+1] condensed block of v_i (blk[0] unused)
     double flops_setup = 0;
+
+    // ---- stacked affine maps for the MFMA assemble kernel (lmpc_kernels.hip) -------------
+    // input vector vin = [x0 (nxp) | u0 (nup) | yref (nyp) | 1,0,0,0], every block padded to a
+    // multiple of 4 (one f64 MFMA k-step); MA rows = [f (nz16) | goff (mg16) | feasibility rows
+    // (ns16) | Qc vin (kq16)], every block padded to a multiple of 16 (one MFMA row tile).
+    int kin = 0, nxp = 0, nup = 0, nyp = 0, ione = 0;
+    int nz16 = 0, mg16 = 0, ns = 0, ns16 = 0, kq16 = 0, rowsA = 0, ldy16 = 0;
+    std::vector<double> MA[2];                   // [0]: shared yref, [1]: per-instance constant yref; rowsA x kin, column-major
+    std::vector<double> slo, shi;                // [ns16] bounds of the feasibility rows
+    std::vector<double> Ym;                      // -Y[:, 0:nz], ldy16 x nz16 column-major (tile padded)
+};
+
+struct AsmOut {
+    std::vector<double> f, goff, sval;
+    double c0 = 0;
 };
 
 struct LmpcController {
@@ -101,6 +116,10 @@ struct LmpcController {
 
     // returns empty string on success, message otherwise
     std::string condense(Condensed &out) const;
+    // host evaluation of what the generic assemble kernel computes for one instance
+    void assemble_host(const Condensed &o, const double *x0, const double *u0, const Mat &yR, const Mat &uR,
+                       const Mat &dR, const Mat &dM, AsmOut &out) const;
+    void build_fast_maps(Condensed &o) const;
 };
 
 }  // namespace mpcx

@@ -36,6 +36,7 @@ struct mpcx_lmpc {
     mpcx::LmpcDev *dev_d = nullptr;     // the same struct, resident in HBM for the kernel
     std::vector<void *> allocs;
     long long *dbg_cycles = nullptr;
+    bool force_generic = false;         // testing aid: route every batch through the generic assemble kernel
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
@@ -387,6 +388,10 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.boxrow_ptr = h->up(o.boxrow_ptr, rc); D.boxrow_ref = h->up(o.boxrow_ref, rc);
     D.boxrow_lo = h->up(o.boxrow_lo, rc); D.boxrow_hi = h->up(o.boxrow_hi, rc);
     D.blk = h->up(o.blk, rc);
+    D.kin = o.kin; D.nxp = o.nxp; D.nup = o.nup; D.nyp = o.nyp; D.ione = o.ione;
+    D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
+    D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
+    D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
         void *p = nullptr;
@@ -447,7 +452,14 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
             return fail(MPCX_E_DEVICE, "workspace allocation failed");
         h->ws_cap = (size_t)b->batch;
     }
-    int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream);
+    // the MFMA assemble kernel serves shared or per-instance-constant output references with
+    // everything else shared; any other layout goes through the generic roll-out kernel
+    int fast = -1;
+    if (b->uref_mode == MPCX_REF_SHARED && b->duref_mode == MPCX_REF_SHARED && b->dmeas_mode == MPCX_REF_SHARED && !h->force_generic) {
+        if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
+        else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
+    }
+    int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
     return MPCX_OK;
@@ -510,12 +522,17 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
     mpcx::LmpcBatchDev B;
     rc = make_batch(h, b, B);
     if (rc != MPCX_OK) return rc;
+    int fast = -1;
+    if (b->uref_mode == MPCX_REF_SHARED && b->duref_mode == MPCX_REF_SHARED && b->dmeas_mode == MPCX_REF_SHARED && !h->force_generic) {
+        if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
+        else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int which = 1; which <= 4; which *= 2) {
         (void)hipEventRecord(e0, s);
-        for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which);
+        for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which, fast);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0;
@@ -523,6 +540,14 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         ms2[which == 1 ? 0 : (which == 2 ? 1 : 2)] = ms / (float)repeats;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MPCX_OK;
+}
+
+/* testing aid: 1 = always use the generic (roll-out) assemble kernel */
+int mpcx_lmpc_debug_force_generic(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->force_generic = on != 0;
     return MPCX_OK;
 }
 

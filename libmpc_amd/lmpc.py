@@ -254,6 +254,10 @@ class LMPC:
         check(f(self._h, name.encode(), _p(out), n))
         return out
 
+    def debug_force_generic(self, on=True):
+        """testing aid: route every batch through the generic (roll-out) assemble kernel"""
+        check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))
+
     # -- the hot path ------------------------------------------------------------------
     def _torch(self):
         import torch
