@@ -383,7 +383,7 @@ void oracle_lparams_default(oracle_lparams *p)
     p->alpha = 1.6; p->rho = 1e-6; p->eps_rel = 1e-4; p->eps_abs = 1e-4;
     p->eps_prim_inf = 1e-3; p->eps_dual_inf = 1e-3;
     p->verbose = 0; p->adaptive_rho = 1; p->polish = 1;
-    p->adaptive_rho_interval = 0; p->nan_faithful = 0;
+    p->adaptive_rho_interval = 0; p->nan_faithful = 1;
 }
 
 /* ResultStatus (Types.hpp:87-94) */

@@ -37,9 +37,13 @@ typedef struct {
     /* OSQP v0.6.3 defaults the reference inherits */
     double sigma, delta, adaptive_rho_tolerance;
     int scaling, adaptive_rho_interval, check_termination, polish_refine_iter;
-    /* 1: reproduce IEEE inf*0 = NaN in the primal-infeasibility test when the
-     *    caller passes true infinities (libmpc++ does).  0 (default):
-     *    infinite bounds contribute nothing, infeasibility is detected. */
+    /* 1: reproduce IEEE inf*0 = NaN in the primal-infeasibility test when the caller passes
+     *    true infinities -- libmpc++ does (mpc::inf, Types.hpp:227), so with the reference an
+     *    infeasible QP is never reported PRIMAL_INFEASIBLE: it runs to max_iter and returns the
+     *    last ADMM iterate as MAX_ITER_REACHED.  The reference's own "Scalar constraints" test
+     *    (test/LMPC/test_constraints.cpp:95-167, infeasible step-0 row) can only pass that way.
+     *    The LMPC oracle defaults to 1.  0: infinite bounds contribute nothing and
+     *    infeasibility is detected (OSQP's documented behaviour with 1e30 "infinities"). */
     int nan_faithful;
 } oq_settings;
 

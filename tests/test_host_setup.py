@@ -1,0 +1,151 @@
+"""CPU tests of the product's host side (no GPU): C-ABI surface, setter semantics of the
+reference front-end, the condensing, and the refusal to solve without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import INF, OracleFrontEnd, configure_quadrotor, configure_random, random_lmpc_spec
+from oracle import lmpc_numpy as LN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from libmpc_amd import _capi
+    hdr = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+    declared = set(re.findall(r"\b(mpcx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _capi.lib()
+    for name in sorted(declared):
+        getattr(lib, name)
+    assert declared <= set(_capi.EXPORTS) | {"mpcx_version", "mpcx_last_error"}
+    assert lib.mpcx_version().startswith(b"mpcx")
+
+
+def test_unsupported_calls_raise_like_the_reference():
+    """LMPC.hpp:68-100: discrete-time only, no scaling"""
+    from libmpc_amd import LMPC
+    c = LMPC(2, 1, 0, 2, 5, 5, device=-1)
+    with pytest.raises(RuntimeError):
+        c.setDiscretizationSamplingTime(0.1)
+    with pytest.raises(RuntimeError):
+        c.setInputScale([1.0])
+    with pytest.raises(RuntimeError):
+        c.setStateScale([1.0, 1.0])
+
+
+def test_slice_validation_and_return_values():
+    """test/LMPC/test_lmpc.cpp: setters return true; invalid slices return false (IMPC.hpp:244-283)"""
+    from libmpc_amd import LMPC
+    nx, nu, ndu, ny, ph, ch = 3, 2, 1, 2, 6, 4
+    c = LMPC(nx, nu, ndu, ny, ph, ch, device=-1)
+    assert c.setStateSpaceModel(np.eye(nx), np.ones((nx, nu)), np.ones((ny, nx)))
+    assert c.setDisturbances(np.zeros((nx, ndu)), np.zeros((ny, ndu)))
+    assert c.setObjectiveWeights(np.ones((ny, ph)), np.ones((nu, ph)), np.ones((nu, ph)))
+    assert c.setObjectiveWeights(np.ones(ny), np.ones(nu), np.ones(nu), (0, ph))
+    assert c.setObjectiveWeights(np.ones(ny), np.ones(nu), np.ones(nu), (-1, -1))
+    assert not c.setObjectiveWeights(np.ones(ny), np.ones(nu), np.ones(nu), (3, 3))
+    assert not c.setObjectiveWeights(np.ones(ny), np.ones(nu), np.ones(nu), (0, ph + 1))
+    assert c.setStateBounds(-np.ones((nx, ph)), np.ones((nx, ph)))
+    assert c.setStateBounds(-np.ones(nx), np.ones(nx), (0, 1))
+    assert not c.setStateBounds(-np.ones(nx), np.ones(nx), (2, 1))
+    assert c.setInputBounds(-np.ones((nu, ch)), np.ones((nu, ch)))
+    assert c.setInputBounds(-np.ones(nu), np.ones(nu), (0, ch))
+    assert not c.setInputBounds(-np.ones(nu), np.ones(nu), (0, ch + 1))      # control-horizon slice
+    assert c.setOutputBounds(-np.ones(ny), np.ones(ny), (0, ph))
+    assert c.setScalarConstraint(-INF, INF, np.ones(nx), np.ones(nu), (-1, -1))
+    assert c.setScalarConstraint(0, -INF, INF, np.ones(nx), np.ones(nu))
+    assert not c.setScalarConstraint(ph, -1.0, 1.0, np.ones(nx), np.ones(nu))
+    assert c.setReferences(np.zeros((ny, ph)), np.zeros((nu, ph)), np.zeros((nu, ph)))
+    assert c.setReferences(np.zeros(ny), np.zeros(nu), np.zeros(nu), (0, ph))
+    assert c.setExogenousInputs(np.zeros((ndu, ph)))
+    assert c.setExogenousInputs(np.zeros(ndu), (0, ph))
+    with pytest.raises(ValueError):
+        c.setStateSpaceModel(np.eye(nx + 1), np.ones((nx, nu)), np.ones((ny, nx)))
+
+
+def test_no_cpu_solve_path():
+    from libmpc_amd import LMPC, MpcxError
+    from libmpc_amd.workloads import quadrotor_lmpc
+    c = quadrotor_lmpc(10, device=-1)
+    with pytest.raises(MpcxError):
+        c.optimize(np.zeros(12), np.zeros(4))
+    bad = LMPC(2, 1, 0, 2, 5, 5, device=-1)
+    with pytest.raises(MpcxError):       # no model yet
+        bad.setup()
+    with pytest.raises(MpcxError):
+        LMPC(80, 1, 0, 2, 5, 5, device=-1)      # one lane per state component: nx <= 64
+
+
+@pytest.mark.parametrize("ph", [10, 20, 50])
+def test_reference_qp_sizes(ph):
+    from libmpc_amd.workloads import quadrotor_lmpc
+    i = quadrotor_lmpc(ph, device=-1).info()
+    assert (i["n_ref"], i["m_ref"], i["neq_ref"]) == ((ph + 1) * 16 + ph * 4, 2 * (ph + 1) * 16 + (ph + 1) * 12 + ph * 4 + ph + 1, (ph + 1) * 16)
+    assert i["nz"] == 4 * ph and i["mg"] == 3 * ph
+
+
+def _dense_condensed_from_oracle_builder(b, nf):
+    """independent numpy condensing of the reference QP (variables eliminated by the dynamics rows)"""
+    d = b.d; nx, nu, ph, na = d.nx, d.nu, d.ph, d.na
+    A = b.ssA[:nx, :nx]; B = b.ssA[:nx, nx:]
+    nz = nf * nu
+    blk = [0] + [min(i, nf) - 1 for i in range(1, ph + 1)]
+    S = [np.zeros((nx, nz))]
+    for i in range(1, ph + 1):
+        Si = A @ S[-1]
+        Si[:, blk[i] * nu:(blk[i] + 1) * nu] += B
+        S.append(Si)
+    # z = Z w + z0: stack [x_i; v_i] and delta_i
+    Z = np.zeros((d.nvar, nz))
+    for i in range(1, ph + 1):
+        Z[i * na:i * na + nx] = S[i]
+        Z[i * na + nx:(i + 1) * na, blk[i] * nu:(blk[i] + 1) * nu] = np.eye(nu)
+    for i in range(ph):
+        r = (ph + 1) * na + i * nu
+        Z[r:r + nu, blk[i + 1] * nu:(blk[i + 1] + 1) * nu] += np.eye(nu)
+        if i > 0:
+            Z[r:r + nu, blk[i] * nu:(blk[i] + 1) * nu] -= np.eye(nu)
+    return Z.T @ b.P @ Z, Z
+
+
+def test_condensed_hessian_matches_reference_qp():
+    """H = Z' P Z where z = Z w + z0 parametrises the reference's equality constraints"""
+    from libmpc_amd.workloads import quadrotor_lmpc
+    ph = 10
+    c = quadrotor_lmpc(ph, device=-1)
+    dims = c.debug_get("dims")
+    nz, mg, ldz, ldg, ldy = (int(v) for v in dims[:5])
+    H = c.debug_get("H").reshape(nz, ldz)[:, :nz]
+    b = LN.quadrotor_builder(ph)
+    Href, Z = _dense_condensed_from_oracle_builder(b, nf=ph)
+    assert np.allclose(H, Href, rtol=1e-10, atol=1e-9)
+    # general rows = rows of the reference A applied to Z
+    Gr = c.debug_get("Gr").reshape(ldg, ldz)[:mg, :nz]
+    rows = c.debug_get("g_refrow").astype(int)[:mg]
+    assert np.allclose(Gr, (b.A @ Z)[rows], atol=1e-12)
+    # ADMM matrix inverse and dual Hessian are what they claim to be
+    Kinv = c.debug_get("Kinv").reshape(nz, ldz)[:, :nz]
+    rho_b = c.debug_get("rho_b")[:nz]; rho_g = c.debug_get("rho_g")[:mg]
+    K = H + 1e-6 * np.eye(nz) + np.diag(rho_b) + Gr.T @ (rho_g[:, None] * Gr)
+    assert np.allclose(K @ Kinv, np.eye(nz), atol=1e-8)
+    Y = c.debug_get("Y").reshape(ldy, ldy)
+    N = np.vstack([np.eye(nz), Gr])
+    Yref = N @ np.linalg.solve(H, N.T)
+    assert np.allclose(Y[:nz, :nz], Yref[:nz, :nz], rtol=1e-8, atol=1e-10)
+    assert np.allclose(Y[ldz:ldz + mg, ldz:ldz + mg], Yref[nz:, nz:], rtol=1e-8, atol=1e-10)
+    assert np.allclose(c.debug_get("lw")[:nz], 9.6 - 10.5916) and np.allclose(c.debug_get("uw")[:nz], 13 - 10.5916)
+
+
+def test_move_blocking_dimensions():
+    """delta-u is free for steps 0..ch inclusive (ProblemBuilder.hpp:782-793): ch+1 free moves"""
+    from libmpc_amd import LMPC
+    spec = random_lmpc_spec(3)
+    c = configure_random(LMPC(*spec["dims"], device=-1), spec)
+    nx, nu, ndu, ny, ph, ch = spec["dims"]
+    dims = c.debug_get("dims")
+    assert int(dims[5]) == min(ph, ch + 1) and int(dims[0]) == min(ph, ch + 1) * nu
+    # same spec is accepted by the oracle front-end
+    configure_random(OracleFrontEnd(*spec["dims"]), spec)
