@@ -142,6 +142,14 @@ int mpcx_lmpc_set_exogenous_inputs_slice(mpcx_lmpc_t h, const double *dmeas, int
 /* LMPC::setOptimizerParameters -> LOptimizer::setParameters (LMPC.hpp:79, LOptimizer.hpp:100) */
 int mpcx_lmpc_set_optimizer_parameters(mpcx_lmpc_t h, const mpcx_lparams *p);
 
+/* Extension (no reference counterpart).  With the reference an infeasible QP is never reported
+ * INFEASIBLE: libmpc++ hands OSQP true infinities, OSQP v0.6.3's certificate test then evaluates
+ * inf*0 = NaN and never fires, the solve runs out of iterations and LOptimizer returns the last
+ * ADMM iterate flagged MAX_ITERATION / is_feasible = true (LOptimizer.hpp:344).  Default (0):
+ * same flags, cmd = the optimum of the QP without the rows that (x0, lastU) alone violate, or the
+ * last ADMM iterate when the infeasibility involves the inputs.  1: status INFEASIBLE, cmd = NaN. */
+int mpcx_lmpc_set_strict_infeasibility(mpcx_lmpc_t h, int on);
+
 /* ---- the hot path --------------------------------------------------------------- */
 /* Condense the controller into device-resident matrices.  Called implicitly by
  * the first solve after any setter; exposed so that set-up cost can be paid

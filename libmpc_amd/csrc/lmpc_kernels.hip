@@ -550,7 +550,13 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int s = 0; s < NZS; ++s) eqb[s] = (lw[s] == uw[s]);
     const d2 tail = ld2(ws + ldz + ldy + 2 * ldg);
     const double c0 = tail.x;
-    const bool infeasible0 = tail.y == 1.0;
+    // A violated step-0 / input-independent row makes the QP infeasible.  The reference never
+    // reports that (OSQP's certificate test yields NaN on libmpc++'s true infinities): it runs
+    // out of iterations and returns an iterate that satisfies everything else, flagged
+    // MAX_ITER_REACHED.  Default: the same outcome (solve without those rows, same flag);
+    // strict mode: INFEASIBLE.
+    const bool fixed_violation = tail.y == 1.0;
+    const bool infeasible0 = fixed_violation && M.strict_infeasible;
     if (ADMM && tail.y == 2.0) return;          // already solved by the polish-only kernel
     stage_store<CPZ>(nt0, t0, ldz, lane);
     stage_store<CPG>(nt0 + ldz, gt0, ldg, lane);
@@ -1048,7 +1054,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             const int nblk = min(M.check_every, M.max_iter - iters);
             for (int k = 0; k < nblk; ++k) admm_iter();
             iters += nblk;
-            if (certificate()) { infeasible = true; break; }
+            if (certificate()) { infeasible = true; break; }       // see below for the non-strict outcome
             if (M.polish) {
 #pragma unroll
                 for (int s = 0; s < NZS; ++s)
@@ -1062,11 +1068,18 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 solved = residual_status() == 1;
             }
         }
-        if (infeasible) solver_status = -3;
-        else if (solved) solver_status = 1;
+        if (infeasible && !M.strict_infeasible) {
+            // the reference would return whatever ADMM iterate max_iter leaves it with; return ours,
+            // moved inside the input box so that cmd is at least admissible
+            infeasible = false; solver_status = -2;
+#pragma unroll
+            for (int s = 0; s < NZS; ++s) x[s] = clampd(x[s], lw[s], uw[s]);
+        }
+        else if (infeasible) solver_status = -3;
+        else if (solved) solver_status = fixed_violation ? -2 : 1;
         else {
             const int rs = residual_status();
-            solver_status = rs == 1 ? 1 : (rs == 2 ? 2 : -2);
+            solver_status = fixed_violation ? -2 : (rs == 1 ? 1 : (rs == 2 ? 2 : -2));
         }
     } else {
         solver_status = -3;

@@ -36,7 +36,8 @@ struct mpcx_lmpc {
     mpcx::LmpcDev *dev_d = nullptr;     // the same struct, resident in HBM for the kernel
     std::vector<void *> allocs;
     long long *dbg_cycles = nullptr;
-    bool force_generic = false;         // testing aid: route every batch through the generic assemble kernel
+    bool force_generic = false;
+    bool strict_infeasible = false;         // testing aid: route every batch through the generic assemble kernel
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
@@ -333,6 +334,14 @@ int mpcx_lmpc_set_optimizer_parameters(mpcx_lmpc_t h, const mpcx_lparams *p)
     return MPCX_OK;
 }
 
+int mpcx_lmpc_set_strict_infeasibility(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->strict_infeasible = on != 0;
+    h->dirty = true;
+    return MPCX_OK;
+}
+
 int mpcx_lmpc_setup(mpcx_lmpc_t h)
 {
     CHECK_H(h);
@@ -351,6 +360,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.has_dist = o.has_dist ? 1 : 0;
     D.n_fixed = (int)o.fixed_rows.size();
     D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
+    D.strict_infeasible = h->strict_infeasible ? 1 : 0;
     D.check_every = 10; D.polish_rounds0 = 30; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
@@ -440,10 +450,10 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     int rc = mpcx_lmpc_setup(h);
     if (rc != MPCX_OK) return rc;
     if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    if (b->batch == 0) return MPCX_OK;      // an empty batch is a no-op, whatever its pointers
     mpcx::LmpcBatchDev B;
     rc = make_batch(h, b, B);
     if (rc != MPCX_OK) return rc;
-    if (b->batch == 0) return MPCX_OK;
     if ((size_t)b->batch > h->ws_cap) {
         // grows only when a larger batch than ever before arrives (not capturable in a graph)
         if (h->ws) (void)hipFree(h->ws);

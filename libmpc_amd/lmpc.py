@@ -166,6 +166,11 @@ class LMPC:
     def setOptimizerParameters(self, params: LParams):
         check(self._lib.mpcx_lmpc_set_optimizer_parameters(self._h, C.byref(params)))
 
+    def setStrictInfeasibility(self, on=True):
+        """extension: report infeasible QPs as INFEASIBLE / NaN instead of the reference's
+        MAX_ITERATION + last iterate (see include/mpcx.h)"""
+        check(self._lib.mpcx_lmpc_set_strict_infeasibility(self._h, int(bool(on))))
+
     def setStateSpaceModel(self, A, B, Cm):
         A, B, Cm = _cm(A, self.nx, self.nx), _cm(B, self.nx, self.nu), _cm(Cm, self.ny, self.nx)
         return self._ok(self._lib.mpcx_lmpc_set_state_space_model(self._h, _p(A), _p(B), _p(Cm)))

@@ -67,3 +67,208 @@ def test_parity_with_oracle(ph, B, generic):
             bad += 1
     assert bad == 0
     assert it.max() <= 250
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases and the rest of the LMPC surface
+# ---------------------------------------------------------------------------------------------
+from helpers import OracleFrontEnd, configure_quadrotor, configure_random, random_lmpc_spec, rel_err  # noqa: E402
+
+
+@pytest.mark.parametrize("B", [0, 1, 3, 17, 65])
+def test_ragged_batch_sizes(B):
+    """empty and ragged batches: partial workgroups and partial MFMA tiles"""
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    import torch
+    c = quadrotor_lmpc(10, device=0)
+    x0, u0, yref = quadrotor_batch(max(B, 1))
+    x0, u0, yref = x0[:B], u0[:B], yref[:B]
+    r = c.optimizeBatch(x0, u0, yref=yref)
+    torch.cuda.synchronize()
+    assert tuple(r.cmd.shape) == (B, 4)
+    if B:
+        ref = quadrotor_oracle(10).solve_batch_constref(x0, u0, yref)
+        pol = ref["polished"] == 1
+        err = np.abs(r.cmd.cpu().numpy() - ref["cmd"]).max(axis=1) / np.maximum(np.abs(ref["cmd"]).max(axis=1), 1e-12)
+        assert err[pol].max() <= RTOL_CMD
+
+
+def test_single_optimize_matches_reference_interface():
+    """IMPC::optimize / getLastResult / getOptimalSequence (IMPC.hpp:149-190) through the batch path"""
+    from libmpc_amd.workloads import quadrotor_lmpc
+    c = quadrotor_lmpc(10, device=0)
+    res = c.optimize(np.zeros(12), np.zeros(4))
+    f = configure_quadrotor(OracleFrontEnd(12, 4, 4, 12, 10, 10), 10)
+    f.setOptimizerParameters(maximum_iteration=250)
+    ref = f.optimize(np.zeros(12), np.zeros(4))
+    assert rel_err(res.cmd, ref["cmd"]) <= RTOL_CMD and res.status == 0 and res.is_feasible
+    assert c.getLastResult() is res
+    seq = c.getOptimalSequence()
+    assert seq.state.shape == (11, 12) and seq.input.shape == (11, 4) and seq.output.shape == (11, 12)
+    assert np.allclose(seq.state, ref["state"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(seq.input, ref["input"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(seq.output, ref["output"], rtol=1e-6, atol=1e-8)
+    assert np.array_equal(seq.state[0], np.zeros(12))       # row 0 = initial condition (CHANGELOG.md:51)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_full_feature_controller_parity(seed):
+    """disturbances, per-step weights, sliced bounds, scalar constraint, move blocking (ch < ph),
+    shared per-step references: generic assemble path, every output compared with the oracle"""
+    from libmpc_amd import LMPC, LParameters
+    import torch
+    spec = random_lmpc_spec(seed)
+    nx, nu, ndu, ny, ph, ch = spec["dims"]
+    c = configure_random(LMPC(*spec["dims"], device=0), spec)
+    c.setOptimizerParameters(LParameters(maximum_iteration=2000))
+    f = configure_random(OracleFrontEnd(*spec["dims"]), spec)
+    f.setOptimizerParameters(maximum_iteration=2000)
+    r = np.random.default_rng(100 + seed)
+    B = 24
+    x0 = r.uniform(-1, 1, size=(B, nx)); x0[:, 0] *= 0.5
+    u0 = r.uniform(-0.5, 0.5, size=(B, nu))
+    out = c.optimizeBatch(x0, u0, want_active=True, want_sequence=True)
+    torch.cuda.synchronize()
+    m = f.o.ncon
+    lo = bits_to_rows(out.active_lower.cpu().numpy(), m); up = bits_to_rows(out.active_upper.cpu().numpy(), m)
+    checked = 0
+    for b in range(B):
+        ref = f.optimize(x0[b], u0[b])
+        if ref["polished"] != 1:
+            continue
+        checked += 1
+        assert int(out.status[b]) == 0
+        assert rel_err(out.cmd[b].cpu().numpy(), ref["cmd"]) <= RTOL_CMD, b
+        assert abs(float(out.cost[b]) - ref["cost"]) <= 1e-6 * max(1.0, abs(ref["cost"]))
+        assert np.allclose(out.seq_state[b].cpu().numpy(), ref["state"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(out.seq_input[b].cpu().numpy(), ref["input"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(out.seq_output[b].cpu().numpy(), ref["output"], rtol=1e-5, atol=1e-7)
+        rl = np.nonzero(ref["active_lower"][f.o.neq:])[0] + f.o.neq
+        ru = np.nonzero(ref["active_upper"][f.o.neq:])[0] + f.o.neq
+        # move blocking pins several identical input rows to one variable: compare as sets of
+        # (bound side, condensed variable) there, exact rows elsewhere
+        # ... and the delta-u rows pinned to zero past the control horizon are equalities (always
+        # active, like the dynamics rows; the condensed QP has eliminated them): not reported
+        na = nx + nu
+        du0 = 2 * f.o.neq + (ph + 1) * ny
+        nonu = lambda rows: [x for x in rows if not (x < 2 * f.o.neq and (x - f.o.neq) % na >= nx and (x - f.o.neq) // na > ch)
+                             and not (du0 <= x < du0 + ph * nu)]
+        assert nonu(lo[b]) == nonu(rl) and nonu(up[b]) == nonu(ru), (b, lo[b], rl, up[b], ru)
+    assert checked >= B // 2
+
+
+def test_per_step_references_and_per_instance_disturbances():
+    """[B x ph x n] references and exogenous inputs: the reference's setReferences(matrix) /
+    setExogenousInputs(matrix) per controller instance"""
+    from libmpc_amd import LMPC, LParameters
+    import torch
+    spec = random_lmpc_spec(7)
+    nx, nu, ndu, ny, ph, ch = spec["dims"]
+    c = configure_random(LMPC(*spec["dims"], device=0), spec)
+    c.setOptimizerParameters(LParameters(maximum_iteration=2000))
+    f = configure_random(OracleFrontEnd(*spec["dims"]), spec)
+    f.setOptimizerParameters(maximum_iteration=2000)
+    r = np.random.default_rng(5)
+    B = 12
+    x0 = r.uniform(-0.5, 0.5, size=(B, nx)); u0 = r.uniform(-0.3, 0.3, size=(B, nu))
+    yref = r.normal(size=(B, ph, ny)); uref = 0.05 * r.normal(size=(B, ph, nu))
+    duref = 0.01 * r.normal(size=(B, ph, nu)); dmeas = 0.2 * r.normal(size=(B, ph, ndu))
+    out = c.optimizeBatch(x0, u0, yref=yref, uref=uref, duref=duref, dmeas=dmeas)
+    torch.cuda.synchronize()
+    n = 0
+    for b in range(B):
+        ref = f.optimize(x0[b], u0[b], yRef=yref[b].T, uRef=uref[b].T, duRef=duref[b].T, dMeas=dmeas[b].T)
+        if ref["polished"] == 1:
+            n += 1
+            assert rel_err(out.cmd[b].cpu().numpy(), ref["cmd"]) <= RTOL_CMD, b
+            assert abs(float(out.cost[b]) - ref["cost"]) <= 1e-6 * max(1.0, abs(ref["cost"]))
+    assert n >= B // 2
+
+
+def test_reference_scalar_constraint_test():
+    """test/LMPC/test_constraints.cpp:95-167 on the GPU path.  Its step-0 scalar row is violated by
+    x0 itself; the reference still returns a usable sequence (see include/mpcx.h on infeasibility)."""
+    import json, os
+    import scipy.linalg as sla
+    from libmpc_amd import LMPC, LParameters
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))["scalar_constraint_property"]
+    nx, nu, ph = 2, 1, 5
+    Mx = sla.expm(np.block([[np.array(g["A_continuous"], float), np.array(g["B_continuous"], float)], [np.zeros((nu, nx + nu))]]) * g["Ts"])
+    c = LMPC(nx, nu, 0, 2, ph, ph, device=0)
+    assert c.setStateSpaceModel(Mx[:nx, :nx], Mx[:nx, nx:], np.eye(2))
+    assert c.setObjectiveWeights(g["OutputW"], g["InputW"], g["DeltaInputW"], (-1, -1))
+    assert c.setScalarConstraint(g["smin"], g["smax"], np.ones(nx), np.ones(nu), (-1, -1))
+    assert c.setReferences(np.zeros((2, ph)), np.zeros((nu, ph)), np.zeros((nu, ph)))
+    c.setOptimizerParameters(LParameters(maximum_iteration=g["maximum_iteration"]))
+    res = c.optimize(np.array(g["x0"]), np.array(g["u0"]))
+    seq = c.getOptimalSequence()
+    assert res.status == 1 and res.is_feasible            # MAX_ITERATION, as the reference reports it
+    for i in range(ph):
+        s = np.ones(nu) @ seq.input[i] + np.ones(nx) @ seq.state[i]
+        assert s <= g["smax"] + g["tol_upper"] and s >= g["smin"] - g["tol_lower"]
+
+
+def test_infeasible_instances_both_modes():
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    import torch
+    x0, u0, yref = quadrotor_batch(8)
+    x0[3, 0] = 1.0                                  # roll outside +-pi/6 at step 0
+    u0[5, 1] = 5.0                                  # lastU outside the input box (quirk 2)
+    c = quadrotor_lmpc(10, device=0)
+    r = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    st = r.status.cpu().numpy(); cmd = r.cmd.cpu().numpy()
+    assert st[3] == 1 and st[5] == 1 and np.isfinite(cmd).all() and (r.is_feasible.cpu().numpy() == 1).all()
+    assert (np.delete(st, [3, 5]) == 0).all()
+    ref = quadrotor_oracle(10).solve_batch_constref(x0, u0, yref)       # faithful: MAX_ITER_REACHED
+    assert ref["status"][3] == 1 and ref["status"][5] == 1
+    # the reference's answer there is an unconverged ADMM iterate: agreement is loose by nature.
+    # 5: only the step-0 row on lastU is violated, the rest of the QP is solvable; 3: the roll
+    # bound cannot be met anywhere along the horizon, any returned iterate is a compromise
+    assert np.abs(cmd[5] - ref["cmd"][5]).max() < 0.05
+    assert cmd[3].min() >= 9.6 - 10.5916 - 1e-9 and cmd[3].max() <= 13 - 10.5916 + 1e-9
+    c.setStrictInfeasibility(True)
+    r = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    st = r.status.cpu().numpy(); cmd = r.cmd.cpu().numpy()
+    assert st[3] == 2 and st[5] == 2 and np.isnan(cmd[3]).all() and np.isnan(cmd[5]).all()
+    assert (r.is_feasible.cpu().numpy()[[3, 5]] == 0).all() and float(r.cost[3]) == 1e30
+
+
+def test_admm_only_mode():
+    """polish = false: plain ADMM to OSQP's eps (1e-4); agreement with the polished oracle is at
+    ADMM accuracy, status still SUCCESS"""
+    from libmpc_amd import LParameters
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    import torch
+    c = quadrotor_lmpc(10, device=0)
+    c.setOptimizerParameters(LParameters(maximum_iteration=1000, polish=0))
+    x0, u0, yref = quadrotor_batch(32)
+    r = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    ref = quadrotor_oracle(10).solve_batch_constref(x0, u0, yref)
+    it = r.iterations.cpu().numpy()
+    assert (r.status.cpu().numpy() == 0).all() and it.min() >= 10 and it.max() <= 1000
+    err = np.abs(r.cmd.cpu().numpy() - ref["cmd"]).max(axis=1) / np.maximum(np.abs(ref["cmd"]).max(axis=1), 1e-12)
+    assert err.max() < 2e-2
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (N=20, B=4096): size-independent properties -- every instance
+    solved, inputs inside their box, bit-identical across launches, instance 0 = the pinned answer,
+    golden fixture for the first 64 instances"""
+    import os
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    import torch
+    c = quadrotor_lmpc(20, device=0)
+    x0, u0, yref = quadrotor_batch(4096)
+    a = c.optimizeBatch(x0, u0, yref=yref, want_sequence=True); torch.cuda.synchronize()
+    b = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    assert torch.equal(a.cmd, b.cmd) and torch.equal(a.cost, b.cost)
+    assert (a.status == 0).all() and (a.is_feasible == 1).all()
+    u = a.seq_input.cpu().numpy()
+    assert u.min() >= 9.6 - 10.5916 - 1e-7 and u.max() <= 13 - 10.5916 + 1e-7
+    x = a.seq_state.cpu().numpy()
+    assert np.abs(x[:, 1:, :2]).max() <= np.pi / 6 + 1e-7 and x[:, 1:, 5].min() >= -1 - 1e-7
+    assert abs(float(a.cmd[0, 1]) - 1.7324892036) < 1e-9
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quadrotor_oracle_n20.npz"))
+    pol = g["polished"] == 1
+    err = np.abs(a.cmd[:64].cpu().numpy() - g["cmd"]).max(axis=1) / np.maximum(np.abs(g["cmd"]).max(axis=1), 1e-12)
+    assert err[pol].max() <= RTOL_CMD
