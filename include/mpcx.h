@@ -103,6 +103,10 @@ typedef struct mpcx_lmpc_batch {
     double *seq_state;
     double *seq_output;
     double *seq_input;
+    /* extension, for work accounting: active-set (polish) rounds spent and size of the final
+     * working set, [B] each */
+    int32_t *polish_rounds;
+    int32_t *active_count;
 } mpcx_lmpc_batch;
 
 /* ---- lifetime (replaces LMPC::onSetup / new LOptimizer, LMPC.hpp:728-735) ---- */

@@ -37,7 +37,8 @@ class Batch(C.Structure):
                 ("status", C.c_void_p), ("solver_status", C.c_void_p), ("is_feasible", C.c_void_p),
                 ("iterations", C.c_void_p),
                 ("active_lower", C.c_void_p), ("active_upper", C.c_void_p),
-                ("seq_state", C.c_void_p), ("seq_output", C.c_void_p), ("seq_input", C.c_void_p)]
+                ("seq_state", C.c_void_p), ("seq_output", C.c_void_p), ("seq_input", C.c_void_p),
+                ("polish_rounds", C.c_void_p), ("active_count", C.c_void_p)]
 
 
 class Info(C.Structure):

@@ -62,6 +62,7 @@ struct LmpcBatchDev {
     int32_t *status, *solver_status, *is_feasible, *iterations;
     uint32_t *active_lower, *active_upper;
     double *seq_state, *seq_output, *seq_input;
+    int32_t *polish_rounds, *active_count;
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 

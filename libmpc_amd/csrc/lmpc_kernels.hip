@@ -591,7 +591,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     double *dg0 = wsb + kMaxActive;                  // original diagonal (pivot scale)
     int *wsidx = reinterpret_cast<int *>(dg0 + kMaxActive);
     double dtol_last = 0;
-    int na_last = 0;
+    int na_last = 0, rounds_total = 0;
 
     // -------- active-set polish with repair: true when the KKT conditions verify
     auto polish = [&](int rounds) -> bool {
@@ -601,6 +601,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         bool safe = false;       // after a cycle: one exchange per round (most negative multiplier out,
                                  // else most violated row in), which does not cycle in practice
         for (int rd = 0; rd < rounds; ++rd) {
+            ++rounds_total;
             int na = 0;
             unsigned long long hsh = 0x9E3779B97F4A7C15ull;
 #pragma unroll
@@ -1129,6 +1130,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         }
         if (Bt.is_feasible) glw(Bt.is_feasible)[b] = (solver_status == 1 || solver_status == 2 || solver_status == -2) ? 1 : 0;
         if (Bt.iterations) glw(Bt.iterations)[b] = iters;
+        if (Bt.polish_rounds) glw(Bt.polish_rounds)[b] = rounds_total;
+        if (Bt.active_count) glw(Bt.active_count)[b] = polished ? na_last : 0;
     }
 
     if (Bt.active_lower && Bt.active_upper) {

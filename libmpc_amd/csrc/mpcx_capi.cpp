@@ -438,6 +438,7 @@ static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDe
     B.is_feasible = b->is_feasible; B.iterations = b->iterations;
     B.active_lower = b->active_lower; B.active_upper = b->active_upper;
     B.seq_state = b->seq_state; B.seq_output = b->seq_output; B.seq_input = b->seq_input;
+    B.polish_rounds = b->polish_rounds; B.active_count = b->active_count;
     B.dbg_cycles = h->dbg_cycles;
     return MPCX_OK;
 }

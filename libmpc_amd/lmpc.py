@@ -90,6 +90,8 @@ class BatchResult:
     seq_state: "object" = None
     seq_output: "object" = None
     seq_input: "object" = None
+    polish_rounds: "object" = None
+    active_count: "object" = None
 
 
 def _cm(a, rows, cols):
@@ -311,7 +313,9 @@ class LMPC:
             status=torch.empty((B,), dtype=i32, device=dev),
             solver_status=torch.empty((B,), dtype=i32, device=dev),
             is_feasible=torch.empty((B,), dtype=i32, device=dev),
-            iterations=torch.empty((B,), dtype=i32, device=dev))
+            iterations=torch.empty((B,), dtype=i32, device=dev),
+            polish_rounds=torch.zeros((B,), dtype=i32, device=dev),
+            active_count=torch.zeros((B,), dtype=i32, device=dev))
         if want_active:
             res.active_lower = torch.zeros((B, i["active_words"]), dtype=i32, device=dev)
             res.active_upper = torch.zeros((B, i["active_words"]), dtype=i32, device=dev)
@@ -335,6 +339,7 @@ class LMPC:
         b.is_feasible, b.iterations = ptr(res.is_feasible), ptr(res.iterations)
         b.active_lower, b.active_upper = ptr(res.active_lower), ptr(res.active_upper)
         b.seq_state, b.seq_output, b.seq_input = ptr(res.seq_state), ptr(res.seq_output), ptr(res.seq_input)
+        b.polish_rounds, b.active_count = ptr(res.polish_rounds), ptr(res.active_count)
         keep = (x0, u0, yr, ur, dr, de)
         return b, res, keep
 
