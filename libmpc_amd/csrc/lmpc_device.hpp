@@ -25,6 +25,7 @@ struct LmpcDev {
     int has_dist, n_fixed;
     // solver parameters
     int max_iter, polish, check_every, polish_rounds0, polish_rounds;
+    int use_quad;                                // 1: four-instances-per-wavefront polish kernel where it applies
     int strict_infeasible;                       // 1: report INFEASIBLE / NaN; 0: behave as the reference does
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
     // per-wave LDS carve (in doubles)

@@ -37,7 +37,8 @@ struct mpcx_lmpc {
     std::vector<void *> allocs;
     long long *dbg_cycles = nullptr;
     bool force_generic = false;
-    bool strict_infeasible = false;         // testing aid: route every batch through the generic assemble kernel
+    bool strict_infeasible = false;
+    bool use_quad = false;              // measured slower than one-instance-per-wave at B = 4096 (1 wave per SIMD)         // testing aid: route every batch through the generic assemble kernel
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
@@ -361,6 +362,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.n_fixed = (int)o.fixed_rows.size();
     D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
     D.strict_infeasible = h->strict_infeasible ? 1 : 0;
+    D.use_quad = h->use_quad ? 1 : 0;
     D.check_every = 10; D.polish_rounds0 = 30; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
@@ -559,6 +561,15 @@ int mpcx_lmpc_debug_force_generic(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);
     h->force_generic = on != 0;
+    return MPCX_OK;
+}
+
+/* testing aid: 0 = never use the four-instances-per-wavefront solve kernel */
+int mpcx_lmpc_debug_use_quad(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->use_quad = on != 0;
+    h->dirty = true;
     return MPCX_OK;
 }
 
