@@ -167,6 +167,14 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
  * back-to-back launches; returns the mean kernel time in milliseconds. */
 int mpcx_lmpc_time_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms_mean);
 
+/* Convenience for callers whose data lives in host memory (the reference's optimize(x0, lastU) is
+ * such a caller): stages the inputs to HBM, runs mpcx_lmpc_solve_batch on the default stream, copies
+ * the results back and synchronises.  References use the matrices given to the host setters.  Any
+ * output pointer may be NULL except cmd.  seq_* are [B x (ph+1) x n] row-major, as in the batch struct. */
+int mpcx_lmpc_solve_host(mpcx_lmpc_t h, int batch, const double *x0, const double *u0,
+                         double *cmd, double *cost, int32_t *status, int32_t *solver_status, int32_t *is_feasible,
+                         double *seq_state, double *seq_output, double *seq_input);
+
 /* ---- introspection -------------------------------------------------------------- */
 /* sizes of the reference QP (ProblemBuilder.hpp:70-76) and of the condensed one */
 typedef struct mpcx_lmpc_info {

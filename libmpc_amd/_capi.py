@@ -59,7 +59,7 @@ EXPORTS = [
     "mpcx_lmpc_set_references", "mpcx_lmpc_set_references_slice",
     "mpcx_lmpc_set_exogenous_inputs", "mpcx_lmpc_set_exogenous_inputs_slice",
     "mpcx_lmpc_set_optimizer_parameters", "mpcx_lmpc_set_strict_infeasibility", "mpcx_lmpc_setup", "mpcx_lmpc_solve_batch",
-    "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_get_info", "mpcx_version",
+    "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
 ]
 
 _lib = None

@@ -478,6 +478,52 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     return MPCX_OK;
 }
 
+int mpcx_lmpc_solve_host(mpcx_lmpc_t h, int batch, const double *x0, const double *u0,
+                         double *cmd, double *cost, int32_t *status, int32_t *solver_status, int32_t *is_feasible,
+                         double *seq_state, double *seq_output, double *seq_input)
+{
+    CHECK_H(h);
+    if (batch < 0 || (batch > 0 && (!x0 || !u0 || !cmd))) return fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
+    if (h->host_only) return fail(MPCX_E_DEVICE, "host-only handle: the solve path needs a HIP device, there is no CPU fallback");
+    if (batch == 0) return MPCX_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    const auto &d = h->ctl.d;
+    const size_t B = (size_t)batch, n1 = (size_t)d.ph + 1;
+    const size_t nd = B * (d.nx + d.nu + d.nu + 1 + n1 * (d.nx + d.ny + d.nu));
+    double *dbuf = nullptr; int32_t *ibuf = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&dbuf), nd * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ibuf), B * 4 * sizeof(int32_t)) != hipSuccess) {
+        if (dbuf) (void)hipFree(dbuf);
+        return fail(MPCX_E_DEVICE, "staging allocation failed");
+    }
+    double *dx0 = dbuf, *du0 = dx0 + B * d.nx, *dcmd = du0 + B * d.nu, *dcost = dcmd + B * d.nu;
+    double *dss = dcost + B, *dso = dss + B * n1 * d.nx, *dsi = dso + B * n1 * d.ny;
+    (void)hipMemcpy(dx0, x0, B * d.nx * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(du0, u0, B * d.nu * sizeof(double), hipMemcpyHostToDevice);
+    mpcx_lmpc_batch b{};
+    b.batch = batch; b.x0 = dx0; b.u0 = du0;
+    b.cmd = dcmd; b.cost = dcost;
+    b.status = ibuf; b.solver_status = ibuf + B; b.is_feasible = ibuf + 2 * B; b.iterations = ibuf + 3 * B;
+    const bool want_seq = seq_state || seq_output || seq_input;
+    if (want_seq) { b.seq_state = dss; b.seq_output = dso; b.seq_input = dsi; }
+    int rc = mpcx_lmpc_solve_batch(h, &b, nullptr);
+    if (rc == MPCX_OK) {
+        if (hipDeviceSynchronize() != hipSuccess) rc = fail(MPCX_E_DEVICE, "kernel execution failed");
+    }
+    if (rc == MPCX_OK) {
+        (void)hipMemcpy(cmd, dcmd, B * d.nu * sizeof(double), hipMemcpyDeviceToHost);
+        if (cost) (void)hipMemcpy(cost, dcost, B * sizeof(double), hipMemcpyDeviceToHost);
+        if (status) (void)hipMemcpy(status, ibuf, B * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (solver_status) (void)hipMemcpy(solver_status, ibuf + B, B * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (is_feasible) (void)hipMemcpy(is_feasible, ibuf + 2 * B, B * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (seq_state) (void)hipMemcpy(seq_state, dss, B * n1 * d.nx * sizeof(double), hipMemcpyDeviceToHost);
+        if (seq_output) (void)hipMemcpy(seq_output, dso, B * n1 * d.ny * sizeof(double), hipMemcpyDeviceToHost);
+        if (seq_input) (void)hipMemcpy(seq_input, dsi, B * n1 * d.nu * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dbuf); (void)hipFree(ibuf);
+    return rc;
+}
+
 int mpcx_lmpc_time_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms_mean)
 {
     CHECK_H(h);

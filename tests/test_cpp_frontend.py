@@ -1,0 +1,41 @@
+"""The C++20 front-end (include/mpc/LMPC.hpp -> include/mpcx/LMPC.hpp -> C ABI): the reference's LMPC
+test scenarios, compiled with g++ against this repository's headers."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "lmpc_frontend_test.cpp")
+OUT = os.path.join(ROOT, "tests", "cpp", "build", "lmpc_frontend_test")
+
+
+def _build():
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    lib = os.path.join(ROOT, "libmpc_amd")
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), SRC, "-o", OUT,
+           "-L" + lib, "-lmpcx", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+def test_cpp_frontend_api_without_gpu():
+    exe = _build()
+    env = dict(os.environ, MPCX_DEVICE="-1")
+    out = subprocess.run([exe, "api"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all C++ front-end checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_frontend_quadrotor_known_answer():
+    """reference test/LMPC/test_common.cpp:89-237, static and dynamic sizes, through the C++ header"""
+    exe = _build()
+    env = {k: v for k, v in os.environ.items() if k != "MPCX_DEVICE"}
+    out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all C++ front-end checks passed" in out.stdout
