@@ -189,6 +189,43 @@ typedef struct mpcx_lmpc_info {
 } mpcx_lmpc_info;
 int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info);
 
+/* ---- NLMPC transcription (rows a10-a20 of SURVEY.md 8) ---------------------------- */
+/* What the reference computes inside every NLopt callback of NLOptimizer<> (NLOptimizer.hpp:760-997):
+ * Mapping::unwrapVector (Mapping.hpp:174-211), Objective::evaluate + forward-difference gradient
+ * (Objective.hpp:91-265), the dynamics equalities with their central-difference Jacobian blocks
+ * (Constraints.hpp:490-628, 844-905) and the user inequalities with theirs (Constraints.hpp:211-316),
+ * for a batch of decision vectors in one launch.  The reference's user hooks are host std::function
+ * objects (IDimensionable.hpp:94-149); device code cannot call those, so the hooks are device
+ * functors compiled into the library and picked by id (the reference's example systems).       */
+typedef struct mpcx_nlmpc *mpcx_nlmpc_t;
+enum { MPCX_MODEL_VANDERPOL = 1,   /* examples/vanderpol_ex.cpp: nx=2 nu=1, continuous, ineq u_i <= 0.5        */
+       MPCX_MODEL_UGV = 2 };       /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
+typedef struct mpcx_nlmpc_dims {
+    int nx, nu, ph, ch;
+    int nz;      /* decision variables  ph*nx + ch*nu + 1 (Objective.hpp:45)                         */
+    int neq;     /* dynamics equalities ph*nx                                                         */
+    int nineq;   /* user inequalities                                                                 */
+    int jeq_w;   /* width of one equality Jacobian block row: 2*nx + nu                               */
+} mpcx_nlmpc_dims;
+/* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
+ * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
+ * for the model's defaults) are the constants its functors capture in the reference example.
+ * UGV: [v_pref_x, v_pref_y, ox0, oy0, r0, ox1, oy1, r1, Ts].  Van der Pol: none (Ts is the
+ * collocation step).                                                                             */
+int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *params, int n_params,
+                      int device, mpcx_nlmpc_t *out);
+int mpcx_nlmpc_destroy(mpcx_nlmpc_t h);
+int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d);
+/* Device pointers, fp64.  z [B x nz] (layout [x_1..x_ph | u blocks (ch) | slack]), x0 [B x nx].
+ * Any output may be NULL.  cost [B]; grad [B x nz]; ceq [B x neq]; cineq [B x nineq];
+ * jineq [B x nineq x nz] row-major (dense: a user inequality may depend on anything);
+ * jeq [B x ph x nx x jeq_w] row-major blocks [dc_i/dx_i | dc_i/dx_{i+1} | dc_i/du_i] -- the
+ * non-zeros of the reference's dense [neq x nz] Jacobian: block i sits in rows i*nx.., columns
+ * (i-1)*nx.. (absent for i = 0, x_0 is data), i*nx.., ph*nx + min(i, ch-1)*nu...                */
+int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const double *x0,
+                              double *cost, double *grad, double *ceq, double *jeq,
+                              double *cineq, double *jineq, void *stream);
+
 const char *mpcx_version(void);
 
 #ifdef __cplusplus

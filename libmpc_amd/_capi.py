@@ -60,7 +60,12 @@ EXPORTS = [
     "mpcx_lmpc_set_exogenous_inputs", "mpcx_lmpc_set_exogenous_inputs_slice",
     "mpcx_lmpc_set_optimizer_parameters", "mpcx_lmpc_set_strict_infeasibility", "mpcx_lmpc_setup", "mpcx_lmpc_solve_batch",
     "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
+    "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
 ]
+
+
+class NlmpcDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w")]
 
 _lib = None
 
@@ -89,6 +94,10 @@ def lib():
         _lib.mpcx_version.restype = C.c_char_p
         _lib.mpcx_lmpc_set_scalar_constraint_slice.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.mpcx_lmpc_set_scalar_constraint_index.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        _lib.mpcx_nlmpc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.mpcx_nlmpc_destroy.argtypes = [C.c_void_p]
+        _lib.mpcx_nlmpc_get_dims.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mpcx_nlmpc_evaluate_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
     return _lib
 
 

@@ -26,6 +26,10 @@ int fail(int code, const std::string &msg)
 
 }  // namespace
 
+namespace mpcx {
+int capi_fail(int code, const std::string &msg) { return fail(code, msg); }   // shared with nlmpc_capi.cpp
+}
+
 struct mpcx_lmpc {
     mpcx::LmpcController ctl;
     int device = 0;
