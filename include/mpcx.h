@@ -199,7 +199,9 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info);
  * functors compiled into the library and picked by id (the reference's example systems).       */
 typedef struct mpcx_nlmpc *mpcx_nlmpc_t;
 enum { MPCX_MODEL_VANDERPOL = 1,   /* examples/vanderpol_ex.cpp: nx=2 nu=1, continuous, ineq u_i <= 0.5        */
-       MPCX_MODEL_UGV = 2 };       /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
+       MPCX_MODEL_UGV = 2,         /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
+       MPCX_MODEL_OSCILLATORS6 = 3,/* examples/networked_oscillators_ex.cpp: 6 coupled oscillators, nx=12 nu=6   */
+       MPCX_MODEL_OSCILLATORS8 = 4 };/* the same network with 8 oscillators (BASELINE config 5), nx=16 nu=8      */
 typedef struct mpcx_nlmpc_dims {
     int nx, nu, ph, ch;
     int nz;      /* decision variables  ph*nx + ch*nu + 1 (Objective.hpp:45)                         */
@@ -210,8 +212,8 @@ typedef struct mpcx_nlmpc_dims {
 /* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
  * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
  * for the model's defaults) are the constants its functors capture in the reference example.
- * UGV: [v_pref_x, v_pref_y, ox0, oy0, r0, ox1, oy1, r1, Ts].  Van der Pol: none (Ts is the
- * collocation step).                                                                             */
+ * UGV: [v_pref_x, v_pref_y, ox0, oy0, r0, ox1, oy1, r1, Ts].  Oscillators: [mu, k].  Van der Pol:
+ * none (Ts is the collocation step).                                                             */
 int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *params, int n_params,
                       int device, mpcx_nlmpc_t *out);
 int mpcx_nlmpc_destroy(mpcx_nlmpc_t h);
@@ -225,6 +227,43 @@ int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d);
 int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const double *x0,
                               double *cost, double *grad, double *ceq, double *jeq,
                               double *cineq, double *jineq, void *stream);
+
+/* mpc::NLParameters (Types.hpp:99-144), field for field.  With every tolerance negative (the
+ * reference default, "disabled") the iteration stops when the largest step component falls below
+ * 1e-6 * max(1, |z|_inf) with the dynamics defects below 1e-8, or when the line search finds no
+ * decrease (finite-difference noise floor).  A positive relative_xtol replaces the 1e-6.          */
+typedef struct mpcx_nlparams {
+    int maximum_iteration;    /* 100 */
+    double time_limit;        /* 0, accepted and ignored */
+    int enable_warm_start;    /* 0; warm starts are driven by mpcx_nlmpc_batch.z_warm */
+    double relative_ftol, relative_xtol, absolute_ftol, absolute_xtol;   /* -1 */
+    int hard_constraints;     /* 1: slack fixed at zero (NLOptimizer.hpp:182-186) */
+} mpcx_nlparams;
+void mpcx_nlparams_default(mpcx_nlparams *p);
+/* NLMPC::setOptimizerParameters -> NLOptimizer::setParameters (NLOptimizer.hpp:129-195) */
+int mpcx_nlmpc_set_optimizer_parameters(mpcx_nlmpc_t h, const mpcx_nlparams *p);
+
+/* One batched NLOptimizer::run (NLOptimizer.hpp:412-638).  Device pointers.  Outputs other than
+ * cmd may be NULL.  status uses MPCX_STATUS_* (ResultStatus), solver_status nlopt's result codes
+ * (4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE) as mapped at NLOptimizer.hpp:729-750; on failure
+ * cmd = u0 and cost = inf as at :613-624.  is_feasible = every user inequality <= 1e-10
+ * (Constraints.hpp:157-202, tolerance NLMPC.hpp:166).                                             */
+typedef struct mpcx_nlmpc_batch {
+    int batch;
+    const double *x0;          /* [B x nx] */
+    const double *u0;          /* [B x nu] */
+    const double *z_warm;      /* [B x nz] previous solutions, shifted one step on entry as at
+                                  NLOptimizer.hpp:460-510; NULL = cold start (:431-451)            */
+    double *cmd;               /* [B x nu] */
+    double *cost;              /* [B] */
+    int32_t *status, *solver_status, *is_feasible, *iterations;   /* [B] each */
+    double *z;                 /* [B x nz] the optimal decision vectors (next call's z_warm)       */
+    double *seq_state;         /* [B x (ph+1) x nx] row-major, row 0 = x0                           */
+    double *seq_input;         /* [B x (ph+1) x nu]                                                 */
+} mpcx_nlmpc_batch;
+int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
+/* `repeats` back-to-back launches bracketed by HIP events on `stream`; mean milliseconds. */
+int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream, int repeats, float *ms_mean);
 
 const char *mpcx_version(void);
 

@@ -61,7 +61,21 @@ EXPORTS = [
     "mpcx_lmpc_set_optimizer_parameters", "mpcx_lmpc_set_strict_infeasibility", "mpcx_lmpc_setup", "mpcx_lmpc_solve_batch",
     "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
     "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
+    "mpcx_nlparams_default", "mpcx_nlmpc_set_optimizer_parameters", "mpcx_nlmpc_solve_batch", "mpcx_nlmpc_time_solve_batch",
 ]
+
+
+class NLParams(C.Structure):
+    """mpcx_nlparams == mpc::NLParameters (Types.hpp:99-144)"""
+    _fields_ = [("maximum_iteration", C.c_int), ("time_limit", C.c_double), ("enable_warm_start", C.c_int),
+                ("relative_ftol", C.c_double), ("relative_xtol", C.c_double), ("absolute_ftol", C.c_double),
+                ("absolute_xtol", C.c_double), ("hard_constraints", C.c_int)]
+
+
+class NlmpcBatch(C.Structure):
+    _fields_ = [("batch", C.c_int), ("x0", C.c_void_p), ("u0", C.c_void_p), ("z_warm", C.c_void_p), ("cmd", C.c_void_p),
+                ("cost", C.c_void_p), ("status", C.c_void_p), ("solver_status", C.c_void_p), ("is_feasible", C.c_void_p),
+                ("iterations", C.c_void_p), ("z", C.c_void_p), ("seq_state", C.c_void_p), ("seq_input", C.c_void_p)]
 
 
 class NlmpcDims(C.Structure):
@@ -98,6 +112,10 @@ def lib():
         _lib.mpcx_nlmpc_destroy.argtypes = [C.c_void_p]
         _lib.mpcx_nlmpc_get_dims.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_evaluate_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
+        _lib.mpcx_nlparams_default.restype = None
+        _lib.mpcx_nlmpc_set_optimizer_parameters.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mpcx_nlmpc_solve_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mpcx_nlmpc_time_solve_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return _lib
 
 

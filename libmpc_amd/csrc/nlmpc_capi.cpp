@@ -1,4 +1,4 @@
-// extern "C" boundary of the NLMPC transcription kernels (include/mpcx.h, mpcx_nlmpc_*).
+// extern "C" boundary of the NLMPC kernels (include/mpcx.h, mpcx_nlmpc_*).  Host code only; no CPU solve path.
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -15,45 +15,55 @@ struct mpcx_nlmpc {
     mpcx::NlmpcDev dev{};
     int device = 0;
     double *params_d = nullptr;
+    double *ws = nullptr;
+    size_t ws_cap = 0;          // instances
+    mpcx_nlparams prm{};
 };
 
 extern "C" {
+
+void mpcx_nlparams_default(mpcx_nlparams *p)
+{
+    if (!p) return;
+    *p = mpcx_nlparams{100, 0.0, 0, -1.0, -1.0, -1.0, -1.0, 1};      // Types.hpp:108-143
+}
 
 int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *params, int n_params, int device,
                       mpcx_nlmpc_t *out)
 {
     using mpcx::capi_fail;
     if (!out) return capi_fail(MPCX_E_INVALID, "null output handle");
-    int nx = 0, nu = 0;
-    if (mpcx::nlmpc_model_dims(model_id, &nx, &nu) != 0) return capi_fail(MPCX_E_INVALID, "unknown NLMPC model id");
     if (ph < 1 || ch < 1 || ch > ph) return capi_fail(MPCX_E_INVALID, "need 1 <= ch <= ph");
+    int nx = 0, nu = 0, nineq = 0;
+    if (mpcx::nlmpc_model_dims(model_id, &nx, &nu, ph, &nineq) != 0) return capi_fail(MPCX_E_INVALID, "unknown NLMPC model id");
     std::vector<double> prm;
-    if (model_id == MPCX_MODEL_UGV) {
-        prm = {0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, Ts};
-        if (params) {
-            if (n_params != 9) return capi_fail(MPCX_E_INVALID, "the UGV model takes 9 parameters");
-            prm.assign(params, params + 9);
-        }
-    } else {
-        prm = {0.0};
-        if (params && n_params != 0) return capi_fail(MPCX_E_INVALID, "the Van der Pol model takes no parameters");
+    int want = 0;
+    if (model_id == MPCX_MODEL_UGV) { prm = {0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, Ts}; want = 9; }
+    else if (model_id == MPCX_MODEL_OSCILLATORS6 || model_id == MPCX_MODEL_OSCILLATORS8) { prm = {1.0, 0.1}; want = 2; }
+    else prm = {0.0};
+    if (params && n_params > 0) {
+        if (n_params != want) return capi_fail(MPCX_E_INVALID, "this model takes " + std::to_string(want) + " parameters");
+        prm.assign(params, params + want);
     }
     if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed: no usable HIP device");
     auto *h = new mpcx_nlmpc;
     h->device = device;
+    mpcx_nlparams_default(&h->prm);
     if (hipMalloc(reinterpret_cast<void **>(&h->params_d), prm.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(h->params_d, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;
         return capi_fail(MPCX_E_DEVICE, "could not upload the model parameters");
     }
     mpcx::NlmpcDev &d = h->dev;
-    d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch;
-    d.nz = ph * nx + ch * nu + 1;
-    d.neq = ph * nx;
-    d.nineq = model_id == MPCX_MODEL_UGV ? 2 * (ph + 1) : ph + 1;
-    d.lds_per_wave = ((ph + 1) * (nx + nu) + ph * nu + 1) & ~1;
+    d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq;
     d.Ts = Ts;
     d.params = h->params_d;
+    mpcx::nlmpc_plan(d);
+    if ((size_t)d.lds_per_wave * sizeof(double) > 64 * 1024) {
+        (void)hipFree(h->params_d);
+        delete h;
+        return capi_fail(MPCX_E_UNSUPPORTED, "horizon too long for the per-wave LDS slice");
+    }
     *out = h;
     return MPCX_OK;
 }
@@ -63,6 +73,7 @@ int mpcx_nlmpc_destroy(mpcx_nlmpc_t h)
     if (!h) return MPCX_OK;
     (void)hipSetDevice(h->device);
     if (h->params_d) (void)hipFree(h->params_d);
+    if (h->ws) (void)hipFree(h->ws);
     delete h;
     return MPCX_OK;
 }
@@ -72,6 +83,14 @@ int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d)
     if (!h || !d) return mpcx::capi_fail(MPCX_E_INVALID, "null argument");
     const mpcx::NlmpcDev &m = h->dev;
     *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu};
+    return MPCX_OK;
+}
+
+int mpcx_nlmpc_set_optimizer_parameters(mpcx_nlmpc_t h, const mpcx_nlparams *p)
+{
+    if (!h || !p) return mpcx::capi_fail(MPCX_E_INVALID, "null argument");
+    if (p->maximum_iteration < 0) return mpcx::capi_fail(MPCX_E_INVALID, "maximum_iteration must be >= 0");
+    h->prm = *p;
     return MPCX_OK;
 }
 
@@ -87,6 +106,64 @@ int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const 
     mpcx::NlmpcBatchDev b{batch, z, x0, cost, grad, ceq, jeq, cineq, jineq};
     const int rc = mpcx::nlmpc_launch(h->dev, b, stream);
     if (rc != 0) return capi_fail(MPCX_E_DEVICE, "NLMPC kernel launch failed (" + std::to_string(rc) + ")");
+    return MPCX_OK;
+}
+
+static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcSolveDev &s)
+{
+    using mpcx::capi_fail;
+    if (!h || !b) return capi_fail(MPCX_E_INVALID, "null argument");
+    if (b->batch < 0) return capi_fail(MPCX_E_INVALID, "negative batch");
+    if (b->batch == 0) return 1;
+    if (!b->x0 || !b->u0 || !b->cmd) return capi_fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
+    if (hipSetDevice(h->device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    if ((size_t)b->batch > h->ws_cap) {
+        if (h->ws) (void)hipFree(h->ws);
+        h->ws = nullptr; h->ws_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.ws.total * sizeof(double)) != hipSuccess)
+            return capi_fail(MPCX_E_DEVICE, "could not allocate the SQP workspace");
+        h->ws_cap = b->batch;
+    }
+    s = mpcx::NlmpcSolveDev{};
+    s.batch = b->batch; s.x0 = b->x0; s.u0 = b->u0; s.z_warm = b->z_warm; s.ws = h->ws;
+    s.max_iter = h->prm.maximum_iteration; s.hard = h->prm.hard_constraints ? 1 : 0;
+    s.tol_step = h->prm.relative_xtol > 0 ? h->prm.relative_xtol : 1e-6;
+    s.tol_con = 1e-8; s.ieq_tol = 1e-10;
+    s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
+    s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input;
+    return MPCX_OK;
+}
+
+int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream)
+{
+    mpcx::NlmpcSolveDev s;
+    const int rc = prepare_solve(h, b, s);
+    if (rc != MPCX_OK) return rc > 0 ? MPCX_OK : rc;
+    const int lr = mpcx::nlmpc_launch_solve(h->dev, s, stream);
+    if (lr != 0) return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")");
+    return MPCX_OK;
+}
+
+int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream, int repeats, float *ms_mean)
+{
+    using mpcx::capi_fail;
+    if (!ms_mean || repeats < 1) return capi_fail(MPCX_E_INVALID, "bad timing arguments");
+    mpcx::NlmpcSolveDev s;
+    const int rc = prepare_solve(h, b, s);
+    if (rc != MPCX_OK) { *ms_mean = 0.f; return rc > 0 ? MPCX_OK : rc; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipEventCreate failed");
+    (void)hipEventRecord(e0, st);
+    int lr = 0;
+    for (int i = 0; i < repeats && lr == 0; ++i) lr = mpcx::nlmpc_launch_solve(h->dev, s, stream);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (lr != 0) return capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed");
+    *ms_mean = ms / repeats;
     return MPCX_OK;
 }
 

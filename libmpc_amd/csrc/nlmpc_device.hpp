@@ -1,13 +1,30 @@
-// POD views handed to the NLMPC transcription kernels (nlmpc_kernels.hip).
+// POD views handed to the NLMPC kernels (nlmpc_kernels.hip).
 #pragma once
+
+#include <cstdint>
 
 namespace mpcx {
 
+constexpr int kNlMaxWorking = 32;      // rows the QP sub-solver may hold active at once
+
+// offsets (in doubles) into one instance's slice of the SQP workspace
+struct NlmpcWsLayout {
+    int z, d, g, c, jeq, gin, jin;      // iterate, step, transcription outputs
+    int r, phi, einv;                   // condensing: x-step for p = 0, d x / d p, inverses of dc_i/dx_{i+1}
+    int gr, art, br;                    // reduced gradient, reduced inequality Jacobian (transposed), its offset
+    int hinv, mu, glold, s, p;          // inverse BFGS matrix, multipliers, BFGS memory, QP solution
+    int qn, qv;                         // QP: normals and Hinv*normals of the working set
+    int scal;                           // scalars: [0] cost
+    int total;
+};
+
 struct NlmpcDev {
     int model_id, nx, nu, ph, ch, nz, neq, nineq;
-    int lds_per_wave;           // doubles: X (ph+1)*nx | U (ph+1)*nu | scratch ph*nu
+    int nzu, nr;                // ch*nu, ch*nu + 1
+    int lds_per_wave;           // doubles
     double Ts;
     const double *params;       // model parameters in HBM
+    NlmpcWsLayout ws;
 };
 
 struct NlmpcBatchDev {
@@ -19,7 +36,21 @@ struct NlmpcBatchDev {
     double *cineq, *jineq;      // [B x nineq], [B x nineq x nz] row-major
 };
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu);
+struct NlmpcSolveDev {
+    int batch;
+    const double *x0, *u0;      // [B x nx], [B x nu]
+    const double *z_warm;       // [B x nz] previous solutions (shifted one step on entry) or null = cold start
+    double *ws;                 // [B x ws.total]
+    int max_iter, hard;
+    double tol_step, tol_con, ieq_tol;
+    double *cmd, *cost, *z_out; // [B x nu], [B], [B x nz]
+    int32_t *status, *solver_status, *is_feasible, *iterations;
+    double *seq_state, *seq_input;      // [B x (ph+1) x nx], [B x (ph+1) x nu]
+};
+
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq);
+void nlmpc_plan(NlmpcDev &m);           // fills nzu, nr, lds_per_wave, ws from the dimensions
 int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream);
+int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream);
 
 }  // namespace mpcx

@@ -1,16 +1,25 @@
-// NLMPC transcription kernels for gfx950: what libmpc++ evaluates inside every NLopt SLSQP callback
-// (reference include/mpc/NLMPC/NLOptimizer.hpp:760-997 -> Objective.hpp:91-265, Constraints.hpp:211-316,
-// 490-905, Mapping.hpp:174-211), for a batch of decision vectors, one instance per wavefront:
-//   - unwrap z into (X, U, slack) with move blocking                       (Mapping::unwrapVector)
-//   - cost + forward-difference gradient, with the reference's step quirk  (Objective::computeGradient)
-//   - dynamics equalities (trapezoidal collocation or one-step) + central-difference blocks A_i, B_i
-//                                                                          (getStateEqConstraints)
-//   - user inequalities + central-difference Jacobian                      (computeIneqJacobian)
-// The user hooks of the reference are host std::function objects (IDimensionable.hpp:94-149) which a
-// kernel cannot call; here they are device functors compiled into the library (a small model zoo with
-// the reference's example systems), selected by id.  Every finite-difference column is an independent
-// re-evaluation of a whole-horizon function: lanes own columns, the unwrapped trajectory sits in the
-// wave's LDS slice and perturbations are applied on the fly by the accessor.
+// NLMPC kernels for gfx950, one instance per wavefront.
+//
+// (1) nlmpc_evaluate: what libmpc++ evaluates inside every NLopt SLSQP callback
+//     (reference include/mpc/NLMPC/NLOptimizer.hpp:760-997 -> Objective.hpp:91-265, Constraints.hpp:211-316,
+//     490-905, Mapping.hpp:174-211) for a batch of decision vectors:
+//       - unwrap z into (X, U, slack) with move blocking                       (Mapping::unwrapVector)
+//       - cost + forward-difference gradient, with the reference's step quirk  (Objective::computeGradient)
+//       - dynamics equalities (trapezoidal collocation or one-step) + central-difference blocks
+//                                                                              (getStateEqConstraints)
+//       - user inequalities + central-difference Jacobian                      (computeIneqJacobian)
+// (2) nlmpc_sqp: the optimisation NLOptimizer::run (NLOptimizer.hpp:412-638) hands to nlopt LD_SLSQP, as a
+//     sequential quadratic programme on the same transcription: the dynamics equalities are eliminated by a
+//     forward sweep over their block-bidiagonal Jacobian (condensing), the quadratic sub-problem lives in the
+//     move-blocked inputs (+ slack), its Hessian is a damped BFGS estimate kept in inverse form, it is solved by
+//     a dual active-set method (Goldfarb-Idnani, range-space form on that inverse), and the step is globalised by
+//     a backtracking search on an l1 merit function whose trial points are evaluated by the lanes in parallel.
+//
+// The user hooks of the reference are host std::function objects (IDimensionable.hpp:94-149) which a kernel
+// cannot call; here they are device functors compiled into the library (the reference's example systems),
+// selected by id.  Every finite-difference column is an independent re-evaluation of a whole-horizon function:
+// lanes own columns, the unwrapped trajectory sits in the wave's LDS slice and perturbations are applied on the
+// fly by the accessor.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -25,6 +34,25 @@ __device__ __forceinline__ void nl_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// largest value and the lowest lane-supplied index holding it
+__device__ __forceinline__ void wave_argmax(double &v, int &idx)
+{
+    for (int o = 32; o; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
 
 // (ph+1) x n matrix in LDS, row-major, with up to two perturbed elements of one column
 struct Pert {
@@ -37,31 +65,40 @@ struct Pert {
         return (j == c && (i == r1 || i == r2)) ? v + d : v;
     }
 };
+// M + a * D: a trial point of the line search
+struct Lin {
+    const double *M, *D;
+    int n;
+    double a;
+    __device__ __forceinline__ double operator()(int i, int j) const { return M[i * n + j] + a * D[i * n + j]; }
+};
 
 // ---- model zoo ----------------------------------------------------------------------------------
 struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
     static constexpr int NX = 2, NU = 1;
     static constexpr bool CONTINUOUS = true;
-    __device__ static int nineq(int ph) { return ph + 1; }
+    __host__ __device__ static int nineq(int ph) { return ph + 1; }
     __device__ static void f(double *dx, const double *x, const double *u, const double *)
     {
         dx[0] = ((1.0 - (x[1] * x[1])) * x[0]) - x[1] + u[0];
         dx[1] = x[0];
     }
-    __device__ static double cost(const Pert &X, const Pert &U, double, int ph, const double *)
+    template <class XA, class UA>
+    __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
     {
         double s = 0;
         for (int i = 0; i <= ph; ++i) { s += X(i, 0) * X(i, 0) + X(i, 1) * X(i, 1); s += U(i, 0) * U(i, 0); }
         return s;
     }
-    __device__ static double ineq(int k, const Pert &, const Pert &U, double, int, const double *) { return U(k, 0) - 0.5; }
+    template <class XA, class UA>
+    __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
 };
 
 struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
     static constexpr int NX = 4, NU = 2;
     static constexpr bool CONTINUOUS = false;
     // params: [0..1] v_pref, [2..4] obstacle 0 (x, y, r), [5..7] obstacle 1, [8] Ts
-    __device__ static int nineq(int ph) { return 2 * (ph + 1); }
+    __host__ __device__ static int nineq(int ph) { return 2 * (ph + 1); }
     __device__ static void f(double *xn, const double *x, const double *u, const double *p)
     {
         const double Ts = p[8];
@@ -70,7 +107,8 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
         xn[2] = x[2] + Ts * u[0];
         xn[3] = x[3] + Ts * u[1];
     }
-    __device__ static double cost(const Pert &X, const Pert &U, double e, int ph, const double *p)
+    template <class XA, class UA>
+    __device__ static double cost(const XA &X, const UA &U, double e, int ph, const double *p)
     {
         double s = 0;
         for (int i = 0; i <= ph; ++i) {
@@ -80,7 +118,8 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
         }
         return s + 1e-5 * e * e;
     }
-    __device__ static double ineq(int k, const Pert &X, const Pert &, double, int, const double *p)
+    template <class XA, class UA>
+    __device__ static double ineq(int k, const XA &X, const UA &, double, int, const double *p)
     {
         const int i = k >> 1, o = k & 1;
         const double dx = X(i, 0) - p[2 + 3 * o], dy = X(i, 1) - p[3 + 3 * o];
@@ -88,193 +127,703 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
     }
 };
 
+template <int N>
+struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
+    static constexpr int NX = 2 * N, NU = N;
+    static constexpr bool CONTINUOUS = true;
+    __host__ __device__ static int nineq(int ph) { return (ph + 1) * N; }
+    __device__ static void f(double *dx, const double *x, const double *u, const double *p)
+    {
+        const double mu = p[0], k = p[1];
+        for (int i = 0; i < N; ++i) {
+            dx[2 * i] = x[2 * i + 1];
+            double a = mu * (1 - x[2 * i] * x[2 * i]) * x[2 * i + 1] - x[2 * i] + u[i];
+            for (int j = 0; j < N; ++j)
+                if (i != j) a += k * (x[2 * j] - x[2 * i]);
+            dx[2 * i + 1] = a;
+        }
+    }
+    template <class XA, class UA>
+    __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
+    {
+        double s = 0;
+        for (int i = 0; i <= ph; ++i) {
+            for (int j = 0; j < NX; ++j) s += X(i, j) * X(i, j);
+            for (int j = 0; j < NU; ++j) s += U(i, j) * U(i, j);
+        }
+        return s;
+    }
+    template <class XA, class UA>
+    __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }
+};
+
+constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
+
+// Mapping::unwrapVector (scalings are 1 for the zoo models)
+template <class Mdl>
+__device__ __forceinline__ void unwrap(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, int lane)
+{
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int ph = M.ph, ch = M.ch;
+    for (int k = lane; k < (ph + 1) * NX; k += 64) {
+        const int i = k / NX, j = k - i * NX;
+        Xs[k] = i == 0 ? x0[j] : z[(i - 1) * NX + j];
+    }
+    for (int k = lane; k < (ph + 1) * NU; k += 64) {
+        const int i = k / NU, j = k - i * NU;
+        const int blk = min(min(i, ph - 1), ch - 1);          // first ch-1 moves one step each, the last one held
+        Us[k] = z[ph * NX + blk * NU + j];
+    }
+    nl_wave_sync();
+}
+
+// the transcription of one instance; any output may be null.  Xs/Us/Jm: this wave's LDS.
+template <class Mdl>
+__device__ void eval_instance(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, double *Jm, int lane,
+                              double *cost, double *grad, double *ceq, double *jeq, double *cineq, double *jineq)
+{
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
+    const double dv = kDv;
+    const double *prm = M.params;
+    unwrap<Mdl>(M, z, x0, Xs, Us, lane);
+    const double e = z[nz - 1];
+    auto Xa = [&](int j) { const double v = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
+    auto Ua = [&](int j) { const double v = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
+    const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
+
+    // ---- Objective::evaluate + computeGradient
+    if (cost || grad) {
+        const double f0 = Mdl::cost(X0, U0, e, ph, prm);
+        if (lane == 0 && cost) *cost = f0;
+        if (grad) {
+            double *g = grad;
+            for (int k = lane; k < ph * NX; k += 64) {
+                const int i = k / NX, j = k - i * NX;
+                const double dx = dv * Xa(j);
+                const Pert Xp{Xs, NX, i + 1, -1, j, dx};
+                g[k] = (Mdl::cost(Xp, U0, e, ph, prm) - f0) / dx;
+            }
+            for (int k = lane; k < ph * NU; k += 64) {
+                const int i = k / NU, j = k - i * NU;
+                const double du = dv * Ua(j);
+                const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du};     // the last row moves with its copy
+                Jm[k] = (Mdl::cost(X0, Up, e, ph, prm) - f0) / du;
+            }
+            nl_wave_sync();
+            for (int k = lane; k < ch * NU; k += 64) {
+                const int bl = k / NU, j = k - bl * NU;
+                double s = 0;
+                for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
+                g[ph * NX + k] = s;                                        // Iz2u' * vec(Jmv)
+            }
+            if (lane == 0) {
+                const double de = fmax(dv, fabs(e)) * dv;
+                g[nz - 1] = (Mdl::cost(X0, U0, e + de, ph, prm) - Mdl::cost(X0, U0, e - de, ph, prm)) / (2 * de);
+            }
+            nl_wave_sync();
+        }
+    }
+
+    // ---- Constraints::getStateEqConstraints: value and the blocks [dc/dx_i | dc/dx_{i+1} | dc/du_i]
+    if (ceq || jeq) {
+        const double h = 0.5 * M.Ts;
+        const int W = 2 * NX + NU;
+        for (int k = lane; k < ph * (W + 1); k += 64) {
+            const int i = k / (W + 1), c = k - i * (W + 1);     // c = 0: value; 1..: one Jacobian column
+            double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
+            for (int a = 0; a < NX; ++a) { xk[a] = Xs[i * NX + a]; xk1[a] = Xs[(i + 1) * NX + a]; }
+            for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
+            if (c == 0) {
+                if (!ceq) continue;
+                double *cv = ceq + i * NX;
+                Mdl::f(fa, xk, uk, prm);
+                if (Mdl::CONTINUOUS) {
+                    Mdl::f(fb, xk1, uk, prm);
+                    for (int a = 0; a < NX; ++a) cv[a] = xk[a] + (h * (fa[a] + fb[a])) - xk1[a];
+                } else {
+                    for (int a = 0; a < NX; ++a) cv[a] = xk1[a] - fa[a];
+                }
+                continue;
+            }
+            if (!jeq) continue;
+            double *J = jeq + (size_t)i * NX * W;          // [NX x W] row-major block of step i
+            const int col = c - 1;
+            auto cdiff = [&](const double *xx, const double *uu, int v, bool isu, double *out) {
+                double xp[NX], up[NU], f1[NX], f2[NX];
+                for (int a = 0; a < NX; ++a) xp[a] = xx[a];
+                for (int a = 0; a < NU; ++a) up[a] = uu[a];
+                const double base = isu ? uu[v] : xx[v];
+                const double d = dv * fmax(fabs(base), 1.0);
+                if (isu) up[v] = base + d; else xp[v] = base + d;
+                Mdl::f(f1, xp, up, prm);
+                if (isu) up[v] = base - d; else xp[v] = base - d;
+                Mdl::f(f2, xp, up, prm);
+                for (int a = 0; a < NX; ++a) out[a] = (f1[a] - f2[a]) / (2 * d);
+            };
+            double dcol[NX];
+            if (col < NX) {                    // d c_i / d x_i  (not a decision variable for i = 0: kept for the caller to drop)
+                cdiff(xk, uk, col, false, dcol);
+                for (int a = 0; a < NX; ++a)
+                    J[a * W + col] = Mdl::CONTINUOUS ? ((a == col ? 1.0 : 0.0) + h * dcol[a]) : -dcol[a];
+            } else if (col < 2 * NX) {         // d c_i / d x_{i+1}
+                const int v = col - NX;
+                if (Mdl::CONTINUOUS) {
+                    cdiff(xk1, uk, v, false, dcol);
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? -1.0 : 0.0) + h * dcol[a];
+                } else {
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? 1.0 : 0.0);
+                }
+            } else {                           // d c_i / d u_i
+                const int v = col - 2 * NX;
+                cdiff(xk, uk, v, true, dcol);
+                if (Mdl::CONTINUOUS) {
+                    double d2[NX];
+                    cdiff(xk1, uk, v, true, d2);
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = h * (dcol[a] + d2[a]);
+                } else {
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = -dcol[a];
+                }
+            }
+        }
+    }
+
+    // ---- Constraints::evaluateIneq + computeIneqJacobian (dense [nineq x nz], row-major)
+    if (cineq)
+        for (int k = lane; k < nineq; k += 64) cineq[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
+    if (jineq) {
+        double *J = jineq;
+        for (int k = lane; k < nz; k += 64) {
+            if (k < ph * NX) {
+                const int i = k / NX, j = k - i * NX;
+                const double dx = dv * Xa(j);
+                const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
+                for (int r = 0; r < nineq; ++r)
+                    J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx);
+            } else if (k < nz - 1) {
+                const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
+                const double du = dv * Ua(j);
+                for (int r = 0; r < nineq; ++r) {
+                    double s = 0;
+                    for (int i = 0; i < ph; ++i) {          // every input row of the block on its own (no pairing here)
+                        if (min(i, ch - 1) != bl) continue;
+                        const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
+                        s += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
+                    }
+                    J[(size_t)r * nz + k] = s;
+                }
+            } else {
+                const double de = fmax(dv, fabs(e)) * dv;
+                for (int r = 0; r < nineq; ++r)
+                    J[(size_t)r * nz + k] = (Mdl::ineq(r, X0, U0, e + de, ph, prm) - Mdl::ineq(r, X0, U0, e - de, ph, prm)) / (2 * de);
+            }
+        }
+    }
+    nl_wave_sync();
+}
+
 template <class Mdl>
 __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const NlmpcBatchDev Bt)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
-    const double dv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
+    const int ph = M.ph, nz = M.nz;
     double *Xs = smem + (size_t)wave * M.lds_per_wave;  // (ph+1) x NX
     double *Us = Xs + (ph + 1) * NX;                    // (ph+1) x NU
     double *Jm = Us + (ph + 1) * NU;                    // ph x NU scratch (gradient wrt the input rows)
-    const double *prm = M.params;
-
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb) {
-        const double *z = Bt.z + (size_t)b * nz;
-        // ---- Mapping::unwrapVector (scalings are 1 for the zoo models)
-        for (int k = lane; k < (ph + 1) * NX; k += 64) {
-            const int i = k / NX, j = k - i * NX;
-            Xs[k] = i == 0 ? Bt.x0[(size_t)b * NX + j] : z[(i - 1) * NX + j];
-        }
-        for (int k = lane; k < (ph + 1) * NU; k += 64) {
-            const int i = k / NU, j = k - i * NU;
-            const int blk = min(min(i, ph - 1), ch - 1);          // first ch-1 moves one step each, the last one held
-            Us[k] = z[ph * NX + blk * NU + j];
+        auto at = [&](double *p, size_t stride) { return p ? p + (size_t)b * stride : nullptr; };
+        eval_instance<Mdl>(M, Bt.z + (size_t)b * nz, Bt.x0 + (size_t)b * NX, Xs, Us, Jm, lane, at(Bt.cost, 1), at(Bt.grad, nz),
+                           at(Bt.ceq, M.neq), at(Bt.jeq, (size_t)ph * NX * (2 * NX + NU)), at(Bt.cineq, M.nineq),
+                           at(Bt.jineq, (size_t)M.nineq * nz));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SQP
+// ---------------------------------------------------------------------------------------------------
+// Dense symmetric positive definite solve in LDS: S [n x ld] (destroyed), rhs t -> solution in t.  n <= 32.
+__device__ void spd_solve(double *S, int ld, double *t, int n, int lane)
+{
+    for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
+        const double piv = S[k * ld + k];
+        if (lane > k && lane < n) {
+            const double fct = S[lane * ld + k] / piv;
+            for (int j = k + 1; j < n; ++j) S[lane * ld + j] -= fct * S[k * ld + j];
+            t[lane] -= fct * t[k];
         }
         nl_wave_sync();
-        const double e = z[nz - 1];
-        auto Xa = [&](int j) { const double v = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
-        auto Ua = [&](int j) { const double v = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
-        const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
+    }
+    for (int k = n - 1; k >= 0; --k) {      // back substitution
+        if (lane == 0) t[k] /= S[k * ld + k];
+        nl_wave_sync();
+        if (lane < k) t[lane] -= S[lane * ld + k] * t[k];
+        nl_wave_sync();
+    }
+}
 
-        // ---- Objective::evaluate + computeGradient
-        if (Bt.cost || Bt.grad) {
-            const double f0 = Mdl::cost(X0, U0, e, ph, prm);
-            if (lane == 0 && Bt.cost) Bt.cost[b] = f0;
-            if (Bt.grad) {
-                double *g = Bt.grad + (size_t)b * nz;
-                for (int k = lane; k < ph * NX; k += 64) {
-                    const int i = k / NX, j = k - i * NX;
-                    const double dx = dv * Xa(j);
-                    const Pert Xp{Xs, NX, i + 1, -1, j, dx};
-                    g[k] = (Mdl::cost(Xp, U0, e, ph, prm) - f0) / dx;
+// In-place Gauss-Jordan inverse of an n x n matrix held as [n x 2n] = [E | I] in LDS, partial pivoting.
+__device__ void invert_small(double *Aug, int n, int lane)
+{
+    const int w = 2 * n;
+    for (int k = 0; k < n; ++k) {
+        int pr = k; double best = fabs(Aug[k * w + k]);
+        for (int i = k + 1; i < n; ++i) { const double v = fabs(Aug[i * w + k]); if (v > best) { best = v; pr = i; } }
+        if (pr != k) for (int j = lane; j < w; j += 64) { const double a = Aug[k * w + j]; Aug[k * w + j] = Aug[pr * w + j]; Aug[pr * w + j] = a; }
+        nl_wave_sync();
+        const double inv = 1.0 / Aug[k * w + k];
+        nl_wave_sync();
+        for (int j = lane; j < w; j += 64) Aug[k * w + j] *= inv;
+        nl_wave_sync();
+        for (int q = lane; q < n * w; q += 64) {
+            const int i = q / w, j = q - i * w;
+            if (i == k || j == k) continue;                 // column k last: its entries are the multipliers
+            Aug[q] -= Aug[i * w + k] * Aug[k * w + j];
+        }
+        nl_wave_sync();
+        for (int i = lane; i < n; i += 64) if (i != k) Aug[i * w + k] = 0.0;
+        nl_wave_sync();
+    }
+}
+
+template <class Mdl>
+__global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
+{
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KW = kNlMaxWorking, SLD = KW + 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const int ph = M.ph, ch = M.ch, nz = M.nz, m = M.nineq, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
+    const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
+    const int mld = (m + 1) & ~1;
+    const double *prm = M.params;
+    double *Xs = smem + (size_t)wave * M.lds_per_wave;
+    double *Us = Xs + (ph + 1) * NX;
+    double *dXs = Us + (ph + 1) * NU;
+    double *dUs = dXs + (ph + 1) * NX;
+    double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
+    double *Ssm = Jm + ph * NU;                           // KW x SLD   working-set Schur complement
+    double *Sfac = Ssm + KW * SLD;                        // KW x SLD   copy that the solve destroys
+    double *tq = Sfac + KW * SLD;                         // KW
+    double *uq = tq + KW;                                 // KW  multipliers of the working set
+    double *wq = uq + KW;                                 // KW  row numbers (as doubles)
+    double *aug = wq + KW;                                // NX x 2NX
+    double *v0 = aug + NX * 2 * NX;                       // 4 vectors of nr
+    double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
+
+    for (int b = blockIdx.x * wpb + wave; b < S.batch; b += gridDim.x * wpb) {
+        double *w = S.ws + (size_t)b * M.ws.total;
+        double *z = w + M.ws.z, *d = w + M.ws.d, *g = w + M.ws.g, *c = w + M.ws.c, *jeq = w + M.ws.jeq, *gin = w + M.ws.gin,
+               *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
+               *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
+               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *scal = w + M.ws.scal;
+        const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
+
+        // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
+        if (S.z_warm) {
+            const double *zw = S.z_warm + (size_t)b * nz;
+            for (int k = lane; k < nxs; k += 64) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
+            for (int k = lane; k < nzu; k += 64) {
+                const int bl = k / NU, j = k - bl * NU;
+                const int step = min(bl + 1, ph - 1);                       // first step of the block, shifted by one
+                z[nxs + k] = zw[nxs + min(step, ch - 1) * NU + j];
+            }
+            if (lane == 0) z[nz - 1] = zw[nz - 1];
+        } else {
+            for (int k = lane; k < nxs; k += 64) z[k] = x0[k % NX];
+            for (int k = lane; k < nzu; k += 64) z[nxs + k] = u0[k % NU];
+            if (lane == 0) z[nz - 1] = 0.0;
+        }
+        for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
+        for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+        nl_wave_sync();
+        eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
+
+        double nu_pen = 0.0, a_prev = 0.0;
+        bool have_old = false;
+        int it = 0, code = 5;                               // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE
+        for (; it < S.max_iter; ++it) {
+            // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
+            if (Mdl::CONTINUOUS) {
+                for (int i = 0; i < ph; ++i) {
+                    for (int q = lane; q < NX * 2 * NX; q += 64) {
+                        const int a = q / (2 * NX), j = q - a * 2 * NX;
+                        aug[q] = j < NX ? jeq[(size_t)i * NX * W + a * W + NX + j] : (j - NX == a ? 1.0 : 0.0);
+                    }
+                    nl_wave_sync();
+                    invert_small(aug, NX, lane);
+                    for (int q = lane; q < NX * NX; q += 64) einv[(size_t)i * NX * NX + q] = aug[(q / NX) * 2 * NX + NX + q % NX];
+                    nl_wave_sync();
                 }
-                for (int k = lane; k < ph * NU; k += 64) {
-                    const int i = k / NU, j = k - i * NU;
-                    const double du = dv * Ua(j);
-                    const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du};     // the last row moves with its copy
-                    Jm[k] = (Mdl::cost(X0, Up, e, ph, prm) - f0) / du;
+            }
+            // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0
+            for (int q = lane; q <= nzu; q += 64) {
+                double v[NX], t[NX];
+                for (int a = 0; a < NX; ++a) v[a] = 0.0;
+                const int bq = q / NU, jq = q - bq * NU;
+                for (int i = 0; i < ph; ++i) {
+                    const double *Jb = jeq + (size_t)i * NX * W;
+                    for (int a = 0; a < NX; ++a) {
+                        double s = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
+                        for (int bb = 0; bb < NX; ++bb) s += Jb[a * W + bb] * v[bb];
+                        t[a] = s;
+                    }
+                    if (Mdl::CONTINUOUS) {
+                        const double *Ei = einv + (size_t)i * NX * NX;
+                        for (int a = 0; a < NX; ++a) {
+                            double s = 0;
+                            for (int bb = 0; bb < NX; ++bb) s += Ei[a * NX + bb] * t[bb];
+                            v[a] = -s;
+                        }
+                    } else {
+                        for (int a = 0; a < NX; ++a) v[a] = -t[a];
+                    }
+                    if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
+                    else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
+                }
+            }
+            nl_wave_sync();
+            // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
+            for (int q = lane; q < nr; q += 64) {
+                if (q == nzu) { gr[q] = g[nz - 1]; continue; }
+                double s = g[nxs + q];
+                for (int row = 0; row < nxs; ++row) s += phi[(size_t)row * nzu + q] * g[row];
+                gr[q] = s;
+            }
+            for (int q = lane; q < nr; q += 64) {
+                for (int k0 = 0; k0 < m; k0 += 16) {
+                    double acc[16];
+                    const int kn = min(16, m - k0);
+                    for (int t = 0; t < 16; ++t) acc[t] = t < kn ? jin[(size_t)(k0 + t) * nz + (q == nzu ? nz - 1 : nxs + q)] : 0.0;
+                    if (q < nzu)
+                        for (int row = 0; row < nxs; ++row) {
+                            const double ph_ = phi[(size_t)row * nzu + q];
+                            for (int t = 0; t < 16; ++t) if (t < kn) acc[t] += jin[(size_t)(k0 + t) * nz + row] * ph_;
+                        }
+                    for (int t = 0; t < kn; ++t) art[(size_t)q * mld + k0 + t] = acc[t];
+                }
+            }
+            for (int k = lane; k < m; k += 64) {
+                double s = gin[k];
+                for (int row = 0; row < nxs; ++row) s += jin[(size_t)k * nz + row] * r[row];
+                br[k] = s;
+            }
+            nl_wave_sync();
+
+            // ---- damped BFGS update of the inverse Hessian estimate (Powell), s = a p, y = change of the reduced Lagrangian gradient
+            if (have_old) {
+                double sBs = 0, sy = 0;
+                for (int q = lane; q < nq; q += 64) {
+                    double gl = gr[q];
+                    for (int k = 0; k < m; ++k) gl += art[(size_t)q * mld + k] * mu[k];
+                    const double y = gl - glold[q], Bs = -a_prev * glold[q];
+                    v0[q] = y; v1[q] = Bs;
+                    sBs += sv[q] * Bs; sy += sv[q] * y;
+                }
+                sBs = wave_sum(sBs); sy = wave_sum(sy);
+                if (sy < 0.2 * sBs) {
+                    const double th = 0.8 * sBs / (sBs - sy);
+                    for (int q = lane; q < nq; q += 64) v0[q] = th * v0[q] + (1 - th) * v1[q];
+                    sy = th * sy + (1 - th) * sBs;
                 }
                 nl_wave_sync();
-                for (int k = lane; k < ch * NU; k += 64) {
-                    const int bl = k / NU, j = k - bl * NU;
-                    double s = 0;
-                    for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
-                    g[ph * NX + k] = s;                                        // Iz2u' * vec(Jmv)
-                }
-                if (lane == 0) {
-                    const double de = fmax(dv, fabs(e)) * dv;
-                    g[nz - 1] = (Mdl::cost(X0, U0, e + de, ph, prm) - Mdl::cost(X0, U0, e - de, ph, prm)) / (2 * de);
+                if (sy > 1e-300) {
+                    const double rho = 1.0 / sy;
+                    double yHy = 0;
+                    for (int q = lane; q < nq; q += 64) {
+                        double s = 0;
+                        for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * v0[j];
+                        v2[q] = s; yHy += s * v0[q];
+                    }
+                    yHy = wave_sum(yHy);
+                    nl_wave_sync();
+                    const double cc = rho * rho * yHy + rho;
+                    for (int q = lane; q < nq; q += 64)
+                        for (int i = 0; i < nq; ++i)
+                            hinv[(size_t)i * nr + q] += -rho * (sv[i] * v2[q] + v2[i] * sv[q]) + cc * sv[i] * sv[q];
                 }
                 nl_wave_sync();
             }
-        }
 
-        // ---- Constraints::getStateEqConstraints: value and the blocks [dc/dx_i | dc/dx_{i+1} | dc/du_i]
-        if (Bt.ceq || Bt.jeq) {
-            const double h = 0.5 * M.Ts;
-            const int W = 2 * NX + NU;
-            for (int k = lane; k < ph * (W + 1); k += 64) {
-                const int i = k / (W + 1), c = k - i * (W + 1);     // c = 0: value; 1..: one Jacobian column
-                double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
-                for (int a = 0; a < NX; ++a) { xk[a] = Xs[i * NX + a]; xk1[a] = Xs[(i + 1) * NX + a]; }
-                for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
-                if (c == 0) {
-                    if (!Bt.ceq) continue;
-                    double *cv = Bt.ceq + (size_t)b * ph * NX + i * NX;
+            // ---- sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0   (Goldfarb-Idnani, range-space form on B^-1)
+            double *xq = v0, *np_ = v1, *vv = v2, *zd = v3;
+            for (int q = lane; q < nq; q += 64) {
+                double s = 0;
+                for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * gr[j];
+                xq[q] = -s;
+            }
+            for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+            nl_wave_sync();
+            int nw = 0; bool qp_ok = true, qp_done = false;
+            for (int qit = 0; qit < 8 * (m + nq) + 16; ++qit) {
+                double vmax = -1e300; int pidx = 0x7fffffff;
+                for (int k = lane; k < m; k += 64) {
+                    double s = br[k];
+                    for (int j = 0; j < nq; ++j) s += art[(size_t)j * mld + k] * xq[j];
+                    bool inw = false;
+                    for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
+                    if (!inw && s > vmax) { vmax = s; pidx = k; }
+                }
+                wave_argmax(vmax, pidx);
+                if (m == 0 || vmax <= 1e-10) { qp_done = true; break; }   // primal feasible: optimal
+                if (nw >= KW) { qp_ok = false; break; }
+                for (int q = lane; q < nq; q += 64) np_[q] = art[(size_t)q * mld + pidx];
+                nl_wave_sync();
+                double up = 0.0, sp = vmax;
+                bool added = false;
+                for (int inner = 0; inner <= KW + 1 && !added; ++inner) {
+                    for (int q = lane; q < nq; q += 64) {
+                        double s = 0;
+                        for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * np_[j];
+                        vv[q] = s;
+                    }
+                    nl_wave_sync();
+                    // t = N_W v (also the new column of S), rr = S^-1 t
+                    for (int t = lane; t < nw; t += 64) {
+                        double s = 0;
+                        for (int j = 0; j < nq; ++j) s += qn[(size_t)t * nr + j] * vv[j];
+                        tq[t] = s;
+                    }
+                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sfac[(e2 / nw) * SLD + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
+                    nl_wave_sync();
+                    double tcol = lane < nw ? tq[lane] : 0.0;          // keep N_W v: it becomes S[:, new]
+                    if (nw) spd_solve(Sfac, SLD, tq, nw, lane);
+                    double zn = 0;
+                    for (int q = lane; q < nq; q += 64) {
+                        double s = vv[q];
+                        for (int t = 0; t < nw; ++t) s -= qv[(size_t)t * nr + q] * tq[t];
+                        zd[q] = s; zn += s * np_[q];
+                    }
+                    zn = wave_sum(zn);
+                    double npn = 0;
+                    for (int q = lane; q < nq; q += 64) npn += np_[q] * np_[q];
+                    npn = wave_sum(npn);
+                    // dual ratio test
+                    double t1 = 1e300; int kdrop = -1;
+                    for (int t = 0; t < nw; ++t) {
+                        const double rr = tq[t];
+                        if (rr > 1e-14) { const double tj = uq[t] / rr; if (tj < t1) { t1 = tj; kdrop = t; } }
+                    }
+                    const bool can_move = zn > 1e-13 * fmax(1.0, npn);
+                    const double t2 = can_move ? sp / zn : 1e300;
+                    const double tt = fmin(t1, t2);
+                    if (tt >= 1e300) { qp_ok = false; break; }          // no step: the linearised constraints are inconsistent
+                    nl_wave_sync();
+                    if (can_move) {
+                        for (int q = lane; q < nq; q += 64) xq[q] -= tt * zd[q];
+                        sp -= tt * zn;
+                    }
+                    if (lane < nw) uq[lane] -= tt * tq[lane];
+                    up += tt;
+                    nl_wave_sync();
+                    if (t2 <= t1) {                                     // full step: the row joins the working set
+                        for (int q = lane; q < nq; q += 64) { qn[(size_t)nw * nr + q] = np_[q]; qv[(size_t)nw * nr + q] = vv[q]; }
+                        if (lane < nw) { Ssm[lane * SLD + nw] = tcol; Ssm[nw * SLD + lane] = tcol; }
+                        double snn = 0;
+                        for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
+                        snn = wave_sum(snn);
+                        if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; }
+                        ++nw; added = true;
+                    } else {                                            // a multiplier hit zero: that row leaves, try again
+                        const int last = nw - 1;
+                        if (kdrop != last) {
+                            for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
+                            nl_wave_sync();
+                            if (lane < nw) Ssm[lane * SLD + kdrop] = Ssm[lane * SLD + last];
+                            nl_wave_sync();
+                            if (lane < nw) Ssm[kdrop * SLD + lane] = Ssm[last * SLD + lane];
+                            nl_wave_sync();
+                            if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; }
+                        }
+                        --nw;
+                    }
+                    nl_wave_sync();
+                }
+                if (!qp_ok) break;
+                if (!added) { qp_ok = false; break; }
+            }
+            if (!qp_ok || !qp_done) { code = -1; break; }
+            for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = uq[t];
+            for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
+            nl_wave_sync();
+
+            // ---- full-space step d = [r + Phi p_u ; p]
+            double dmax = 0, cmax = 0, gd = 0, viol = 0;
+            for (int row = lane; row < nxs; row += 64) {
+                double s = r[row];
+                for (int q = 0; q < nzu; ++q) s += phi[(size_t)row * nzu + q] * p[q];
+                d[row] = s;
+            }
+            for (int q = lane; q < nr; q += 64) d[nxs + q] = p[q];
+            nl_wave_sync();
+            for (int k = lane; k < nz; k += 64) { dmax = fmax(dmax, fabs(d[k])); gd += g[k] * d[k]; }
+            for (int k = lane; k < nxs; k += 64) { cmax = fmax(cmax, fabs(c[k])); viol += fabs(c[k]); }
+            for (int k = lane; k < m; k += 64) viol += fmax(gin[k], 0.0);
+            dmax = wave_max(dmax); cmax = wave_max(cmax); gd = wave_sum(gd); viol = wave_sum(viol);
+            double zmax = 0;
+            for (int k = lane; k < nz; k += 64) zmax = fmax(zmax, fabs(z[k]));
+            zmax = wave_max(zmax);
+            if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) { code = 4; break; }
+
+            // new reduced Lagrangian gradient at this point with the new multipliers: BFGS memory and p'Bp
+            double pBp = 0;
+            for (int q = lane; q < nq; q += 64) {
+                double gl = gr[q];
+                for (int k = 0; k < m; ++k) gl += art[(size_t)q * mld + k] * mu[k];
+                glold[q] = gl; pBp -= p[q] * gl;
+            }
+            pBp = wave_sum(pBp);
+            if (viol > 1e-300) {
+                const double need = (gd + 0.5 * fmax(pBp, 0.0)) / (0.9 * viol);
+                if (need > nu_pen) nu_pen = 2 * need;
+            }
+            const double phi0 = scal[0] + nu_pen * viol;
+            const double dphi = fmin(gd - nu_pen * viol, 0.0);
+
+            // ---- line search: lane l tries a = 2^-l on the l1 merit function
+            unwrap<Mdl>(M, z, x0, Xs, Us, lane);
+            for (int k = lane; k < (ph + 1) * NX; k += 64) { const int i = k / NX; dXs[k] = i == 0 ? 0.0 : d[k - NX]; }
+            for (int k = lane; k < (ph + 1) * NU; k += 64) {
+                const int i = k / NU, j = k - i * NU;
+                dUs[k] = d[nxs + min(min(i, ph - 1), ch - 1) * NU + j];
+            }
+            nl_wave_sync();
+            double a_step;
+            {
+                const double al = ldexp(1.0, -min(lane, 40));
+                const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
+                const double et = z[nz - 1] + al * d[nz - 1];
+                double mer = Mdl::cost(XL, UL, et, ph, prm), vio = 0;
+                const double h = 0.5 * M.Ts;
+                for (int i = 0; i < ph; ++i) {
+                    double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
+                    for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
+                    for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
                     Mdl::f(fa, xk, uk, prm);
                     if (Mdl::CONTINUOUS) {
                         Mdl::f(fb, xk1, uk, prm);
-                        for (int a = 0; a < NX; ++a) cv[a] = xk[a] + (h * (fa[a] + fb[a])) - xk1[a];
+                        for (int a = 0; a < NX; ++a) vio += fabs(xk[a] + (h * (fa[a] + fb[a])) - xk1[a]);
                     } else {
-                        for (int a = 0; a < NX; ++a) cv[a] = xk1[a] - fa[a];
-                    }
-                    continue;
-                }
-                if (!Bt.jeq) continue;
-                double *J = Bt.jeq + ((size_t)b * ph + i) * NX * W;          // [NX x W] row-major block of step i
-                const int col = c - 1;
-                auto cdiff = [&](const double *xx, const double *uu, int v, bool isu, double *out) {
-                    double xp[NX], up[NU], f1[NX], f2[NX];
-                    for (int a = 0; a < NX; ++a) xp[a] = xx[a];
-                    for (int a = 0; a < NU; ++a) up[a] = uu[a];
-                    const double base = isu ? uu[v] : xx[v];
-                    const double d = dv * fmax(fabs(base), 1.0);
-                    if (isu) up[v] = base + d; else xp[v] = base + d;
-                    Mdl::f(f1, xp, up, prm);
-                    if (isu) up[v] = base - d; else xp[v] = base - d;
-                    Mdl::f(f2, xp, up, prm);
-                    for (int a = 0; a < NX; ++a) out[a] = (f1[a] - f2[a]) / (2 * d);
-                };
-                double dcol[NX];
-                if (col < NX) {                    // d c_i / d x_i  (not a decision variable for i = 0: kept for the caller to drop)
-                    cdiff(xk, uk, col, false, dcol);
-                    for (int a = 0; a < NX; ++a)
-                        J[a * W + col] = Mdl::CONTINUOUS ? ((a == col ? 1.0 : 0.0) + h * dcol[a]) : -dcol[a];
-                } else if (col < 2 * NX) {         // d c_i / d x_{i+1}
-                    const int v = col - NX;
-                    if (Mdl::CONTINUOUS) {
-                        cdiff(xk1, uk, v, false, dcol);
-                        for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? -1.0 : 0.0) + h * dcol[a];
-                    } else {
-                        for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? 1.0 : 0.0);
-                    }
-                } else {                           // d c_i / d u_i
-                    const int v = col - 2 * NX;
-                    cdiff(xk, uk, v, true, dcol);
-                    if (Mdl::CONTINUOUS) {
-                        double d2[NX];
-                        cdiff(xk1, uk, v, true, d2);
-                        for (int a = 0; a < NX; ++a) J[a * W + col] = h * (dcol[a] + d2[a]);
-                    } else {
-                        for (int a = 0; a < NX; ++a) J[a * W + col] = -dcol[a];
+                        for (int a = 0; a < NX; ++a) vio += fabs(xk1[a] - fa[a]);
                     }
                 }
+                for (int k = 0; k < m; ++k) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+                mer += nu_pen * vio;
+                const bool ok = lane <= 40 && mer <= phi0 + 1e-4 * al * dphi;
+                const unsigned long long bal = __ballot(ok);
+                if (!bal) {                                         // no decrease left within 2^-40: the iteration has stalled
+                    code = (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) ? 4 : -1;
+                    break;
+                }
+                a_step = ldexp(1.0, -(int)__builtin_ctzll(bal));
             }
+            for (int q = lane; q < nr; q += 64) sv[q] = a_step * p[q];
+            for (int k = lane; k < nz; k += 64) z[k] += a_step * d[k];
+            a_prev = a_step; have_old = true;
+            nl_wave_sync();
+            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
         }
 
-        // ---- Constraints::evaluateIneq + computeIneqJacobian (dense [nineq x nz], row-major)
-        if (Bt.cineq)
-            for (int k = lane; k < nineq; k += 64) Bt.cineq[(size_t)b * nineq + k] = Mdl::ineq(k, X0, U0, e, ph, prm);
-        if (Bt.jineq) {
-            double *J = Bt.jineq + (size_t)b * nineq * nz;
-            for (int k = lane; k < nz; k += 64) {
-                if (k < ph * NX) {
-                    const int i = k / NX, j = k - i * NX;
-                    const double dx = dv * Xa(j);
-                    const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
-                    for (int r = 0; r < nineq; ++r)
-                        J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx);
-                } else if (k < nz - 1) {
-                    const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
-                    const double du = dv * Ua(j);
-                    for (int r = 0; r < nineq; ++r) {
-                        double s = 0;
-                        for (int i = 0; i < ph; ++i) {          // every input row of the block on its own (no pairing here)
-                            if (min(i, ch - 1) != bl) continue;
-                            const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
-                            s += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
-                        }
-                        J[(size_t)r * nz + k] = s;
-                    }
-                } else {
-                    const double de = fmax(dv, fabs(e)) * dv;
-                    for (int r = 0; r < nineq; ++r)
-                        J[(size_t)r * nz + k] = (Mdl::ineq(r, X0, U0, e + de, ph, prm) - Mdl::ineq(r, X0, U0, e - de, ph, prm)) / (2 * de);
-                }
-            }
+        // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
+        double gmax = -1e300;
+        for (int k = lane; k < m; k += 64) gmax = fmax(gmax, gin[k]);
+        gmax = wave_max(gmax);
+        unwrap<Mdl>(M, z, x0, Xs, Us, lane);
+        const bool failed = code < 0;
+        if (S.cmd) for (int j = lane; j < NU; j += 64) S.cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
+        if (S.z_out) for (int k = lane; k < nz; k += 64) S.z_out[(size_t)b * nz + k] = z[k];
+        if (S.seq_state) for (int k = lane; k < (ph + 1) * NX; k += 64) S.seq_state[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
+        if (S.seq_input) for (int k = lane; k < (ph + 1) * NU; k += 64) S.seq_input[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
+        if (lane == 0) {
+            if (S.cost) S.cost[b] = failed ? INFINITY : scal[0];
+            if (S.solver_status) S.solver_status[b] = code;
+            if (S.status) S.status[b] = code == 4 ? 0 : (code == 5 ? 1 : 3);         // SUCCESS / MAX_ITERATION / ERROR
+            if (S.is_feasible) S.is_feasible[b] = (m == 0 || gmax <= S.ieq_tol) ? 1 : 0;
+            if (S.iterations) S.iterations[b] = it;
         }
         nl_wave_sync();
+    }
+}
+
+template <class F>
+int dispatch_model(int model_id, F &&fn)
+{
+    switch (model_id) {
+    case 1: return fn(VanDerPol{});
+    case 2: return fn(Ugv{});
+    case 3: return fn(Oscillators<6>{});
+    case 4: return fn(Oscillators<8>{});
+    default: return -1;
     }
 }
 
 }  // namespace
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu)
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq)
 {
-    switch (model_id) {
-    case 1: *nx = VanDerPol::NX; *nu = VanDerPol::NU; return 0;
-    case 2: *nx = Ugv::NX; *nu = Ugv::NU; return 0;
-    default: return -1;
-    }
+    return dispatch_model(model_id, [&](auto mdl) {
+        using Mdl = decltype(mdl);
+        *nx = Mdl::NX; *nu = Mdl::NU; *nineq = Mdl::nineq(ph);
+        return 0;
+    });
+}
+
+void nlmpc_plan(NlmpcDev &m)
+{
+    const int nx = m.nx, nu = m.nu, ph = m.ph;
+    m.nzu = m.ch * nu; m.nr = m.nzu + 1;
+    m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
+    const int KW = kNlMaxWorking;
+    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + 2 * KW * (KW + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr + 1) & ~1;
+    int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
+    NlmpcWsLayout &w = m.ws;
+    const int mld = (m.nineq + 1) & ~1;
+    w.z = take(m.nz); w.d = take(m.nz); w.g = take(m.nz); w.c = take(m.neq); w.jeq = take(ph * nx * (2 * nx + nu));
+    w.gin = take(m.nineq); w.jin = take(m.nineq * m.nz);
+    w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
+    w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(m.nineq);
+    w.hinv = take(m.nr * m.nr); w.mu = take(m.nineq); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
+    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.scal = take(4);
+    w.total = o;
+}
+
+static int waves_per_block(const NlmpcDev &m)
+{
+    int wpb = (int)((64 * 1024) / (m.lds_per_wave * sizeof(double)));
+    return wpb > 4 ? 4 : wpb;
 }
 
 int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int wpb = 4;
+    const int wpb = waves_per_block(m);
+    if (wpb < 1) return -2;
     int blocks = (b.batch + wpb - 1) / wpb;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
     const size_t lds = (size_t)wpb * m.lds_per_wave * sizeof(double);
-    if (lds > 64 * 1024) return -2;
-    switch (m.model_id) {
-    case 1: hipLaunchKernelGGL(nlmpc_evaluate<VanDerPol>, dim3(blocks), dim3(wpb * 64), lds, s, m, b); break;
-    case 2: hipLaunchKernelGGL(nlmpc_evaluate<Ugv>, dim3(blocks), dim3(wpb * 64), lds, s, m, b); break;
-    default: return -1;
-    }
+    const int rc = dispatch_model(m.model_id, [&](auto mdl) {
+        using Mdl = decltype(mdl);
+        hipLaunchKernelGGL(nlmpc_evaluate<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, m, b);
+        return 0;
+    });
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int wpb = waves_per_block(m);
+    if (wpb < 1) return -2;
+    int blocks = (b.batch + wpb - 1) / wpb;
+    const size_t lds = (size_t)wpb * m.lds_per_wave * sizeof(double);
+    const int rc = dispatch_model(m.model_id, [&](auto mdl) {
+        using Mdl = decltype(mdl);
+        hipLaunchKernelGGL(nlmpc_sqp<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, m, b);
+        return 0;
+    });
+    if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

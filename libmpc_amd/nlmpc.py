@@ -17,7 +17,18 @@ import numpy as np
 from . import _capi
 from ._capi import check
 
-VANDERPOL, UGV = 1, 2
+VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8 = 1, 2, 3, 4
+
+
+def NLParameters(**kw) -> _capi.NLParams:
+    """mpc::NLParameters with the reference defaults (Types.hpp:99-144)."""
+    p = _capi.NLParams()
+    _capi.lib().mpcx_nlparams_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 class NLMPCEvaluator:
@@ -68,3 +79,62 @@ class NLMPCEvaluator:
             b = min(i, ch - 1)
             J[:, r, ph * nx + b * nu: ph * nx + (b + 1) * nu] += jb[:, i, :, 2 * nx:]
         return J
+
+
+class NLMPC(NLMPCEvaluator):
+    """Batched counterpart of `mpc::NLMPC<>` (reference include/mpc/NLMPC.hpp) for the built-in systems: the hooks
+    the reference takes as closures (`setStateSpaceFunction`, `setObjectiveFunction`, `setIneqConFunction`,
+    NLMPC.hpp:139-280) are fixed by `model`; `setOptimizerParameters` and `optimize` keep their meaning, and
+    `optimizeBatch` runs B instances of NLOptimizer::run (NLOptimizer.hpp:412-638) in one kernel launch."""
+
+    def setOptimizerParameters(self, p):
+        check(self._lib.mpcx_nlmpc_set_optimizer_parameters(self._h, C.byref(p)))
+        self._warm = bool(p.enable_warm_start)
+
+    def _closures_are_fixed(self, *_a, **_k):
+        raise RuntimeError("the system, objective and constraint functions of this controller are the built-in device "
+                           "functors of its model; host callables cannot run inside the kernel")
+    setStateSpaceFunction = setObjectiveFunction = setIneqConFunction = setEqConFunction = setOutputFunction = _closures_are_fixed
+
+    def make_batch(self, x0, u0, z_warm=None, sequences=False):
+        import torch
+        dev = torch.device("cuda", self.device)
+        x0 = x0.to(dev, torch.float64).contiguous(); u0 = u0.to(dev, torch.float64).contiguous()
+        B = x0.shape[0]
+        assert x0.shape == (B, self.nx) and u0.shape == (B, self.nu)
+        f = lambda *sh: torch.empty((B,) + sh, dtype=torch.float64, device=dev)
+        i = lambda: torch.empty(B, dtype=torch.int32, device=dev)
+        out = dict(cmd=f(self.nu), cost=f(), status=i(), solver_status=i(), is_feasible=i(), iterations=i(), z=f(self.nz))
+        if sequences:
+            out["seq_state"] = f(self.ph + 1, self.nx); out["seq_input"] = f(self.ph + 1, self.nu)
+        zw = None if z_warm is None else z_warm.to(dev, torch.float64).contiguous()
+        b = _capi.NlmpcBatch(batch=B, x0=x0.data_ptr(), u0=u0.data_ptr(), z_warm=None if zw is None else zw.data_ptr(),
+                             **{k: v.data_ptr() for k, v in out.items()})
+        out["_keep"] = (x0, u0, zw)
+        return b, out
+
+    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None):
+        import torch
+        b, out = self.make_batch(x0, u0, z_warm, sequences)
+        s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if stream is None else stream
+        check(self._lib.mpcx_nlmpc_solve_batch(self._h, C.byref(b), s))
+        return out
+
+    def time_launches(self, b, repeats, stream=None):
+        import torch
+        s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if stream is None else stream
+        ms = C.c_float()
+        check(self._lib.mpcx_nlmpc_time_solve_batch(self._h, C.byref(b), s, int(repeats), C.byref(ms)))
+        return ms.value
+
+    def optimize(self, x0, u0):
+        """mpc::NLMPC::optimize(x0, lastU) (IMPC.hpp:154) through the batched kernel with B = 1; carries the previous
+        solution as the next initial guess when enable_warm_start is set, as NLOptimizer does."""
+        import torch
+        x0 = torch.as_tensor(np.asarray(x0, float)).reshape(1, -1); u0 = torch.as_tensor(np.asarray(u0, float)).reshape(1, -1)
+        zw = getattr(self, "_zprev", None) if getattr(self, "_warm", False) else None
+        r = self.optimizeBatch(x0, u0, z_warm=zw, sequences=True)
+        torch.cuda.synchronize()
+        if int(r["status"][0]) != 3:
+            self._zprev = r["z"]
+        return r

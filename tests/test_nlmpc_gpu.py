@@ -74,3 +74,93 @@ def test_partial_outputs_and_empty_batch():
     assert abs(o["cost"][0].item() - m.objective(np.zeros(m.nz), False)[0]) < 1e-12
     o = ev.evaluate(z[:0], x0[:0])
     assert o["cost"].shape == (0,)
+
+
+# ---- the SQP solve (rows a21-a23) --------------------------------------------------------------------------------
+# Tolerance: both sides differentiate by finite differences (forward, step 1.5e-8) and stall at that noise floor; the
+# oracle (scipy SLSQP on the restated callbacks) itself stops with "positive directional derivative" there.  u* is
+# compared at 2e-5 relative, the optimal cost at 1e-8 relative.
+def _solve_case(name, kw, X0, U0, hard, max_iter):
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV
+    c = NLMPC(VANDERPOL if name == "vanderpol" else UGV, kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+    c.setOptimizerParameters(NLParameters(maximum_iteration=max_iter, hard_constraints=int(hard)))
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), sequences=True)
+    torch.cuda.synchronize()
+    return c, {k: v.cpu().numpy() for k, v in r.items() if k != "_keep"}
+
+
+def test_vanderpol_solve_matches_oracle():
+    kw = dict(ph=10, ch=5, Ts=0.1)
+    rng = np.random.default_rng(11)
+    B = 24
+    X0 = rng.uniform(-1.0, 1.0, size=(B, 2)); X0[0] = [0.0, 1.0]          # examples/vanderpol_ex.cpp:67
+    U0 = np.zeros((B, 1))
+    c, r = _solve_case("vanderpol", kw, X0, U0, True, 200)
+    assert (r["status"] == 0).all(), (r["status"], r["solver_status"], r["iterations"])
+    m = ref.vanderpol(**kw)
+    compared = 0
+    for b in range(B):
+        o = m.solve(X0[b], U0[b], max_iter=1000)
+        if not o["success"]:            # scipy's SLSQP gives up on some starts (infeasible end point): nothing to compare with
+            assert np.abs(m.state_eq(o["z"], False)[0]).max() > 1e-6
+            continue
+        compared += 1
+        assert abs(r["cost"][b] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"]))
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r["seq_state"][b], o["X"], atol=2e-5)
+        assert r["is_feasible"][b] == 1 and (r["seq_input"][b] <= 0.5 + 1e-9).all()
+    assert compared >= B - 2
+
+
+def test_ugv_solve_matches_oracle():
+    kw = dict(ph=30, ch=30)
+    rng = np.random.default_rng(1)
+    B = 6
+    X0 = np.zeros((B, 4)); X0[1:, :2] = rng.uniform(-0.5, 0.5, size=(B - 1, 2))
+    U0 = np.zeros((B, 2))
+    c, r = _solve_case("ugv", kw, X0, U0, False, 150)
+    m = ref.ugv(**kw)
+    assert (r["status"] != 3).all(), (r["status"], r["solver_status"], r["iterations"])
+    for b in range(B):
+        o = m.solve(X0[b], U0[b], max_iter=100, hard=False)
+        assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * abs(o["cost"]), (b, r["cost"][b], o["cost"])
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=2e-5, atol=2e-5)
+
+
+def test_solution_satisfies_kkt_at_scale():
+    """size-independent properties on a full batch: dynamics defects ~ 0, inequalities respected, cost not above cold start"""
+    import torch
+    kw = dict(ph=30, ch=30)
+    rng = np.random.default_rng(5)
+    B = 512
+    X0 = np.zeros((B, 4)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    U0 = np.zeros((B, 2))
+    c, r = _solve_case("ugv", kw, X0, U0, False, 150)
+    ok = r["status"] != 3
+    assert ok.mean() > 0.98, ok.mean()
+    ev = c.evaluate(torch.from_numpy(r["z"]), torch.from_numpy(X0), grad=False, eq_jac=False, ineq_jac=False)
+    assert ev["ceq"].abs().max().item() < 1e-7
+    assert ev["cineq"][torch.from_numpy(ok).cuda()].max().item() < 1e-7
+    z0 = np.concatenate([np.tile(X0, (1, 30)), np.zeros((B, 61))], axis=1)
+    f0 = c.evaluate(torch.from_numpy(z0), torch.from_numpy(X0), grad=False, eq=False, eq_jac=False, ineq=False, ineq_jac=False)["cost"]
+    assert (ev["cost"] <= f0)[torch.from_numpy(ok).cuda()].all()
+
+
+def test_warm_start_reproduces_and_is_cheaper():
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL
+    c = NLMPC(VANDERPOL, 10, 5, 0.1)
+    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+    x0 = torch.tensor([[0.0, 1.0]] * 4, dtype=torch.float64); u0 = torch.zeros(4, 1, dtype=torch.float64)
+    a = c.optimizeBatch(x0, u0)
+    # plant step as in the example's closed loop (vanderpol_ex.cpp:76-85), then re-solve from the shifted solution
+    x = x0.cuda(); u = a["cmd"]
+    dx = torch.stack([(1 - x[:, 1] ** 2) * x[:, 0] - x[:, 1] + u[:, 0], x[:, 0]], dim=1)
+    x1 = x + 0.1 * dx
+    cold = c.optimizeBatch(x1, u)
+    warm = c.optimizeBatch(x1, u, z_warm=a["z"])
+    torch.cuda.synchronize()
+    assert (warm["status"] == 0).all() and (cold["status"] == 0).all()
+    np.testing.assert_allclose(warm["cmd"].cpu().numpy(), cold["cmd"].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert warm["iterations"].float().mean().item() <= cold["iterations"].float().mean().item()
