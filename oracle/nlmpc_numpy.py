@@ -255,3 +255,26 @@ def ugv(ph=30, ch=30, v_pref=(0.7071067811865476, 0.7071067811865476)):
         return g.reshape(-1)
     m.ineq_fun = ineq
     return m
+
+
+def oscillators(N=6, ph=20, ch=10, Ts=0.1, mu=1.0, k=0.1):
+    """examples/networked_oscillators_ex.cpp:5-76: N Van der Pol oscillators with diffusive coupling k, continuous
+    time, cost sum x^2 + sum u^2, u_ij <= 0.5 on every step"""
+    m = NlmpcRef(2 * N, N, 2 * N, ph, ch, (ph + 1) * N)
+    m.continuous = True; m.Ts = Ts
+
+    def f(x, u, p):
+        dx = np.zeros(2 * N)
+        pos = x[0::2]
+        for i in range(N):
+            dx[2 * i] = x[2 * i + 1]
+            a = mu * (1 - x[2 * i] * x[2 * i]) * x[2 * i + 1] - x[2 * i] + u[i]
+            for j in range(N):
+                if i != j:
+                    a += k * (pos[j] - x[2 * i])
+            dx[2 * i + 1] = a
+        return dx
+    m.f = f
+    m.cost = lambda X, Y, U, e: np.sum(X * X) + np.sum(U * U)
+    m.ineq_fun = lambda X, Y, U, e: (U - 0.5).reshape(-1)
+    return m

@@ -10,13 +10,17 @@ pytestmark = pytest.mark.gpu
 
 def _cases():
     return [("vanderpol", dict(ph=10, ch=5, Ts=0.1)), ("vanderpol", dict(ph=10, ch=10, Ts=0.1)),
-            ("vanderpol", dict(ph=7, ch=3, Ts=0.05)), ("ugv", dict(ph=30, ch=30)), ("ugv", dict(ph=12, ch=4))]
+            ("vanderpol", dict(ph=7, ch=3, Ts=0.05)), ("ugv", dict(ph=30, ch=30)), ("ugv", dict(ph=12, ch=4)),
+            ("osc6", dict(ph=20, ch=10, Ts=0.1)), ("osc8", dict(ph=6, ch=3, Ts=0.1))]
 
 
 def _make(name, kw):
-    from libmpc_amd.nlmpc import NLMPCEvaluator, VANDERPOL, UGV
+    from libmpc_amd.nlmpc import NLMPCEvaluator, VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8
     if name == "vanderpol":
         return ref.vanderpol(**kw), NLMPCEvaluator(VANDERPOL, kw["ph"], kw["ch"], kw["Ts"])
+    if name.startswith("osc"):
+        n = int(name[3:])
+        return ref.oscillators(N=n, **kw), NLMPCEvaluator(OSCILLATORS6 if n == 6 else OSCILLATORS8, kw["ph"], kw["ch"], kw["Ts"])
     return ref.ugv(**kw), NLMPCEvaluator(UGV, kw["ph"], kw["ch"], 0.1)
 
 
@@ -26,7 +30,7 @@ def test_transcription_matches_oracle(name, kw):
     m, ev = _make(name, kw)
     assert (ev.nz, ev.neq, ev.nineq) == (m.nz, m.ph * m.nx, m.ineq)
     rng = np.random.default_rng(7)
-    B = 9
+    B = 9 if m.nz < 100 else 3
     Z = rng.normal(scale=1.5, size=(B, m.nz)); Z[:, -1] = rng.normal(scale=0.1, size=B)
     Z[0] = 0.0                                    # cold-start point: all finite-difference steps at their floor
     X0 = rng.normal(size=(B, m.nx))
@@ -82,8 +86,8 @@ def test_partial_outputs_and_empty_batch():
 # compared at 2e-5 relative, the optimal cost at 1e-8 relative.
 def _solve_case(name, kw, X0, U0, hard, max_iter):
     import torch
-    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV
-    c = NLMPC(VANDERPOL if name == "vanderpol" else UGV, kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV, OSCILLATORS6
+    c = NLMPC(dict(vanderpol=VANDERPOL, ugv=UGV, osc6=OSCILLATORS6)[name], kw["ph"], kw["ch"], kw.get("Ts", 0.1))
     c.setOptimizerParameters(NLParameters(maximum_iteration=max_iter, hard_constraints=int(hard)))
     r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), sequences=True)
     torch.cuda.synchronize()
@@ -164,3 +168,20 @@ def test_warm_start_reproduces_and_is_cheaper():
     assert (warm["status"] == 0).all() and (cold["status"] == 0).all()
     np.testing.assert_allclose(warm["cmd"].cpu().numpy(), cold["cmd"].cpu().numpy(), rtol=2e-5, atol=2e-6)
     assert warm["iterations"].float().mean().item() <= cold["iterations"].float().mean().item()
+
+
+def test_oscillator_network_solve_matches_oracle():
+    """examples/networked_oscillators_ex.cpp: x0 = e_0 (one oscillator displaced), and two perturbed starts (config 5)"""
+    kw = dict(ph=20, ch=10, Ts=0.1)
+    rng = np.random.default_rng(2)
+    B = 3
+    X0 = rng.uniform(-0.1, 0.1, size=(B, 12)); X0[:, 0] += 1.0; X0[0] = 0.0; X0[0, 0] = 1.0
+    U0 = np.zeros((B, 6))
+    c, r = _solve_case("osc6", kw, X0, U0, True, 200)
+    assert (r["status"] == 0).all(), (r["status"], r["solver_status"], r["iterations"])
+    m = ref.oscillators(N=6, **kw)
+    for b in range(B):
+        o = m.solve(X0[b], U0[b], max_iter=200)
+        assert o["success"], o["message"]
+        assert abs(r["cost"][b] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"]))
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=2e-5, atol=2e-6)

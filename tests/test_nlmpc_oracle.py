@@ -115,3 +115,12 @@ def test_ugv_functions_shapes():
     c, Je = m.state_eq(z)
     assert g.shape == (m.nz,) and gi.shape == (22,) and J.shape == (22, m.nz) and Je.shape == (40, m.nz)
     assert np.isclose(v, 1e3 * 11 * 1.0)       # |0 - v_pref|^2 = 1 at each of the 11 steps
+
+
+def test_oscillators_model_shapes_and_field():
+    from oracle.nlmpc_numpy import oscillators
+    m = oscillators(N=6, ph=20, ch=10)
+    assert (m.nz, m.ph * m.nx, m.ineq) == (301, 240, 126)          # osc-ref sizes
+    x = np.zeros(12); x[0] = 1.0
+    dx = m.f(x, np.zeros(6), 0)
+    assert abs(dx[1] + 1.5) < 1e-15 and abs(dx[3] - 0.1) < 1e-15 and dx[0] == 0.0   # -x0 - 5 k x0 on itself, k x0 on a neighbour
