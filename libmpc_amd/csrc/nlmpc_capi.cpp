@@ -168,3 +168,22 @@ int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void 
 }
 
 }  // extern "C"
+
+// Testing aid (not part of include/mpcx.h): copy one instance's SQP workspace to the host together with its layout.
+extern "C" int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, int *layout, int nlayout)
+{
+    if (!h || !h->ws || instance < 0 || (size_t)instance >= h->ws_cap) return mpcx::capi_fail(MPCX_E_INVALID, "no such workspace");
+    const int total = h->dev.ws.total;
+    if (layout) {
+        const int *src = reinterpret_cast<const int *>(&h->dev.ws);
+        const int n = (int)(sizeof(mpcx::NlmpcWsLayout) / sizeof(int));
+        for (int i = 0; i < n && i < nlayout; ++i) layout[i] = src[i];
+    }
+    if (!out) return total;
+    if (cap < total) return mpcx::capi_fail(MPCX_E_INVALID, "buffer too small");
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(out, h->ws + (size_t)instance * total, (size_t)total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return mpcx::capi_fail(MPCX_E_DEVICE, "copy failed");
+    return total;
+}

@@ -5,7 +5,7 @@
 
 namespace mpcx {
 
-constexpr int kNlMaxWorking = 32;      // rows the QP sub-solver may hold active at once
+constexpr int kNlMaxWorking = 64;      // rows the QP sub-solver may hold active at once
 
 // offsets (in doubles) into one instance's slice of the SQP workspace
 struct NlmpcWsLayout {
@@ -13,7 +13,7 @@ struct NlmpcWsLayout {
     int r, phi, einv;                   // condensing: x-step for p = 0, d x / d p, inverses of dc_i/dx_{i+1}
     int gr, art, br;                    // reduced gradient, reduced inequality Jacobian (transposed), its offset
     int hinv, mu, glold, s, p;          // inverse BFGS matrix, multipliers, BFGS memory, QP solution
-    int qn, qv;                         // QP: normals and Hinv*normals of the working set
+    int qn, qv, qs;                     // QP: normals and Hinv*normals of the working set, their Schur complement
     int scal;                           // scalars: [0] cost
     int total;
 };

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const Nl
 // ---------------------------------------------------------------------------------------------------
 // SQP
 // ---------------------------------------------------------------------------------------------------
-// Dense symmetric positive definite solve in LDS: S [n x ld] (destroyed), rhs t -> solution in t.  n <= 32.
+// Dense symmetric positive definite solve in LDS: S [n x ld] (destroyed), rhs t -> solution in t.  n <= 64.
 __device__ void spd_solve(double *S, int ld, double *t, int n, int lane)
 {
     for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
@@ -402,8 +402,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
     double *dXs = Us + (ph + 1) * NU;
     double *dUs = dXs + (ph + 1) * NX;
     double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
-    double *Ssm = Jm + ph * NU;                           // KW x SLD   working-set Schur complement
-    double *Sfac = Ssm + KW * SLD;                        // KW x SLD   copy that the solve destroys
+    double *Sfac = Jm + ph * NU;                          // KW x SLD   copy of the working-set Schur complement for the solve
     double *tq = Sfac + KW * SLD;                         // KW
     double *uq = tq + KW;                                 // KW  multipliers of the working set
     double *wq = uq + KW;                                 // KW  row numbers (as doubles)
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
         double *z = w + M.ws.z, *d = w + M.ws.d, *g = w + M.ws.g, *c = w + M.ws.c, *jeq = w + M.ws.jeq, *gin = w + M.ws.gin,
                *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
                *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
-               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *scal = w + M.ws.scal;
+               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *scal = w + M.ws.scal;
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
 
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
-        int it = 0, code = 5;                               // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE
+        int it = 0, code = 5;       // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
         for (; it < S.max_iter; ++it) {
             // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
             if (Mdl::CONTINUOUS) {
@@ -554,19 +553,19 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             }
             for (int k = lane; k < m; k += 64) mu[k] = 0.0;
             nl_wave_sync();
-            int nw = 0; bool qp_ok = true, qp_done = false;
+            int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
             for (int qit = 0; qit < 8 * (m + nq) + 16; ++qit) {
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < m; k += 64) {
                     double s = br[k];
                     for (int j = 0; j < nq; ++j) s += art[(size_t)j * mld + k] * xq[j];
-                    bool inw = false;
+                    bool inw = mu[k] < 0.0;                              // set aside (see below)
                     for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
                     if (!inw && s > vmax) { vmax = s; pidx = k; }
                 }
                 wave_argmax(vmax, pidx);
                 if (m == 0 || vmax <= 1e-10) { qp_done = true; break; }   // primal feasible: optimal
-                if (nw >= KW) { qp_ok = false; break; }
+                if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
                 for (int q = lane; q < nq; q += 64) np_[q] = art[(size_t)q * mld + pidx];
                 nl_wave_sync();
                 double up = 0.0, sp = vmax;
@@ -607,7 +606,12 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     const bool can_move = zn > 1e-13 * fmax(1.0, npn);
                     const double t2 = can_move ? sp / zn : 1e300;
                     const double tt = fmin(t1, t2);
-                    if (tt >= 1e300) { qp_ok = false; break; }          // no step: the linearised constraints are inconsistent
+                    if (tt >= 1e300) {
+                        // no step: the row is a combination of working rows.  Violated by round-off only (a copy of an
+                        // active row): set it aside; violated for real: the linearised constraints are inconsistent.
+                        if (sp <= 1e-7) { if (lane == 0) mu[pidx] = -1.0; nl_wave_sync(); added = true; break; }
+                        qp_ok = false; break;
+                    }
                     nl_wave_sync();
                     if (can_move) {
                         for (int q = lane; q < nq; q += 64) xq[q] -= tt * zd[q];
@@ -642,7 +646,9 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 if (!qp_ok) break;
                 if (!added) { qp_ok = false; break; }
             }
-            if (!qp_ok || !qp_done) { code = -1; break; }
+            if (!qp_ok || !qp_done) { code = qp_fail ? qp_fail : -1; break; }
+            for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+            nl_wave_sync();
             for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = uq[t];
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 const bool ok = lane <= 40 && mer <= phi0 + 1e-4 * al * dphi;
                 const unsigned long long bal = __ballot(ok);
                 if (!bal) {                                         // no decrease left within 2^-40: the iteration has stalled
-                    code = (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) ? 4 : -1;
+                    code = (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) ? 4 : -4;
                     break;
                 }
                 a_step = ldexp(1.0, -(int)__builtin_ctzll(bal));
@@ -774,7 +780,7 @@ void nlmpc_plan(NlmpcDev &m)
     m.nzu = m.ch * nu; m.nr = m.nzu + 1;
     m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
     const int KW = kNlMaxWorking;
-    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + 2 * KW * (KW + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr + 1) & ~1;
+    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + KW * (KW + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr + 1) & ~1;
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
@@ -784,7 +790,7 @@ void nlmpc_plan(NlmpcDev &m)
     w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(m.nineq);
     w.hinv = take(m.nr * m.nr); w.mu = take(m.nineq); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
-    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.scal = take(4);
+    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.scal = take(4);
     w.total = o;
 }
 

@@ -138,3 +138,21 @@ class NLMPC(NLMPCEvaluator):
         if int(r["status"][0]) != 3:
             self._zprev = r["z"]
         return r
+
+    _WS_FIELDS = ("z", "d", "g", "c", "jeq", "gin", "jin", "r", "phi", "einv", "gr", "art", "br", "hinv", "mu", "glold", "s", "p",
+                  "qn", "qv", "qs", "scal", "total")
+
+    def debug_workspace(self, instance):
+        """testing aid: the SQP workspace of one instance after the last solve, as a dict of numpy arrays"""
+        n = len(self._WS_FIELDS)
+        lay = (C.c_int * n)()
+        fn = self._lib.mpcx_nlmpc_debug_get_ws
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        total = check(fn(self._h, int(instance), None, 0, lay, n))
+        buf = np.empty(total)
+        check(fn(self._h, int(instance), buf.ctypes.data, total, lay, n))
+        offs = list(lay)
+        out = {}
+        for i, name in enumerate(self._WS_FIELDS[:-1]):
+            out[name] = buf[offs[i]:offs[i + 1] if i + 1 < n - 1 else total].copy()
+        return out

@@ -36,7 +36,10 @@ if __name__ == "__main__":
     b, out = c.make_batch(x0, u0)
     ms = c.time_launches(b, 1)          # warm-up (also grows the workspace)
     ms = c.time_launches(b, reps)
-    st = out["status"].cpu().numpy(); it = out["iterations"].cpu().numpy()
+    st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy()
+    bad = np.concatenate([np.nonzero(st == k)[0][:2] for k in (-1, -3, -4)])
+    for i in bad:
+        print("failed", int(i), int(st[i]), int(it[i]), x0[i].numpy().tolist(), file=sys.stderr)
     print(json.dumps(dict(workload=name, batch=B, nz=c.nz, ms_per_batch=ms, solves_per_s=B / ms * 1e3,
-                          status_counts={int(k): int((st == k).sum()) for k in np.unique(st)},
+                          solver_status_counts={int(k): int((st == k).sum()) for k in np.unique(st)},
                           iterations_mean=float(it.mean()), iterations_max=int(it.max()))))
