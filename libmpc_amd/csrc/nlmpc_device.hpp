@@ -6,6 +6,7 @@
 namespace mpcx {
 
 constexpr int kNlMaxWorking = 64;      // rows the QP sub-solver may hold active at once
+constexpr int kNlLdsWorking = 24;      // up to this many, their Schur complement is factored in LDS
 
 // offsets (in doubles) into one instance's slice of the SQP workspace
 struct NlmpcWsLayout {
@@ -13,8 +14,9 @@ struct NlmpcWsLayout {
     int r, phi, einv;                   // condensing: x-step for p = 0, d x / d p, inverses of dc_i/dx_{i+1}
     int gr, art, br;                    // reduced gradient, reduced inequality Jacobian (transposed), its offset
     int hinv, mu, glold, s, p;          // inverse BFGS matrix, multipliers, BFGS memory, QP solution
-    int qn, qv, qs;                     // QP: normals and Hinv*normals of the working set, their Schur complement
-    int scal;                           // scalars: [0] cost
+    int qn, qv, qs, qs2;                   // QP: normals and Hinv*normals of the working set, their Schur complement
+    int scal;                           // scalars: [0] cost, [2..7] per-phase cycle counts
+    int flag;                           // bytes: non-zero (row tile, state) pairs of the inequality Jacobian
     int total;
 };
 

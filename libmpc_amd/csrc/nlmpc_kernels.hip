@@ -92,6 +92,10 @@ struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
     }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
+    // structure of the inequality Jacobian: which rows of X / U constraint k reads (anything else differentiates to an exact 0)
+    static constexpr bool INEQ_USES_SLACK = false;
+    __device__ static bool ineq_reads_x(int, int) { return false; }
+    __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
 };
 
 struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
@@ -125,6 +129,9 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
         const double dx = X(i, 0) - p[2 + 3 * o], dy = X(i, 1) - p[3 + 3 * o];
         return p[4 + 3 * o] - sqrt(dx * dx + dy * dy);
     }
+    static constexpr bool INEQ_USES_SLACK = false;
+    __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
+    __device__ static bool ineq_reads_u(int, int) { return false; }
 };
 
 template <int N>
@@ -155,6 +162,9 @@ struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76
     }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }
+    static constexpr bool INEQ_USES_SLACK = false;
+    __device__ static bool ineq_reads_x(int, int) { return false; }
+    __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
 };
 
 constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
@@ -180,7 +190,7 @@ __device__ __forceinline__ void unwrap(const NlmpcDev &M, const double *z, const
 // the transcription of one instance; any output may be null.  Xs/Us/Jm: this wave's LDS.
 template <class Mdl>
 __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, double *Jm, int lane,
-                              double *cost, double *grad, double *ceq, double *jeq, double *cineq, double *jineq)
+                              double *cost, double *grad, double *ceq, double *jeq, double *cineq, double *jineq, bool jin_fill = true)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
@@ -298,15 +308,17 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 const int i = k / NX, j = k - i * NX;
                 const double dx = dv * Xa(j);
                 const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
-                for (int r = 0; r < nineq; ++r)
+                for (int r = 0; r < nineq; ++r) {
+                    if (!Mdl::ineq_reads_x(r, i + 1)) { if (jin_fill) J[(size_t)r * nz + k] = 0.0; continue; }
                     J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx);
+                }
             } else if (k < nz - 1) {
                 const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
                 const double du = dv * Ua(j);
                 for (int r = 0; r < nineq; ++r) {
                     double s = 0;
                     for (int i = 0; i < ph; ++i) {          // every input row of the block on its own (no pairing here)
-                        if (min(i, ch - 1) != bl) continue;
+                        if (min(i, ch - 1) != bl || !Mdl::ineq_reads_u(r, i)) continue;
                         const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
                         s += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
                     }
@@ -314,8 +326,10 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 }
             } else {
                 const double de = fmax(dv, fabs(e)) * dv;
-                for (int r = 0; r < nineq; ++r)
+                for (int r = 0; r < nineq; ++r) {
+                    if (!Mdl::INEQ_USES_SLACK) { if (jin_fill) J[(size_t)r * nz + k] = 0.0; continue; }
                     J[(size_t)r * nz + k] = (Mdl::ineq(r, X0, U0, e + de, ph, prm) - Mdl::ineq(r, X0, U0, e - de, ph, prm)) / (2 * de);
+                }
             }
         }
     }
@@ -390,7 +404,7 @@ __device__ void invert_small(double *Aug, int n, int lane)
 template <class Mdl>
 __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
 {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KW = kNlMaxWorking, SLD = KW + 1;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KW = kNlMaxWorking, SLD = KW + 1, KL = kNlLdsWorking;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     const int ph = M.ph, ch = M.ch, nz = M.nz, m = M.nineq, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
@@ -402,20 +416,21 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
     double *dXs = Us + (ph + 1) * NU;
     double *dUs = dXs + (ph + 1) * NX;
     double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
-    double *Sfac = Jm + ph * NU;                          // KW x SLD   copy of the working-set Schur complement for the solve
-    double *tq = Sfac + KW * SLD;                         // KW
+    double *Sfac = Jm + ph * NU;                          // KL x (KL+1) copy of the working-set Schur complement for the solve
+    double *tq = Sfac + KL * (KL + 1);                    // KW
     double *uq = tq + KW;                                 // KW  multipliers of the working set
     double *wq = uq + KW;                                 // KW  row numbers (as doubles)
     double *aug = wq + KW;                                // NX x 2NX
     double *v0 = aug + NX * 2 * NX;                       // 4 vectors of nr
     double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
+    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(v3 + nr);   // structure bits of d g / d x
 
     for (int b = blockIdx.x * wpb + wave; b < S.batch; b += gridDim.x * wpb) {
         double *w = S.ws + (size_t)b * M.ws.total;
         double *z = w + M.ws.z, *d = w + M.ws.d, *g = w + M.ws.g, *c = w + M.ws.c, *jeq = w + M.ws.jeq, *gin = w + M.ws.gin,
                *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
                *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
-               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *scal = w + M.ws.scal;
+               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal;
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
@@ -440,6 +455,8 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
 
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
+        long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
+        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         int it = 0, code = 5;       // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
         for (; it < S.max_iter; ++it) {
             // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
@@ -482,6 +499,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 }
             }
             nl_wave_sync();
+            lap(0);
             // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
             for (int q = lane; q < nr; q += 64) {
                 if (q == nzu) { gr[q] = g[nz - 1]; continue; }
@@ -489,26 +507,44 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 for (int row = 0; row < nxs; ++row) s += phi[(size_t)row * nzu + q] * g[row];
                 gr[q] = s;
             }
+            // user inequalities read few states: one bit per (row, state) entry of d g / d x that holds anything
+            const int nchunk = (nxs + 63) >> 6;
+            for (int e0 = 0; e0 < m * nchunk; ++e0) {
+                const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
+                const bool any = col < nxs && jin[(size_t)k * nz + col] != 0.0;
+                const unsigned long long bal = __ballot(any);
+                if (lane == 0) fmask[e0] = bal;
+            }
+            nl_wave_sync();
             for (int q = lane; q < nr; q += 64) {
-                for (int k0 = 0; k0 < m; k0 += 16) {
-                    double acc[16];
-                    const int kn = min(16, m - k0);
-                    for (int t = 0; t < 16; ++t) acc[t] = t < kn ? jin[(size_t)(k0 + t) * nz + (q == nzu ? nz - 1 : nxs + q)] : 0.0;
+                for (int k = 0; k < m; ++k) {
+                    double acc = jin[(size_t)k * nz + (q == nzu ? nz - 1 : nxs + q)];
                     if (q < nzu)
-                        for (int row = 0; row < nxs; ++row) {
-                            const double ph_ = phi[(size_t)row * nzu + q];
-                            for (int t = 0; t < 16; ++t) if (t < kn) acc[t] += jin[(size_t)(k0 + t) * nz + row] * ph_;
+                        for (int cb = 0; cb < nchunk; ++cb) {
+                            unsigned long long mk = fmask[k * nchunk + cb];
+                            while (mk) {
+                                const int row = cb * 64 + (int)__builtin_ctzll(mk);
+                                mk &= mk - 1;
+                                acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
+                            }
                         }
-                    for (int t = 0; t < kn; ++t) art[(size_t)q * mld + k0 + t] = acc[t];
+                    art[(size_t)q * mld + k] = acc;
                 }
             }
             for (int k = lane; k < m; k += 64) {
                 double s = gin[k];
-                for (int row = 0; row < nxs; ++row) s += jin[(size_t)k * nz + row] * r[row];
+                for (int cb = 0; cb < nchunk; ++cb) {
+                    unsigned long long mk = fmask[k * nchunk + cb];
+                    while (mk) {
+                        const int row = cb * 64 + (int)__builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        s += jin[(size_t)k * nz + row] * r[row];
+                    }
+                }
                 br[k] = s;
             }
             nl_wave_sync();
-
+            lap(1);
             // ---- damped BFGS update of the inverse Hessian estimate (Powell), s = a p, y = change of the reduced Lagrangian gradient
             if (have_old) {
                 double sBs = 0, sy = 0;
@@ -544,6 +580,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 nl_wave_sync();
             }
 
+            lap(2);
             // ---- sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0   (Goldfarb-Idnani, range-space form on B^-1)
             double *xq = v0, *np_ = v1, *vv = v2, *zd = v3;
             for (int q = lane; q < nq; q += 64) {
@@ -583,10 +620,13 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                         for (int j = 0; j < nq; ++j) s += qn[(size_t)t * nr + j] * vv[j];
                         tq[t] = s;
                     }
-                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sfac[(e2 / nw) * SLD + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
+                    // small working sets factor in LDS, large ones in the workspace
+                    double *Sf = nw <= KL ? Sfac : Sbig;
+                    const int sfld = nw <= KL ? KL + 1 : SLD;
+                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
                     nl_wave_sync();
                     double tcol = lane < nw ? tq[lane] : 0.0;          // keep N_W v: it becomes S[:, new]
-                    if (nw) spd_solve(Sfac, SLD, tq, nw, lane);
+                    if (nw) spd_solve(Sf, sfld, tq, nw, lane);
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
                         double s = vv[q];
@@ -653,6 +693,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
 
+            lap(3);
             // ---- full-space step d = [r + Phi p_u ; p]
             double dmax = 0, cmax = 0, gd = 0, viol = 0;
             for (int row = lane; row < nxs; row += 64) {
@@ -727,8 +768,11 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int k = lane; k < nz; k += 64) z[k] += a_step * d[k];
             a_prev = a_step; have_old = true;
             nl_wave_sync();
-            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
+            lap(4);
+            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin, false);    // structural zeros are in place
+            lap(5);
         }
+        if (lane == 0) for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k];
 
         // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
         double gmax = -1e300;
@@ -780,7 +824,8 @@ void nlmpc_plan(NlmpcDev &m)
     m.nzu = m.ch * nu; m.nr = m.nzu + 1;
     m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
     const int KW = kNlMaxWorking;
-    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + KW * (KW + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr + 1) & ~1;
+    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + kNlLdsWorking * (kNlLdsWorking + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr +
+                      m.nineq * ((ph * nx + 63) / 64) + 1) & ~1;
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
@@ -790,7 +835,8 @@ void nlmpc_plan(NlmpcDev &m)
     w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(m.nineq);
     w.hinv = take(m.nr * m.nr); w.mu = take(m.nineq); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
-    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.scal = take(4);
+    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
+    w.flag = take(2);
     w.total = o;
 }
 

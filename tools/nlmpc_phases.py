@@ -1,0 +1,22 @@
+"""Where the SQP kernel spends its cycles: per-phase shader-clock counts averaged over a batch (testing aid)."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from tools.nlmpc_bench import make  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "ugv"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+c, x0, u0 = make(name, B)
+r = c.optimizeBatch(x0, u0); torch.cuda.synchronize()
+it = r["iterations"].cpu().numpy()
+acc = np.zeros(6)
+for i in range(0, B, max(1, B // 16)):
+    acc += c.debug_workspace(i)["scal"][2:8]
+names = ["condense", "reduce(gr,Ar,br)", "bfgs", "qp", "step+linesearch", "evaluate"]
+tot = acc.sum()
+for n, v in zip(names, acc):
+    print("%-18s %5.1f %%" % (n, 100 * v / tot))
+print("iterations mean", it.mean())
