@@ -16,6 +16,7 @@ struct NlmpcWsLayout {
     int hinv, mu, glold, s, p;          // inverse BFGS matrix, multipliers, BFGS memory, QP solution
     int qn, qv, qs, qs2;                   // QP: normals and Hinv*normals of the working set, their Schur complement
     int scal;                           // scalars: [0] cost, [2..7] per-phase cycle counts
+    int lamw, pen_eq, pen_in;           // merit function: scratch, weights of the equalities / inequalities
     int flag;                           // bytes: non-zero (row tile, state) pairs of the inequality Jacobian
     int total;
 };

@@ -358,10 +358,14 @@ __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const Nl
 // SQP
 // ---------------------------------------------------------------------------------------------------
 // Dense symmetric positive definite solve in LDS: S [n x ld] (destroyed), rhs t -> solution in t.  n <= 64.
-__device__ void spd_solve(double *S, int ld, double *t, int n, int lane)
+__device__ bool spd_solve(double *S, int ld, double *t, int n, int lane)
 {
+    double dmax = lane < n ? S[lane * ld + lane] : 0.0;
+    dmax = wave_max(dmax);
+    bool ok = true;
     for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
         const double piv = S[k * ld + k];
+        ok &= piv > 1e-13 * dmax;
         if (lane > k && lane < n) {
             const double fct = S[lane * ld + k] / piv;
             for (int j = k + 1; j < n; ++j) S[lane * ld + j] -= fct * S[k * ld + j];
@@ -375,6 +379,7 @@ __device__ void spd_solve(double *S, int ld, double *t, int n, int lane)
         if (lane < k) t[lane] -= S[lane * ld + k] * t[k];
         nl_wave_sync();
     }
+    return ok;
 }
 
 // In-place Gauss-Jordan inverse of an n x n matrix held as [n x 2n] = [E | I] in LDS, partial pivoting.
@@ -430,7 +435,8 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
         double *z = w + M.ws.z, *d = w + M.ws.d, *g = w + M.ws.g, *c = w + M.ws.c, *jeq = w + M.ws.jeq, *gin = w + M.ws.gin,
                *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
                *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
-               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal;
+               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal,
+               *lamw = w + M.ws.lamw;
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
@@ -455,6 +461,8 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
 
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
+        int resets = 0;
+        int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
         long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
         auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         int it = 0, code = 5;       // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 double sBs = 0, sy = 0;
                 for (int q = lane; q < nq; q += 64) {
                     double gl = gr[q];
-                    for (int k = 0; k < m; ++k) gl += art[(size_t)q * mld + k] * mu[k];
+                    for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * uq[t];
                     const double y = gl - glold[q], Bs = -a_prev * glold[q];
                     v0[q] = y; v1[q] = Bs;
                     sBs += sv[q] * Bs; sy += sv[q] * y;
@@ -591,6 +599,70 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int k = lane; k < m; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
+            auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
+                const int last = nw - 1;
+                if (kdrop != last) {
+                    for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
+                    nl_wave_sync();
+                    if (lane < nw) Ssm[lane * SLD + kdrop] = Ssm[lane * SLD + last];
+                    nl_wave_sync();
+                    if (lane < nw) Ssm[kdrop * SLD + lane] = Ssm[last * SLD + lane];
+                    nl_wave_sync();
+                    if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; }
+                }
+                --nw;
+                nl_wave_sync();
+            };
+            // warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative --
+            // the minimiser on that set with u >= 0 is a valid state of the dual method
+            if (nw_keep > 0) {
+                nw = nw_keep;
+                for (int t = 0; t < nw; ++t) {
+                    const int k = (int)wq[t];
+                    for (int q = lane; q < nq; q += 64) vv[q] = art[(size_t)q * mld + k];
+                    nl_wave_sync();
+                    for (int q = lane; q < nq; q += 64) {
+                        double s2 = 0;
+                        for (int j = 0; j < nq; ++j) s2 += hinv[(size_t)j * nr + q] * vv[j];
+                        qn[(size_t)t * nr + q] = vv[q]; qv[(size_t)t * nr + q] = s2;
+                    }
+                    nl_wave_sync();
+                }
+                for (int e2 = lane; e2 < nw * nw; e2 += 64) {
+                    const int a = e2 / nw, b2 = e2 - a * nw;
+                    double s2 = 0;
+                    for (int j = 0; j < nq; ++j) s2 += qn[(size_t)a * nr + j] * qv[(size_t)b2 * nr + j];
+                    Ssm[a * SLD + b2] = s2;
+                }
+                nl_wave_sync();
+                while (nw > 0) {
+                    for (int t = lane; t < nw; t += 64) {
+                        double s2 = br[(int)wq[t]];
+                        for (int j = 0; j < nq; ++j) s2 += qn[(size_t)t * nr + j] * xq[j];
+                        tq[t] = s2;
+                    }
+                    double *Sf = nw <= KL ? Sfac : Sbig;
+                    const int sfld = nw <= KL ? KL + 1 : SLD;
+                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
+                    nl_wave_sync();
+                    if (!spd_solve(Sf, sfld, tq, nw, lane)) { nw = 0; break; }      // dependent rows: start cold
+                    int neg = -1;
+                    for (int t = 0; t < nw; ++t) if (tq[t] < 0.0) neg = t;
+                    if (neg < 0) break;
+                    for (int t = nw - 1; t >= 0; --t) {
+                        if (tq[t] < 0.0) { const double tl = tq[nw - 1]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
+                    }
+                }
+                if (nw > 0) {
+                    for (int q = lane; q < nq; q += 64) {
+                        double s2 = xq[q];
+                        for (int t = 0; t < nw; ++t) s2 -= qv[(size_t)t * nr + q] * tq[t];
+                        xq[q] = s2;
+                    }
+                    if (lane < nw) uq[lane] = tq[lane];
+                    nl_wave_sync();
+                }
+            }
             for (int qit = 0; qit < 8 * (m + nq) + 16; ++qit) {
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < m; k += 64) {
@@ -601,7 +673,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     if (!inw && s > vmax) { vmax = s; pidx = k; }
                 }
                 wave_argmax(vmax, pidx);
-                if (m == 0 || vmax <= 1e-10) { qp_done = true; break; }   // primal feasible: optimal
+                if (m == 0 || vmax <= 1e-12) { qp_done = true; break; }   // primal feasible (well inside the reported 1e-10): optimal
                 if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
                 for (int q = lane; q < nq; q += 64) np_[q] = art[(size_t)q * mld + pidx];
                 nl_wave_sync();
@@ -669,17 +741,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                         if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; }
                         ++nw; added = true;
                     } else {                                            // a multiplier hit zero: that row leaves, try again
-                        const int last = nw - 1;
-                        if (kdrop != last) {
-                            for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
-                            nl_wave_sync();
-                            if (lane < nw) Ssm[lane * SLD + kdrop] = Ssm[lane * SLD + last];
-                            nl_wave_sync();
-                            if (lane < nw) Ssm[kdrop * SLD + lane] = Ssm[last * SLD + lane];
-                            nl_wave_sync();
-                            if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; }
-                        }
-                        --nw;
+                        drop_row(kdrop);
                     }
                     nl_wave_sync();
                 }
@@ -690,12 +752,13 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int k = lane; k < m; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = uq[t];
+            nw_keep = nw;
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
 
             lap(3);
             // ---- full-space step d = [r + Phi p_u ; p]
-            double dmax = 0, cmax = 0, gd = 0, viol = 0;
+            double dmax = 0, cmax = 0, gd = 0;
             for (int row = lane; row < nxs; row += 64) {
                 double s = r[row];
                 for (int q = 0; q < nzu; ++q) s += phi[(size_t)row * nzu + q] * p[q];
@@ -704,26 +767,69 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int q = lane; q < nr; q += 64) d[nxs + q] = p[q];
             nl_wave_sync();
             for (int k = lane; k < nz; k += 64) { dmax = fmax(dmax, fabs(d[k])); gd += g[k] * d[k]; }
-            for (int k = lane; k < nxs; k += 64) { cmax = fmax(cmax, fabs(c[k])); viol += fabs(c[k]); }
-            for (int k = lane; k < m; k += 64) viol += fmax(gin[k], 0.0);
-            dmax = wave_max(dmax); cmax = wave_max(cmax); gd = wave_sum(gd); viol = wave_sum(viol);
+            for (int k = lane; k < nxs; k += 64) cmax = fmax(cmax, fabs(c[k]));
+            dmax = wave_max(dmax); cmax = wave_max(cmax); gd = wave_sum(gd);
             double zmax = 0;
             for (int k = lane; k < nz; k += 64) zmax = fmax(zmax, fabs(z[k]));
             zmax = wave_max(zmax);
-            if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) { code = 4; break; }
+            if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
+                // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
+                for (int k = lane; k < nz; k += 64) z[k] += d[k];
+                nl_wave_sync();
+                eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, nullptr, c, nullptr, gin, nullptr);
+                code = 4; ++it;
+                break;
+            }
 
-            // new reduced Lagrangian gradient at this point with the new multipliers: BFGS memory and p'Bp
-            double pBp = 0;
+            // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
             for (int q = lane; q < nq; q += 64) {
                 double gl = gr[q];
-                for (int k = 0; k < m; ++k) gl += art[(size_t)q * mld + k] * mu[k];
-                glold[q] = gl; pBp -= p[q] * gl;
+                for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * uq[t];
+                glold[q] = gl;
             }
-            pBp = wave_sum(pBp);
-            if (viol > 1e-300) {
-                const double need = (gd + 0.5 * fmax(pBp, 0.0)) / (0.9 * viol);
-                if (need > nu_pen) nu_pen = 2 * need;
+            // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
+            // the weight of the l1 merit function has to dominate them and mu
+            for (int row = lane; row < nxs; row += 64) {
+                double s2 = g[row];
+                for (int t = 0; t < nw_keep; ++t) s2 += jin[(size_t)((int)wq[t]) * nz + row] * uq[t];      // mu lives on the working set
+                lamw[row] = s2;
             }
+            nl_wave_sync();
+            double lam_max = 0;
+            {
+                double *tl = aug, *ln = aug + NX;                  // t and lam_{i+1}
+                for (int i = ph - 1; i >= 0; --i) {
+                    if (lane < NX) {
+                        double s2 = lamw[i * NX + lane];
+                        if (i + 1 < ph) {
+                            const double *Jb = jeq + (size_t)(i + 1) * NX * W;
+                            for (int bb = 0; bb < NX; ++bb) s2 += Jb[bb * W + lane] * ln[bb];
+                        }
+                        tl[lane] = s2;
+                    }
+                    nl_wave_sync();
+                    if (lane < NX) {
+                        double lam;
+                        if (Mdl::CONTINUOUS) {
+                            const double *Ei = einv + (size_t)i * NX * NX;
+                            lam = 0;
+                            for (int bb = 0; bb < NX; ++bb) lam -= Ei[bb * NX + lane] * tl[bb];
+                        } else {
+                            lam = -tl[lane];
+                        }
+                        ln[lane] = lam;
+                        lam_max = fmax(lam_max, fabs(lam));
+                    }
+                    nl_wave_sync();
+                }
+            }
+            if (lane < nw_keep) lam_max = fmax(lam_max, uq[lane]);
+            lam_max = wave_max(lam_max);
+            if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
+            double viol = 0;
+            for (int k = lane; k < nxs; k += 64) viol += fabs(c[k]);
+            for (int k = lane; k < m; k += 64) viol += fmax(gin[k], 0.0);
+            viol = wave_sum(viol);
             const double phi0 = scal[0] + nu_pen * viol;
             const double dphi = fmin(gd - nu_pen * viol, 0.0);
 
@@ -759,8 +865,14 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 const bool ok = lane <= 40 && mer <= phi0 + 1e-4 * al * dphi;
                 const unsigned long long bal = __ballot(ok);
                 if (!bal) {                                         // no decrease left within 2^-40: the iteration has stalled
-                    code = (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) ? 4 : -4;
-                    break;
+                    if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
+                    if (resets >= 5) { code = -4; break; }
+                    // far from a solution: the curvature estimate has gone bad -- forget it and try a steepest-descent-like step
+                    ++resets;
+                    for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
+                    have_old = false;
+                    nl_wave_sync();
+                    continue;
                 }
                 a_step = ldexp(1.0, -(int)__builtin_ctzll(bal));
             }
@@ -836,7 +948,7 @@ void nlmpc_plan(NlmpcDev &m)
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(m.nineq);
     w.hinv = take(m.nr * m.nr); w.mu = take(m.nineq); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
     w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
-    w.flag = take(2);
+    w.lamw = take(m.neq); w.pen_eq = take(m.neq); w.pen_in = take(m.nineq); w.flag = take(2);
     w.total = o;
 }
 
