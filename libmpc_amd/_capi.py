@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpcx.so")
+LIB_PATH = os.environ.get("MPCX_LIBRARY", os.path.join(_HERE, "libmpcx.so"))   # override: testing aid for build variants
 
 OK = 0
 E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_STATE = -1, -2, -3, -4, -5

@@ -33,7 +33,10 @@ namespace mpcx {
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+#ifndef MPCX_WAVES_PER_BLOCK
+#define MPCX_WAVES_PER_BLOCK 2
+#endif
+constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 3
 #endif

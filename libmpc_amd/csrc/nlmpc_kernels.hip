@@ -25,9 +25,12 @@
 #include <cmath>
 
 #include "nlmpc_device.hpp"
+#include "nlmpc_models.hpp"
 
 namespace mpcx {
 namespace {
+
+using namespace models;
 
 __device__ __forceinline__ void nl_wave_sync()
 {
@@ -53,119 +56,6 @@ __device__ __forceinline__ void wave_argmax(double &v, int &idx)
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
 }
-
-// (ph+1) x n matrix in LDS, row-major, with up to two perturbed elements of one column
-struct Pert {
-    const double *M;
-    int n, r1, r2, c;
-    double d;
-    __device__ __forceinline__ double operator()(int i, int j) const
-    {
-        const double v = M[i * n + j];
-        return (j == c && (i == r1 || i == r2)) ? v + d : v;
-    }
-};
-// M + a * D: a trial point of the line search
-struct Lin {
-    const double *M, *D;
-    int n;
-    double a;
-    __device__ __forceinline__ double operator()(int i, int j) const { return M[i * n + j] + a * D[i * n + j]; }
-};
-
-// ---- model zoo ----------------------------------------------------------------------------------
-struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
-    static constexpr int NX = 2, NU = 1;
-    static constexpr bool CONTINUOUS = true;
-    __host__ __device__ static int nineq(int ph) { return ph + 1; }
-    __device__ static void f(double *dx, const double *x, const double *u, const double *)
-    {
-        dx[0] = ((1.0 - (x[1] * x[1])) * x[0]) - x[1] + u[0];
-        dx[1] = x[0];
-    }
-    template <class XA, class UA>
-    __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
-    {
-        double s = 0;
-        for (int i = 0; i <= ph; ++i) { s += X(i, 0) * X(i, 0) + X(i, 1) * X(i, 1); s += U(i, 0) * U(i, 0); }
-        return s;
-    }
-    template <class XA, class UA>
-    __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
-    // structure of the inequality Jacobian: which rows of X / U constraint k reads (anything else differentiates to an exact 0)
-    static constexpr bool INEQ_USES_SLACK = false;
-    __device__ static bool ineq_reads_x(int, int) { return false; }
-    __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
-};
-
-struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
-    static constexpr int NX = 4, NU = 2;
-    static constexpr bool CONTINUOUS = false;
-    // params: [0..1] v_pref, [2..4] obstacle 0 (x, y, r), [5..7] obstacle 1, [8] Ts
-    __host__ __device__ static int nineq(int ph) { return 2 * (ph + 1); }
-    __device__ static void f(double *xn, const double *x, const double *u, const double *p)
-    {
-        const double Ts = p[8];
-        xn[0] = x[0] + Ts * x[2] + 0.5 * Ts * Ts * u[0];
-        xn[1] = x[1] + Ts * x[3] + 0.5 * Ts * Ts * u[1];
-        xn[2] = x[2] + Ts * u[0];
-        xn[3] = x[3] + Ts * u[1];
-    }
-    template <class XA, class UA>
-    __device__ static double cost(const XA &X, const UA &U, double e, int ph, const double *p)
-    {
-        double s = 0;
-        for (int i = 0; i <= ph; ++i) {
-            const double a = X(i, 2) - p[0], b = X(i, 3) - p[1];
-            s += 1e3 * (a * a + b * b);
-            s += 1e-2 * (U(i, 0) * U(i, 0) + U(i, 1) * U(i, 1));
-        }
-        return s + 1e-5 * e * e;
-    }
-    template <class XA, class UA>
-    __device__ static double ineq(int k, const XA &X, const UA &, double, int, const double *p)
-    {
-        const int i = k >> 1, o = k & 1;
-        const double dx = X(i, 0) - p[2 + 3 * o], dy = X(i, 1) - p[3 + 3 * o];
-        return p[4 + 3 * o] - sqrt(dx * dx + dy * dy);
-    }
-    static constexpr bool INEQ_USES_SLACK = false;
-    __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
-    __device__ static bool ineq_reads_u(int, int) { return false; }
-};
-
-template <int N>
-struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
-    static constexpr int NX = 2 * N, NU = N;
-    static constexpr bool CONTINUOUS = true;
-    __host__ __device__ static int nineq(int ph) { return (ph + 1) * N; }
-    __device__ static void f(double *dx, const double *x, const double *u, const double *p)
-    {
-        const double mu = p[0], k = p[1];
-        for (int i = 0; i < N; ++i) {
-            dx[2 * i] = x[2 * i + 1];
-            double a = mu * (1 - x[2 * i] * x[2 * i]) * x[2 * i + 1] - x[2 * i] + u[i];
-            for (int j = 0; j < N; ++j)
-                if (i != j) a += k * (x[2 * j] - x[2 * i]);
-            dx[2 * i + 1] = a;
-        }
-    }
-    template <class XA, class UA>
-    __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
-    {
-        double s = 0;
-        for (int i = 0; i <= ph; ++i) {
-            for (int j = 0; j < NX; ++j) s += X(i, j) * X(i, j);
-            for (int j = 0; j < NU; ++j) s += U(i, j) * U(i, j);
-        }
-        return s;
-    }
-    template <class XA, class UA>
-    __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }
-    static constexpr bool INEQ_USES_SLACK = false;
-    __device__ static bool ineq_reads_x(int, int) { return false; }
-    __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
-};
 
 constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
 
