@@ -107,6 +107,14 @@ typedef struct mpcx_lmpc_batch {
      * working set, [B] each */
     int32_t *polish_rounds;
     int32_t *active_count;
+    /* warm start (inputs, may be NULL): the active_lower / active_upper words of the previous solve
+     * of each instance.  The reference warm-starts OSQP with the previous primal/dual pair
+     * (LOptimizer.hpp:268-281, LParameters::enable_warm_start); for the active-set iteration the
+     * information that carries over is which rows were active: they are the first working set, and
+     * an unchanged active set verifies in one round.  Results do not depend on it.               */
+    const uint32_t *warm_active_lower;
+    const uint32_t *warm_active_upper;
+    int warm_shift;                /* 1: receding horizon -- the previous tick's row of step i+1 seeds step i */
 } mpcx_lmpc_batch;
 
 /* ---- lifetime (replaces LMPC::onSetup / new LOptimizer, LMPC.hpp:728-735) ---- */

@@ -38,7 +38,8 @@ class Batch(C.Structure):
                 ("iterations", C.c_void_p),
                 ("active_lower", C.c_void_p), ("active_upper", C.c_void_p),
                 ("seq_state", C.c_void_p), ("seq_output", C.c_void_p), ("seq_input", C.c_void_p),
-                ("polish_rounds", C.c_void_p), ("active_count", C.c_void_p)]
+                ("polish_rounds", C.c_void_p), ("active_count", C.c_void_p),
+                ("warm_active_lower", C.c_void_p), ("warm_active_upper", C.c_void_p), ("warm_shift", C.c_int)]
 
 
 class Info(C.Structure):

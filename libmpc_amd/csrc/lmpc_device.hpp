@@ -64,6 +64,8 @@ struct LmpcBatchDev {
     uint32_t *active_lower, *active_upper;
     double *seq_state, *seq_output, *seq_input;
     int32_t *polish_rounds, *active_count;
+    const uint32_t *warm_lower, *warm_upper;      // optional previous active sets (reference row numbering)
+    int warm_shift;
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 

@@ -582,6 +582,42 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         actg[s] = eqg[s] ? 1 : (gt0[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s])) ? -1 : (gt0[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s])) ? 1 : 0));
     }
 
+    if (Bt.warm_lower) {
+        // warm start: the first working set is the previous solve's active set (bits over the reference's rows,
+        // ProblemBuilder.hpp:814-822: equalities | box on [x; x_u] | outputs | delta-u | scalar).  With warm_shift the
+        // row looked up is the same constraint one step later: the previous tick's step i+1 is this tick's step i.
+        const unsigned MPCX_GAS *wl = gl(Bt.warm_lower) + (size_t)b * M.active_words;
+        const unsigned MPCX_GAS *wu = gl(Bt.warm_upper) + (size_t)b * M.active_words;
+        const int na = M.nx + M.nu, n1 = M.ph + 1;
+        const int b_box = M.neq_ref, b_out = b_box + n1 * na, b_du = b_out + n1 * M.ny, b_sc = b_du + M.ph * M.nu;
+        auto look = [&](int rr) {
+            if (!Bt.warm_shift) return rr;
+            if (rr < b_out) return rr + na < b_out ? rr + na : rr;
+            if (rr < b_du) return rr + M.ny < b_du ? rr + M.ny : rr;
+            if (rr < b_sc) return rr;
+            return rr + 1 < M.m_ref ? rr + 1 : rr;
+        };
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) {
+            const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+            if (e >= nz || eqb[s]) continue;
+            int side = 0;
+            for (int p = GP(boxrow_ptr)[e]; p < GP(boxrow_ptr)[e + 1]; ++p) {
+                const int rr = look(GP(boxrow_ref)[p]);
+                if (((wl[rr >> 5] >> (rr & 31)) & 1u) && GP(boxrow_lo)[p] == lw[s]) side = -1;
+                if (((wu[rr >> 5] >> (rr & 31)) & 1u) && GP(boxrow_hi)[p] == uw[s]) side = 1;
+            }
+            actb[s] = side;
+        }
+#pragma unroll
+        for (int s = 0; s < NGS; ++s) {
+            const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+            if (r >= mg || eqg[s]) continue;
+            const int rr = look(GP(g_refrow)[r]);
+            actg[s] = ((wl[rr >> 5] >> (rr & 31)) & 1u) ? -1 : (((wu[rr >> 5] >> (rr & 31)) & 1u) ? 1 : 0);
+        }
+    }
+
     // polished point
     double wv[NZS], gw[NGS];
 #pragma unroll

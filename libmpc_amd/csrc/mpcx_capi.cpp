@@ -445,6 +445,8 @@ static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDe
     B.active_lower = b->active_lower; B.active_upper = b->active_upper;
     B.seq_state = b->seq_state; B.seq_output = b->seq_output; B.seq_input = b->seq_input;
     B.polish_rounds = b->polish_rounds; B.active_count = b->active_count;
+    B.warm_lower = b->warm_active_lower; B.warm_upper = b->warm_active_upper; B.warm_shift = b->warm_shift;
+    if ((B.warm_lower == nullptr) != (B.warm_upper == nullptr)) return fail(MPCX_E_INVALID, "warm_active_lower and warm_active_upper go together");
     B.dbg_cycles = h->dbg_cycles;
     return MPCX_OK;
 }

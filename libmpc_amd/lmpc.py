@@ -167,6 +167,8 @@ class LMPC:
 
     def setOptimizerParameters(self, params: LParams):
         check(self._lib.mpcx_lmpc_set_optimizer_parameters(self._h, C.byref(params)))
+        self._warm_enabled = bool(params.enable_warm_start)
+        self._warm_prev = None
 
     def setStrictInfeasibility(self, on=True):
         """extension: report infeasible QPs as INFEASIBLE / NaN instead of the reference's
@@ -298,7 +300,7 @@ class LMPC:
         raise ValueError(f"reference must be [B,{n}] or [B,{self.ph},{n}], got {tuple(t.shape)}")
 
     def make_batch(self, x0, u0, yref=None, uref=None, duref=None, dmeas=None,
-                   want_active=False, want_sequence=False):
+                   want_active=False, want_sequence=False, warm=None, warm_shift=False):
         """Allocate outputs and fill the mpcx_lmpc_batch descriptor.  Returns (Batch, BatchResult, keepalive)."""
         torch, dev = self._torch()
         x0t = x0 if hasattr(x0, "shape") else np.asarray(x0)
@@ -344,7 +346,17 @@ class LMPC:
         b.active_lower, b.active_upper = ptr(res.active_lower), ptr(res.active_upper)
         b.seq_state, b.seq_output, b.seq_input = ptr(res.seq_state), ptr(res.seq_output), ptr(res.seq_input)
         b.polish_rounds, b.active_count = ptr(res.polish_rounds), ptr(res.active_count)
-        keep = (x0, u0, yr, ur, dr, de)
+        wl = wu = None
+        if warm is not None:                       # a previous BatchResult (with its active sets) or a (lower, upper) pair
+            wl, wu = (warm.active_lower, warm.active_upper) if hasattr(warm, "active_lower") else warm
+            if wl is None or wu is None:
+                raise ValueError("warm start needs the previous solve's active sets (want_active=True)")
+            wl = wl.to(dev).contiguous(); wu = wu.to(dev).contiguous()
+            if tuple(wl.shape) != (B, i["active_words"]) or tuple(wu.shape) != (B, i["active_words"]):
+                raise ValueError("warm-start active sets have the wrong shape")
+            b.warm_active_lower, b.warm_active_upper = ptr(wl), ptr(wu)
+            b.warm_shift = int(bool(warm_shift))
+        keep = (x0, u0, yr, ur, dr, de, wl, wu)
         return b, res, keep
 
     def launch(self, batch, stream=None):
@@ -362,17 +374,23 @@ class LMPC:
         return ms.value
 
     def optimizeBatch(self, x0, lastU, yref=None, uref=None, duref=None, dmeas=None,
-                      want_active=False, want_sequence=False, stream=None) -> BatchResult:
-        """B independent LOptimizer::run calls (LOptimizer.hpp:189) in one launch."""
-        b, res, keep = self.make_batch(x0, lastU, yref, uref, duref, dmeas, want_active, want_sequence)
+                      want_active=False, want_sequence=False, stream=None, warm=None, warm_shift=False) -> BatchResult:
+        """B independent LOptimizer::run calls (LOptimizer.hpp:189) in one launch.  `warm`: the BatchResult of the
+        previous control tick (solved with want_active=True) -- its active sets seed the working sets; warm_shift=True
+        looks each row up one horizon step later (receding horizon)."""
+        b, res, keep = self.make_batch(x0, lastU, yref, uref, duref, dmeas, want_active or warm is not None, want_sequence, warm, warm_shift)
         self.launch(b, stream)
         self._keep = keep
         return res
 
     def optimize(self, x0, lastU) -> Result:
         """IMPC::optimize (IMPC.hpp:149-166) for one instance, through the batched path."""
+        warm = getattr(self, "_warm_prev", None) if getattr(self, "_warm_enabled", False) else None
         r = self.optimizeBatch(np.asarray(x0, dtype=np.float64).reshape(1, self.nx),
-                               np.asarray(lastU, dtype=np.float64).reshape(1, self.nu), want_sequence=True)
+                               np.asarray(lastU, dtype=np.float64).reshape(1, self.nu), want_sequence=True,
+                               want_active=getattr(self, "_warm_enabled", False), warm=warm)
+        if getattr(self, "_warm_enabled", False):
+            self._warm_prev = r                   # LOptimizer keeps optimal_prev_x / _y (LOptimizer.hpp:295-296, 372)
         sst = int(r.solver_status[0].item())
         self._last = Result(solver_status=sst, is_feasible=bool(r.is_feasible[0].item()), solver_status_msg="",
                             cost=float(r.cost[0].item()), status=int(r.status[0].item()),

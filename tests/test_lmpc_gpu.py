@@ -273,3 +273,35 @@ def test_full_size_properties():
     pol = g["polished"] == 1
     err = np.abs(a.cmd[:64].cpu().numpy() - g["cmd"]).max(axis=1) / np.maximum(np.abs(g["cmd"]).max(axis=1), 1e-12)
     assert err[pol].max() <= RTOL_CMD
+
+
+def test_warm_start_carries_the_working_set():
+    """f1: the previous tick's active set seeds the working set (LOptimizer.hpp:268-281 carries x, y): same results,
+    an unchanged active set verifies in one round, a plant step needs fewer rounds than a cold start."""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    ph, B = 20, 512
+    c = quadrotor_lmpc(ph, device=0)
+    x0, u0, yref = quadrotor_batch(B)
+    cold = c.optimizeBatch(x0, u0, yref=yref, want_active=True)
+    again = c.optimizeBatch(x0, u0, yref=yref, warm=cold)
+    torch.cuda.synchronize()
+    ok = (cold.status == 0)
+    assert torch.equal(again.status, cold.status)
+    np.testing.assert_allclose(again.cmd.cpu().numpy(), cold.cmd.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    assert torch.equal(again.active_lower, cold.active_lower) and torch.equal(again.active_upper, cold.active_upper)
+    assert (again.polish_rounds[ok] == 1).all()
+    # one plant step x+ = A x + B (u_trim + cmd) for every instance, then the next tick warm and cold
+    from libmpc_amd.workloads import quadrotor_matrices
+    Ad, Bd, _ = quadrotor_matrices()
+    x1 = torch.as_tensor(x0).cuda() @ torch.as_tensor(Ad).cuda().T + cold.cmd @ torch.as_tensor(Bd).cuda().T
+    nxt_cold = c.optimizeBatch(x1, cold.cmd, yref=yref, want_active=True)
+    nxt_warm = c.optimizeBatch(x1, cold.cmd, yref=yref, warm=cold, warm_shift=True)
+    torch.cuda.synchronize()
+    assert torch.equal(nxt_warm.status, nxt_cold.status)
+    ok = (nxt_cold.status == 0)
+    err = (nxt_warm.cmd - nxt_cold.cmd).abs().max(dim=1).values / nxt_cold.cmd.abs().max(dim=1).values.clamp_min(1e-12)
+    assert err[ok].max().item() <= 1e-8
+    assert torch.equal(nxt_warm.active_lower[ok], nxt_cold.active_lower[ok])
+    assert nxt_warm.polish_rounds[ok].float().mean().item() < nxt_cold.polish_rounds[ok].float().mean().item()
+    print("rounds cold %.2f warm %.2f" % (nxt_cold.polish_rounds[ok].float().mean().item(), nxt_warm.polish_rounds[ok].float().mean().item()))
