@@ -274,6 +274,14 @@ int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stre
 /* `repeats` back-to-back launches bracketed by HIP events on `stream`; mean milliseconds. */
 int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream, int repeats, float *ms_mean);
 
+/* ---- set-up utility -------------------------------------------------------- */
+/* mpc::discretization<nx, nu>(A, B, Ts, Ad, Bd) (Utils.hpp:23-47) for a batch of continuous-time models on the
+ * device: [Ad Bd; 0 I] = exp([[A B]; [0 0]] Ts).  Device pointers, column-major matrices per instance
+ * (A [B x nx x nx], B [B x nx x nu]); Ts one value (ts_per_instance = 0) or [B].  The variant with a
+ * disturbance matrix (Utils.hpp:63-89) is the same call with Be appended to B's columns.  nx + nu <= 48.   */
+int mpcx_discretize_batch(int device, int nx, int nu, int batch, const double *A, const double *B, const double *Ts,
+                          int ts_per_instance, double *Ad, double *Bd, void *stream);
+
 const char *mpcx_version(void);
 
 #ifdef __cplusplus

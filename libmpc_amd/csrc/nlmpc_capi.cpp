@@ -169,6 +169,25 @@ int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void 
 
 }  // extern "C"
 
+namespace mpcx {
+int c2d_launch(int nx, int nu, int batch, const double *A, const double *B, const double *Ts, int ts_stride, double *Ad, double *Bd,
+               void *stream);
+}
+
+extern "C" int mpcx_discretize_batch(int device, int nx, int nu, int batch, const double *A, const double *B, const double *Ts,
+                                     int ts_per_instance, double *Ad, double *Bd, void *stream)
+{
+    using mpcx::capi_fail;
+    if (nx < 1 || nu < 0 || batch < 0) return capi_fail(MPCX_E_INVALID, "bad dimensions");
+    if (batch == 0) return MPCX_OK;
+    if (!A || (nu > 0 && !B) || !Ts || !Ad || (nu > 0 && !Bd)) return capi_fail(MPCX_E_INVALID, "null argument");
+    if (nx + nu > 48) return capi_fail(MPCX_E_UNSUPPORTED, "nx + nu > 48");
+    if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    const int rc = mpcx::c2d_launch(nx, nu, batch, A, B, Ts, ts_per_instance ? 1 : 0, Ad, Bd, stream);
+    if (rc != 0) return capi_fail(MPCX_E_DEVICE, "discretisation kernel launch failed");
+    return MPCX_OK;
+}
+
 // Testing aid (not part of include/mpcx.h): copy one instance's SQP workspace to the host together with its layout.
 extern "C" int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, int *layout, int nlayout)
 {
