@@ -42,6 +42,31 @@ def _slice(s):
     return HorizonSlice(a, b)
 
 
+class SolutionStats:
+    """mpc::SolutionStats (Profiler.hpp:19-60) as the pybind module exposes it; times in seconds"""
+
+    def __init__(self):
+        self.totalSolutionTime = 0.0
+        self.numberOfSolutions = 0
+        self.minSolutionTime = float("inf")
+        self.maxSolutionTime = 0.0
+        self.averageSolutionTime = 0.0
+        self.standardDeviation = 0.0
+        self.solutionsStates = {}
+        self._sq = 0.0
+
+    def add(self, dt, status):
+        self.totalSolutionTime += dt
+        self.numberOfSolutions += 1
+        self.minSolutionTime = min(self.minSolutionTime, dt)
+        self.maxSolutionTime = max(self.maxSolutionTime, dt)
+        self._sq += dt * dt
+        n = self.numberOfSolutions
+        self.averageSolutionTime = self.totalSolutionTime / n
+        self.standardDeviation = max(self._sq / n - self.averageSolutionTime ** 2, 0.0) ** 0.5
+        self.solutionsStates[status] = self.solutionsStates.get(status, 0) + 1
+
+
 class ResultStatus:
     SUCCESS, MAX_ITERATION, INFEASIBLE, ERROR, UNKNOWN = range(5)
 
@@ -131,6 +156,8 @@ class LMPC:
         self._h = C.c_void_p()
         check(self._lib.mpcx_lmpc_create(C.byref(d), self.device, C.byref(self._h)))
         self._last = Result(cmd=np.zeros(self.nu))
+        self._stats = SolutionStats()
+        self._last_u0 = np.zeros(self.nu)
         self._seq = OptSequence(np.zeros((self.ph + 1, self.nx)), np.zeros((self.ph + 1, self.ny)),
                                 np.zeros((self.ph + 1, self.nu)))
 
@@ -385,6 +412,9 @@ class LMPC:
 
     def optimize(self, x0, lastU) -> Result:
         """IMPC::optimize (IMPC.hpp:149-166) for one instance, through the batched path."""
+        import time
+        t_start = time.perf_counter()
+        self._last_u0 = np.asarray(lastU, dtype=np.float64).reshape(self.nu).copy()
         warm = getattr(self, "_warm_prev", None) if getattr(self, "_warm_enabled", False) else None
         r = self.optimizeBatch(np.asarray(x0, dtype=np.float64).reshape(1, self.nx),
                                np.asarray(lastU, dtype=np.float64).reshape(1, self.nu), want_sequence=True,
@@ -397,6 +427,7 @@ class LMPC:
                             cmd=r.cmd[0].cpu().numpy().copy())
         self._seq = OptSequence(r.seq_state[0].cpu().numpy().copy(), r.seq_output[0].cpu().numpy().copy(),
                                 r.seq_input[0].cpu().numpy().copy())
+        self._stats.add(time.perf_counter() - t_start, self._last.status)
         return self._last
 
     def getLastResult(self) -> Result:
@@ -404,3 +435,51 @@ class LMPC:
 
     def getOptimalSequence(self) -> OptSequence:
         return self._seq
+
+    # ---- the rest of the pybind module's LMPC surface (python/pybind_export.cpp:93-123) --------------------------
+    def getExecutionStats(self) -> "SolutionStats":
+        """IMPC::getExecutionStats (IMPC.hpp:201-204, Profiler.hpp): wall time of the optimize() calls made so far."""
+        return self._stats
+
+    def resetStats(self):
+        self._stats = SolutionStats()
+
+    def getSolverWarmStartDual(self):
+        """LMPC::getSolverWarmStartDual (LMPC.hpp:697-700) returns OSQP's dual vector; what this engine carries between
+        ticks is the active set, so the vector holds -1 / 0 / +1 per reference row (lower / inactive / upper): the
+        sign pattern of OSQP's y."""
+        r = getattr(self, "_warm_prev", None)
+        i = self.info()
+        y = np.zeros(i["m_ref"])
+        if r is not None:
+            al, au = (r.active_lower, r.active_upper) if hasattr(r, "active_lower") else r
+            lo = al[0].cpu().numpy().view(np.uint32); hi = au[0].cpu().numpy().view(np.uint32)
+            for k in range(i["m_ref"]):
+                if (lo[k >> 5] >> (k & 31)) & 1:
+                    y[k] = -1.0
+                elif (hi[k >> 5] >> (k & 31)) & 1:
+                    y[k] = 1.0
+        return y
+
+    def getSolverWarmStartPrimal(self):
+        """LMPC::getSolverWarmStartPrimal (LMPC.hpp:677-680): the reference QP's primal vector [xi_0..xi_ph | du_0..du_ph-1]
+        (ProblemBuilder.hpp:70-76), rebuilt from the last optimal sequence."""
+        seq = self._seq
+        ph, nx, nu = self.ph, self.nx, self.nu
+        v = np.vstack([self._last_u0[None, :], seq.input[:ph]])              # v_i = u_{i-1}
+        xi = np.hstack([seq.state, v])
+        du = np.diff(v, axis=0)
+        return np.concatenate([xi.reshape(-1), du.reshape(-1)])
+
+    def setSolverWarmStart(self, warm_primal, warm_dual):
+        """LMPC::setSolverWarmStart (LMPC.hpp:716-722): only the sign pattern of the dual is used (see above)."""
+        import torch
+        i = self.info()
+        y = np.asarray(warm_dual, dtype=np.float64).reshape(-1)
+        if y.size != i["m_ref"]:
+            raise ValueError("dual vector must have one entry per reference constraint row")
+        lo = np.zeros(i["active_words"], dtype=np.uint32); hi = np.zeros(i["active_words"], dtype=np.uint32)
+        for k in np.nonzero(y)[0]:
+            (lo if y[k] < 0 else hi)[k >> 5] |= np.uint32(1 << (k & 31))
+        dev = torch.device("cuda", self.device)
+        self._warm_prev = (torch.from_numpy(lo.view(np.int32)[None, :]).to(dev), torch.from_numpy(hi.view(np.int32)[None, :]).to(dev))

@@ -305,3 +305,33 @@ def test_warm_start_carries_the_working_set():
     assert torch.equal(nxt_warm.active_lower[ok], nxt_cold.active_lower[ok])
     assert nxt_warm.polish_rounds[ok].float().mean().item() < nxt_cold.polish_rounds[ok].float().mean().item()
     print("rounds cold %.2f warm %.2f" % (nxt_cold.polish_rounds[ok].float().mean().item(), nxt_warm.polish_rounds[ok].float().mean().item()))
+
+
+def test_single_instance_front_end_warm_start_and_stats():
+    """pybind surface (python/pybind_export.cpp:93-123): optimize() with enable_warm_start, getExecutionStats,
+    get/setSolverWarmStart* -- the closed loop of examples/quadrotor_ex.cpp for a few ticks, warm vs cold"""
+    from libmpc_amd import LParameters
+    from libmpc_amd.workloads import quadrotor_lmpc, quadrotor_matrices
+    Ad, Bd, _ = quadrotor_matrices()
+    cold = quadrotor_lmpc(10, device=0)
+    warm = quadrotor_lmpc(10, device=0)
+    warm.setOptimizerParameters(LParameters(maximum_iteration=250, enable_warm_start=1))
+    x = np.zeros(12); u = np.zeros(4)
+    for k in range(6):
+        rc = cold.optimize(x, u); rw = warm.optimize(x, u)
+        assert rc.status == rw.status == 0
+        np.testing.assert_allclose(rw.cmd, rc.cmd, rtol=1e-9, atol=1e-12)
+        x = Ad @ x + Bd @ rc.cmd; u = rc.cmd
+    st = warm.getExecutionStats()
+    assert st.numberOfSolutions == 6 and st.minSolutionTime <= st.averageSolutionTime <= st.maxSolutionTime
+    assert st.solutionsStates == {0: 6}
+    y = warm.getSolverWarmStartDual(); z = warm.getSolverWarmStartPrimal()
+    i = warm.info()
+    assert y.shape == (i["m_ref"],) and z.shape == (i["n_ref"],) and set(np.unique(y)) <= {-1.0, 0.0, 1.0}
+    other = quadrotor_lmpc(10, device=0)
+    other.setOptimizerParameters(LParameters(maximum_iteration=250, enable_warm_start=1))
+    other.setSolverWarmStart(z, y)
+    ro = other.optimize(x, u); rc = cold.optimize(x, u)
+    np.testing.assert_allclose(ro.cmd, rc.cmd, rtol=1e-9, atol=1e-12)
+    warm.resetStats()
+    assert warm.getExecutionStats().numberOfSolutions == 0
