@@ -251,6 +251,14 @@ void mpcx_nlparams_default(mpcx_nlparams *p);
 /* NLMPC::setOptimizerParameters -> NLOptimizer::setParameters (NLOptimizer.hpp:129-195) */
 int mpcx_nlmpc_set_optimizer_parameters(mpcx_nlmpc_t h, const mpcx_nlparams *p);
 
+/* NLMPC::setStateBounds / setInputBounds, vector + HorizonSlice form (NLMPC.hpp:346-398 -> NLOptimizer.hpp:346-404):
+ * box bounds on the states x_1..x_ph (slice over the prediction horizon) and on the input blocks (slice over the
+ * control horizon); {-1,-1} = the whole horizon.  They become rows of the sub-problem.  A starting point outside
+ * them is moved to (ub - lb) / 2 as NLOptimizer::fixOptimalSolution does (NLOptimizer.hpp:705-716).  Output bounds
+ * do not exist for NLMPC (NLMPC.hpp:318-325 throws).                                                        */
+int mpcx_nlmpc_set_state_bounds_slice(mpcx_nlmpc_t h, const double *lo, const double *hi, int start, int end);
+int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const double *hi, int start, int end);
+
 /* One batched NLOptimizer::run (NLOptimizer.hpp:412-638).  Device pointers.  Outputs other than
  * cmd may be NULL.  status uses MPCX_STATUS_* (ResultStatus), solver_status nlopt's result codes
  * (4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE = inconsistent linearised constraints,

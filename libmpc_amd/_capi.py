@@ -63,6 +63,7 @@ EXPORTS = [
     "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
     "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
     "mpcx_nlparams_default", "mpcx_nlmpc_set_optimizer_parameters", "mpcx_nlmpc_solve_batch", "mpcx_nlmpc_time_solve_batch", "mpcx_discretize_batch",
+    "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice",
 ]
 
 
@@ -114,6 +115,8 @@ def lib():
         _lib.mpcx_nlmpc_get_dims.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_evaluate_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.mpcx_nlparams_default.restype = None
+        for _n in ("mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice"):
+            getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.mpcx_discretize_batch.argtypes = [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
         _lib.mpcx_nlmpc_set_optimizer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_solve_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

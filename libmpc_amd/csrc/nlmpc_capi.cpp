@@ -1,6 +1,7 @@
 // extern "C" boundary of the NLMPC kernels (include/mpcx.h, mpcx_nlmpc_*).  Host code only; no CPU solve path.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,46 @@ struct mpcx_nlmpc {
     double *ws = nullptr;
     size_t ws_cap = 0;          // instances
     mpcx_nlparams prm{};
+    // NLOptimizer::lb / ub (NLOptimizer.hpp:346-404): bounds on the decision vector, host copy + device tables
+    std::vector<double> lb, ub;
+    bool bounds_dirty = true;
+    void *bnd_block = nullptr;  // one allocation: zlb | zub | bnd_val | bnd_sign | bnd_idx
+
+    int sync_bounds()
+    {
+        if (!bounds_dirty) return MPCX_OK;
+        const int nz = dev.nz;
+        std::vector<int> idx; std::vector<double> sign, val;
+        for (int k = 0; k < nz - 1; ++k) {          // the slack is handled by hard_constraints
+            if (ub[k] < 1e30) { idx.push_back(k); sign.push_back(1.0); val.push_back(ub[k]); }
+            if (lb[k] > -1e30) { idx.push_back(k); sign.push_back(-1.0); val.push_back(lb[k]); }
+        }
+        const int nb = (int)idx.size();
+        if (bnd_block) (void)hipFree(bnd_block);
+        bnd_block = nullptr;
+        const size_t bytes = sizeof(double) * (2 * (size_t)nz + 2 * (size_t)nb + 2) + sizeof(int) * ((size_t)nb + 2);
+        if (hipMalloc(&bnd_block, bytes) != hipSuccess) return MPCX_E_DEVICE;
+        double *d = static_cast<double *>(bnd_block);
+        bool ok = hipMemcpy(d, lb.data(), sizeof(double) * nz, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(d + nz, ub.data(), sizeof(double) * nz, hipMemcpyHostToDevice) == hipSuccess;
+        double *dval = d + 2 * nz, *dsign = dval + nb + 1;
+        int *didx = reinterpret_cast<int *>(dsign + nb + 1);
+        if (nb) {
+            ok = ok && hipMemcpy(dval, val.data(), sizeof(double) * nb, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(dsign, sign.data(), sizeof(double) * nb, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(didx, idx.data(), sizeof(int) * nb, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (!ok) return MPCX_E_DEVICE;
+        dev.zlb = d; dev.zub = d + nz; dev.bnd_val = dval; dev.bnd_sign = dsign; dev.bnd_idx = didx;
+        if (nb != dev.nbnd) {                       // the workspace layout depends on the number of rows
+            dev.nbnd = nb;
+            mpcx::nlmpc_plan(dev);
+            if (ws) (void)hipFree(ws);
+            ws = nullptr; ws_cap = 0;
+        }
+        bounds_dirty = false;
+        return MPCX_OK;
+    }
 };
 
 extern "C" {
@@ -58,7 +99,9 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq;
     d.Ts = Ts;
     d.params = h->params_d;
+    d.nbnd = 0;
     mpcx::nlmpc_plan(d);
+    h->lb.assign(d.nz, -INFINITY); h->ub.assign(d.nz, INFINITY);
     if ((size_t)d.lds_per_wave * sizeof(double) > 64 * 1024) {
         (void)hipFree(h->params_d);
         delete h;
@@ -74,6 +117,7 @@ int mpcx_nlmpc_destroy(mpcx_nlmpc_t h)
     (void)hipSetDevice(h->device);
     if (h->params_d) (void)hipFree(h->params_d);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->bnd_block) (void)hipFree(h->bnd_block);
     delete h;
     return MPCX_OK;
 }
@@ -92,6 +136,33 @@ int mpcx_nlmpc_set_optimizer_parameters(mpcx_nlmpc_t h, const mpcx_nlparams *p)
     if (p->maximum_iteration < 0) return mpcx::capi_fail(MPCX_E_INVALID, "maximum_iteration must be >= 0");
     h->prm = *p;
     return MPCX_OK;
+}
+
+static int set_bounds(mpcx_nlmpc_t h, const double *lo, const double *hi, int start, int end, bool state)
+{
+    using mpcx::capi_fail;
+    if (!h || !lo || !hi) return capi_fail(MPCX_E_INVALID, "null argument");
+    const mpcx::NlmpcDev &d = h->dev;
+    const int horizon = state ? d.ph : d.ch, n = state ? d.nx : d.nu, base = state ? 0 : d.ph * d.nx;
+    // HorizonSlice validity as IMPC.hpp:244-283: {-1,-1} = everything, otherwise 0 <= start < end <= horizon
+    const bool unset = start == -1 && end == -1;
+    if (!unset && !(start >= 0 && end > start && end <= horizon)) return capi_fail(MPCX_E_INVALID, "invalid horizon slice");
+    const int a = unset ? 0 : start, b = unset ? horizon : end;
+    for (int j = 0; j < n; ++j) if (lo[j] > hi[j]) return capi_fail(MPCX_E_INVALID, "lower bound above upper bound");
+    for (int i = a; i < b; ++i)
+        for (int j = 0; j < n; ++j) { h->lb[base + i * n + j] = lo[j]; h->ub[base + i * n + j] = hi[j]; }
+    h->bounds_dirty = true;
+    return MPCX_OK;
+}
+
+int mpcx_nlmpc_set_state_bounds_slice(mpcx_nlmpc_t h, const double *lo, const double *hi, int start, int end)
+{
+    return set_bounds(h, lo, hi, start, end, true);
+}
+
+int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const double *hi, int start, int end)
+{
+    return set_bounds(h, lo, hi, start, end, false);
 }
 
 int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const double *x0, double *cost, double *grad,
@@ -117,6 +188,7 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     if (b->batch == 0) return 1;
     if (!b->x0 || !b->u0 || !b->cmd) return capi_fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
     if (hipSetDevice(h->device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    if (h->sync_bounds() != MPCX_OK) return capi_fail(MPCX_E_DEVICE, "could not upload the bounds");
     if ((size_t)b->batch > h->ws_cap) {
         if (h->ws) (void)hipFree(h->ws);
         h->ws = nullptr; h->ws_cap = 0;

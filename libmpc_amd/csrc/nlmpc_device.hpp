@@ -27,6 +27,12 @@ struct NlmpcDev {
     int lds_per_wave;           // doubles
     double Ts;
     const double *params;       // model parameters in HBM
+    // box bounds on the decision vector (NLOptimizer::lb / ub): all of them, and the finite ones as sub-problem rows
+    const double *zlb, *zub;    // [nz]
+    int nbnd;
+    const int *bnd_idx;         // [nbnd] index into z
+    const double *bnd_sign;     // [nbnd] +1: z <= val, -1: z >= val
+    const double *bnd_val;      // [nbnd]
     NlmpcWsLayout ws;
 };
 

@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     const int ph = M.ph, ch = M.ch, nz = M.nz, m = M.nineq, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
+    const int mt = m + M.nbnd;                           // sub-problem rows: user inequalities, then the finite bounds on z
     const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
-    const int mld = (m + 1) & ~1;
+    const int mld = (mt + 1) & ~1;
     const double *prm = M.params;
     double *Xs = smem + (size_t)wave * M.lds_per_wave;
     double *Us = Xs + (ph + 1) * NX;
@@ -345,7 +346,12 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             if (lane == 0) z[nz - 1] = 0.0;
         }
         for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
-        for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+        for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
+        // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
+        for (int k = lane; k < nz; k += 64) {
+            const double lo = M.zlb[k], hi = M.zub[k];
+            if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
+        }
         nl_wave_sync();
         eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
 
@@ -429,6 +435,18 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     art[(size_t)q * mld + k] = acc;
                 }
             }
+            // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
+            for (int kb = 0; kb < M.nbnd; ++kb) {
+                const int zi = M.bnd_idx[kb];
+                const double sg = M.bnd_sign[kb];
+                for (int q = lane; q < nr; q += 64) {
+                    double v = 0.0;
+                    if (zi < nxs) v = q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0;
+                    else v = (q == zi - nxs) ? sg : 0.0;
+                    art[(size_t)q * mld + m + kb] = v;
+                }
+                if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - M.bnd_val[kb]);
+            }
             for (int k = lane; k < m; k += 64) {
                 double s = gin[k];
                 for (int cb = 0; cb < nchunk; ++cb) {
@@ -486,7 +504,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * gr[j];
                 xq[q] = -s;
             }
-            for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+            for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
             auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
@@ -553,9 +571,9 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     nl_wave_sync();
                 }
             }
-            for (int qit = 0; qit < 8 * (m + nq) + 16; ++qit) {
+            for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
                 double vmax = -1e300; int pidx = 0x7fffffff;
-                for (int k = lane; k < m; k += 64) {
+                for (int k = lane; k < mt; k += 64) {
                     double s = br[k];
                     for (int j = 0; j < nq; ++j) s += art[(size_t)j * mld + k] * xq[j];
                     bool inw = mu[k] < 0.0;                              // set aside (see below)
@@ -563,7 +581,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     if (!inw && s > vmax) { vmax = s; pidx = k; }
                 }
                 wave_argmax(vmax, pidx);
-                if (m == 0 || vmax <= 1e-12) { qp_done = true; break; }   // primal feasible (well inside the reported 1e-10): optimal
+                if (mt == 0 || vmax <= 1e-12) { qp_done = true; break; }   // primal feasible (well inside the reported 1e-10): optimal
                 if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
                 for (int q = lane; q < nq; q += 64) np_[q] = art[(size_t)q * mld + pidx];
                 nl_wave_sync();
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 if (!added) { qp_ok = false; break; }
             }
             if (!qp_ok || !qp_done) { code = qp_fail ? qp_fail : -1; break; }
-            for (int k = lane; k < m; k += 64) mu[k] = 0.0;
+            for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = uq[t];
             nw_keep = nw;
@@ -681,7 +699,11 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             // the weight of the l1 merit function has to dominate them and mu
             for (int row = lane; row < nxs; row += 64) {
                 double s2 = g[row];
-                for (int t = 0; t < nw_keep; ++t) s2 += jin[(size_t)((int)wq[t]) * nz + row] * uq[t];      // mu lives on the working set
+                for (int t = 0; t < nw_keep; ++t) {                     // mu lives on the working set
+                    const int k = (int)wq[t];
+                    if (k < m) s2 += jin[(size_t)k * nz + row] * uq[t];
+                    else if (M.bnd_idx[k - m] == row) s2 += M.bnd_sign[k - m] * uq[t];
+                }
                 lamw[row] = s2;
             }
             nl_wave_sync();
@@ -831,12 +853,13 @@ void nlmpc_plan(NlmpcDev &m)
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
-    const int mld = (m.nineq + 1) & ~1;
+    const int mtot = m.nineq + m.nbnd;
+    const int mld = (mtot + 1) & ~1;
     w.z = take(m.nz); w.d = take(m.nz); w.g = take(m.nz); w.c = take(m.neq); w.jeq = take(ph * nx * (2 * nx + nu));
     w.gin = take(m.nineq); w.jin = take(m.nineq * m.nz);
     w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
-    w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(m.nineq);
-    w.hinv = take(m.nr * m.nr); w.mu = take(m.nineq); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
+    w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(mtot);
+    w.hinv = take(m.nr * m.nr); w.mu = take(mtot); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
     w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
     w.lamw = take(m.neq); w.pen_eq = take(m.neq); w.pen_in = take(m.nineq); w.flag = take(2);
     w.total = o;

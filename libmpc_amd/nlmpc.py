@@ -91,6 +91,27 @@ class NLMPC(NLMPCEvaluator):
         check(self._lib.mpcx_nlmpc_set_optimizer_parameters(self._h, C.byref(p)))
         self._warm = bool(p.enable_warm_start)
 
+    def _bounds(self, fn, lo, hi, n, horizon, slice_):
+        lo = np.asarray(lo, dtype=np.float64); hi = np.asarray(hi, dtype=np.float64)
+        if lo.ndim == 2:                        # matrix form: one column per step (NLMPC.hpp:285-316)
+            ok = True
+            for i in range(horizon):
+                ok &= self._bounds(fn, lo[:, i], hi[:, i], n, horizon, (i, i + 1))
+            return ok
+        lo = np.ascontiguousarray(lo.reshape(n)); hi = np.ascontiguousarray(hi.reshape(n))
+        a, b = (-1, -1) if slice_ is None else (slice_.start, slice_.end) if hasattr(slice_, "start") else slice_
+        return fn(self._h, lo.ctypes.data, hi.ctypes.data, int(a), int(b)) == 0
+
+    def setStateBounds(self, lo, hi, slice_=None):
+        """NLMPC::setStateBounds (NLMPC.hpp:285-299, 346-358): returns False on an invalid slice, like the reference"""
+        return self._bounds(self._lib.mpcx_nlmpc_set_state_bounds_slice, lo, hi, self.nx, self.ph, slice_)
+
+    def setInputBounds(self, lo, hi, slice_=None):
+        return self._bounds(self._lib.mpcx_nlmpc_set_input_bounds_slice, lo, hi, self.nu, self.ch, slice_)
+
+    def setOutputBounds(self, *_a, **_k):
+        raise RuntimeError("Output constraints cannot be set for this type of MPC")        # NLMPC.hpp:318-325
+
     def _closures_are_fixed(self, *_a, **_k):
         raise RuntimeError("the system, objective and constraint functions of this controller are the built-in device "
                            "functors of its model; host callables cannot run inside the kernel")
