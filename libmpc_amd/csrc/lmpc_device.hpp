@@ -15,6 +15,8 @@
 
 namespace mpcx {
 
+constexpr int kLmpcQueues = 256;        // dispatch queues: 4 difficulty classes (initially violated rows / 4) x 64 ways
+constexpr int kLmpcQueueWays = 64;
 constexpr int kMaxActive = 28;          // working-set capacity of the in-kernel polish
 constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
 
@@ -66,6 +68,7 @@ struct LmpcBatchDev {
     int32_t *polish_rounds, *active_count;
     const uint32_t *warm_lower, *warm_upper;      // optional previous active sets (reference row numbering)
     int warm_shift;
+    int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 

@@ -37,6 +37,8 @@ namespace {
 #define MPCX_WAVES_PER_BLOCK 2
 #endif
 constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
+constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
+constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 3
 #endif
@@ -393,6 +395,8 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
     double *Bf = Bv + (size_t)kin4 * 64;             // [nz4][64]    f as MFMA B operands
     double *c0s = Bf + (size_t)nz4 * 64;             // [16]
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + 16);   // [16]
+    unsigned *nviol = bad + 16;                                // [16] rows violated at the unconstrained optimum
+    double *offs = c0s + 16 + 32;                              // [ldg][16] row offsets (only when the queue is built)
     const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
 
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             else if (k == M.ione) v = 1.0;
             Bv[kb * 64 + lane] = v;
         }
-        if (threadIdx.x < 16) { c0s[threadIdx.x] = 0.0; bad[threadIdx.x] = 0u; }
+        if (threadIdx.x < 16) { c0s[threadIdx.x] = 0.0; bad[threadIdx.x] = 0u; nviol[threadIdx.x] = 0u; }
         __syncthreads();
 
         gdw wsj = glw(wsbase) + (size_t)bc * M.wsld;
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
                         wsj[ldz + ldy + row] = GP(lg0)[row] - acc[r];
                         wsj[ldz + ldy + ldg + row] = GP(ug0)[row] - acc[r];
                     }
+                    if (Bt.qcnt && row < ldg) offs[row * 16 + j] = acc[r];
                 }
             } else if (t < tq) {
 #pragma unroll
@@ -485,20 +490,50 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             }
             for (; kb < nz4; ++kb)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
+            unsigned nv = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
                 if (live && row < ldy) wsj[ldz + row] = acc[r];
+                if (Bt.qcnt) {              // same test as the first working set of lmpc_solve
+                    double lo = -__builtin_inf(), hi = __builtin_inf();
+                    if (row < nz) { lo = GP(lw)[row]; hi = GP(uw)[row]; }
+                    else if (row >= ldz && row - ldz < mg) { const double o = offs[(row - ldz) * 16 + j]; lo = GP(lg0)[row - ldz] - o; hi = GP(ug0)[row - ldz] - o; }
+                    nv += (acc[r] < lo - 1e-8 * fmax(1.0, fabs(lo))) || (acc[r] > hi + 1e-8 * fmax(1.0, fabs(hi)));
+                }
             }
+            if (Bt.qcnt && nv) atomicAdd(&nviol[j], nv);
         }
+        __syncthreads();
         if (threadIdx.x < 16 && b0 + (int)threadIdx.x < Bt.batch) {
             gdw wst = glw(wsbase) + (size_t)(b0 + threadIdx.x) * M.wsld + ldz + ldy + 2 * ldg;
             wst[0] = c0s[threadIdx.x];
             wst[1] = bad[threadIdx.x] ? 1.0 : 0.0;
         }
+        if (Bt.qcnt) {
+            // difficulty queues: the rounds an instance needs grow with its working set, and a launch lasts as long as its
+            // slowest wavefront -- instances with many violated rows are dispatched first.  kQueueKeys classes x kQueueWays
+            // ways (the way is the workgroup's, which spreads the device-scope atomics: one per class and workgroup).
+            int *cls = reinterpret_cast<int *>(nviol + 16), *cbase = cls + 16;
+            const int way = blockIdx.x & (kQueueWays - 1);
+            if (threadIdx.x < 16) cls[threadIdx.x] = b0 + (int)threadIdx.x < Bt.batch ? min((int)nviol[threadIdx.x] >> 2, kQueueKeys - 1) : -1;
+            __syncthreads();
+            if (threadIdx.x < kQueueKeys) {
+                int n = 0;
+                for (int u = 0; u < 16; ++u) n += cls[u] == (int)threadIdx.x;
+                cbase[threadIdx.x] = n ? atomicAdd(&Bt.qcnt[threadIdx.x * kQueueWays + way], n) : 0;
+            }
+            __syncthreads();
+            if (threadIdx.x < 16 && cls[threadIdx.x] >= 0) {
+                const int c = cls[threadIdx.x];
+                int rank = 0;
+                for (int u = 0; u < (int)threadIdx.x; ++u) rank += cls[u] == c;
+                const int pos = cbase[c] + rank;
+                if (pos < Bt.qcap) Bt.qlist[(size_t)(c * kQueueWays + way) * Bt.qcap + pos] = b0 + threadIdx.x;
+            }
+        }
         __syncthreads();
     }
-    (void)nz; (void)mg;
 }
 
 // =====================================================================================
@@ -1279,6 +1314,28 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < tsi ? tstamp[k] : 0;
 }
 
+// i-th instance in dispatch order: hardest class first, its ways in turn (identity when no queues were built).
+// kQueueWays == 64: lane l reads the counter of way l, a wave scan finds the way that holds position i.
+__device__ __forceinline__ int queued_instance(const LmpcBatchDev &Bt, int i, int lane)
+{
+    if (!Bt.qcnt) return i;
+    int rem = i;
+    for (int c = kQueueKeys - 1; c >= 0; --c) {
+        const int n = min(Bt.qcnt[c * kQueueWays + lane], Bt.qcap);
+        int incl = n;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        const int tot = __shfl(incl, 63);
+        if (rem < tot) {
+            const unsigned long long hit = __ballot(incl > rem);
+            const int L = (int)__builtin_ctzll(hit);
+            const int pos = rem - (__shfl(incl, L) - __shfl(n, L));
+            return Bt.qlist[(size_t)(c * kQueueWays + L) * Bt.qcap + pos];
+        }
+        rem -= tot;
+    }
+    return i;        // not reached when every instance was queued
+}
+
 template <int CPZ, int CPG>
 __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
 {
@@ -1289,8 +1346,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_so
     double *nt0 = stage + M.stage_len;
     double *arena = nt0 + M.ldy;
     const int wpb = blockDim.x >> 6;
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
+        const int b = queued_instance(Bt, i, lane);
         solve_one<CPZ, CPG, false>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+    }
 }
 
 // Fallback for the instances the polish-only kernel left unsolved (a handful in a thousand, or
@@ -1307,6 +1366,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
     const int wpb = blockDim.x >> 6;
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
         solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+    // last kernel of a launch: leave the dispatch queues empty for the next one
+    if (Bt.qcnt && Bt.qreset && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < kQueues; q += blockDim.x) Bt.qcnt[q] = 0;
 }
 
 
@@ -1763,8 +1825,10 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (which & 1) {
+        // the counters are cleared by the last kernel of a full launch; partial launches (profiling) clear them here
+        if (b.qcnt && which != 7) (void)hipMemsetAsync(b.qcnt, 0, kQueues * sizeof(int), stream);
         if (fast >= 0) {
-            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 16 + 8) * sizeof(double);
+            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 16 + 32 + (b.qcnt ? (size_t)m.ldg * 16 : 0)) * sizeof(double);
             int blocks1 = (b.batch + 15) / 16;
             if (blocks1 > 4096) blocks1 = 4096;
             hipLaunchKernelGGL(lmpc_assemble_mfma, dim3(blocks1), dim3(256), lds1, stream, m_dev, b, ws, fast);

@@ -42,8 +42,10 @@ struct mpcx_lmpc {
     long long *dbg_cycles = nullptr;
     bool force_generic = false;
     bool strict_infeasible = false;
+    bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
     bool use_quad = false;              // measured slower than one-instance-per-wave at B = 4096 (1 wave per SIMD)         // testing aid: route every batch through the generic assemble kernel
     double *ws = nullptr;               // per-instance workspace between assemble and solve
+    int *queues = nullptr;              // dispatch queues: kLmpcQueues counters, then kLmpcQueues lists of ws_cap instances
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
 
@@ -52,7 +54,8 @@ struct mpcx_lmpc {
         for (void *p : allocs) (void)hipFree(p);
         allocs.clear();
         if (ws) (void)hipFree(ws);
-        ws = nullptr; ws_cap = 0;
+        if (queues) (void)hipFree(queues);
+        ws = nullptr; queues = nullptr; ws_cap = 0;
     }
     template <typename T>
     const T *up(const std::vector<T> &v, int &rc)
@@ -466,9 +469,14 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     if ((size_t)b->batch > h->ws_cap) {
         // grows only when a larger batch than ever before arrives (not capturable in a graph)
         if (h->ws) (void)hipFree(h->ws);
-        h->ws = nullptr; h->ws_cap = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess)
+        if (h->queues) (void)hipFree(h->queues);
+        h->ws = nullptr; h->queues = nullptr; h->ws_cap = 0;
+        const size_t qcap = (size_t)b->batch / mpcx::kLmpcQueueWays + 16;       // a way only receives its own workgroups' instances
+        const size_t qn = (size_t)mpcx::kLmpcQueues * (qcap + 1);
+        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&h->queues), qn * sizeof(int)) != hipSuccess)
             return fail(MPCX_E_DEVICE, "workspace allocation failed");
+        (void)hipMemset(h->queues, 0, mpcx::kLmpcQueues * sizeof(int));
         h->ws_cap = (size_t)b->batch;
     }
     // the MFMA assemble kernel serves shared or per-instance-constant output references with
@@ -478,6 +486,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
+    if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
@@ -592,6 +601,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
+    if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -604,7 +614,16 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         (void)hipEventElapsedTime(&ms, e0, e1);
         ms2[which == 1 ? 0 : (which == 2 ? 1 : 2)] = ms / (float)repeats;
     }
+    if (B.qcnt) (void)hipMemsetAsync(B.qcnt, 0, mpcx::kLmpcQueues * sizeof(int), s);     // full launches expect empty queues
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MPCX_OK;
+}
+
+/* testing aid: 0 = dispatch lmpc_solve in instance order instead of hardest-first */
+int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->use_queues = on != 0;
     return MPCX_OK;
 }
 

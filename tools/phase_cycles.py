@@ -32,3 +32,14 @@ print("both kernels ms", ms)
 ms2 = (C.c_float * 3)()
 c._lib.mpcx_lmpc_debug_time_kernels(c._h, C.byref(batch), C.c_void_p(torch.cuda.current_stream().cuda_stream), 20, ms2)
 print("assemble ms %.4f  polish-solve ms %.4f  admm-fallback ms %.4f" % (ms2[0], ms2[1], ms2[2]))
+rd = res.polish_rounds.cpu().numpy()
+start = t[:, 0] - t[:, 0].min(); end = t[:, 3] - t[:, 0].min()
+order = np.argsort(end)[::-1][:8]
+print("last finishers: (instance, rounds, start, end, own cycles)")
+for i in order:
+    print("   ", int(i), int(rd[i]), int(start[i]), int(end[i]), int(tot[i]))
+print("cycles per round (median over instances with >=3 rounds):", np.median((d[:, 1] / np.maximum(rd, 1))[rd >= 3]))
+print("start-time distribution: p50 %d p90 %d max %d" % (np.median(start), np.percentile(start, 90), start.max()))
+import collections
+late = start > np.percentile(start, 75)
+print("instances starting late (4th quartile): mean rounds %.2f ; early: %.2f" % (rd[late].mean(), rd[~late].mean()))
