@@ -47,6 +47,42 @@ __device__ __forceinline__ double wave_max(double v)
     for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+
+// sum_j a[j * stride] * x[j]: the loads of a batch are issued together and waited for once -- the compiler does not
+// pipeline loads across the iterations of a plain loop, and every iteration would pay the full memory latency
+__device__ __forceinline__ double gdot(const double *__restrict__ a, size_t stride, const double *x, int n)
+{
+    constexpr int U = 8;
+    double s = 0;
+    int j = 0;
+    for (; j + U <= n; j += U) {
+        double v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = a[(size_t)(j + u) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = x[j + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s = fma(v[u], w[u], s);
+    }
+    for (; j < n; ++j) s = fma(a[(size_t)j * stride], x[j], s);
+    return s;
+}
+// the same with both operands strided in memory
+__device__ __forceinline__ double gdot2(const double *__restrict__ a, size_t sa, const double *__restrict__ b, size_t sb, int n)
+{
+    constexpr int U = 8;
+    double s = 0;
+    int j = 0;
+    for (; j + U <= n; j += U) {
+        double v[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = a[(size_t)(j + u) * sa]; w[u] = b[(size_t)(j + u) * sb]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) s = fma(v[u], w[u], s);
+    }
+    for (; j < n; ++j) s = fma(a[(size_t)j * sa], b[(size_t)j * sb], s);
+    return s;
+}
 // largest value and the lowest lane-supplied index holding it
 __device__ __forceinline__ void wave_argmax(double &v, int &idx)
 {
@@ -297,7 +333,7 @@ __device__ void invert_small(double *Aug, int n, int lane)
 }
 
 template <class Mdl>
-__global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
+__global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KW = kNlMaxWorking, SLD = KW + 1, KL = kNlLdsWorking;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -407,32 +443,88 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
             for (int q = lane; q < nr; q += 64) {
                 if (q == nzu) { gr[q] = g[nz - 1]; continue; }
-                double s = g[nxs + q];
-                for (int row = 0; row < nxs; ++row) s += phi[(size_t)row * nzu + q] * g[row];
+                const double s = g[nxs + q] + gdot2(phi + q, nzu, g, 1, nxs);
                 gr[q] = s;
             }
             // user inequalities read few states: one bit per (row, state) entry of d g / d x that holds anything
             const int nchunk = (nxs + 63) >> 6;
-            for (int e0 = 0; e0 < m * nchunk; ++e0) {
-                const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
-                const bool any = col < nxs && jin[(size_t)k * nz + col] != 0.0;
-                const unsigned long long bal = __ballot(any);
-                if (lane == 0) fmask[e0] = bal;
+            for (int e0 = 0; e0 < m * nchunk; e0 += 8) {           // eight loads in flight, then eight ballots
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u, m * nchunk - 1), k = e / nchunk, col = (e - k * nchunk) * 64 + lane;
+                    v[u] = jin[(size_t)k * nz + min(col, nxs - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u, col = (e % nchunk) * 64 + lane;
+                    const unsigned long long bal = __ballot(col < nxs && v[u] != 0.0);
+                    if (lane == 0 && e < m * nchunk) fmask[e] = bal;
+                }
             }
             nl_wave_sync();
             for (int q = lane; q < nr; q += 64) {
-                for (int k = 0; k < m; ++k) {
-                    double acc = jin[(size_t)k * nz + (q == nzu ? nz - 1 : nxs + q)];
-                    if (q < nzu)
-                        for (int cb = 0; cb < nchunk; ++cb) {
-                            unsigned long long mk = fmask[k * nchunk + cb];
-                            while (mk) {
-                                const int row = cb * 64 + (int)__builtin_ctzll(mk);
-                                mk &= mk - 1;
-                                acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
+                const bool realq = q < nzu;
+                const size_t qq = realq ? q : 0, ucol = q == nzu ? nz - 1 : nxs + q;
+                if (nchunk <= 2) {
+                    // four rows at a time, up to four entries of each gathered first so that their loads are in flight together
+                    for (int k0 = 0; k0 < m; k0 += 4) {
+                        int c4[4][4];
+                        unsigned long long rest0[4], rest1[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int k = min(k0 + rr, m - 1);
+                            unsigned long long m0 = fmask[k * nchunk], m1 = nchunk > 1 ? fmask[k * nchunk + 1] : 0ull;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                int cc = -1;
+                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; }
+                                else if (m1) { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
+                                c4[rr][u] = cc;
+                            }
+                            rest0[rr] = m0; rest1[rr] = m1;
+                        }
+                        double a0[4], jv[4][4], pv[4][4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const size_t k = min(k0 + rr, m - 1);
+                            a0[rr] = jin[k * nz + ucol];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const size_t cc = c4[rr][u] < 0 ? 0 : c4[rr][u];
+                                jv[rr][u] = jin[k * nz + cc];
+                                pv[rr][u] = phi[cc * nzu + qq];
                             }
                         }
-                    art[(size_t)q * mld + k] = acc;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            double acc = a0[rr];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (realq && c4[rr][u] >= 0) acc = fma(jv[rr][u], pv[rr][u], acc);
+                            const size_t k = min(k0 + rr, m - 1);
+                            unsigned long long m0 = rest0[rr], m1 = rest1[rr];
+                            while (realq && (m0 | m1)) {                   // rows with more than four entries
+                                int cc;
+                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; } else { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
+                                acc = fma(jin[k * nz + cc], phi[(size_t)cc * nzu + qq], acc);
+                            }
+                            if (k0 + rr < m) art[(size_t)q * mld + k0 + rr] = acc;
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < m; ++k) {
+                        double acc = jin[(size_t)k * nz + ucol];
+                        if (realq)
+                            for (int cb = 0; cb < nchunk; ++cb) {
+                                unsigned long long mk = fmask[k * nchunk + cb];
+                                while (mk) {
+                                    const int row = cb * 64 + (int)__builtin_ctzll(mk);
+                                    mk &= mk - 1;
+                                    acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
+                                }
+                            }
+                        art[(size_t)q * mld + k] = acc;
+                    }
                 }
             }
             // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
@@ -482,8 +574,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     const double rho = 1.0 / sy;
                     double yHy = 0;
                     for (int q = lane; q < nq; q += 64) {
-                        double s = 0;
-                        for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * v0[j];
+                        const double s = gdot(hinv + q, nr, v0, nq);
                         v2[q] = s; yHy += s * v0[q];
                     }
                     yHy = wave_sum(yHy);
@@ -500,8 +591,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             // ---- sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0   (Goldfarb-Idnani, range-space form on B^-1)
             double *xq = v0, *np_ = v1, *vv = v2, *zd = v3;
             for (int q = lane; q < nq; q += 64) {
-                double s = 0;
-                for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * gr[j];
+                const double s = gdot2(hinv + q, nr, gr, 1, nq);
                 xq[q] = -s;
             }
             for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
@@ -530,23 +620,20 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     for (int q = lane; q < nq; q += 64) vv[q] = art[(size_t)q * mld + k];
                     nl_wave_sync();
                     for (int q = lane; q < nq; q += 64) {
-                        double s2 = 0;
-                        for (int j = 0; j < nq; ++j) s2 += hinv[(size_t)j * nr + q] * vv[j];
+                        const double s2 = gdot(hinv + q, nr, vv, nq);
                         qn[(size_t)t * nr + q] = vv[q]; qv[(size_t)t * nr + q] = s2;
                     }
                     nl_wave_sync();
                 }
                 for (int e2 = lane; e2 < nw * nw; e2 += 64) {
                     const int a = e2 / nw, b2 = e2 - a * nw;
-                    double s2 = 0;
-                    for (int j = 0; j < nq; ++j) s2 += qn[(size_t)a * nr + j] * qv[(size_t)b2 * nr + j];
+                    const double s2 = gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
                     Ssm[a * SLD + b2] = s2;
                 }
                 nl_wave_sync();
                 while (nw > 0) {
                     for (int t = lane; t < nw; t += 64) {
-                        double s2 = br[(int)wq[t]];
-                        for (int j = 0; j < nq; ++j) s2 += qn[(size_t)t * nr + j] * xq[j];
+                        const double s2 = br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
                         tq[t] = s2;
                     }
                     double *Sf = nw <= KL ? Sfac : Sbig;
@@ -563,8 +650,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 }
                 if (nw > 0) {
                     for (int q = lane; q < nq; q += 64) {
-                        double s2 = xq[q];
-                        for (int t = 0; t < nw; ++t) s2 -= qv[(size_t)t * nr + q] * tq[t];
+                        const double s2 = xq[q] - gdot(qv + q, nr, tq, nw);
                         xq[q] = s2;
                     }
                     if (lane < nw) uq[lane] = tq[lane];
@@ -574,8 +660,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < mt; k += 64) {
-                    double s = br[k];
-                    for (int j = 0; j < nq; ++j) s += art[(size_t)j * mld + k] * xq[j];
+                    const double s = br[k] + gdot(art + k, mld, xq, nq);
                     bool inw = mu[k] < 0.0;                              // set aside (see below)
                     for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
                     if (!inw && s > vmax) { vmax = s; pidx = k; }
@@ -589,15 +674,13 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                 bool added = false;
                 for (int inner = 0; inner <= KW + 1 && !added; ++inner) {
                     for (int q = lane; q < nq; q += 64) {
-                        double s = 0;
-                        for (int j = 0; j < nq; ++j) s += hinv[(size_t)j * nr + q] * np_[j];
+                        const double s = gdot(hinv + q, nr, np_, nq);
                         vv[q] = s;
                     }
                     nl_wave_sync();
                     // t = N_W v (also the new column of S), rr = S^-1 t
                     for (int t = lane; t < nw; t += 64) {
-                        double s = 0;
-                        for (int j = 0; j < nq; ++j) s += qn[(size_t)t * nr + j] * vv[j];
+                        const double s = gdot(qn + (size_t)t * nr, 1, vv, nq);
                         tq[t] = s;
                     }
                     // small working sets factor in LDS, large ones in the workspace
@@ -609,8 +692,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
                     if (nw) spd_solve(Sf, sfld, tq, nw, lane);
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
-                        double s = vv[q];
-                        for (int t = 0; t < nw; ++t) s -= qv[(size_t)t * nr + q] * tq[t];
+                        const double s = vv[q] - gdot(qv + q, nr, tq, nw);
                         zd[q] = s; zn += s * np_[q];
                     }
                     zn = wave_sum(zn);
@@ -668,8 +750,7 @@ __global__ __launch_bounds__(256) void nlmpc_sqp(const NlmpcDev M, const NlmpcSo
             // ---- full-space step d = [r + Phi p_u ; p]
             double dmax = 0, cmax = 0, gd = 0;
             for (int row = lane; row < nxs; row += 64) {
-                double s = r[row];
-                for (int q = 0; q < nzu; ++q) s += phi[(size_t)row * nzu + q] * p[q];
+                const double s = r[row] + gdot2(phi + (size_t)row * nzu, 1, p, 1, nzu);
                 d[row] = s;
             }
             for (int q = lane; q < nr; q += 64) d[nxs + q] = p[q];
