@@ -391,6 +391,17 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
         nl_wave_sync();
         eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
 
+        // user inequalities read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
+        // structure the model declares (the finite differences leave exact zeros everywhere else)
+        {
+            const int nchunk = (nxs + 63) >> 6;
+            for (int e0 = 0; e0 < m * nchunk; ++e0) {
+                const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
+                const unsigned long long bal = __ballot(col < nxs && Mdl::ineq_reads_x(k, col / NX + 1));
+                if (lane == 0) fmask[e0] = bal;
+            }
+            nl_wave_sync();
+        }
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
         int resets = 0;
@@ -412,30 +423,89 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     nl_wave_sync();
                 }
             }
-            // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0
-            for (int q = lane; q <= nzu; q += 64) {
-                double v[NX], t[NX];
-                for (int a = 0; a < NX; ++a) v[a] = 0.0;
-                const int bq = q / NU, jq = q - bq * NU;
-                for (int i = 0; i < ph; ++i) {
-                    const double *Jb = jeq + (size_t)i * NX * W;
-                    for (int a = 0; a < NX; ++a) {
-                        double s = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
-                        for (int bb = 0; bb < NX; ++bb) s += Jb[a * W + bb] * v[bb];
-                        t[a] = s;
-                    }
-                    if (Mdl::CONTINUOUS) {
-                        const double *Ei = einv + (size_t)i * NX * NX;
-                        for (int a = 0; a < NX; ++a) {
-                            double s = 0;
-                            for (int bb = 0; bb < NX; ++bb) s += Ei[a * NX + bb] * t[bb];
-                            v[a] = -s;
+            // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0.  A_i = dc_i/dx_i (and E_i^-1) are the same for
+            // every lane: they are staged in LDS, the next step's share already in flight while this step computes.
+            if constexpr (NX >= 8) {
+            for (int q0 = 0; q0 <= nzu; q0 += 64) {
+                    const int q = q0 + lane;
+                    const bool qlive = q <= nzu;
+                    const int bq = q / NU, jq = q - bq * NU;
+                    constexpr int NST = Mdl::CONTINUOUS ? 2 * NX * NX : NX * NX;     // staged doubles per step: A | Einv
+                    constexpr int PL = (NST + 63) / 64;
+                    double *As = aug, *Es = aug + NX * NX;
+                    double nxt[PL], rhs[NX], rhs_n[NX], v[NX], t[NX];
+                    auto fetch = [&](int i, double (&dst)[PL], double (&rh)[NX]) {
+                        const double *Jb = jeq + (size_t)i * NX * W;
+    #pragma unroll
+                        for (int u = 0; u < PL; ++u) {
+                            const int e = min(lane + 64 * u, NST - 1);
+                            dst[u] = e < NX * NX ? Jb[(e / NX) * W + e % NX] : einv[(size_t)i * NX * NX + (e - NX * NX)];
                         }
-                    } else {
-                        for (int a = 0; a < NX; ++a) v[a] = -t[a];
+    #pragma unroll
+                        for (int a = 0; a < NX; ++a)
+                            rh[a] = !qlive ? 0.0 : (q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0));
+                    };
+    #pragma unroll
+                    for (int a = 0; a < NX; ++a) v[a] = 0.0;
+                    fetch(0, nxt, rhs_n);
+                    for (int i = 0; i < ph; ++i) {
+    #pragma unroll
+                        for (int u = 0; u < PL; ++u) if (lane + 64 * u < NST) aug[lane + 64 * u] = nxt[u];
+    #pragma unroll
+                        for (int a = 0; a < NX; ++a) rhs[a] = rhs_n[a];
+                        nl_wave_sync();
+                        if (i + 1 < ph) fetch(i + 1, nxt, rhs_n);
+    #pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double s2 = rhs[a];
+    #pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) s2 = fma(As[a * NX + bb], v[bb], s2);
+                            t[a] = s2;
+                        }
+                        if (Mdl::CONTINUOUS) {
+    #pragma unroll
+                            for (int a = 0; a < NX; ++a) {
+                                double s2 = 0;
+    #pragma unroll
+                                for (int bb = 0; bb < NX; ++bb) s2 = fma(Es[a * NX + bb], t[bb], s2);
+                                v[a] = -s2;
+                            }
+                        } else {
+    #pragma unroll
+                            for (int a = 0; a < NX; ++a) v[a] = -t[a];
+                        }
+                        if (qlive) {
+                            if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
+                            else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
+                        }
+                        nl_wave_sync();
                     }
-                    if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
-                    else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
+                }
+            } else {
+                for (int q = lane; q <= nzu; q += 64) {
+                    double v[NX], t[NX];
+                    for (int a = 0; a < NX; ++a) v[a] = 0.0;
+                    const int bq = q / NU, jq = q - bq * NU;
+                    for (int i = 0; i < ph; ++i) {
+                        const double *Jb = jeq + (size_t)i * NX * W;
+                        for (int a = 0; a < NX; ++a) {
+                            double s = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
+                            for (int bb = 0; bb < NX; ++bb) s += Jb[a * W + bb] * v[bb];
+                            t[a] = s;
+                        }
+                        if (Mdl::CONTINUOUS) {
+                            const double *Ei = einv + (size_t)i * NX * NX;
+                            for (int a = 0; a < NX; ++a) {
+                                double s = 0;
+                                for (int bb = 0; bb < NX; ++bb) s += Ei[a * NX + bb] * t[bb];
+                                v[a] = -s;
+                            }
+                        } else {
+                            for (int a = 0; a < NX; ++a) v[a] = -t[a];
+                        }
+                        if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
+                        else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
+                    }
                 }
             }
             nl_wave_sync();
@@ -446,22 +516,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 const double s = g[nxs + q] + gdot2(phi + q, nzu, g, 1, nxs);
                 gr[q] = s;
             }
-            // user inequalities read few states: one bit per (row, state) entry of d g / d x that holds anything
             const int nchunk = (nxs + 63) >> 6;
-            for (int e0 = 0; e0 < m * nchunk; e0 += 8) {           // eight loads in flight, then eight ballots
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = min(e0 + u, m * nchunk - 1), k = e / nchunk, col = (e - k * nchunk) * 64 + lane;
-                    v[u] = jin[(size_t)k * nz + min(col, nxs - 1)];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u, col = (e % nchunk) * 64 + lane;
-                    const unsigned long long bal = __ballot(col < nxs && v[u] != 0.0);
-                    if (lane == 0 && e < m * nchunk) fmask[e] = bal;
-                }
-            }
             nl_wave_sync();
             for (int q = lane; q < nr; q += 64) {
                 const bool realq = q < nzu;
