@@ -279,6 +279,11 @@ typedef struct mpcx_nlmpc_batch {
     double *seq_input;         /* [B x (ph+1) x nu]                                                 */
 } mpcx_nlmpc_batch;
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
+/* The same for callers whose data lives in host memory (the reference's optimize(x0, lastU) is such a caller): stages,
+ * solves on the default stream, copies back, synchronises.  Outputs other than cmd may be NULL; z_warm may be NULL. */
+int mpcx_nlmpc_solve_host(mpcx_nlmpc_t h, int batch, const double *x0, const double *u0, const double *z_warm, double *cmd,
+                          double *cost, int32_t *status, int32_t *solver_status, int32_t *is_feasible, int32_t *iterations,
+                          double *z, double *seq_state, double *seq_input);
 /* `repeats` back-to-back launches bracketed by HIP events on `stream`; mean milliseconds. */
 int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream, int repeats, float *ms_mean);
 

@@ -63,7 +63,7 @@ EXPORTS = [
     "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
     "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
     "mpcx_nlparams_default", "mpcx_nlmpc_set_optimizer_parameters", "mpcx_nlmpc_solve_batch", "mpcx_nlmpc_time_solve_batch", "mpcx_discretize_batch",
-    "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice",
+    "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice", "mpcx_nlmpc_solve_host",
 ]
 
 

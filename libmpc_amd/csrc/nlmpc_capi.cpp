@@ -216,6 +216,49 @@ int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stre
     return MPCX_OK;
 }
 
+int mpcx_nlmpc_solve_host(mpcx_nlmpc_t h, int batch, const double *x0, const double *u0, const double *z_warm, double *cmd,
+                          double *cost, int32_t *status, int32_t *solver_status, int32_t *is_feasible, int32_t *iterations,
+                          double *z, double *seq_state, double *seq_input)
+{
+    using mpcx::capi_fail;
+    if (!h) return capi_fail(MPCX_E_INVALID, "null handle");
+    if (batch < 0) return capi_fail(MPCX_E_INVALID, "negative batch");
+    if (batch == 0) return MPCX_OK;
+    if (!x0 || !u0 || !cmd) return capi_fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
+    if (hipSetDevice(h->device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    const mpcx::NlmpcDev &d = h->dev;
+    const size_t B = (size_t)batch, n1 = (size_t)d.ph + 1;
+    const size_t nd = B * (d.nx + d.nu + 2 * (size_t)d.nz + d.nu + 1 + n1 * (d.nx + d.nu));
+    double *dbuf = nullptr; int32_t *ibuf = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&dbuf), nd * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ibuf), B * 4 * sizeof(int32_t)) != hipSuccess) {
+        if (dbuf) (void)hipFree(dbuf);
+        return capi_fail(MPCX_E_DEVICE, "staging allocation failed");
+    }
+    double *dx0 = dbuf, *du0 = dx0 + B * d.nx, *dzw = du0 + B * d.nu, *dz = dzw + B * d.nz, *dcmd = dz + B * d.nz,
+           *dcost = dcmd + B * d.nu, *dss = dcost + B, *dsi = dss + B * n1 * d.nx;
+    bool ok = hipMemcpy(dx0, x0, B * d.nx * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(du0, u0, B * d.nu * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (z_warm) ok = ok && hipMemcpy(dzw, z_warm, B * d.nz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    mpcx_nlmpc_batch b{};
+    b.batch = batch; b.x0 = dx0; b.u0 = du0; b.z_warm = z_warm ? dzw : nullptr; b.cmd = dcmd; b.cost = dcost;
+    b.status = ibuf; b.solver_status = ibuf + B; b.is_feasible = ibuf + 2 * B; b.iterations = ibuf + 3 * B;
+    b.z = dz; b.seq_state = dss; b.seq_input = dsi;
+    int rc = ok ? mpcx_nlmpc_solve_batch(h, &b, nullptr) : MPCX_E_DEVICE;
+    if (rc == MPCX_OK) {
+        auto back = [&](void *dst, const void *src, size_t bytes) { if (dst) ok = ok && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+        back(cmd, dcmd, B * d.nu * sizeof(double)); back(cost, dcost, B * sizeof(double));
+        back(status, ibuf, B * 4); back(solver_status, ibuf + B, B * 4); back(is_feasible, ibuf + 2 * B, B * 4);
+        back(iterations, ibuf + 3 * B, B * 4); back(z, dz, B * d.nz * sizeof(double));
+        back(seq_state, dss, B * n1 * d.nx * sizeof(double)); back(seq_input, dsi, B * n1 * d.nu * sizeof(double));
+        if (!ok) rc = capi_fail(MPCX_E_DEVICE, "copy failed");
+    } else if (!ok) {
+        rc = capi_fail(MPCX_E_DEVICE, "copy failed");
+    }
+    (void)hipFree(dbuf); (void)hipFree(ibuf);
+    return rc;
+}
+
 int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream, int repeats, float *ms_mean)
 {
     using mpcx::capi_fail;

@@ -11,16 +11,16 @@ SRC = os.path.join(ROOT, "tests", "cpp", "lmpc_frontend_test.cpp")
 OUT = os.path.join(ROOT, "tests", "cpp", "build", "lmpc_frontend_test")
 
 
-def _build():
+def _build(src=SRC, out=OUT):
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = os.path.join(ROOT, "libmpc_amd")
-    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), SRC, "-o", OUT,
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            "-L" + lib, "-lmpcx", "-L/opt/rocm/lib", "-lamdhip64",
            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 def test_cpp_frontend_api_without_gpu():
@@ -39,3 +39,24 @@ def test_cpp_frontend_quadrotor_known_answer():
     out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all C++ front-end checks passed" in out.stdout
+
+
+NL_SRC = os.path.join(ROOT, "tests", "cpp", "nlmpc_frontend_test.cpp")
+NL_OUT = os.path.join(ROOT, "tests", "cpp", "build", "nlmpc_frontend_test")
+
+
+def test_cpp_nlmpc_frontend_api_without_gpu():
+    exe = _build(NL_SRC, NL_OUT)
+    out = subprocess.run([exe, "api"], env=dict(os.environ, MPCX_DEVICE="-1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all C++ NLMPC front-end checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_nlmpc_frontend_vanderpol_closed_loop():
+    """reference examples/vanderpol_ex.cpp through include/mpc/NLMPC.hpp: closed loop to the origin, first move = the oracle's"""
+    exe = _build(NL_SRC, NL_OUT)
+    env = {k: v for k, v in os.environ.items() if k != "MPCX_DEVICE"}
+    out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all C++ NLMPC front-end checks passed" in out.stdout
