@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps rotate over (each with its own controller handle, workspace and outputs): "
+                         "the tail of one batch overlaps the start of the next; 1 = strictly serial steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -45,17 +48,25 @@ def main():
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
 
     B, ph = args.batch, args.horizon
-    ctl = quadrotor_lmpc(ph, device=local)
-    info = ctl.info()
     x0, u0, yref = quadrotor_batch(B, first=rank * B)
-    batch, res, keep = ctl.make_batch(x0, u0, yref=yref)
-    stream = torch.cuda.current_stream(local)
+    ns = max(1, args.streams)
+    lanes = []
+    for k in range(ns):
+        c_k = quadrotor_lmpc(ph, device=local)
+        b_k, r_k, keep_k = c_k.make_batch(x0, u0, yref=yref)
+        lanes.append((c_k, b_k, r_k, keep_k, torch.cuda.current_stream(local) if ns == 1 else torch.cuda.Stream(device=dev)))
+    ctl, batch, res, keep, stream = lanes[0]
+    info = ctl.info()
+    counter = [0]
 
     def step():
-        ctl.launch(batch, stream)
-        if world > 1:
-            return allgather_controls(res.cmd)
-        return res.cmd
+        c_k, b_k, r_k, _, s_k = lanes[counter[0] % ns]
+        counter[0] += 1
+        with torch.cuda.stream(s_k):
+            c_k.launch(b_k, s_k)
+            if world > 1:
+                return allgather_controls(r_k.cmd)
+        return r_k.cmd
 
     for _ in range(args.warmup):
         step()
@@ -75,6 +86,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # the same steps strictly one after the other on one stream (what a single caller without pipelining sees)
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
+    nser = max(10, args.steps // 4)
+    for _ in range(nser):
+        lanes[0][0].launch(lanes[0][1], lanes[0][4])
+    torch.cuda.synchronize()
+    serial_rate = world * B * nser / (time.perf_counter() - ts0)
 
     # per-step latency distribution (host-synchronised single steps), outside the timed region
     lat = []
@@ -154,8 +174,10 @@ def main():
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "quadrotor_ex.cpp LMPC nx=12 nu=4 ny=12 ph=ch=%d, batch %d per GPU, "
                                       "SplitMix64 x0/u0/yref (SURVEY 8d), maximum_iteration=250" % (ph, B),
-                          "parallelism": "batch-sharded x%d, all-gather of u*" % world if world > 1 else "single GPU"},
+                          "parallelism": "batch-sharded x%d, all-gather of u*" % world if world > 1 else "single GPU",
+                          "streams": ns},
                "p50_step_latency_ms": lat_p50,
+               "serial_steps_value": serial_rate,   # one stream, no overlap between consecutive batches (no all-gather in this leg)
                "solved_fraction": float((status == 0).mean()),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
