@@ -5,7 +5,7 @@
 
 namespace mpcx {
 
-constexpr int kNlMaxWorking = 64;      // rows the QP sub-solver may hold active at once
+constexpr int kNlMaxWorking = 128;     // rows the QP sub-solver may hold active at once
 constexpr int kNlLdsWorking = 24;      // up to this many, their Schur complement is factored in LDS
 
 // offsets (in doubles) into one instance's slice of the SQP workspace
@@ -16,14 +16,14 @@ struct NlmpcWsLayout {
     int hinv, mu, glold, s, p;          // inverse BFGS matrix, multipliers, BFGS memory, QP solution
     int qn, qv, qs, qs2;                   // QP: normals and Hinv*normals of the working set, their Schur complement
     int scal;                           // scalars: [0] cost, [2..7] per-phase cycle counts
-    int lamw, pen_eq, pen_in;           // merit function: scratch, weights of the equalities / inequalities
-    int flag;                           // bytes: non-zero (row tile, state) pairs of the inequality Jacobian
+    int lamw;                           // right-hand side of the backward sweep for the dynamics multipliers
     int total;
 };
 
 struct NlmpcDev {
     int model_id, nx, nu, ph, ch, nz, neq, nineq;
     int nzu, nr;                // ch*nu, ch*nu + 1
+    int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
     int lds_per_wave;           // doubles
     double Ts;
     const double *params;       // model parameters in HBM

@@ -283,26 +283,31 @@ __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const Nl
 // ---------------------------------------------------------------------------------------------------
 // SQP
 // ---------------------------------------------------------------------------------------------------
-// Dense symmetric positive definite solve in LDS: S [n x ld] (destroyed), rhs t -> solution in t.  n <= 64.
+// Dense symmetric positive definite solve: S [n x ld] (destroyed; LDS for small n, the workspace otherwise), rhs t ->
+// solution in t.  Lanes own rows (two each beyond 64).  n <= 128.
 __device__ bool spd_solve(double *S, int ld, double *t, int n, int lane)
 {
-    double dmax = lane < n ? S[lane * ld + lane] : 0.0;
+    double dmax = 0.0;
+    for (int r = lane; r < n; r += 64) dmax = fmax(dmax, S[r * ld + r]);
     dmax = wave_max(dmax);
     bool ok = true;
     for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
         const double piv = S[k * ld + k];
         ok &= piv > 1e-13 * dmax;
-        if (lane > k && lane < n) {
-            const double fct = S[lane * ld + k] / piv;
-            for (int j = k + 1; j < n; ++j) S[lane * ld + j] -= fct * S[k * ld + j];
-            t[lane] -= fct * t[k];
+        const double tk = t[k];
+        for (int r = lane; r < n; r += 64) {
+            if (r <= k) continue;
+            const double fct = S[r * ld + k] / piv;
+            for (int j = k + 1; j < n; ++j) S[r * ld + j] -= fct * S[k * ld + j];
+            t[r] -= fct * tk;
         }
         nl_wave_sync();
     }
     for (int k = n - 1; k >= 0; --k) {      // back substitution
         if (lane == 0) t[k] /= S[k * ld + k];
         nl_wave_sync();
-        if (lane < k) t[lane] -= S[lane * ld + k] * t[k];
+        const double tk = t[k];
+        for (int r = lane; r < k; r += 64) t[r] -= S[r * ld + k] * tk;
         nl_wave_sync();
     }
     return ok;
@@ -335,7 +340,8 @@ __device__ void invert_small(double *Aug, int n, int lane)
 template <class Mdl>
 __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
 {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KW = kNlMaxWorking, SLD = KW + 1, KL = kNlLdsWorking;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KL = kNlLdsWorking;
+    const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     const int ph = M.ph, ch = M.ch, nz = M.nz, m = M.nineq, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
@@ -657,9 +663,9 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 if (kdrop != last) {
                     for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
                     nl_wave_sync();
-                    if (lane < nw) Ssm[lane * SLD + kdrop] = Ssm[lane * SLD + last];
+                    for (int r = lane; r < nw; r += 64) Ssm[r * SLD + kdrop] = Ssm[r * SLD + last];
                     nl_wave_sync();
-                    if (lane < nw) Ssm[kdrop * SLD + lane] = Ssm[last * SLD + lane];
+                    for (int r = lane; r < nw; r += 64) Ssm[kdrop * SLD + r] = Ssm[last * SLD + r];
                     nl_wave_sync();
                     if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; }
                 }
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                         const double s2 = xq[q] - gdot(qv + q, nr, tq, nw);
                         xq[q] = s2;
                     }
-                    if (lane < nw) uq[lane] = tq[lane];
+                    for (int r = lane; r < nw; r += 64) uq[r] = tq[r];
                     nl_wave_sync();
                 }
             }
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     const int sfld = nw <= KL ? KL + 1 : SLD;
                     for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
                     nl_wave_sync();
-                    double tcol = lane < nw ? tq[lane] : 0.0;          // keep N_W v: it becomes S[:, new]
+                    const double tcol = lane < nw ? tq[lane] : 0.0, tcol2 = lane + 64 < nw ? tq[lane + 64] : 0.0;   // keep N_W v: it becomes S[:, new]
                     if (nw) spd_solve(Sf, sfld, tq, nw, lane);
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
@@ -774,12 +780,13 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                         for (int q = lane; q < nq; q += 64) xq[q] -= tt * zd[q];
                         sp -= tt * zn;
                     }
-                    if (lane < nw) uq[lane] -= tt * tq[lane];
+                    for (int r = lane; r < nw; r += 64) uq[r] -= tt * tq[r];
                     up += tt;
                     nl_wave_sync();
                     if (t2 <= t1) {                                     // full step: the row joins the working set
                         for (int q = lane; q < nq; q += 64) { qn[(size_t)nw * nr + q] = np_[q]; qv[(size_t)nw * nr + q] = vv[q]; }
                         if (lane < nw) { Ssm[lane * SLD + nw] = tcol; Ssm[nw * SLD + lane] = tcol; }
+                        if (lane + 64 < nw) { Ssm[(lane + 64) * SLD + nw] = tcol2; Ssm[nw * SLD + lane + 64] = tcol2; }
                         double snn = 0;
                         for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
                         snn = wave_sum(snn);
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     nl_wave_sync();
                 }
             }
-            if (lane < nw_keep) lam_max = fmax(lam_max, uq[lane]);
+            for (int r = lane; r < nw_keep; r += 64) lam_max = fmax(lam_max, uq[r]);
             lam_max = wave_max(lam_max);
             if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
             double viol = 0;
@@ -983,7 +990,9 @@ void nlmpc_plan(NlmpcDev &m)
     const int nx = m.nx, nu = m.nu, ph = m.ph;
     m.nzu = m.ch * nu; m.nr = m.nzu + 1;
     m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
-    const int KW = kNlMaxWorking;
+    // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
+    m.kw = min(kNlMaxWorking, max(kNlLdsWorking, min(m.nineq + m.nbnd, m.nr)));
+    const int KW = m.kw;
     m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + kNlLdsWorking * (kNlLdsWorking + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr +
                       m.nineq * ((ph * nx + 63) / 64) + 1) & ~1;
     int o = 0;
@@ -997,7 +1006,7 @@ void nlmpc_plan(NlmpcDev &m)
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(mtot);
     w.hinv = take(m.nr * m.nr); w.mu = take(mtot); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
     w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
-    w.lamw = take(m.neq); w.pen_eq = take(m.neq); w.pen_in = take(m.nineq); w.flag = take(2);
+    w.lamw = take(m.neq);
     w.total = o;
 }
 

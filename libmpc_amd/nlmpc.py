@@ -161,7 +161,7 @@ class NLMPC(NLMPCEvaluator):
         return r
 
     _WS_FIELDS = ("z", "d", "g", "c", "jeq", "gin", "jin", "r", "phi", "einv", "gr", "art", "br", "hinv", "mu", "glold", "s", "p",
-                  "qn", "qv", "qs", "qs2", "scal", "lamw", "pen_eq", "pen_in", "flag", "total")
+                  "qn", "qv", "qs", "qs2", "scal", "lamw", "total")
 
     def debug_workspace(self, instance):
         """testing aid: the SQP workspace of one instance after the last solve, as a dict of numpy arrays"""

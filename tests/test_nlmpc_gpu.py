@@ -228,3 +228,23 @@ def test_state_and_input_bounds_match_oracle():
     r2 = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), sequences=True)
     torch.cuda.synchronize()
     assert (r2["status"] == 0).all() and (r2["seq_input"].abs() <= 0.2 + 1e-9).all()
+
+
+def test_eight_oscillator_config_matches_golden_oracle_solutions():
+    """BASELINE config 5 (nz = 601, 480 equalities, 248 inequalities): the oracle needs ~50 s per instance, its solutions
+    are kept in tests/golden/nlmpc_oracle_solutions.json (generated by tests/golden/make_nlmpc_golden.py)"""
+    import json
+    import os
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS8
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nlmpc_oracle_solutions.json")))["oscillators8_ph30_ch15"]
+    c = NLMPC(OSCILLATORS8, gold["ph"], gold["ch"], gold["Ts"])
+    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+    X0 = np.array([k["x0"] for k in gold["cases"]]); U0 = np.array([k["u0"] for k in gold["cases"]])
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0))
+    torch.cuda.synchronize()
+    assert (r["status"] == 0).all(), (r["status"], r["solver_status"])
+    for b, k in enumerate(gold["cases"]):
+        assert k["success"]
+        assert abs(r["cost"][b].item() - k["cost"]) <= 1e-8 * k["cost"]
+        np.testing.assert_allclose(r["cmd"][b].cpu().numpy(), k["cmd"], rtol=2e-5, atol=2e-6)
