@@ -86,6 +86,15 @@ __device__ __forceinline__ double readlane_d(double v, int l)
     return __hiloint2double(hi, lo);
 }
 constexpr int kRegCap = 16;      // working sets up to this size are factored in registers
+// 1/d for a positive, well-scaled pivot: hardware estimate + two Newton steps (full precision, a third of the latency of the
+// IEEE division sequence, which sits on the dependent chain of every elimination step)
+__device__ __forceinline__ double pivot_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // acc += M[:, 0..ncols) * xs.  M column-major, leading dimension ld, R (even) valid rows.
@@ -551,6 +560,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     const gdp gY = GP(Y);
 
     long long tstamp[8];
+    long long pacc[4] = {0, 0, 0, 0}, plast = 0;
+    // profiling aid (tools/phase_cycles.py): cycles per phase of a polish round, only when a cycle buffer is attached
+    auto plap = [&](int k) { if (Bt.dbg_cycles) { const long long now = (long long)__builtin_readcyclecounter(); pacc[k] += now - plast; plast = now; } };
     int tsi = 0;
     auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 8) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
     stamp();
@@ -677,6 +689,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                                  // else most violated row in), which does not cycle in practice
         for (int rd = 0; rd < rounds; ++rd) {
             ++rounds_total;
+            if (Bt.dbg_cycles) plast = (long long)__builtin_readcyclecounter();
             int na = 0;
             unsigned long long hsh = 0x9E3779B97F4A7C15ull;
 #pragma unroll
@@ -719,6 +732,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
             seen[0] = hsh;
             na_last = na;
             wave_sync();
+            plap(0);
             int dep_at = -1;
             if (na > 0) {
                 // ---- Schur complement in registers: lane i owns row i; LDL' with the pivot column
@@ -748,15 +762,14 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                             if (!(dk > 1e-11 * d0)) {
                                 dep_at = k;
                             } else {
-                                const double rinv = 1.0 / dk;
+                                const double rinv = pivot_rcp(dk);
                                 if (lane == k) mydinv = rinv;
                                 const double lik = Sr[k] * rinv;
+                                // (columns past na only touch lanes past na: no guard, no branch)
 #pragma unroll
                                 for (int j = k + 1; j < CAPB; ++j) {
-                                    if (j < na) {
-                                        const double tjk = readlane_d(Sr[k], j);
-                                        if (lane >= j) Sr[j] = fma(-lik, tjk, Sr[j]);
-                                    }
+                                    const double tjk = readlane_d(Sr[k], j);
+                                    if (lane >= j) Sr[j] = fma(-lik, tjk, Sr[j]);
                                 }
                                 if (lane > k) Sr[k] = lik;
                             }
@@ -765,10 +778,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     if (dep_at < 0) {
 #pragma unroll
                         for (int k = 0; k < CAPB; ++k) {
-                            if (k < na) {
-                                const double yk = readlane_d(y, k);
-                                if (lane > k) y = fma(-Sr[k], yk, y);
-                            }
+                            const double yk = readlane_d(y, k);
+                            if (lane > k && lane < na) y = fma(-Sr[k], yk, y);
                         }
                         y *= mydinv;
                         // transpose L through LDS so that the back-substitution also walks registers
@@ -849,6 +860,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 wave_sync();
                 continue;
             }
+            plap(1);
             // w = t0 - Y[:, A] lambda, all row fetches unpredicated
             int offz[CPZ], offg[CPG];
 #pragma unroll
@@ -887,6 +899,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     }
                 }
             }
+            plap(2);
             const double dtol = 1e-9 * lmax + 1e-300;
             dtol_last = dtol;
             bool nanv = false, changed = false;
@@ -1004,6 +1017,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     }
                 }
             }
+            plap(3);
             if (wave_any(nanv)) return false;
             if (!changed) return true;
             wave_sync();
@@ -1311,7 +1325,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     if (!ADMM && lane == 0) ws[ldz + ldy + 2 * ldg + 1] = 2.0;     // done: the fallback kernel skips it
     stamp();   // 3: unpacked
     if (Bt.dbg_cycles && lane == 0)
-        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < tsi ? tstamp[k] : 0;
+        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < 4 ? (k < tsi ? tstamp[k] : 0) : pacc[k - 4];
 }
 
 // i-th instance in dispatch order: hardest class first, its ways in turn (identity when no queues were built).

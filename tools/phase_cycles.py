@@ -43,3 +43,8 @@ print("start-time distribution: p50 %d p90 %d max %d" % (np.median(start), np.pe
 import collections
 late = start > np.percentile(start, 75)
 print("instances starting late (4th quartile): mean rounds %.2f ; early: %.2f" % (rd[late].mean(), rd[~late].mean()))
+pa = t[:, 4:8].astype(np.float64)
+if pa.sum() > 0:
+    sel = rd >= 3
+    per = pa[sel] / rd[sel, None]
+    print("per-round cycles (median): ws-build+hash %.0f | gather+factor+solve %.0f | w = t0 - Y[:,A] lam %.0f | KKT check + repair %.0f" % tuple(np.median(per, axis=0)))
