@@ -560,9 +560,14 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     const gdp gY = GP(Y);
 
     long long tstamp[8];
+    // profiling aid (tools/phase_cycles.py): cycles per phase of a polish round.  Compiled in with -DMPCX_PROFILE_ROUNDS only:
+    // even switched off at run time the counters cost registers the kernel does not have (16 more spilled VGPRs).
+#ifdef MPCX_PROFILE_ROUNDS
     long long pacc[4] = {0, 0, 0, 0}, plast = 0;
-    // profiling aid (tools/phase_cycles.py): cycles per phase of a polish round, only when a cycle buffer is attached
     auto plap = [&](int k) { if (Bt.dbg_cycles) { const long long now = (long long)__builtin_readcyclecounter(); pacc[k] += now - plast; plast = now; } };
+#else
+    auto plap = [](int) {};
+#endif
     int tsi = 0;
     auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 8) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
     stamp();
@@ -689,7 +694,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                                  // else most violated row in), which does not cycle in practice
         for (int rd = 0; rd < rounds; ++rd) {
             ++rounds_total;
+#ifdef MPCX_PROFILE_ROUNDS
             if (Bt.dbg_cycles) plast = (long long)__builtin_readcyclecounter();
+#endif
             int na = 0;
             unsigned long long hsh = 0x9E3779B97F4A7C15ull;
 #pragma unroll
@@ -1325,7 +1332,11 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     if (!ADMM && lane == 0) ws[ldz + ldy + 2 * ldg + 1] = 2.0;     // done: the fallback kernel skips it
     stamp();   // 3: unpacked
     if (Bt.dbg_cycles && lane == 0)
+#ifdef MPCX_PROFILE_ROUNDS
         for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < 4 ? (k < tsi ? tstamp[k] : 0) : pacc[k - 4];
+#else
+        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < tsi ? tstamp[k] : 0;
+#endif
 }
 
 // i-th instance in dispatch order: hardest class first, its ways in turn (identity when no queues were built).
