@@ -234,21 +234,32 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 const int i = k / NX, j = k - i * NX;
                 const double dx = dv * Xa(j);
                 const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
-                for (int r = 0; r < nineq; ++r) {
-                    if (!Mdl::ineq_reads_x(r, i + 1)) { if (jin_fill) J[(size_t)r * nz + k] = 0.0; continue; }
+                if (jin_fill) for (int r = 0; r < nineq; ++r) J[(size_t)r * nz + k] = 0.0;
+                int first, count;
+                Mdl::ineq_rows_of_x(i + 1, first, count);           // the lane's own rows: no divergence over the union of rows
+                for (int t = 0; t < count; ++t) {
+                    const int r = first + t;
                     J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx);
                 }
             } else if (k < nz - 1) {
                 const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
                 const double du = dv * Ua(j);
-                for (int r = 0; r < nineq; ++r) {
-                    double s = 0;
-                    for (int i = 0; i < ph; ++i) {          // every input row of the block on its own (no pairing here)
-                        if (min(i, ch - 1) != bl || !Mdl::ineq_reads_u(r, i)) continue;
-                        const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
-                        s += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
+                const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;       // the steps this block drives
+                if (jin_fill) for (int r = 0; r < nineq; ++r) J[(size_t)r * nz + k] = 0.0;
+                else
+                    for (int i = i_first; i <= i_last; ++i) {      // the entries that get contributions below start from zero
+                        int first, count;
+                        Mdl::ineq_rows_of_u(i, first, count);
+                        for (int t = 0; t < count; ++t) J[(size_t)(first + t) * nz + k] = 0.0;
                     }
-                    J[(size_t)r * nz + k] = s;
+                for (int i = i_first; i <= i_last; ++i) {          // every input row of the block on its own (no pairing here)
+                    int first, count;
+                    Mdl::ineq_rows_of_u(i, first, count);
+                    const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
+                    for (int t = 0; t < count; ++t) {
+                        const int r = first + t;
+                        J[(size_t)r * nz + k] += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
+                    }
                 }
             } else {
                 const double de = fmax(dv, fabs(e)) * dv;

@@ -12,10 +12,11 @@
 //   cost(X, U, e, ph, params)   ObjFunHandle: X(i, j), U(i, j) are rows i = 0..ph of the (ph+1) x n matrices the
 //                               reference passes (row 0 = x0, U row ph = copy of row ph-1), e the slack
 //   ineq(k, X, U, e, ph, p)     component k of IConFunHandle's output vector, g_k <= 0
-//   ineq_reads_x/u(k, i), INEQ_USES_SLACK
-//                               structure of that vector: which rows constraint k reads.  Everything else
-//                               differentiates to an exact zero (also in the reference's finite differences) and is
-//                               skipped.
+//   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK
+//                               structure of that vector, both ways round: which rows of X / U constraint k reads, and
+//                               which (contiguous) constraints read row i.  Everything else differentiates to an exact
+//                               zero (also in the reference's finite differences) and is skipped; the second form lets
+//                               every lane walk its own few rows instead of the wavefront walking the union of them.
 // X and U are accessor objects (a perturbed or a shifted view of the trajectory in LDS), hence the templates.  A new
 // system is one more struct here plus one line in dispatch_model() (nlmpc_kernels.hip) and in mpcx_nlmpc_create.
 #pragma once
@@ -58,6 +59,7 @@ struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
     __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
     {
         double s = 0;
+#pragma unroll 4
         for (int i = 0; i <= ph; ++i) { s += X(i, 0) * X(i, 0) + X(i, 1) * X(i, 1); s += U(i, 0) * U(i, 0); }
         return s;
     }
@@ -67,6 +69,8 @@ struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
     static constexpr bool INEQ_USES_SLACK = false;
     __device__ static bool ineq_reads_x(int, int) { return false; }
     __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
+    __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
+    __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i; count = 1; }
 };
 
 struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
@@ -86,8 +90,10 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
     __device__ static double cost(const XA &X, const UA &U, double e, int ph, const double *p)
     {
         double s = 0;
+        const double vx = p[0], vy = p[1];
+#pragma unroll 4
         for (int i = 0; i <= ph; ++i) {
-            const double a = X(i, 2) - p[0], b = X(i, 3) - p[1];
+            const double a = X(i, 2) - vx, b = X(i, 3) - vy;
             s += 1e3 * (a * a + b * b);
             s += 1e-2 * (U(i, 0) * U(i, 0) + U(i, 1) * U(i, 1));
         }
@@ -103,6 +109,8 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
     static constexpr bool INEQ_USES_SLACK = false;
     __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
     __device__ static bool ineq_reads_u(int, int) { return false; }
+    __device__ static void ineq_rows_of_x(int i, int &first, int &count) { first = 2 * i; count = 2; }
+    __device__ static void ineq_rows_of_u(int, int &first, int &count) { first = 0; count = 0; }
 };
 
 template <int N>
@@ -125,6 +133,7 @@ struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76
     __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
     {
         double s = 0;
+#pragma unroll 2
         for (int i = 0; i <= ph; ++i) {
             for (int j = 0; j < NX; ++j) s += X(i, j) * X(i, j);
             for (int j = 0; j < NU; ++j) s += U(i, j) * U(i, j);
@@ -136,6 +145,8 @@ struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76
     static constexpr bool INEQ_USES_SLACK = false;
     __device__ static bool ineq_reads_x(int, int) { return false; }
     __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
+    __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
+    __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i * N; count = N; }
 };
 
 }  // namespace models

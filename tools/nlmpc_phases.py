@@ -19,4 +19,4 @@ names = ["condense", "reduce(gr,Ar,br)", "bfgs", "qp", "step+linesearch", "evalu
 tot = acc.sum()
 for n, v in zip(names, acc):
     print("%-18s %5.1f %%" % (n, 100 * v / tot))
-print("iterations mean", it.mean())
+print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
