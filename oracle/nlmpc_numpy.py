@@ -34,6 +34,7 @@ class NlmpcRef:
         self.out = None        # out(x, u, step) -> y
         self.cost = None       # cost(X, Y, U, e) -> float
         self.ineq_fun = None   # ineq_fun(X, Y, U, e) -> [ineq]
+        self.eq_fun = None     # eq_fun(X, U) -> [eq]
         self.x0 = np.zeros(nx)
         self._mapping()
 
@@ -193,6 +194,39 @@ class NlmpcRef:
         J[:, :ph * nx] *= np.tile(self.state_scaling, ph)[None, :]      # :269-284
         return g0, J
 
+    # -- Constraints::evaluateEq + computeEqJacobian (Constraints.hpp:365-442, 731-832) ----------
+    def user_eq(self, z):
+        """user equalities h(X, U) = 0 and their central-difference Jacobian.  Unlike the inequality Jacobian the step is
+        taken from the perturbed element itself for the states (:751), from row ph-1 for every input step (:780, :806), and
+        the last input row is perturbed together with its copy (:803-829)."""
+        nx, nu, ph = self.nx, self.nu, self.ph
+        X, U, e = self.unwrap(z)
+        fu = lambda X_, U_: np.asarray(self.eq_fun(X_, U_), float)
+        h0 = fu(X, U)
+        Jx = np.zeros((self.eq, ph * nx)); Jmv = np.zeros((self.eq, ph * nu))
+        Xa = np.maximum(np.abs(X), 1.0); Ua = np.maximum(np.abs(U), 1.0)
+        Xp = X.copy(); Up = U.copy()
+        for i in range(ph):
+            for j in range(nx):
+                dx = DV * Xa[i + 1, j]
+                Xp[i + 1, j] += dx; fp = fu(Xp, Up)
+                Xp[i + 1, j] -= 2 * dx; fm = fu(Xp, Up)
+                Xp[i + 1, j] += dx
+                Jx[:, i * nx + j] = (fp - fm) / (2 * dx)
+        for i in range(ph):
+            rows = [i] if i < ph - 1 else [ph - 1, ph]
+            for j in range(nu):
+                du = DV * Ua[ph - 1, j]
+                for r in rows: Up[r, j] += du
+                fp = fu(Xp, Up)
+                for r in rows: Up[r, j] -= 2 * du
+                fm = fu(Xp, Up)
+                for r in rows: Up[r, j] += du
+                Jmv[:, i * nu + j] = (fp - fm) / (2 * du)
+        J = self._glue(Jx, Jmv, np.zeros(self.eq))
+        J[:, :ph * nx] *= np.tile(self.state_scaling, ph)[None, :]      # :399-413
+        return h0, J
+
     # -- NLOptimizer::run, cold start (NLOptimizer.hpp:412-638) with scipy's SLSQP ---------------
     def solve(self, x0, u0, max_iter=100, hard=True, lb_x=None, ub_x=None, lb_u=None, ub_u=None):
         from scipy.optimize import minimize
@@ -209,6 +243,8 @@ class NlmpcRef:
         cons = [{"type": "eq", "fun": lambda z: self.state_eq(z, False)[0], "jac": lambda z: self.state_eq(z, True)[1]}]
         if self.ineq_fun is not None:
             cons.append({"type": "ineq", "fun": lambda z: -self.user_ineq(z)[0], "jac": lambda z: -self.user_ineq(z)[1]})
+        if self.eq_fun is not None:
+            cons.append({"type": "eq", "fun": lambda z: self.user_eq(z)[0], "jac": lambda z: self.user_eq(z)[1]})
         r = minimize(lambda z: self.objective(z, False)[0], z0, jac=lambda z: self.objective(z, True)[1], method="SLSQP",
                      bounds=list(zip(lo, hi)), constraints=cons, options={"maxiter": max_iter, "ftol": 1e-12})
         X, U, e = self.unwrap(r.x)
@@ -225,6 +261,15 @@ def vanderpol(ph=10, ch=5, Ts=0.1):
     m.f = lambda x, u, p: np.array([(1.0 - x[1] * x[1]) * x[0] - x[1] + u[0], x[0]])
     m.cost = lambda X, Y, U, e: np.sum(X * X) + np.sum(U * U)
     m.ineq_fun = lambda X, Y, U, e: U[:, 0] - 0.5
+    return m
+
+
+def vanderpol_terminal(ph=10, ch=5, Ts=0.1):
+    """the Van der Pol example with a terminal equality x(ph) = 0 -- the textbook use of NLMPC::setEqConFunction
+    (NLMPC.hpp:246-262); no reference example sets one"""
+    m = vanderpol(ph, ch, Ts)
+    m.eq = 2
+    m.eq_fun = lambda X, U: X[ph].copy()
     return m
 
 

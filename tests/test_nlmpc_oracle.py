@@ -124,3 +124,28 @@ def test_oscillators_model_shapes_and_field():
     x = np.zeros(12); x[0] = 1.0
     dx = m.f(x, np.zeros(6), 0)
     assert abs(dx[1] + 1.5) < 1e-15 and abs(dx[3] - 0.1) < 1e-15 and dx[0] == 0.0   # -x0 - 5 k x0 on itself, k x0 on a neighbour
+
+
+def test_user_equality_constraints_known_answer():
+    """test/NLMPC/test_constraints.cpp:211-274: eq_con[0] = x(0, 0) with x0 = (10, 0) -> value 10, Jacobian zero"""
+    m = NlmpcRef(2, 1, 1, 5, 5, 0, eq=1)
+    m.continuous = True; m.Ts = 0.1
+    m.f = lambda x, u, p: np.array([(1.0 - x[1] * x[1]) * x[0] - x[1] + u[0], x[0]])
+    m.eq_fun = lambda X, U: np.array([X[0, 0]])
+    m.x0 = np.array([10.0, 0.0])
+    z = np.arange(m.nz, dtype=float)
+    h, J = m.user_eq(z)
+    assert h.tolist() == [10.0] and not J.any()
+    # a constraint that does depend on the decision variables: the Jacobian is the derivative, the last input row pairs
+    m.eq_fun = lambda X, U: np.array([X[5, 1] ** 2 + 3.0 * U[4, 0] + U[5, 0]])
+    h, J = m.user_eq(z)
+    assert abs(h[0] - (z[9] ** 2 + 4.0 * z[14])) < 1e-12
+    expect = np.zeros(m.nz); expect[9] = 2 * z[9]; expect[14] = 4.0
+    np.testing.assert_allclose(J[0], expect, rtol=1e-6, atol=1e-6)
+
+
+def test_terminal_constraint_solve_property():
+    from oracle.nlmpc_numpy import vanderpol_terminal
+    m = vanderpol_terminal(ph=10, ch=10)
+    o = m.solve([0.1, 0.1], [0.0], max_iter=500)
+    assert o["success"] and np.abs(o["X"][10]).max() < 1e-8 and (o["U"][:, 0] <= 0.5 + 1e-9).all()
