@@ -209,13 +209,15 @@ typedef struct mpcx_nlmpc *mpcx_nlmpc_t;
 enum { MPCX_MODEL_VANDERPOL = 1,   /* examples/vanderpol_ex.cpp: nx=2 nu=1, continuous, ineq u_i <= 0.5        */
        MPCX_MODEL_UGV = 2,         /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
        MPCX_MODEL_OSCILLATORS6 = 3,/* examples/networked_oscillators_ex.cpp: 6 coupled oscillators, nx=12 nu=6   */
-       MPCX_MODEL_OSCILLATORS8 = 4 };/* the same network with 8 oscillators (BASELINE config 5), nx=16 nu=8      */
+       MPCX_MODEL_OSCILLATORS8 = 4,/* the same network with 8 oscillators (BASELINE config 5), nx=16 nu=8        */
+       MPCX_MODEL_VANDERPOL_TERMINAL = 5 };/* Van der Pol + the user equality x(ph) = 0 (setEqConFunction path)  */
 typedef struct mpcx_nlmpc_dims {
     int nx, nu, ph, ch;
     int nz;      /* decision variables  ph*nx + ch*nu + 1 (Objective.hpp:45)                         */
     int neq;     /* dynamics equalities ph*nx                                                         */
     int nineq;   /* user inequalities                                                                 */
     int jeq_w;   /* width of one equality Jacobian block row: 2*nx + nu                               */
+    int neq_user;/* user equalities (NLMPC::setEqConFunction)                                         */
 } mpcx_nlmpc_dims;
 /* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
  * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
@@ -227,8 +229,9 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
 int mpcx_nlmpc_destroy(mpcx_nlmpc_t h);
 int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d);
 /* Device pointers, fp64.  z [B x nz] (layout [x_1..x_ph | u blocks (ch) | slack]), x0 [B x nx].
- * Any output may be NULL.  cost [B]; grad [B x nz]; ceq [B x neq]; cineq [B x nineq];
- * jineq [B x nineq x nz] row-major (dense: a user inequality may depend on anything);
+ * Any output may be NULL.  cost [B]; grad [B x nz]; ceq [B x neq]; cineq [B x (nineq + neq_user)]: the user
+ * inequalities, then the user equalities (Constraints::evaluateEq, Constraints.hpp:365-442);
+ * jineq [B x (nineq + neq_user) x nz] row-major (dense: a user constraint may depend on anything);
  * jeq [B x ph x nx x jeq_w] row-major blocks [dc_i/dx_i | dc_i/dx_{i+1} | dc_i/du_i] -- the
  * non-zeros of the reference's dense [neq x nz] Jacobian: block i sits in rows i*nx.., columns
  * (i-1)*nx.. (absent for i = 0, x_0 is data), i*nx.., ph*nx + min(i, ch-1)*nu...                */
@@ -263,8 +266,8 @@ int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const do
  * cmd may be NULL.  status uses MPCX_STATUS_* (ResultStatus), solver_status nlopt's result codes
  * (4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE = inconsistent linearised constraints,
  * -3 OUT_OF_MEMORY = more than 128 rows active at once, -4 ROUNDOFF_LIMITED = line search stalled far from a solution) as mapped at NLOptimizer.hpp:729-750; on failure
- * cmd = u0 and cost = inf as at :613-624.  is_feasible = every user inequality <= 1e-10
- * (Constraints.hpp:157-202, tolerance NLMPC.hpp:166).                                             */
+ * cmd = u0 and cost = inf as at :613-624.  is_feasible = every user inequality <= 1e-10 and every user
+ * equality within 1e-10 (Constraints.hpp:157-202, tolerances NLMPC.hpp:166, 262).                 */
 typedef struct mpcx_nlmpc_batch {
     int batch;
     const double *x0;          /* [B x nx] */

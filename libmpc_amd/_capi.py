@@ -81,7 +81,7 @@ class NlmpcBatch(C.Structure):
 
 
 class NlmpcDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w")]
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w", "neq_user")]
 
 _lib = None
 

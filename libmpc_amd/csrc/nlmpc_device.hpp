@@ -22,6 +22,7 @@ struct NlmpcWsLayout {
 
 struct NlmpcDev {
     int model_id, nx, nu, ph, ch, nz, neq, nineq;
+    int nue;                    // user equalities: rows nineq .. nineq+nue-1 of the user constraint arrays
     int nzu, nr;                // ch*nu, ch*nu + 1
     int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
     int lds_per_wave;           // doubles
@@ -42,7 +43,7 @@ struct NlmpcBatchDev {
     const double *x0;           // [B x nx]
     double *cost, *grad;        // [B], [B x nz]
     double *ceq, *jeq;          // [B x ph*nx], [B x ph x nx x (2nx+nu)] blocks [dc/dx_i | dc/dx_{i+1} | dc/du_i]
-    double *cineq, *jineq;      // [B x nineq], [B x nineq x nz] row-major
+    double *cineq, *jineq;      // [B x (nineq+nue)], [B x (nineq+nue) x nz] row-major: user inequalities, then user equalities
 };
 
 struct NlmpcSolveDev {
@@ -51,13 +52,13 @@ struct NlmpcSolveDev {
     const double *z_warm;       // [B x nz] previous solutions (shifted one step on entry) or null = cold start
     double *ws;                 // [B x ws.total]
     int max_iter, hard;
-    double tol_step, tol_con, ieq_tol;
+    double tol_step, tol_con, ieq_tol, eq_tol;
     double *cmd, *cost, *z_out; // [B x nu], [B], [B x nz]
     int32_t *status, *solver_status, *is_feasible, *iterations;
     double *seq_state, *seq_input;      // [B x (ph+1) x nx], [B x (ph+1) x nu]
 };
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq);
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq, int *nue);
 void nlmpc_plan(NlmpcDev &m);           // fills nzu, nr, lds_per_wave, ws from the dimensions
 int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream);
 int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream);

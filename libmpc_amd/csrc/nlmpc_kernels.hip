@@ -270,6 +270,37 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
             }
         }
     }
+    // ---- Constraints::evaluateEq + computeEqJacobian (Constraints.hpp:365-442, 731-832): rows nineq.. of the same arrays.
+    // Steps: the perturbed element's own magnitude for the states, row ph-1's for every input step, last input row paired.
+    const int nue = M.nue;
+    if (nue && cineq)
+        for (int k = lane; k < nue; k += 64) cineq[nineq + k] = Mdl::eq(k, X0, U0, ph, prm);
+    if (nue && jineq) {
+        double *J = jineq + (size_t)nineq * nz;
+        for (int k = lane; k < nz; k += 64) {
+            if (k < ph * NX) {
+                const int i = k / NX, j = k - i * NX;
+                const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
+                const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
+                for (int r = 0; r < nue; ++r)
+                    J[(size_t)r * nz + k] = (Mdl::eq(r, Xp, U0, ph, prm) - Mdl::eq(r, Xm, U0, ph, prm)) / (2 * dx);
+            } else if (k < nz - 1) {
+                const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
+                const double du = dv * fmax(fabs(Us[(ph - 1) * NU + j]), 1.0);
+                const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;
+                for (int r = 0; r < nue; ++r) {
+                    double s = 0;
+                    for (int i = i_first; i <= i_last; ++i) {
+                        const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du}, Um{Us, NU, i, i == ph - 1 ? ph : -1, j, -du};
+                        s += (Mdl::eq(r, X0, Up, ph, prm) - Mdl::eq(r, X0, Um, ph, prm)) / (2 * du);
+                    }
+                    J[(size_t)r * nz + k] = s;
+                }
+            } else {
+                for (int r = 0; r < nue; ++r) J[(size_t)r * nz + k] = 0.0;
+            }
+        }
+    }
     nl_wave_sync();
 }
 
@@ -286,8 +317,8 @@ __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const Nl
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb) {
         auto at = [&](double *p, size_t stride) { return p ? p + (size_t)b * stride : nullptr; };
         eval_instance<Mdl>(M, Bt.z + (size_t)b * nz, Bt.x0 + (size_t)b * NX, Xs, Us, Jm, lane, at(Bt.cost, 1), at(Bt.grad, nz),
-                           at(Bt.ceq, M.neq), at(Bt.jeq, (size_t)ph * NX * (2 * NX + NU)), at(Bt.cineq, M.nineq),
-                           at(Bt.jineq, (size_t)M.nineq * nz));
+                           at(Bt.ceq, M.neq), at(Bt.jeq, (size_t)ph * NX * (2 * NX + NU)), at(Bt.cineq, M.nineq + M.nue),
+                           at(Bt.jineq, (size_t)(M.nineq + M.nue) * nz));
     }
 }
 
@@ -355,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
     const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
-    const int ph = M.ph, ch = M.ch, nz = M.nz, m = M.nineq, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
+    const int ph = M.ph, ch = M.ch, nz = M.nz, mi = M.nineq, m = M.nineq + M.nue, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
+    // user rows: [0, mi) inequalities g <= 0, [mi, m) equalities h = 0; then the bounds
     const int mt = m + M.nbnd;                           // sub-problem rows: user inequalities, then the finite bounds on z
     const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
     const int mld = (mt + 1) & ~1;
@@ -369,7 +401,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
     double *tq = Sfac + KL * (KL + 1);                    // KW
     double *uq = tq + KW;                                 // KW  multipliers of the working set
     double *wq = uq + KW;                                 // KW  row numbers (as doubles)
-    double *aug = wq + KW;                                // NX x 2NX
+    double *sgq = wq + KW;                                // KW  orientation of the row in the working set (+1; -1 for an equality entered from below)
+    double *aug = sgq + KW;                               // NX x 2NX
     double *v0 = aug + NX * 2 * NX;                       // 4 vectors of nr
     double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
     unsigned long long *fmask = reinterpret_cast<unsigned long long *>(v3 + nr);   // structure bits of d g / d x
@@ -414,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             const int nchunk = (nxs + 63) >> 6;
             for (int e0 = 0; e0 < m * nchunk; ++e0) {
                 const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
-                const unsigned long long bal = __ballot(col < nxs && Mdl::ineq_reads_x(k, col / NX + 1));
+                const unsigned long long bal = __ballot(col < nxs && (k < mi ? Mdl::ineq_reads_x(k, col / NX + 1) : Mdl::eq_reads_x(k - mi, col / NX + 1)));
                 if (lane == 0) fmask[e0] = bal;
             }
             nl_wave_sync();
@@ -630,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 double sBs = 0, sy = 0;
                 for (int q = lane; q < nq; q += 64) {
                     double gl = gr[q];
-                    for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * uq[t];
+                    for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
                     const double y = gl - glold[q], Bs = -a_prev * glold[q];
                     v0[q] = y; v1[q] = Bs;
                     sBs += sv[q] * Bs; sy += sv[q] * y;
@@ -678,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     nl_wave_sync();
                     for (int r = lane; r < nw; r += 64) Ssm[kdrop * SLD + r] = Ssm[last * SLD + r];
                     nl_wave_sync();
-                    if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; }
+                    if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; sgq[kdrop] = sgq[last]; }
                 }
                 --nw;
                 nl_wave_sync();
@@ -689,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 nw = nw_keep;
                 for (int t = 0; t < nw; ++t) {
                     const int k = (int)wq[t];
-                    for (int q = lane; q < nq; q += 64) vv[q] = art[(size_t)q * mld + k];
+                    for (int q = lane; q < nq; q += 64) vv[q] = sgq[t] * art[(size_t)q * mld + k];
                     nl_wave_sync();
                     for (int q = lane; q < nq; q += 64) {
                         const double s2 = gdot(hinv + q, nr, vv, nq);
@@ -705,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 nl_wave_sync();
                 while (nw > 0) {
                     for (int t = lane; t < nw; t += 64) {
-                        const double s2 = br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
+                        const double s2 = sgq[t] * br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
                         tq[t] = s2;
                     }
                     double *Sf = nw <= KL ? Sfac : Sbig;
@@ -713,11 +746,12 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
                     nl_wave_sync();
                     if (!spd_solve(Sf, sfld, tq, nw, lane)) { nw = 0; break; }      // dependent rows: start cold
+                    auto sheds = [&](int t) { const int k = (int)wq[t]; return tq[t] < 0.0 && !(k >= mi && k < m); };   // equalities stay
                     int neg = -1;
-                    for (int t = 0; t < nw; ++t) if (tq[t] < 0.0) neg = t;
+                    for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
                     if (neg < 0) break;
                     for (int t = nw - 1; t >= 0; --t) {
-                        if (tq[t] < 0.0) { const double tl = tq[nw - 1]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
+                        if (sheds(t)) { const double tl = tq[nw - 1]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
                     }
                 }
                 if (nw > 0) {
@@ -732,15 +766,24 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < mt; k += 64) {
-                    const double s = br[k] + gdot(art + k, mld, xq, nq);
-                    bool inw = mu[k] < 0.0;                              // set aside (see below)
+                    double s = br[k] + gdot(art + k, mld, xq, nq);
+                    if (k >= mi && k < m) s = fabs(s);                   // an equality is violated on either side
+                    bool inw = mu[k] == -1.0 && !(k >= mi && k < m);     // set aside (see below)
                     for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
                     if (!inw && s > vmax) { vmax = s; pidx = k; }
                 }
                 wave_argmax(vmax, pidx);
                 if (mt == 0 || vmax <= 1e-12) { qp_done = true; break; }   // primal feasible (well inside the reported 1e-10): optimal
                 if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
-                for (int q = lane; q < nq; q += 64) np_[q] = art[(size_t)q * mld + pidx];
+                // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
+                const bool p_is_eq = pidx >= mi && pidx < m;
+                double sgn = 1.0;
+                if (p_is_eq) {
+                    double part = 0;
+                    for (int q = lane; q < nq; q += 64) part += art[(size_t)q * mld + pidx] * xq[q];
+                    sgn = br[pidx] + wave_sum(part) < 0.0 ? -1.0 : 1.0;
+                }
+                for (int q = lane; q < nq; q += 64) np_[q] = sgn * art[(size_t)q * mld + pidx];
                 nl_wave_sync();
                 double up = 0.0, sp = vmax;
                 bool added = false;
@@ -775,7 +818,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     double t1 = 1e300; int kdrop = -1;
                     for (int t = 0; t < nw; ++t) {
                         const double rr = tq[t];
-                        if (rr > 1e-14) { const double tj = uq[t] / rr; if (tj < t1) { t1 = tj; kdrop = t; } }
+                        const int kt = (int)wq[t];
+                        if (rr > 1e-14 && !(kt >= mi && kt < m)) { const double tj = uq[t] / rr; if (tj < t1) { t1 = tj; kdrop = t; } }
                     }
                     const bool can_move = zn > 1e-13 * fmax(1.0, npn);
                     const double t2 = can_move ? sp / zn : 1e300;
@@ -783,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     if (tt >= 1e300) {
                         // no step: the row is a combination of working rows.  Violated by round-off only (a copy of an
                         // active row): set it aside; violated for real: the linearised constraints are inconsistent.
-                        if (sp <= 1e-7) { if (lane == 0) mu[pidx] = -1.0; nl_wave_sync(); added = true; break; }
+                        if (sp <= 1e-7 && !p_is_eq) { if (lane == 0) mu[pidx] = -1.0; nl_wave_sync(); added = true; break; }
                         qp_ok = false; break;
                     }
                     nl_wave_sync();
@@ -801,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                         double snn = 0;
                         for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
                         snn = wave_sum(snn);
-                        if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; }
+                        if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; sgq[nw] = sgn; }
                         ++nw; added = true;
                     } else {                                            // a multiplier hit zero: that row leaves, try again
                         drop_row(kdrop);
@@ -814,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             if (!qp_ok || !qp_done) { code = qp_fail ? qp_fail : -1; break; }
             for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
             nl_wave_sync();
-            for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = uq[t];
+            for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = sgq[t] * uq[t];
             nw_keep = nw;
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
@@ -834,6 +878,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             double zmax = 0;
             for (int k = lane; k < nz; k += 64) zmax = fmax(zmax, fabs(z[k]));
             zmax = wave_max(zmax);
+            for (int k = mi + lane; k < m; k += 64) cmax = fmax(cmax, fabs(gin[k]));     // user equalities count as defects
+            cmax = wave_max(cmax);
             if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
                 // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
                 for (int k = lane; k < nz; k += 64) z[k] += d[k];
@@ -846,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
             for (int q = lane; q < nq; q += 64) {
                 double gl = gr[q];
-                for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * uq[t];
+                for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
                 glold[q] = gl;
             }
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
@@ -855,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 double s2 = g[row];
                 for (int t = 0; t < nw_keep; ++t) {                     // mu lives on the working set
                     const int k = (int)wq[t];
-                    if (k < m) s2 += jin[(size_t)k * nz + row] * uq[t];
+                    if (k < m) s2 += jin[(size_t)k * nz + row] * (sgq[t] * uq[t]);
                     else if (M.bnd_idx[k - m] == row) s2 += M.bnd_sign[k - m] * uq[t];
                 }
                 lamw[row] = s2;
@@ -889,12 +935,12 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     nl_wave_sync();
                 }
             }
-            for (int r = lane; r < nw_keep; r += 64) lam_max = fmax(lam_max, uq[r]);
+            for (int r = lane; r < nw_keep; r += 64) lam_max = fmax(lam_max, fabs(uq[r]));
             lam_max = wave_max(lam_max);
             if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
             double viol = 0;
             for (int k = lane; k < nxs; k += 64) viol += fabs(c[k]);
-            for (int k = lane; k < m; k += 64) viol += fmax(gin[k], 0.0);
+            for (int k = lane; k < m; k += 64) viol += k < mi ? fmax(gin[k], 0.0) : fabs(gin[k]);
             viol = wave_sum(viol);
             const double phi0 = scal[0] + nu_pen * viol;
             const double dphi = fmin(gd - nu_pen * viol, 0.0);
@@ -926,7 +972,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                         for (int a = 0; a < NX; ++a) vio += fabs(xk1[a] - fa[a]);
                     }
                 }
-                for (int k = 0; k < m; ++k) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+                for (int k = 0; k < mi; ++k) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+                for (int k = 0; k < m - mi; ++k) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
                 mer += nu_pen * vio;
                 const bool ok = lane <= 40 && mer <= phi0 + 1e-4 * al * dphi;
                 const unsigned long long bal = __ballot(ok);
@@ -954,8 +1001,9 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
 
         // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
         double gmax = -1e300;
-        for (int k = lane; k < m; k += 64) gmax = fmax(gmax, gin[k]);
-        gmax = wave_max(gmax);
+        double hmax = 0.0;
+        for (int k = lane; k < m; k += 64) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
+        gmax = wave_max(gmax); hmax = wave_max(hmax);
         unwrap<Mdl>(M, z, x0, Xs, Us, lane);
         const bool failed = code < 0;
         if (S.cmd) for (int j = lane; j < NU; j += 64) S.cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
@@ -966,7 +1014,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             if (S.cost) S.cost[b] = failed ? INFINITY : scal[0];
             if (S.solver_status) S.solver_status[b] = code;
             if (S.status) S.status[b] = code == 4 ? 0 : (code == 5 ? 1 : 3);         // SUCCESS / MAX_ITERATION / ERROR
-            if (S.is_feasible) S.is_feasible[b] = (m == 0 || gmax <= S.ieq_tol) ? 1 : 0;
+            if (S.is_feasible) S.is_feasible[b] = ((mi == 0 || gmax <= S.ieq_tol) && hmax <= S.eq_tol) ? 1 : 0;    // Constraints.hpp:157-202
             if (S.iterations) S.iterations[b] = it;
         }
         nl_wave_sync();
@@ -981,17 +1029,18 @@ int dispatch_model(int model_id, F &&fn)
     case 2: return fn(Ugv{});
     case 3: return fn(Oscillators<6>{});
     case 4: return fn(Oscillators<8>{});
+    case 5: return fn(VanDerPolTerminal{});
     default: return -1;
     }
 }
 
 }  // namespace
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq)
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq, int *nue)
 {
     return dispatch_model(model_id, [&](auto mdl) {
         using Mdl = decltype(mdl);
-        *nx = Mdl::NX; *nu = Mdl::NU; *nineq = Mdl::nineq(ph);
+        *nx = Mdl::NX; *nu = Mdl::NU; *nineq = Mdl::nineq(ph); *nue = Mdl::neq_user(ph);
         return 0;
     });
 }
@@ -1002,17 +1051,17 @@ void nlmpc_plan(NlmpcDev &m)
     m.nzu = m.ch * nu; m.nr = m.nzu + 1;
     m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
     // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
-    m.kw = min(kNlMaxWorking, max(kNlLdsWorking, min(m.nineq + m.nbnd, m.nr)));
+    m.kw = min(kNlMaxWorking, max(kNlLdsWorking, min(m.nineq + m.nue + m.nbnd, m.nr)));
     const int KW = m.kw;
-    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + kNlLdsWorking * (kNlLdsWorking + 1) + 3 * KW + nx * 2 * nx + 4 * m.nr +
-                      m.nineq * ((ph * nx + 63) / 64) + 1) & ~1;
+    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + kNlLdsWorking * (kNlLdsWorking + 1) + 4 * KW + nx * 2 * nx + 4 * m.nr +
+                      (m.nineq + m.nue) * ((ph * nx + 63) / 64) + 1) & ~1;
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
-    const int mtot = m.nineq + m.nbnd;
+    const int mtot = m.nineq + m.nue + m.nbnd;
     const int mld = (mtot + 1) & ~1;
     w.z = take(m.nz); w.d = take(m.nz); w.g = take(m.nz); w.c = take(m.neq); w.jeq = take(ph * nx * (2 * nx + nu));
-    w.gin = take(m.nineq); w.jin = take(m.nineq * m.nz);
+    w.gin = take(m.nineq + m.nue); w.jin = take((m.nineq + m.nue) * m.nz);
     w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(mtot);
     w.hinv = take(m.nr * m.nr); w.mu = take(mtot); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);

@@ -12,6 +12,8 @@
 //   cost(X, U, e, ph, params)   ObjFunHandle: X(i, j), U(i, j) are rows i = 0..ph of the (ph+1) x n matrices the
 //                               reference passes (row 0 = x0, U row ph = copy of row ph-1), e the slack
 //   ineq(k, X, U, e, ph, p)     component k of IConFunHandle's output vector, g_k <= 0
+//   neq_user(ph), eq(k, X, U, ph, p)
+//                               EConFunHandle: component k of the user equalities h_k = 0 (defaults: none, NoUserEq)
 //   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK
 //                               structure of that vector, both ways round: which rows of X / U constraint k reads, and
 //                               which (contiguous) constraints read row i.  Everything else differentiates to an exact
@@ -45,8 +47,16 @@ struct Lin {
     __device__ __forceinline__ double operator()(int i, int j) const { return M[i * n + j] + a * D[i * n + j]; }
 };
 
+// defaults for systems without user equalities (EConFunHandle, IDimensionable.hpp:118-122 / NLMPC::setEqConFunction)
+struct NoUserEq {
+    __host__ __device__ static int neq_user(int) { return 0; }
+    template <class XA, class UA>
+    __device__ static double eq(int, const XA &, const UA &, int, const double *) { return 0.0; }
+    __device__ static bool eq_reads_x(int, int) { return true; }       // dense unless the model says otherwise
+};
+
 // ---- model zoo ----------------------------------------------------------------------------------
-struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
+struct VanDerPol : NoUserEq {      // reference examples/vanderpol_ex.cpp:33-65
     static constexpr int NX = 2, NU = 1;
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return ph + 1; }
@@ -73,7 +83,15 @@ struct VanDerPol {      // reference examples/vanderpol_ex.cpp:33-65
     __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i; count = 1; }
 };
 
-struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
+// The same system with the terminal equality x(ph) = 0: the textbook use of NLMPC::setEqConFunction (NLMPC.hpp:246-262).
+// No reference example sets user equalities; this model exists so that the path is exercised.
+struct VanDerPolTerminal : VanDerPol {
+    __host__ __device__ static int neq_user(int) { return 2; }
+    template <class XA, class UA>
+    __device__ static double eq(int k, const XA &X, const UA &, int ph, const double *) { return X(ph, k); }
+};
+
+struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
     static constexpr int NX = 4, NU = 2;
     static constexpr bool CONTINUOUS = false;
     // params: [0..1] v_pref, [2..4] obstacle 0 (x, y, r), [5..7] obstacle 1, [8] Ts
@@ -114,7 +132,7 @@ struct Ugv {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold
 };
 
 template <int N>
-struct Oscillators {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
+struct Oscillators : NoUserEq {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
     static constexpr int NX = 2 * N, NU = N;
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return (ph + 1) * N; }

@@ -17,7 +17,7 @@ import numpy as np
 from . import _capi
 from ._capi import check
 
-VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8 = 1, 2, 3, 4
+VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8, VANDERPOL_TERMINAL = 1, 2, 3, 4, 5
 
 
 def NLParameters(**kw) -> _capi.NLParams:
@@ -42,8 +42,8 @@ class NLMPCEvaluator:
                                           int(device), C.byref(self._h)))
         d = _capi.NlmpcDims()
         check(self._lib.mpcx_nlmpc_get_dims(self._h, C.byref(d)))
-        self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w = (
-            d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w)
+        self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w, self.neq_user = (
+            d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w, d.neq_user)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -59,7 +59,7 @@ class NLMPCEvaluator:
         assert z.shape == (B, self.nz) and x0.shape == (B, self.nx)
         mk = lambda on, *shape: torch.empty((B,) + shape, dtype=torch.float64, device=dev) if on else None
         out = dict(cost=mk(cost), grad=mk(grad, self.nz), ceq=mk(eq, self.neq), jeq=mk(eq_jac, self.ph, self.nx, self.jeq_w),
-                   cineq=mk(ineq, self.nineq), jineq=mk(ineq_jac, self.nineq, self.nz))
+                   cineq=mk(ineq, self.nineq + self.neq_user), jineq=mk(ineq_jac, self.nineq + self.neq_user, self.nz))
         ptr = lambda t: None if t is None else t.data_ptr()
         s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         check(self._lib.mpcx_nlmpc_evaluate_batch(self._h, B, z.data_ptr(), x0.data_ptr(), ptr(out["cost"]), ptr(out["grad"]),

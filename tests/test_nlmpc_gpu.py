@@ -248,3 +248,43 @@ def test_eight_oscillator_config_matches_golden_oracle_solutions():
         assert k["success"]
         assert abs(r["cost"][b].item() - k["cost"]) <= 1e-8 * k["cost"]
         np.testing.assert_allclose(r["cmd"][b].cpu().numpy(), k["cmd"], rtol=2e-5, atol=2e-6)
+
+
+def test_user_equality_constraints_match_oracle():
+    """a19: NLMPC::setEqConFunction -- Constraints::evaluateEq / computeEqJacobian and the equalities in the solve, on the
+    Van der Pol system with the terminal constraint x(ph) = 0"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL_TERMINAL
+    for ch in (10, 5):
+        m = ref.vanderpol_terminal(ph=10, ch=ch)
+        c = NLMPC(VANDERPOL_TERMINAL, 10, ch, 0.1)
+        assert c.neq_user == 2 and c.nineq == 11
+        rng = np.random.default_rng(13)
+        B = 6
+        Z = rng.normal(size=(B, m.nz)); X0 = rng.normal(size=(B, 2))
+        ev = c.evaluate(torch.from_numpy(Z), torch.from_numpy(X0))
+        torch.cuda.synchronize()
+        for b in range(B):
+            m.x0 = X0[b]
+            h, Jh = m.user_eq(Z[b])
+            np.testing.assert_allclose(ev["cineq"][b, 11:].cpu().numpy(), h, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(ev["jineq"][b, 11:].cpu().numpy(), Jh, rtol=1e-9, atol=1e-6)
+            gi, Ji = m.user_ineq(Z[b])
+            np.testing.assert_allclose(ev["jineq"][b, :11].cpu().numpy(), Ji, rtol=1e-9, atol=1e-6)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=300))
+        X0 = rng.uniform(-0.12, 0.12, size=(B, 2)); X0[0] = [0.1, 0.1]
+        U0 = np.zeros((B, 1))
+        r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), sequences=True)
+        torch.cuda.synchronize()
+        r = {k: v.cpu().numpy() for k, v in r.items() if k != "_keep"}
+        compared = 0
+        for b in range(B):
+            o = m.solve(X0[b], U0[b], max_iter=500)
+            if not o["success"]:
+                continue
+            compared += 1
+            assert r["status"][b] == 0 and r["is_feasible"][b] == 1, (b, r["solver_status"][b])
+            assert np.abs(r["seq_state"][b][10]).max() <= 1e-9
+            assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
+            np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=5e-5, atol=5e-6)
+        assert compared >= B - 1
