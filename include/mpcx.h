@@ -218,6 +218,7 @@ typedef struct mpcx_nlmpc_dims {
     int nineq;   /* user inequalities                                                                 */
     int jeq_w;   /* width of one equality Jacobian block row: 2*nx + nu                               */
     int neq_user;/* user equalities (NLMPC::setEqConFunction)                                         */
+    int ny;      /* outputs (NLMPC::setOutputFunction; zeros in the sequence when the model has none)  */
 } mpcx_nlmpc_dims;
 /* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
  * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
@@ -280,6 +281,7 @@ typedef struct mpcx_nlmpc_batch {
     double *z;                 /* [B x nz] the optimal decision vectors (next call's z_warm)       */
     double *seq_state;         /* [B x (ph+1) x nx] row-major, row 0 = x0                           */
     double *seq_input;         /* [B x (ph+1) x nu]                                                 */
+    double *seq_output;        /* [B x (ph+1) x ny] Model::getOutput (Model.hpp:72-96)                */
 } mpcx_nlmpc_batch;
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
 /* The same for callers whose data lives in host memory (the reference's optimize(x0, lastU) is such a caller): stages,

@@ -75,8 +75,8 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     using mpcx::capi_fail;
     if (!out) return capi_fail(MPCX_E_INVALID, "null output handle");
     if (ph < 1 || ch < 1 || ch > ph) return capi_fail(MPCX_E_INVALID, "need 1 <= ch <= ph");
-    int nx = 0, nu = 0, nineq = 0, nue = 0;
-    if (mpcx::nlmpc_model_dims(model_id, &nx, &nu, ph, &nineq, &nue) != 0) return capi_fail(MPCX_E_INVALID, "unknown NLMPC model id");
+    int nx = 0, nu = 0, ny = 0, nineq = 0, nue = 0;
+    if (mpcx::nlmpc_model_dims(model_id, &nx, &nu, &ny, ph, &nineq, &nue) != 0) return capi_fail(MPCX_E_INVALID, "unknown NLMPC model id");
     std::vector<double> prm;
     int want = 0;
     if (model_id == MPCX_MODEL_UGV) { prm = {0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, Ts}; want = 9; }
@@ -96,7 +96,7 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
         return capi_fail(MPCX_E_DEVICE, "could not upload the model parameters");
     }
     mpcx::NlmpcDev &d = h->dev;
-    d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq; d.nue = nue;
+    d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq; d.nue = nue; d.ny = ny;
     d.Ts = Ts;
     d.params = h->params_d;
     d.nbnd = 0;
@@ -126,7 +126,7 @@ int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d)
 {
     if (!h || !d) return mpcx::capi_fail(MPCX_E_INVALID, "null argument");
     const mpcx::NlmpcDev &m = h->dev;
-    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue};
+    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue, m.ny};
     return MPCX_OK;
 }
 
@@ -202,7 +202,7 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     s.tol_step = h->prm.relative_xtol > 0 ? h->prm.relative_xtol : 1e-6;
     s.tol_con = 1e-8; s.ieq_tol = 1e-10; s.eq_tol = 1e-10;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
-    s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input;
+    s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input; s.seq_output = b->seq_output;
     return MPCX_OK;
 }
 

@@ -22,6 +22,7 @@ struct NlmpcWsLayout {
 
 struct NlmpcDev {
     int model_id, nx, nu, ph, ch, nz, neq, nineq;
+    int ny;                     // outputs (OptSequence::output)
     int nue;                    // user equalities: rows nineq .. nineq+nue-1 of the user constraint arrays
     int nzu, nr;                // ch*nu, ch*nu + 1
     int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
@@ -56,9 +57,10 @@ struct NlmpcSolveDev {
     double *cmd, *cost, *z_out; // [B x nu], [B], [B x nz]
     int32_t *status, *solver_status, *is_feasible, *iterations;
     double *seq_state, *seq_input;      // [B x (ph+1) x nx], [B x (ph+1) x nu]
+    double *seq_output;                 // [B x (ph+1) x ny]
 };
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq, int *nue);
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq, int *nue);
 void nlmpc_plan(NlmpcDev &m);           // fills nzu, nr, lds_per_wave, ws from the dimensions
 int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream);
 int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream);

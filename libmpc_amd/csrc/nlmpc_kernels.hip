@@ -1010,6 +1010,13 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
         if (S.z_out) for (int k = lane; k < nz; k += 64) S.z_out[(size_t)b * nz + k] = z[k];
         if (S.seq_state) for (int k = lane; k < (ph + 1) * NX; k += 64) S.seq_state[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
         if (S.seq_input) for (int k = lane; k < (ph + 1) * NU; k += 64) S.seq_input[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
+        if (S.seq_output)                                   // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
+            for (int i = lane; i <= ph; i += 64) {
+                double y[Mdl::NY];
+                for (int a = 0; a < Mdl::NY; ++a) y[a] = 0.0;
+                if (Mdl::HAS_OUTPUT && !failed) Mdl::out(y, Xs + i * NX, Us + i * NU, prm);
+                for (int a = 0; a < Mdl::NY; ++a) S.seq_output[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
+            }
         if (lane == 0) {
             if (S.cost) S.cost[b] = failed ? INFINITY : scal[0];
             if (S.solver_status) S.solver_status[b] = code;
@@ -1036,11 +1043,11 @@ int dispatch_model(int model_id, F &&fn)
 
 }  // namespace
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu, int ph, int *nineq, int *nue)
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq, int *nue)
 {
     return dispatch_model(model_id, [&](auto mdl) {
         using Mdl = decltype(mdl);
-        *nx = Mdl::NX; *nu = Mdl::NU; *nineq = Mdl::nineq(ph); *nue = Mdl::neq_user(ph);
+        *nx = Mdl::NX; *nu = Mdl::NU; *ny = Mdl::NY; *nineq = Mdl::nineq(ph); *nue = Mdl::neq_user(ph);
         return 0;
     });
 }

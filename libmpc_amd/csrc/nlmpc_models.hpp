@@ -48,6 +48,14 @@ struct Lin {
 };
 
 // defaults for systems without user equalities (EConFunHandle, IDimensionable.hpp:118-122 / NLMPC::setEqConFunction)
+// OutFunHandle (IDimensionable.hpp:138-143, NLMPC::setOutputFunction): y = out(x, u) feeds OptSequence::output.  Without an
+// output function the reference's outputs are zeros (Model.hpp:72-96); the zoo's cost and constraint functors read X
+// and U directly, as the reference examples' do.
+struct NoOutput {
+    static constexpr bool HAS_OUTPUT = false;
+    __device__ static void out(double *, const double *, const double *, const double *) {}
+};
+
 struct NoUserEq {
     __host__ __device__ static int neq_user(int) { return 0; }
     template <class XA, class UA>
@@ -56,8 +64,8 @@ struct NoUserEq {
 };
 
 // ---- model zoo ----------------------------------------------------------------------------------
-struct VanDerPol : NoUserEq {      // reference examples/vanderpol_ex.cpp:33-65
-    static constexpr int NX = 2, NU = 1;
+struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.cpp:33-65
+    static constexpr int NX = 2, NU = 1, NY = 2;
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return ph + 1; }
     __device__ static void f(double *dx, const double *x, const double *u, const double *)
@@ -92,8 +100,10 @@ struct VanDerPolTerminal : VanDerPol {
 };
 
 struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
-    static constexpr int NX = 4, NU = 2;
+    static constexpr int NX = 4, NU = 2, NY = 4;
     static constexpr bool CONTINUOUS = false;
+    static constexpr bool HAS_OUTPUT = true;                       // y = Cd x + Dd u with C = I, D = 0 (ugv_ex.cpp:34-77)
+    __device__ static void out(double *y, const double *x, const double *, const double *) { for (int a = 0; a < 4; ++a) y[a] = x[a]; }
     // params: [0..1] v_pref, [2..4] obstacle 0 (x, y, r), [5..7] obstacle 1, [8] Ts
     __host__ __device__ static int nineq(int ph) { return 2 * (ph + 1); }
     __device__ static void f(double *xn, const double *x, const double *u, const double *p)
@@ -132,8 +142,8 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
 };
 
 template <int N>
-struct Oscillators : NoUserEq {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
-    static constexpr int NX = 2 * N, NU = N;
+struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
+    static constexpr int NX = 2 * N, NU = N, NY = 2 * N;
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return (ph + 1) * N; }
     __device__ static void f(double *dx, const double *x, const double *u, const double *p)

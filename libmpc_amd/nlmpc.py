@@ -42,8 +42,8 @@ class NLMPCEvaluator:
                                           int(device), C.byref(self._h)))
         d = _capi.NlmpcDims()
         check(self._lib.mpcx_nlmpc_get_dims(self._h, C.byref(d)))
-        self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w, self.neq_user = (
-            d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w, d.neq_user)
+        self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w, self.neq_user, self.ny = (
+            d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w, d.neq_user, d.ny)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -128,6 +128,7 @@ class NLMPC(NLMPCEvaluator):
         out = dict(cmd=f(self.nu), cost=f(), status=i(), solver_status=i(), is_feasible=i(), iterations=i(), z=f(self.nz))
         if sequences:
             out["seq_state"] = f(self.ph + 1, self.nx); out["seq_input"] = f(self.ph + 1, self.nu)
+            out["seq_output"] = f(self.ph + 1, self.ny)
         zw = None if z_warm is None else z_warm.to(dev, torch.float64).contiguous()
         b = _capi.NlmpcBatch(batch=B, x0=x0.data_ptr(), u0=u0.data_ptr(), z_warm=None if zw is None else zw.data_ptr(),
                              **{k: v.data_ptr() for k, v in out.items()})

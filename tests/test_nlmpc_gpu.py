@@ -115,6 +115,7 @@ def test_vanderpol_solve_matches_oracle():
         np.testing.assert_allclose(r["seq_state"][b], o["X"], atol=2e-5)
         assert r["is_feasible"][b] == 1 and (r["seq_input"][b] <= 0.5 + 1e-9).all()
     assert compared >= B - 2
+    assert not r["seq_output"].any()                  # no output function in the example: zeros (Model.hpp:72-96)
 
 
 def test_ugv_solve_matches_oracle():
@@ -126,6 +127,7 @@ def test_ugv_solve_matches_oracle():
     c, r = _solve_case("ugv", kw, X0, U0, False, 150)
     m = ref.ugv(**kw)
     assert (r["status"] != 3).all(), (r["status"], r["solver_status"], r["iterations"])
+    assert c.ny == 4 and np.array_equal(r["seq_output"], r["seq_state"])       # y = C x with C = I (ugv_ex.cpp:34-77)
     for b in range(B):
         o = m.solve(X0[b], U0[b], max_iter=100, hard=False)
         assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * abs(o["cost"]), (b, r["cost"][b], o["cost"])
