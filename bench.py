@@ -41,9 +41,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    # MPCX_FORCE_DIST=1: take the RCCL path (process group, all-gather, barriers) even with one rank -- a single-GPU box can
+    # then exercise the code the multi-GPU launches run
+    use_dist = world > 1 or os.environ.get("MPCX_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -67,25 +71,25 @@ def main():
         counter[0] += 1
         with torch.cuda.stream(s_k):
             c_k.launch(b_k, s_k)
-            if world > 1:
-                return allgather_controls(r_k.cmd)
+            if use_dist:
+                return allgather_controls(r_k.cmd, force=True)
         return r_k.cmd
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -195,7 +199,7 @@ def main():
                "solved_fraction": float((status == 0).mean()),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

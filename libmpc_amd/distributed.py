@@ -20,13 +20,13 @@ def shard_range(total: int, rank: int, world: int):
     return lo, hi
 
 
-def allgather_controls(cmd_local: torch.Tensor, total: int | None = None, group=None) -> torch.Tensor:
+def allgather_controls(cmd_local: torch.Tensor, total: int | None = None, group=None, force: bool = False) -> torch.Tensor:
     """All-gather the per-rank optimal controls into [total, nu] on every rank.
 
     Equal shards use one all_gather_into_tensor (a single RCCL ring collective);
     ragged shards are padded to the largest shard and trimmed afterwards."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return cmd_local
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return cmd_local           # force: run the collective even on a single rank (exercises the RCCL path)
     world = dist.get_world_size(group)
     n_local, nu = cmd_local.shape
     if total is None or total == n_local * world:
