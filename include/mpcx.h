@@ -1,10 +1,13 @@
 /* mpcx -- C ABI of the MI355X-native batched MPC solve engine.
  *
  * This is the drop-in boundary for ONE path of libmpc++: what sits behind
- * IOptimizer<sizer>::run (reference include/mpc/IOptimizer.hpp:24-58) for the
- * linear MPC back-end, i.e. LOptimizer::run + ProblemBuilder
- * (include/mpc/LMPC/LOptimizer.hpp:189-368, include/mpc/LMPC/ProblemBuilder.hpp),
- * for a *batch* of independent MPC instances that share one controller set-up.
+ * IOptimizer<sizer>::run (reference include/mpc/IOptimizer.hpp:24-58), for a
+ * *batch* of independent MPC instances that share one controller set-up:
+ *   mpcx_lmpc_*   the linear back-end, LOptimizer::run + ProblemBuilder
+ *                 (include/mpc/LMPC/LOptimizer.hpp:189-368, LMPC/ProblemBuilder.hpp);
+ *   mpcx_nlmpc_*  the non-linear back-end, NLOptimizer::run with Mapping / Model /
+ *                 Objective / Constraints (include/mpc/NLMPC/NLOptimizer.hpp:412-638);
+ *   mpcx_discretize_batch  the c2d set-up helper (include/mpc/Utils.hpp:23-89).
  *
  * Conventions
  *   - plain C, opaque handle, no C++/torch types in any signature;
