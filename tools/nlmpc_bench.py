@@ -40,18 +40,6 @@ if __name__ == "__main__":
     bad = np.concatenate([np.nonzero(st == k)[0][:2] for k in (-1, -3, -4)])
     for i in bad:
         print("failed", int(i), int(st[i]), int(it[i]), x0[i].numpy().tolist(), file=sys.stderr)
-    cpu = None
-    if "--cpu" in sys.argv:                       # the oracle (numpy callbacks + scipy SLSQP) on one host core, a few instances
-        import time
-        from oracle import nlmpc_numpy as ref
-        n = int(sys.argv[sys.argv.index("--cpu") + 1])
-        m = dict(ugv=lambda: ref.ugv(30, 30), vanderpol=lambda: ref.vanderpol(10, 5, 0.1), osc6=lambda: ref.oscillators(6, 20, 10),
-                 osc8=lambda: ref.oscillators(8, 30, 15))[name]()
-        t0 = time.perf_counter()
-        for i in range(n):
-            m.solve(x0[i].numpy(), u0[i].numpy(), max_iter=150, hard=(name != "ugv"))
-        dt = time.perf_counter() - t0
-        cpu = dict(value=n / dt, unit="solves/s", cores=1, kind="port", sample="first %d instances, numpy callbacks + scipy SLSQP" % n)
-    print(json.dumps(dict(workload=name, batch=B, nz=c.nz, ms_per_batch=ms, solves_per_s=B / ms * 1e3, cpu_baseline=cpu,
+    print(json.dumps(dict(workload=name, batch=B, nz=c.nz, ms_per_batch=ms, solves_per_s=B / ms * 1e3,
                           solver_status_counts={int(k): int((st == k).sum()) for k in np.unique(st)},
                           iterations_mean=float(it.mean()), iterations_max=int(it.max()))))
