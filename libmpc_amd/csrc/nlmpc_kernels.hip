@@ -439,7 +439,6 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
         }
         nl_wave_sync();
-        eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin);
 
         // user inequalities read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
         // structure the model declares (the finite differences leave exact zeros everywhere else)
@@ -459,7 +458,17 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
         long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
         auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         int it = 0, code = 5;       // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
-        for (; it < S.max_iter; ++it) {
+        // One call site for the transcription (the solver has to stay inside the 64 KB instruction cache, and three inlined
+        // copies of it do not): every pass of the loop starts with the evaluation at the current point -- everything on the
+        // first pass and after a step, values only after the last, converged step.
+        bool first_eval = true, final_eval = false;
+        for (;;) {
+            if (!first_eval) lap(4);
+            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, final_eval ? nullptr : g, c, final_eval ? nullptr : jeq, gin,
+                               final_eval ? nullptr : jin, first_eval);     // structural zeros are written once
+            if (!first_eval) lap(5); else tstamp = __builtin_readcyclecounter();
+            first_eval = false;
+            if (final_eval || it >= S.max_iter) break;
             // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
             if (Mdl::CONTINUOUS) {
                 for (int i = 0; i < ph; ++i) {
@@ -884,9 +893,9 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
                 for (int k = lane; k < nz; k += 64) z[k] += d[k];
                 nl_wave_sync();
-                eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, nullptr, c, nullptr, gin, nullptr);
                 code = 4; ++it;
-                break;
+                final_eval = true;
+                continue;
             }
 
             // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
@@ -985,6 +994,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
                     have_old = false;
                     nl_wave_sync();
+                    ++it;
                     continue;
                 }
                 a_step = ldexp(1.0, -(int)__builtin_ctzll(bal));
@@ -993,9 +1003,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             for (int k = lane; k < nz; k += 64) z[k] += a_step * d[k];
             a_prev = a_step; have_old = true;
             nl_wave_sync();
-            lap(4);
-            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, g, c, jeq, gin, jin, false);    // structural zeros are in place
-            lap(5);
+            ++it;
         }
         if (lane == 0) for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k];
 
