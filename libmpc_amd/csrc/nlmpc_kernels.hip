@@ -704,10 +704,6 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             lap(2);
             // ---- sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0   (Goldfarb-Idnani, range-space form on B^-1)
             double *xq = v0, *np_ = v1, *vv = v2, *zd = v3;
-            for (int q = lane; q < nq; q += 64) {
-                const double s = gdot2(hinv + q, nr, gr, 1, nq);
-                xq[q] = -s;
-            }
             for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
@@ -725,20 +721,45 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 --nw;
                 nl_wave_sync();
             };
+            // One sweep over B^-1 serves the unconstrained minimiser x = -B^-1 gr and B^-1 n for three rows of the previous
+            // working set at a time (their normals parked in LDS): every product with B^-1 costs a full pass of loads, and
+            // the warm start needs one per row.
+            for (int t0 = 0; t0 == 0 || t0 < nw_keep; t0 += 3) {
+                const int nv = min(3, nw_keep - t0);
+                for (int u = 0; u < nv; ++u) {
+                    const int k = (int)wq[t0 + u];
+                    for (int q = lane; q < nq; q += 64) v1[u * nr + q] = sgq[t0 + u] * art[(size_t)q * mld + k];
+                }
+                nl_wave_sync();
+                for (int q = lane; q < nq; q += 64) {
+                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    const double *hq = hinv + q;
+                    int j = 0;
+                    for (; j + 8 <= nq; j += 8) {
+                        double h[8], gv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { h[u] = hq[(size_t)(j + u) * nr]; gv[u] = t0 == 0 ? gr[j + u] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            a0 = fma(h[u], gv[u], a0);
+                            a1 = fma(h[u], v1[j + u], a1); a2 = fma(h[u], v1[nr + j + u], a2); a3 = fma(h[u], v1[2 * nr + j + u], a3);
+                        }
+                    }
+                    for (; j < nq; ++j) {
+                        const double hv = hq[(size_t)j * nr];
+                        a0 = fma(hv, t0 == 0 ? gr[j] : 0.0, a0);
+                        a1 = fma(hv, v1[j], a1); a2 = fma(hv, v1[nr + j], a2); a3 = fma(hv, v1[2 * nr + j], a3);
+                    }
+                    if (t0 == 0) xq[q] = -a0;
+                    const double acc[3] = {a1, a2, a3};
+                    for (int u = 0; u < nv; ++u) { qn[(size_t)(t0 + u) * nr + q] = v1[u * nr + q]; qv[(size_t)(t0 + u) * nr + q] = acc[u]; }
+                }
+                nl_wave_sync();
+            }
             // warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative --
             // the minimiser on that set with u >= 0 is a valid state of the dual method
             if (nw_keep > 0) {
                 nw = nw_keep;
-                for (int t = 0; t < nw; ++t) {
-                    const int k = (int)wq[t];
-                    for (int q = lane; q < nq; q += 64) vv[q] = sgq[t] * art[(size_t)q * mld + k];
-                    nl_wave_sync();
-                    for (int q = lane; q < nq; q += 64) {
-                        const double s2 = gdot(hinv + q, nr, vv, nq);
-                        qn[(size_t)t * nr + q] = vv[q]; qv[(size_t)t * nr + q] = s2;
-                    }
-                    nl_wave_sync();
-                }
                 for (int e2 = lane; e2 < nw * nw; e2 += 64) {
                     const int a = e2 / nw, b2 = e2 - a * nw;
                     const double s2 = gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
