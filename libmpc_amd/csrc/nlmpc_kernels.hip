@@ -985,28 +985,37 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             nl_wave_sync();
             double a_step;
             {
-                const double al = ldexp(1.0, -min(lane, 40));
-                const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
-                const double et = z[nz - 1] + al * d[nz - 1];
-                double mer = Mdl::cost(XL, UL, et, ph, prm), vio = 0;
-                const double h = 0.5 * M.Ts;
-                for (int i = 0; i < ph; ++i) {
-                    double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
-                    for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
-                    for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
-                    Mdl::f(fa, xk, uk, prm);
-                    if (Mdl::CONTINUOUS) {
-                        Mdl::f(fb, xk1, uk, prm);
-                        for (int a = 0; a < NX; ++a) vio += fabs(xk[a] + (h * (fa[a] + fb[a])) - xk1[a]);
-                    } else {
-                        for (int a = 0; a < NX; ++a) vio += fabs(xk1[a] - fa[a]);
+                // eight step lengths at a time, eight lanes each: lane (g, part) evaluates every eighth defect and constraint of
+                // trial point a = 2^-(g + 8 round), the cost is one lane's (it is a black box over the whole horizon), a
+                // three-step butterfly adds the parts up.  Almost always the first round holds an acceptable length.
+                const int grp = lane >> 3, part = lane & 7;
+                unsigned long long bal = 0;
+                int round = 0;
+                for (; round < 5 && !bal; ++round) {
+                    const double al = ldexp(1.0, -(grp + 8 * round));
+                    const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
+                    const double et = z[nz - 1] + al * d[nz - 1];
+                    double mer = part == 0 ? Mdl::cost(XL, UL, et, ph, prm) : 0.0, vio = 0;
+                    const double h = 0.5 * M.Ts;
+                    for (int i = part; i < ph; i += 8) {
+                        double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
+                        for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
+                        for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
+                        Mdl::f(fa, xk, uk, prm);
+                        if (Mdl::CONTINUOUS) {
+                            Mdl::f(fb, xk1, uk, prm);
+                            for (int a = 0; a < NX; ++a) vio += fabs(xk[a] + (h * (fa[a] + fb[a])) - xk1[a]);
+                        } else {
+                            for (int a = 0; a < NX; ++a) vio += fabs(xk1[a] - fa[a]);
+                        }
                     }
+                    for (int k = part; k < mi; k += 8) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+                    for (int k = part; k < m - mi; k += 8) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
+                    mer += nu_pen * vio;
+                    mer += __shfl_xor(mer, 1); mer += __shfl_xor(mer, 2); mer += __shfl_xor(mer, 4);
+                    const bool ok = part == 0 && mer <= phi0 + 1e-4 * al * dphi;
+                    bal = __ballot(ok);
                 }
-                for (int k = 0; k < mi; ++k) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
-                for (int k = 0; k < m - mi; ++k) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
-                mer += nu_pen * vio;
-                const bool ok = lane <= 40 && mer <= phi0 + 1e-4 * al * dphi;
-                const unsigned long long bal = __ballot(ok);
                 if (!bal) {                                         // no decrease left within 2^-40: the iteration has stalled
                     if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
                     if (resets >= 5) { code = -4; break; }
@@ -1018,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     ++it;
                     continue;
                 }
-                a_step = ldexp(1.0, -(int)__builtin_ctzll(bal));
+                a_step = ldexp(1.0, -((int)__builtin_ctzll(bal) / 8 + 8 * (round - 1)));
             }
             for (int q = lane; q < nr; q += 64) sv[q] = a_step * p[q];
             for (int k = lane; k < nz; k += 64) z[k] += a_step * d[k];
