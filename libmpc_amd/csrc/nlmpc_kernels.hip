@@ -940,22 +940,44 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             double lam_max = 0;
             {
                 double *tl = aug, *ln = aug + NX;                  // t and lam_{i+1}
-                for (int i = ph - 1; i >= 0; --i) {
+                // the operands of step i-1 are requested before step i computes: the sweep is a chain of ph dependent steps and
+                // would otherwise pay a memory latency in each
+                double an[NX], en[NX], wn = 0.0;
+                auto fetch = [&](int i) {
                     if (lane < NX) {
-                        double s2 = lamw[i * NX + lane];
-                        if (i + 1 < ph) {
-                            const double *Jb = jeq + (size_t)(i + 1) * NX * W;
-                            for (int bb = 0; bb < NX; ++bb) s2 += Jb[bb * W + lane] * ln[bb];
+                        wn = lamw[i * NX + lane];
+                        const double *Jb = jeq + (size_t)min(i + 1, ph - 1) * NX * W;
+#pragma unroll
+                        for (int bb = 0; bb < NX; ++bb) an[bb] = i + 1 < ph ? Jb[bb * W + lane] : 0.0;
+                        if (Mdl::CONTINUOUS) {
+                            const double *Ei = einv + (size_t)i * NX * NX;
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) en[bb] = Ei[bb * NX + lane];
                         }
+                    }
+                };
+                if (lane < NX) ln[lane] = 0.0;
+                fetch(ph - 1);
+                nl_wave_sync();
+                for (int i = ph - 1; i >= 0; --i) {
+                    double ac[NX], ec[NX];
+                    const double wc = wn;
+#pragma unroll
+                    for (int bb = 0; bb < NX; ++bb) { ac[bb] = an[bb]; ec[bb] = en[bb]; }
+                    if (i > 0) fetch(i - 1);
+                    if (lane < NX) {
+                        double s2 = wc;
+#pragma unroll
+                        for (int bb = 0; bb < NX; ++bb) s2 = fma(ac[bb], ln[bb], s2);
                         tl[lane] = s2;
                     }
                     nl_wave_sync();
                     if (lane < NX) {
                         double lam;
                         if (Mdl::CONTINUOUS) {
-                            const double *Ei = einv + (size_t)i * NX * NX;
                             lam = 0;
-                            for (int bb = 0; bb < NX; ++bb) lam -= Ei[bb * NX + lane] * tl[bb];
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) lam = fma(-ec[bb], tl[bb], lam);
                         } else {
                             lam = -tl[lane];
                         }
