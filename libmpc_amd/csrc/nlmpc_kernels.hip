@@ -542,24 +542,50 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 }
             } else {
                 for (int q = lane; q <= nzu; q += 64) {
-                    double v[NX], t[NX];
+                    // small blocks come straight from L2, the next step's already requested while this one computes (the
+                    // stores to Phi in between keep the compiler from moving the loads up by itself)
+                    double v[NX], t[NX], An[NX * NX], rn[NX], En[Mdl::CONTINUOUS ? NX * NX : 1];
                     for (int a = 0; a < NX; ++a) v[a] = 0.0;
                     const int bq = q / NU, jq = q - bq * NU;
-                    for (int i = 0; i < ph; ++i) {
+                    auto fetch = [&](int i) {
                         const double *Jb = jeq + (size_t)i * NX * W;
+#pragma unroll
                         for (int a = 0; a < NX; ++a) {
-                            double s = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
-                            for (int bb = 0; bb < NX; ++bb) s += Jb[a * W + bb] * v[bb];
-                            t[a] = s;
+                            rn[a] = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) An[a * NX + bb] = Jb[a * W + bb];
                         }
                         if (Mdl::CONTINUOUS) {
                             const double *Ei = einv + (size_t)i * NX * NX;
+#pragma unroll
+                            for (int e2 = 0; e2 < NX * NX; ++e2) En[e2] = Ei[e2];
+                        }
+                    };
+                    fetch(0);
+                    for (int i = 0; i < ph; ++i) {
+                        double Ac[NX * NX], rc[NX], Ec[Mdl::CONTINUOUS ? NX * NX : 1];
+#pragma unroll
+                        for (int e2 = 0; e2 < NX * NX; ++e2) { Ac[e2] = An[e2]; if (Mdl::CONTINUOUS) Ec[e2] = En[e2]; }
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) rc[a] = rn[a];
+                        if (i + 1 < ph) fetch(i + 1);
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double s2 = rc[a];
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) s2 = fma(Ac[a * NX + bb], v[bb], s2);
+                            t[a] = s2;
+                        }
+                        if (Mdl::CONTINUOUS) {
+#pragma unroll
                             for (int a = 0; a < NX; ++a) {
-                                double s = 0;
-                                for (int bb = 0; bb < NX; ++bb) s += Ei[a * NX + bb] * t[bb];
-                                v[a] = -s;
+                                double s2 = 0;
+#pragma unroll
+                                for (int bb = 0; bb < NX; ++bb) s2 = fma(Ec[a * NX + bb], t[bb], s2);
+                                v[a] = -s2;
                             }
                         } else {
+#pragma unroll
                             for (int a = 0; a < NX; ++a) v[a] = -t[a];
                         }
                         if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
