@@ -720,9 +720,22 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     yHy = wave_sum(yHy);
                     nl_wave_sync();
                     const double cc = rho * rho * yHy + rho;
-                    for (int q = lane; q < nq; q += 64)
-                        for (int i = 0; i < nq; ++i)
-                            hinv[(size_t)i * nr + q] += -rho * (sv[i] * v2[q] + v2[i] * sv[q]) + cc * sv[i] * sv[q];
+                    for (int q = lane; q < nq; q += 64) v3[q] = sv[q];          // s next to Hy in LDS
+                    nl_wave_sync();
+                    for (int q = lane; q < nq; q += 64) {
+                        const double hyq = v2[q], sq = v3[q];
+                        int i = 0;
+                        for (; i + 8 <= nq; i += 8) {                           // eight loads, eight updates, eight stores
+                            double hv[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) hv[u] = hinv[(size_t)(i + u) * nr + q];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) hv[u] += -rho * (v3[i + u] * hyq + v2[i + u] * sq) + cc * v3[i + u] * sq;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) hinv[(size_t)(i + u) * nr + q] = hv[u];
+                        }
+                        for (; i < nq; ++i) hinv[(size_t)i * nr + q] += -rho * (v3[i] * hyq + v2[i] * sq) + cc * v3[i] * sq;
+                    }
                 }
                 nl_wave_sync();
             }
