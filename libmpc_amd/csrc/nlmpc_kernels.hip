@@ -863,9 +863,25 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                     }
                     nl_wave_sync();
                     // t = N_W v (also the new column of S), rr = S^-1 t
-                    for (int t = lane; t < nw; t += 64) {
-                        const double s = gdot(qn + (size_t)t * nr, 1, vv, nq);
-                        tq[t] = s;
+                    if (nw <= 16 && nq <= 64) {
+                        // few rows: the lanes split each dot product (coalesced loads, all rows in flight, a butterfly per row)
+                        // instead of each walking one row on its own
+                        for (int t0 = 0; t0 < nw; t0 += 8) {
+                            double part[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) part[u] = (t0 + u < nw && lane < nq) ? qn[(size_t)(t0 + u) * nr + lane] : 0.0;
+                            const double vl = lane < nq ? vv[lane] : 0.0;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double sred = wave_sum(part[u] * vl);
+                                if (lane == 0 && t0 + u < nw) tq[t0 + u] = sred;
+                            }
+                        }
+                    } else {
+                        for (int t = lane; t < nw; t += 64) {
+                            const double s = gdot(qn + (size_t)t * nr, 1, vv, nq);
+                            tq[t] = s;
+                        }
                     }
                     // small working sets factor in LDS, large ones in the workspace
                     double *Sf = nw <= KL ? Sfac : Sbig;
