@@ -806,9 +806,23 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
                 }
                 nl_wave_sync();
                 while (nw > 0) {
-                    for (int t = lane; t < nw; t += 64) {
-                        const double s2 = sgq[t] * br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
-                        tq[t] = s2;
+                    if (nw <= 16 && nq <= 64) {
+                        for (int t0 = 0; t0 < nw; t0 += 8) {
+                            double part[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) part[u] = (t0 + u < nw && lane < nq) ? qn[(size_t)(t0 + u) * nr + lane] : 0.0;
+                            const double xl = lane < nq ? xq[lane] : 0.0;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double sred = wave_sum(part[u] * xl);
+                                if (lane == 0 && t0 + u < nw) tq[t0 + u] = sgq[t0 + u] * br[(int)wq[t0 + u]] + sred;
+                            }
+                        }
+                    } else {
+                        for (int t = lane; t < nw; t += 64) {
+                            const double s2 = sgq[t] * br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
+                            tq[t] = s2;
+                        }
                     }
                     double *Sf = nw <= KL ? Sfac : Sbig;
                     const int sfld = nw <= KL ? KL + 1 : SLD;
