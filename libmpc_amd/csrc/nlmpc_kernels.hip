@@ -355,30 +355,6 @@ __device__ bool spd_solve(double *S, int ld, double *t, int n, int lane)
     return ok;
 }
 
-// In-place Gauss-Jordan inverse of an n x n matrix held as [n x 2n] = [E | I] in LDS, partial pivoting.
-__device__ void invert_small(double *Aug, int n, int lane)
-{
-    const int w = 2 * n;
-    for (int k = 0; k < n; ++k) {
-        int pr = k; double best = fabs(Aug[k * w + k]);
-        for (int i = k + 1; i < n; ++i) { const double v = fabs(Aug[i * w + k]); if (v > best) { best = v; pr = i; } }
-        if (pr != k) for (int j = lane; j < w; j += 64) { const double a = Aug[k * w + j]; Aug[k * w + j] = Aug[pr * w + j]; Aug[pr * w + j] = a; }
-        nl_wave_sync();
-        const double inv = 1.0 / Aug[k * w + k];
-        nl_wave_sync();
-        for (int j = lane; j < w; j += 64) Aug[k * w + j] *= inv;
-        nl_wave_sync();
-        for (int q = lane; q < n * w; q += 64) {
-            const int i = q / w, j = q - i * w;
-            if (i == k || j == k) continue;                 // column k last: its entries are the multipliers
-            Aug[q] -= Aug[i * w + k] * Aug[k * w + j];
-        }
-        nl_wave_sync();
-        for (int i = lane; i < n; i += 64) if (i != k) Aug[i * w + k] = 0.0;
-        nl_wave_sync();
-    }
-}
-
 template <class Mdl>
 __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
 {
@@ -471,16 +447,42 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             if (final_eval || it >= S.max_iter) break;
             // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
             if (Mdl::CONTINUOUS) {
-                for (int i = 0; i < ph; ++i) {
-                    for (int q = lane; q < NX * 2 * NX; q += 64) {
-                        const int a = q / (2 * NX), j = q - a * 2 * NX;
-                        aug[q] = j < NX ? jeq[(size_t)i * NX * W + a * W + NX + j] : (j - NX == a ? 1.0 : 0.0);
+                // Gauss-Jordan on [E | I] with one column per lane held in registers: the pivot column's entries reach the
+                // other lanes by shuffles, so a pivot step is NX shuffles and NX FMAs with no LDS traffic and no barrier; 2 NX
+                // lanes serve one step, the wavefront inverts 64 / (2 NX) steps at a time.  Partial pivoting as before.
+                constexpr int GW = 2 * NX, G = 64 / GW;
+                const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
+                for (int i0 = 0; i0 < ph; i0 += G) {
+                    const int i = i0 + g;
+                    const bool live = g < G && i < ph;
+                    double col[NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a)
+                        col[a] = (live && cidx < NX) ? jeq[(size_t)i * NX * W + a * W + NX + cidx] : ((cidx < NX ? cidx : cidx - NX) == a ? 1.0 : 0.0);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        int pr = k;
+                        double best = fabs(col[k]);
+#pragma unroll
+                        for (int a = k + 1; a < NX; ++a) { const double v = fabs(col[a]); if (v > best) { best = v; pr = a; } }
+                        pr = __shfl(pr, base + k);                     // the pivot column's choice
+                        double cp = col[k];
+#pragma unroll
+                        for (int a = k + 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[k]; }
+                        col[k] = cp;                                    // rows k and pr swapped in every column
+                        const double piv = __shfl(col[k], base + k);
+                        double mlt[NX];
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) mlt[a] = __shfl(col[a], base + k);     // pivot column, before anyone updates
+                        const double cs = col[k] / piv;
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) col[a] = a == k ? cs : fma(-mlt[a], cs, col[a]);
                     }
-                    nl_wave_sync();
-                    invert_small(aug, NX, lane);
-                    for (int q = lane; q < NX * NX; q += 64) einv[(size_t)i * NX * NX + q] = aug[(q / NX) * 2 * NX + NX + q % NX];
-                    nl_wave_sync();
+                    if (live && cidx >= NX)
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) einv[(size_t)i * NX * NX + a * NX + (cidx - NX)] = col[a];
                 }
+                nl_wave_sync();
             }
             // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0.  A_i = dc_i/dx_i (and E_i^-1) are the same for
             // every lane: they are staged in LDS, the next step's share already in flight while this step computes.
