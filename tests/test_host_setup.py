@@ -149,3 +149,23 @@ def test_move_blocking_dimensions():
     assert int(dims[5]) == min(ph, ch + 1) and int(dims[0]) == min(ph, ch + 1) * nu
     # same spec is accepted by the oracle front-end
     configure_random(OracleFrontEnd(*spec["dims"]), spec)
+
+
+def test_nlmpc_create_validates_before_touching_a_device():
+    """mpcx_nlmpc_create: argument errors are MPCX_E_INVALID, a missing GPU is MPCX_E_DEVICE -- never a silent CPU path"""
+    import ctypes as C
+    from libmpc_amd import _capi
+    lib = _capi.lib()
+    h = C.c_void_p()
+    assert lib.mpcx_nlmpc_create(99, 10, 5, 0.1, None, 0, 0, C.byref(h)) == _capi.E_INVALID          # unknown model
+    assert lib.mpcx_nlmpc_create(1, 5, 6, 0.1, None, 0, 0, C.byref(h)) == _capi.E_INVALID           # ch > ph
+    assert lib.mpcx_nlmpc_create(1, 0, 0, 0.1, None, 0, 0, C.byref(h)) == _capi.E_INVALID
+    bad = (C.c_double * 3)(1.0, 2.0, 3.0)
+    assert lib.mpcx_nlmpc_create(2, 10, 10, 0.1, bad, 3, 0, C.byref(h)) == _capi.E_INVALID          # the UGV takes 9 parameters
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.mpcx_nlmpc_create(1, 10, 5, 0.1, None, 0, 0, C.byref(h)) == _capi.E_DEVICE
+        assert b"HIP device" in lib.mpcx_last_error()
+    p = _capi.NLParams()
+    lib.mpcx_nlparams_default(C.byref(p))
+    assert (p.maximum_iteration, p.relative_ftol, p.relative_xtol, p.hard_constraints, p.enable_warm_start) == (100, -1.0, -1.0, 1, 0)

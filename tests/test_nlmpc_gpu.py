@@ -290,3 +290,30 @@ def test_user_equality_constraints_match_oracle():
             assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
             np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=5e-5, atol=5e-6)
         assert compared >= B - 1
+
+
+@pytest.mark.parametrize("name,kw,hard", [("ugv", dict(ph=12, ch=4), False), ("vanderpol", dict(ph=10, ch=10, Ts=0.1), True),
+                                           ("vanderpol", dict(ph=7, ch=3, Ts=0.05), True)])
+def test_move_blocking_variants_solve_like_the_oracle(name, kw, hard):
+    """Mapping::computeMapping (Mapping.hpp:221-257): ch < ph holds the last move, ch = ph does not block at all"""
+    rng = np.random.default_rng(31)
+    B = 5
+    nx = 4 if name == "ugv" else 2
+    X0 = np.zeros((B, nx)); X0[:, :2] = rng.uniform(-0.4, 0.4, size=(B, 2))
+    U0 = np.zeros((B, 2 if name == "ugv" else 1))
+    c, r = _solve_case(name, kw, X0, U0, hard, 200)
+    m = ref.ugv(**kw) if name == "ugv" else ref.vanderpol(**kw)
+    compared = 0
+    for b in range(B):
+        o = m.solve(X0[b], U0[b], max_iter=300, hard=hard)
+        if not o["success"] and "Positive directional" not in o["message"]:
+            continue
+        if np.abs(m.state_eq(o["z"], False)[0]).max() > 1e-8:
+            continue
+        compared += 1
+        assert r["status"][b] != 3, (b, r["solver_status"][b])
+        assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=5e-5, atol=2e-5)
+        # the held last block: every step from ch-1 on applies the same input
+        assert np.abs(r["seq_input"][b][kw["ch"] - 1:] - r["seq_input"][b][kw["ch"] - 1]).max() == 0.0
+    assert compared >= B - 1
