@@ -285,6 +285,9 @@ typedef struct mpcx_nlmpc_batch {
     double *seq_state;         /* [B x (ph+1) x nx] row-major, row 0 = x0                           */
     double *seq_input;         /* [B x (ph+1) x nu]                                                 */
     double *seq_output;        /* [B x (ph+1) x ny] Model::getOutput (Model.hpp:72-96)                */
+    int warm_curvature;        /* extension, with z_warm only: 1 = also keep the curvature estimate the previous solve of
+                                  the same batch left in the handle's workspace (NLopt restarts its BFGS matrix on every
+                                  optimize(); the optimum is the same, the iterations are fewer)                   */
 } mpcx_nlmpc_batch;
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
 /* The same for callers whose data lives in host memory (the reference's optimize(x0, lastU) is such a caller): stages,

@@ -18,6 +18,7 @@ struct mpcx_nlmpc {
     double *params_d = nullptr;
     double *ws = nullptr;
     size_t ws_cap = 0;          // instances
+    int solved_batch = 0;       // batch size of the last solve whose state is still in the workspace (0: none)
     mpcx_nlparams prm{};
     // NLOptimizer::lb / ub (NLOptimizer.hpp:346-404): bounds on the decision vector, host copy + device tables
     std::vector<double> lb, ub;
@@ -54,7 +55,7 @@ struct mpcx_nlmpc {
             dev.nbnd = nb;
             mpcx::nlmpc_plan(dev);
             if (ws) (void)hipFree(ws);
-            ws = nullptr; ws_cap = 0;
+            ws = nullptr; ws_cap = 0; solved_batch = 0;
         }
         bounds_dirty = false;
         return MPCX_OK;
@@ -191,7 +192,7 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     if (h->sync_bounds() != MPCX_OK) return capi_fail(MPCX_E_DEVICE, "could not upload the bounds");
     if ((size_t)b->batch > h->ws_cap) {
         if (h->ws) (void)hipFree(h->ws);
-        h->ws = nullptr; h->ws_cap = 0;
+        h->ws = nullptr; h->ws_cap = 0; h->solved_batch = 0;
         if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.ws.total * sizeof(double)) != hipSuccess)
             return capi_fail(MPCX_E_DEVICE, "could not allocate the SQP workspace");
         h->ws_cap = b->batch;
@@ -201,6 +202,8 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     s.max_iter = h->prm.maximum_iteration; s.hard = h->prm.hard_constraints ? 1 : 0;
     s.tol_step = h->prm.relative_xtol > 0 ? h->prm.relative_xtol : 1e-6;
     s.tol_con = 1e-8; s.ieq_tol = 1e-10; s.eq_tol = 1e-10;
+    s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch) ? 1 : 0;
+    h->solved_batch = b->batch;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
     s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input; s.seq_output = b->seq_output;
     return MPCX_OK;

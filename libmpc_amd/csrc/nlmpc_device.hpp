@@ -53,6 +53,7 @@ struct NlmpcSolveDev {
     const double *z_warm;       // [B x nz] previous solutions (shifted one step on entry) or null = cold start
     double *ws;                 // [B x ws.total]
     int max_iter, hard;
+    int keep_curvature;         // 1: start from the inverse BFGS matrix already in the workspace (receding-horizon extension)
     double tol_step, tol_con, ieq_tol, eq_tol;
     double *cmd, *cost, *z_out; // [B x nu], [B], [B x nz]
     int32_t *status, *solver_status, *is_feasible, *iterations;

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const Nlmp
             for (int k = lane; k < nzu; k += 64) z[nxs + k] = u0[k % NU];
             if (lane == 0) z[nz - 1] = 0.0;
         }
-        for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
+        if (!S.keep_curvature)                              // otherwise: the estimate the previous tick's solve left in the workspace
+            for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
         for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
         // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
         for (int k = lane; k < nz; k += 64) {

@@ -117,7 +117,7 @@ class NLMPC(NLMPCEvaluator):
                            "functors of its model; host callables cannot run inside the kernel")
     setStateSpaceFunction = setObjectiveFunction = setIneqConFunction = setEqConFunction = setOutputFunction = _closures_are_fixed
 
-    def make_batch(self, x0, u0, z_warm=None, sequences=False):
+    def make_batch(self, x0, u0, z_warm=None, sequences=False, warm_curvature=False):
         import torch
         dev = torch.device("cuda", self.device)
         x0 = x0.to(dev, torch.float64).contiguous(); u0 = u0.to(dev, torch.float64).contiguous()
@@ -132,12 +132,13 @@ class NLMPC(NLMPCEvaluator):
         zw = None if z_warm is None else z_warm.to(dev, torch.float64).contiguous()
         b = _capi.NlmpcBatch(batch=B, x0=x0.data_ptr(), u0=u0.data_ptr(), z_warm=None if zw is None else zw.data_ptr(),
                              **{k: v.data_ptr() for k, v in out.items()})
+        b.warm_curvature = int(bool(warm_curvature))
         out["_keep"] = (x0, u0, zw)
         return b, out
 
-    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None):
+    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None, warm_curvature=False):
         import torch
-        b, out = self.make_batch(x0, u0, z_warm, sequences)
+        b, out = self.make_batch(x0, u0, z_warm, sequences, warm_curvature)
         s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if stream is None else stream
         check(self._lib.mpcx_nlmpc_solve_batch(self._h, C.byref(b), s))
         return out

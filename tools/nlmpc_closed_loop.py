@@ -11,7 +11,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from tools.nlmpc_bench import make  # noqa: E402
 
 
-def run(B, ticks, warm):
+def run(B, ticks, warm, curvature=False):
     c, x0, u0 = make("ugv", B)
     Ts = 0.1
     x = x0.cuda(); u = u0.cuda()
@@ -20,7 +20,7 @@ def run(B, ticks, warm):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(ticks):
-        r = c.optimizeBatch(x, u, z_warm=z if warm else None)
+        r = c.optimizeBatch(x, u, z_warm=z if warm else None, warm_curvature=curvature)
         u = r["cmd"]
         x = torch.stack([x[:, 0] + Ts * x[:, 2] + 0.5 * Ts * Ts * u[:, 0], x[:, 1] + Ts * x[:, 3] + 0.5 * Ts * Ts * u[:, 1],
                          x[:, 2] + Ts * u[:, 0], x[:, 3] + Ts * u[:, 1]], dim=1)
@@ -29,12 +29,12 @@ def run(B, ticks, warm):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = float((r["status"] != 3).float().mean())
-    return dict(warm=warm, batch=B, ticks=ticks, solves_per_s=B * ticks / dt, ms_per_tick=dt / ticks * 1e3,
+    return dict(warm=warm, keep_curvature=curvature, batch=B, ticks=ticks, solves_per_s=B * ticks / dt, ms_per_tick=dt / ticks * 1e3,
                 mean_iterations=float(its) / ticks, not_failed=ok)
 
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    for w in (False, True):
-        print(json.dumps(run(B, ticks, w)))
+    for w, k in ((False, False), (True, False), (True, True)):
+        print(json.dumps(run(B, ticks, w, k)))
