@@ -40,7 +40,7 @@ constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
 constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
 constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
 #ifndef MPCX_SOLVE_WAVES
-#define MPCX_SOLVE_WAVES 3
+#define MPCX_SOLVE_WAVES 2
 #endif
 
 // Pointers that come out of the model struct are generic pointers to the compiler, which
