@@ -8,6 +8,7 @@
 //       - dynamics equalities (trapezoidal collocation or one-step) + central-difference blocks
 //                                                                              (getStateEqConstraints)
 //       - user inequalities + central-difference Jacobian                      (computeIneqJacobian)
+//       - user equalities + central-difference Jacobian, with their own step rules (computeEqJacobian)
 // (2) nlmpc_sqp: the optimisation NLOptimizer::run (NLOptimizer.hpp:412-638) hands to nlopt LD_SLSQP, as a
 //     sequential quadratic programme on the same transcription: the dynamics equalities are eliminated by a
 //     forward sweep over their block-bidiagonal Jacobian (condensing), the quadratic sub-problem lives in the
