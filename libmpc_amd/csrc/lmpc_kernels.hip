@@ -814,6 +814,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 };
                 if (na <= 4) reg_polish(std::integral_constant<int, 4>{});
                 else if (na <= 8) reg_polish(std::integral_constant<int, 8>{});
+                else if (na <= 12) reg_polish(std::integral_constant<int, 12>{});      // the slow instances live here: |A| of 9..12
                 else if (na <= kRegCap) reg_polish(std::integral_constant<int, kRegCap>{});
                 else {
                 for (int p = lane; p < na * na; p += 64) {
