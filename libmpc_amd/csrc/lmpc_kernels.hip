@@ -813,7 +813,9 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                     }
                 };
                 if (na <= 4) reg_polish(std::integral_constant<int, 4>{});
+                else if (na <= 6) reg_polish(std::integral_constant<int, 6>{});
                 else if (na <= 8) reg_polish(std::integral_constant<int, 8>{});
+                else if (na <= 10) reg_polish(std::integral_constant<int, 10>{});
                 else if (na <= 12) reg_polish(std::integral_constant<int, 12>{});      // the slow instances live here: |A| of 9..12
                 else if (na <= kRegCap) reg_polish(std::integral_constant<int, kRegCap>{});
                 else {
