@@ -68,6 +68,7 @@ struct LmpcBatchDev {
     int32_t *polish_rounds, *active_count;
     const uint32_t *warm_lower, *warm_upper;      // optional previous active sets (reference row numbering)
     int warm_shift;
+    int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };

@@ -37,6 +37,7 @@ namespace {
 #define MPCX_WAVES_PER_BLOCK 2
 #endif
 constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
+constexpr int kFallbackChunk = 8;
 constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
 constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
 #ifndef MPCX_SOLVE_WAVES
@@ -1392,8 +1393,25 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
     double *nt0 = stage + M.stage_len;
     double *arena = nt0 + M.ldy;
     const int wpb = blockDim.x >> 6;
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+    if (Bt.chunked) {
+        // after the polish-only kernel almost nothing is left: a wavefront looks at the flags of kFallbackChunk instances at
+        // once (one load each, side by side) and only enters the solver for those still open -- an eighth of the wavefronts
+        // to launch and retire
+        for (int c0 = (blockIdx.x * wpb + wave) * kFallbackChunk; c0 < Bt.batch; c0 += gridDim.x * wpb * kFallbackChunk) {
+            const int bi = c0 + lane;
+            const bool open = lane < kFallbackChunk && bi < Bt.batch &&
+                              glw(wsbase)[(size_t)bi * M.wsld + M.ldz + M.ldy + 2 * M.ldg + 1] != 2.0;
+            unsigned long long todo = __ballot(open);
+            while (todo) {
+                const int b = c0 + (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+            }
+        }
+    } else {
+        for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+            solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+    }
     // last kernel of a launch: leave the dispatch queues empty for the next one
     if (Bt.qcnt && Bt.qreset && blockIdx.x == 0)
         for (int q = threadIdx.x; q < kQueues; q += blockDim.x) Bt.qcnt[q] = 0;
@@ -1892,7 +1910,17 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
             hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
         }
     }
-    if (which & 4) hipLaunchKernelGGL(k3, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+    if (which & 4) {
+        LmpcBatchDev b3 = b;
+        int blocks3 = blocks;
+        if (m.polish && (which & 2)) {          // the polish-only kernel ran first: few instances are left
+            b3.chunked = 1;
+            blocks3 = (b.batch + kFallbackChunk * kWavesPerBlock - 1) / (kFallbackChunk * kWavesPerBlock);
+            if (blocks3 > cap) blocks3 = cap;
+            if (blocks3 < 1) blocks3 = 1;
+        }
+        hipLaunchKernelGGL(k3, dim3(blocks3), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b3, ws);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
