@@ -1913,7 +1913,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (which & 4) {
         LmpcBatchDev b3 = b;
         int blocks3 = blocks;
-        if (m.polish && (which & 2)) {          // the polish-only kernel ran first: few instances are left
+        if (m.polish) {                          // a polish pass always comes first then: few instances are left
             b3.chunked = 1;
             blocks3 = (b.batch + kFallbackChunk * kWavesPerBlock - 1) / (kFallbackChunk * kWavesPerBlock);
             if (blocks3 > cap) blocks3 = cap;
