@@ -40,6 +40,12 @@ constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
 constexpr int kFallbackChunk = 8;
 constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
 constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
+// a working set with all signs right grows by the rows violated by at least this fraction of the largest violation: adding
+// every violated row at once over-constrains, the surplus rows are shed one round later and the slowest instances ping-pong
+// (max rounds 18-22 over six batches of 4096 with 0, 12-14 with 0.3; 0.1 and 0.5 are worse than either)
+#ifndef MPCX_ADD_THETA
+#define MPCX_ADD_THETA 0.3
+#endif
 #ifndef MPCX_SOLVE_WAVES
 #define MPCX_SOLVE_WAVES 2
 #endif
@@ -945,18 +951,26 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
                 changed = wave_any(drop);
                 if (!changed) {
                     bool add = false;
+                    double vb[NZS], vg[NGS], vm = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NZS; ++s) {
+                        vb[s] = 0.0;
+                        if (actb[s] == 0) vb[s] = fmax(fmax(lw[s] - ptol * fmax(1.0, fabs(lw[s])) - wv[s], wv[s] - uw[s] - ptol * fmax(1.0, fabs(uw[s]))), 0.0);
+                        vm = fmax(vm, vb[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NGS; ++s) {
+                        vg[s] = 0.0;
+                        if (actg[s] == 0) vg[s] = fmax(fmax(lg[s] - ptol * fmax(1.0, fabs(lg[s])) - gw[s], gw[s] - ug[s] - ptol * fmax(1.0, fabs(ug[s]))), 0.0);
+                        vm = fmax(vm, vg[s]);
+                    }
+                    const double thr = MPCX_ADD_THETA * wave_max(vm);
 #pragma unroll
                     for (int s = 0; s < NZS; ++s)
-                        if (actb[s] == 0) {
-                            if (wv[s] < lw[s] - ptol * fmax(1.0, fabs(lw[s]))) { actb[s] = -1; add = true; }
-                            else if (wv[s] > uw[s] + ptol * fmax(1.0, fabs(uw[s]))) { actb[s] = 1; add = true; }
-                        }
+                        if (vb[s] > 0.0 && vb[s] >= thr) { actb[s] = wv[s] < lw[s] ? -1 : 1; add = true; }
 #pragma unroll
                     for (int s = 0; s < NGS; ++s)
-                        if (actg[s] == 0) {
-                            if (gw[s] < lg[s] - ptol * fmax(1.0, fabs(lg[s]))) { actg[s] = -1; add = true; }
-                            else if (gw[s] > ug[s] + ptol * fmax(1.0, fabs(ug[s]))) { actg[s] = 1; add = true; }
-                        }
+                        if (vg[s] > 0.0 && vg[s] >= thr) { actg[s] = gw[s] < lg[s] ? -1 : 1; add = true; }
                     changed = wave_any(add);
                 }
             } else {
