@@ -169,3 +169,32 @@ def test_nlmpc_create_validates_before_touching_a_device():
     p = _capi.NLParams()
     lib.mpcx_nlparams_default(C.byref(p))
     assert (p.maximum_iteration, p.relative_ftol, p.relative_xtol, p.hard_constraints, p.enable_warm_start) == (100, -1.0, -1.0, 1, 0)
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """the Python mirror of every struct in include/mpcx.h has the size and field offsets the C compiler gives it"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from libmpc_amd import _capi
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    pairs = {"mpcx_dims": _capi.Dims, "mpcx_lparams": _capi.LParams, "mpcx_lmpc_batch": _capi.Batch, "mpcx_lmpc_info": _capi.Info,
+             "mpcx_nlmpc_dims": _capi.NlmpcDims, "mpcx_nlparams": _capi.NLParams, "mpcx_nlmpc_batch": _capi.NlmpcBatch}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpcx.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"; exe = tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line in out:
+        parts = line.split()
+        cls = pairs[parts[0]]
+        assert int(parts[1]) == C.sizeof(cls), parts[0]
+        offs = [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(p) for p in parts[2:]] == offs, parts[0]
