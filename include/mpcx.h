@@ -206,8 +206,10 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info);
  * (Objective.hpp:91-265), the dynamics equalities with their central-difference Jacobian blocks
  * (Constraints.hpp:490-628, 844-905) and the user inequalities with theirs (Constraints.hpp:211-316),
  * for a batch of decision vectors in one launch.  The reference's user hooks are host std::function
- * objects (IDimensionable.hpp:94-149); device code cannot call those, so the hooks are device
- * functors compiled into the library and picked by id (the reference's example systems).       */
+ * objects (IDimensionable.hpp:94-149); device code cannot call those.  The hooks are device code instead:
+ * the reference's example systems are built in and picked by id (below); any other system comes in through
+ * mpcx_nlmpc_create_custom (hooks compiled by the caller with hipcc, what mpc::NLMPC<>'s setters use) or
+ * mpcx_nlmpc_create_from_source (hooks compiled at run time from the lambda bodies, what the Python front-end uses). */
 typedef struct mpcx_nlmpc *mpcx_nlmpc_t;
 enum { MPCX_MODEL_VANDERPOL = 1,   /* examples/vanderpol_ex.cpp: nx=2 nu=1, continuous, ineq u_i <= 0.5        */
        MPCX_MODEL_UGV = 2,         /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
@@ -222,6 +224,7 @@ typedef struct mpcx_nlmpc_dims {
     int jeq_w;   /* width of one equality Jacobian block row: 2*nx + nu                               */
     int neq_user;/* user equalities (NLMPC::setEqConFunction)                                         */
     int ny;      /* outputs (NLMPC::setOutputFunction; zeros in the sequence when the model has none)  */
+    int nbnd;    /* finite state / input bounds: rows nineq + neq_user .. of the sub-problem (multipliers) */
 } mpcx_nlmpc_dims;
 /* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
  * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
@@ -232,6 +235,59 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
                       int device, mpcx_nlmpc_t *out);
 int mpcx_nlmpc_destroy(mpcx_nlmpc_t h);
 int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d);
+
+/* ---- user hooks (NLMPC::setStateSpaceFunction / setOutputFunction / setObjectiveFunction / setIneqConFunction /
+ * setEqConFunction, NLMPC.hpp:139-281; handle types IDimensionable.hpp:94-149) ----------------------------------------
+ * The reference's hooks are host closures, which a kernel cannot call.  Two ways to give this library device code with the
+ * same signatures instead of picking a built-in model:
+ *
+ * (1) compiled by the caller.  The engine is a header (include/mpcx/nlmpc_engine.hpp); a translation unit compiled with
+ *     hipcc instantiates it for its own hook types (include/mpcx/nlmpc_hooks.hpp -- what mpc::NLMPC<>'s setters do in
+ *     include/mpcx/NLMPC.hpp) and registers the two launch thunks here.  The library keeps owning the workspace, bounds,
+ *     parameters and every entry point below; `hooks` (the closure objects, hooks_bytes of them) is copied to HBM and
+ *     handed to the kernels.                                                                                           */
+typedef struct mpcx_nlmpc_custom {
+    int nx, nu, ny, ph, ch, nineq, neq_user;
+    int has_output;        /* an output function was set (otherwise outputs read as zeros, Model.hpp:72-96)              */
+    int vector_hooks;      /* 1: hooks with the reference's whole-vector signatures (mpcx::HookModel); 0: a zoo-style
+                              model struct with component-wise constraints and declared structure                        */
+    const void *hooks; int hooks_bytes;
+    /* mpcx::engine::launch_evaluate<Model> / launch_solve<Model>; the struct arguments are mpcx::NlmpcDev,
+     * mpcx::NlmpcBatchDev, mpcx::NlmpcSolveDev (include/mpcx/nlmpc_device.hpp), ctx is passed back unchanged          */
+    int (*launch_evaluate)(void *ctx, const void *dev, const void *batch, void *stream);
+    int (*launch_solve)(void *ctx, const void *dev, const void *solve, void *stream);
+    void *launch_ctx;
+} mpcx_nlmpc_custom;
+/* Ts > 0: the state function is a vector field dx/dt and the transcription is trapezoidal collocation with step Ts
+ * (NLMPC::setDiscretizationSamplingTime, NLMPC.hpp:80-90); Ts <= 0: the state function returns x(k+1).                  */
+int mpcx_nlmpc_create_custom(const mpcx_nlmpc_custom *c, double Ts, int device, mpcx_nlmpc_t *out);
+
+/* (2) compiled at run time (hipRTC).  The hooks are given as C++ source: each string is the BODY of the corresponding
+ *     reference lambda, with these parameter names --
+ *       state_fn      (dx, x, u, step)           fills dx (or the next state, Ts <= 0)          required
+ *       objective_fn  (x, y, u, e)               returns the cost                               required
+ *       ineq_fn       (in_con, x, y, u, e)       fills in_con, in_con <= 0                      NULL when nineq = 0
+ *       eq_fn         (eq_con, x, u)             fills eq_con, eq_con = 0                       NULL when neq_user = 0
+ *       output_fn     (y, x, u, step)            fills y                                        NULL: outputs are zeros
+ *     with the reference's types (mpc::cvec<n>, mpc::mat<ph+1, n>, include/mpcx/matrix.hpp) and the constants num_states,
+ *     num_inputs, num_output, pred_hor, ctrl_hor, ineq_c, eq_c in scope; `preamble` (may be NULL) is pasted before them at
+ *     namespace scope (constants, helper __device__ functions).  Example, the reference's examples/vanderpol_ex.cpp:
+ *       state_fn     "dx(0) = ((1.0 - (x(1) * x(1))) * x(0)) - x(1) + u(0); dx(1) = x(0);"
+ *       objective_fn "return x.array().square().sum() + u.array().square().sum();"
+ *       ineq_fn      "for (int i = 0; i < ineq_c; i++) in_con(i) = u(i, 0) - 0.5;"
+ *     The compiler's log is available through mpcx_last_error() when compilation fails.  Needs libhiprtc.so.7.         */
+typedef struct mpcx_nlmpc_source {
+    int nx, nu, ny, ph, ch, nineq, neq_user;
+    const char *preamble, *state_fn, *objective_fn, *ineq_fn, *eq_fn, *output_fn;
+} mpcx_nlmpc_source;
+int mpcx_nlmpc_create_from_source(const mpcx_nlmpc_source *src, double Ts, int device, mpcx_nlmpc_t *out);
+
+/* NLMPC::setInputScale / setStateScale (NLMPC.hpp:108,123 -> Mapping::setInputScaling / setStateScaling, Mapping.hpp:71-86):
+ * the hooks see U = input_scale * z_u and X = [x0; z_x] / state_scale (Mapping.hpp:174-211), and the Jacobians carry the
+ * factors the reference gives them, including what it leaves out (no chain rule on the cost's state gradient,
+ * Objective.hpp:107-144; inequality state columns multiplied, not divided, Constraints.hpp:269-284).  nu / nx doubles.   */
+int mpcx_nlmpc_set_input_scale(mpcx_nlmpc_t h, const double *scaling);
+int mpcx_nlmpc_set_state_scale(mpcx_nlmpc_t h, const double *scaling);
 /* Device pointers, fp64.  z [B x nz] (layout [x_1..x_ph | u blocks (ch) | slack]), x0 [B x nx].
  * Any output may be NULL.  cost [B]; grad [B x nz]; ceq [B x neq]; cineq [B x (nineq + neq_user)]: the user
  * inequalities, then the user equalities (Constraints::evaluateEq, Constraints.hpp:365-442);
@@ -243,10 +299,13 @@ int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const 
                               double *cost, double *grad, double *ceq, double *jeq,
                               double *cineq, double *jineq, void *stream);
 
-/* mpc::NLParameters (Types.hpp:99-144), field for field.  With every tolerance negative (the
- * reference default, "disabled") the iteration stops when the largest step component falls below
- * 1e-6 * max(1, |z|_inf) with the dynamics defects below 1e-8, or when the line search finds no
- * decrease (finite-difference noise floor).  A positive relative_xtol replaces the 1e-6.          */
+/* mpc::NLParameters (Types.hpp:99-144), field for field.  The iteration stops when the largest step component falls below
+ * 1e-6 * max(1, |z|_inf) with the dynamics defects below 1e-8 (solver_status 4), or when the line search finds no decrease
+ * (finite-difference noise floor).  Positive tolerances add nlopt's own rules (set_ftol_rel / set_ftol_abs / set_xtol_rel /
+ * set_xtol_abs, NLOptimizer.hpp:135-138, unit x weights :140), tested like SLSQP tests them, after a step that ends at a
+ * feasible point: |f - f_prev| < absolute_ftol or < relative_ftol * (|f| + |f_prev|) / 2 -> solver_status 3 (FTOL_REACHED);
+ * sum |dz| <= relative_xtol * sum |z| or every |dz_i| < absolute_xtol -> 4 (XTOL_REACHED).  Negative (the reference's
+ * default): disabled.                                                                                              */
 typedef struct mpcx_nlparams {
     int maximum_iteration;    /* 100 */
     double time_limit;        /* 0, accepted and ignored */
@@ -268,7 +327,7 @@ int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const do
 
 /* One batched NLOptimizer::run (NLOptimizer.hpp:412-638).  Device pointers.  Outputs other than
  * cmd may be NULL.  status uses MPCX_STATUS_* (ResultStatus), solver_status nlopt's result codes
- * (4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE = inconsistent linearised constraints,
+ * (3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE = inconsistent linearised constraints,
  * -3 OUT_OF_MEMORY = more than 128 rows active at once, -4 ROUNDOFF_LIMITED = line search stalled far from a solution) as mapped at NLOptimizer.hpp:729-750; on failure
  * cmd = u0 and cost = inf as at :613-624.  is_feasible = every user inequality <= 1e-10 and every user
  * equality within 1e-10 (Constraints.hpp:157-202, tolerances NLMPC.hpp:166, 262).                 */
@@ -288,6 +347,9 @@ typedef struct mpcx_nlmpc_batch {
     int warm_curvature;        /* extension, with z_warm only: 1 = also keep the curvature estimate the previous solve of
                                   the same batch left in the handle's workspace (NLopt restarts its BFGS matrix on every
                                   optimize(); the optimum is the same, the iterations are fewer)                   */
+    double *multipliers;       /* extension, may be NULL: [B x (nineq + neq_user + nbnd)] multipliers of the last quadratic
+                                  sub-problem -- user inequalities, user equalities, then the finite bounds in the order
+                                  (index into z ascending; upper before lower); non-zero = in the active set        */
 } mpcx_nlmpc_batch;
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
 /* The same for callers whose data lives in host memory (the reference's optimize(x0, lastU) is such a caller): stages,
@@ -305,6 +367,27 @@ int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void 
  * disturbance matrix (Utils.hpp:63-89) is the same call with Be appended to B's columns.  nx + nu <= 48.   */
 int mpcx_discretize_batch(int device, int nx, int nu, int batch, const double *A, const double *B, const double *Ts,
                           int ts_per_instance, double *Ad, double *Bd, void *stream);
+
+/* ---- multi-GPU: the one collective on the path --------------------------------- */
+/* The reference solves one controller per object and has no coupling between objects (LMPC.hpp:751), so a batch shards
+ * as contiguous slices, one process per GPU, and nothing is exchanged during the solve.  Afterwards every rank
+ * contributes its block of optimal controls and receives everybody's: one RCCL ncclAllGather of doubles over xGMI.
+ * mpcx_comm_* wraps the communicator so that a C++ host needs neither rccl.h nor PyTorch: rank 0 calls
+ * mpcx_comm_get_unique_id, ships the MPCX_COMM_ID_BYTES bytes to the other ranks by any means (file, socket, MPI,
+ * torch.distributed store), then every rank calls mpcx_comm_create (collective).  RCCL is bound at run time
+ * (librccl.so.1); without it these calls return MPCX_E_DEVICE.                                                      */
+#define MPCX_COMM_ID_BYTES 128
+typedef struct mpcx_comm *mpcx_comm_t;
+int mpcx_comm_get_unique_id(void *id_out /* MPCX_COMM_ID_BYTES bytes */);
+int mpcx_comm_create(int device, int rank, int world, const void *id, mpcx_comm_t *out);
+int mpcx_comm_destroy(mpcx_comm_t c);
+int mpcx_comm_rank(mpcx_comm_t c);
+int mpcx_comm_world(mpcx_comm_t c);
+/* u_local [rows_per_rank x nu] -> u_all [world x rows_per_rank x nu], device pointers, every rank the same
+ * rows_per_rank (ragged shards: pad the local block to the largest shard, libmpc_amd/distributed.py shows how).
+ * Enqueued on `stream` -- pass the stream of the preceding mpcx_*_solve_batch so that the collective starts when the
+ * solve retires, with no host synchronisation in between.  u_all may not alias u_local.                              */
+int mpcx_allgather_u(mpcx_comm_t c, const double *u_local, int rows_per_rank, int nu, double *u_all, void *stream);
 
 const char *mpcx_version(void);
 

@@ -4,11 +4,10 @@
 // one path this repository replaces, so that code written against the reference -- e.g. its
 // examples/quadrotor_ex.cpp or test/LMPC/test_common.cpp:89-237 -- compiles against this header
 // and runs its optimize() on an MI355X.  The reference gets its matrix types from Eigen, which
-// is not part of this repository: mpc::mat / mpc::cvec below are a deliberately small stand-in
-// covering what controller set-up code uses (comma initialisation, setZero/Ones/Identity/
-// Constant, Zero()/Ones(), array() +=/-=, *=, col(), isApprox, streaming).  Storage is
-// column-major doubles like Eigen's default (reference include/mpc/Types.hpp:42), which is what
-// the C ABI expects, so nothing is converted on the way down.
+// is not part of this repository: mpc::mat / mpc::cvec (mpcx/matrix.hpp) are a deliberately small
+// stand-in covering what controller set-up code and hook bodies use.  Storage is column-major
+// doubles like Eigen's default (reference include/mpc/Types.hpp:42), which is what the C ABI
+// expects, so nothing is converted on the way down.
 //
 // Every method forwards to the entry point of include/mpcx.h that replaces the corresponding
 // reference call.  Added on top of the reference API:
@@ -26,111 +25,12 @@
 #include <vector>
 
 #include "../mpcx.h"
+#include "matrix.hpp"      // mpc::mat / mpc::cvec / mpc::rvec
 
 namespace mpc {
 
-constexpr int Dynamic = -1;
 constexpr double inf = std::numeric_limits<double>::infinity();
 
-// ---------------------------------------------------------------------------------------------
-// minimal dense matrix (column-major doubles)
-// ---------------------------------------------------------------------------------------------
-template <int M = Dynamic, int N = Dynamic>
-class mat {
-    int r_ = M < 0 ? 0 : M, c_ = N < 0 ? 0 : N;
-    std::vector<double> a_;
-
-public:
-    class CommaInit {
-        mat &m_;
-        int k_ = 0;
-
-    public:
-        CommaInit(mat &m, double first) : m_(m) { put(first); }
-        CommaInit &operator,(double v) { put(v); return *this; }
-        void put(double v)
-        {
-            if (k_ >= m_.r_ * m_.c_) throw std::out_of_range("too many coefficients passed to comma initialiser");
-            const int i = k_ / m_.c_, j = k_ % m_.c_;      // row-major fill order, as Eigen
-            m_(i, j) = v;
-            ++k_;
-        }
-    };
-    struct ArrayProxy {
-        mat &m;
-        ArrayProxy &operator-=(double s) { for (double &v : m.a_) v -= s; return *this; }
-        ArrayProxy &operator+=(double s) { for (double &v : m.a_) v += s; return *this; }
-        ArrayProxy &operator*=(double s) { for (double &v : m.a_) v *= s; return *this; }
-    };
-    struct ColProxy {
-        mat &m;
-        int j;
-        template <int R2, int C2> ColProxy &operator=(const mat<R2, C2> &v)
-        {
-            if (v.size() != m.rows()) throw std::invalid_argument("column size mismatch");
-            for (int i = 0; i < m.rows(); ++i) m(i, j) = v.data()[i];
-            return *this;
-        }
-        CommaInit operator<<(double first) = delete;
-    };
-
-    mat() : a_((size_t)r_ * c_, 0.0) {}
-    mat(int r, int c) : r_(r), c_(c), a_((size_t)r * c, 0.0) {}
-    explicit mat(int n) : r_(N == 1 ? n : (M == 1 ? 1 : n)), c_(N == 1 ? 1 : (M == 1 ? n : 1)), a_((size_t)n, 0.0) {}
-
-    void resize(int r, int c) { r_ = r; c_ = c; a_.assign((size_t)r * c, 0.0); }
-    void resize(int n) { if (c_ == 1 || N == 1) resize(n, 1); else resize(1, n); }
-    int rows() const { return r_; }
-    int cols() const { return c_; }
-    int size() const { return r_ * c_; }
-    double *data() { return a_.data(); }
-    const double *data() const { return a_.data(); }
-    double &operator()(int i, int j) { return a_[(size_t)i + (size_t)j * r_]; }
-    double operator()(int i, int j) const { return a_[(size_t)i + (size_t)j * r_]; }
-    double &operator()(int i) { return a_[(size_t)i]; }
-    double operator()(int i) const { return a_[(size_t)i]; }
-    double &operator[](int i) { return a_[(size_t)i]; }
-    double operator[](int i) const { return a_[(size_t)i]; }
-
-    CommaInit operator<<(double first) { return CommaInit(*this, first); }
-    mat &setZero() { return setConstant(0.0); }
-    mat &setOnes() { return setConstant(1.0); }
-    mat &setConstant(double v) { for (double &x : a_) x = v; return *this; }
-    mat &setIdentity()
-    {
-        setZero();
-        for (int i = 0; i < (r_ < c_ ? r_ : c_); ++i) (*this)(i, i) = 1.0;
-        return *this;
-    }
-    mat &fill(double v) { return setConstant(v); }
-    static mat Zero() { mat m; return m; }
-    static mat Zero(int r, int c) { return mat(r, c); }
-    static mat Ones() { mat m; m.setOnes(); return m; }
-    static mat Identity() { mat m; m.setIdentity(); return m; }
-    ArrayProxy array() { return ArrayProxy{*this}; }
-    ColProxy col(int j) { return ColProxy{*this, j}; }
-    mat &operator*=(double s) { for (double &v : a_) v *= s; return *this; }
-    bool isApprox(const mat &o, double prec = 1e-12) const
-    {
-        // Eigen's definition: ||a - b||_2 <= prec * min(||a||_2, ||b||_2)
-        if (o.size() != size()) return false;
-        double d = 0, na = 0, nb = 0;
-        for (int i = 0; i < size(); ++i) {
-            d += (a_[i] - o.a_[i]) * (a_[i] - o.a_[i]); na += a_[i] * a_[i]; nb += o.a_[i] * o.a_[i];
-        }
-        return std::sqrt(d) <= prec * std::sqrt(na < nb ? na : nb);
-    }
-    friend std::ostream &operator<<(std::ostream &os, const mat &m)
-    {
-        for (int i = 0; i < m.r_; ++i) {
-            for (int j = 0; j < m.c_; ++j) os << (j ? " " : "") << m(i, j);
-            if (i + 1 < m.r_) os << "\n";
-        }
-        return os;
-    }
-};
-template <int N = Dynamic> using cvec = mat<N, 1>;
-template <int N = Dynamic> using rvec = mat<1, N>;
 
 // ---------------------------------------------------------------------------------------------
 // types of the reference API (include/mpc/Types.hpp)

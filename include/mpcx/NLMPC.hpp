@@ -1,18 +1,32 @@
-// mpc::NLMPC<> over the mpcx C ABI -- the non-linear front-end of libmpc++ (reference include/mpc/NLMPC.hpp) for the
-// systems that exist as device functors in libmpcx.so.  C++20, header-only, needs only <mpcx.h> and the small matrix
-// types of mpcx/LMPC.hpp.
+// mpc::NLMPC<> over the mpcx C ABI -- the non-linear front-end of libmpc++ (reference include/mpc/NLMPC.hpp).
+// C++20, header-only; needs <mpcx.h>, the small matrix types of mpcx/matrix.hpp and, for device hooks, hipcc.
 //
-// What differs from the reference, and why: its hooks are std::function closures called on the host solver thread
-// (IDimensionable.hpp:94-149); a GPU kernel cannot call them.  Here the system is chosen with setModel(id, params)
-// -- one of the reference's example systems compiled into the library (libmpc_amd/csrc/nlmpc_models.hpp, where a new
-// one is a 20-line struct) -- and the closure setters throw, saying so.  Everything else keeps its name and meaning:
-// setDiscretizationSamplingTime, setOptimizerParameters(NLParameters), setStateBounds / setInputBounds (vector + slice
-// and matrix forms), optimize(x0, lastU), getLastResult, getOptimalSequence, plus optimizeBatch.
+// The reference's hooks are std::function closures called on the host solver thread (IDimensionable.hpp:94-149); a GPU
+// kernel cannot call host code.  Three ways to give this controller its system, cost and constraints, all ending in the
+// same engine (mpcx/nlmpc_engine.hpp):
+//   1. setStateSpaceFunction / setOutputFunction / setObjectiveFunction / setIneqConFunction / setEqConFunction with the
+//      reference's names, order and parameter lists, when this header is compiled by hipcc: the arguments are device
+//      callables -- a lambda whose captures are by value and trivially copyable (`[=] __device__`, or no capture at all), or
+//      a functor struct -- and their bodies are the reference's.  Set one at a time their types are never known together,
+//      so each is reached through a device function pointer; setHooks(f, obj, ineq, eq, out) takes them together and has
+//      every call inlined (same results, faster).
+//   2. setHookSources(...): the lambda BODIES as text, compiled at run time (hipRTC) -- works from a host compiler too.
+//   3. setModel(id, params): one of the reference's example systems built into libmpcx.so (the fastest form: component-
+//      wise constraints with declared structure, mpcx/nlmpc_models.hpp).
+// Everything else keeps its name and meaning: setDiscretizationSamplingTime, setOptimizerParameters(NLParameters),
+// setInputScale / setStateScale, setStateBounds / setInputBounds (vector + slice and matrix forms), optimize(x0, lastU),
+// getLastResult, getOptimalSequence, plus optimizeBatch.  The handle is (re)built lazily by the first optimize() after a
+// change of hooks or sampling time.
 #pragma once
 
+#include <cstring>
 #include <functional>
+#include <memory>
 
 #include "LMPC.hpp"
+#if defined(__HIPCC__)
+#include "nlmpc_hooks.hpp"
+#endif
 
 namespace mpc {
 
@@ -28,7 +42,15 @@ class NLMPC {
     mpcx_nlmpc_t h_ = nullptr;
     int model_ = 0;
     double ts_ = 0.0;
-    std::vector<double> params_, zprev_;
+    bool dirty_ = false;                       // hooks or sampling time changed: rebuild before the next solve
+    std::vector<double> params_, zprev_, su_, ss_;
+    // device hooks (mpcx/nlmpc_hooks.hpp): the closure objects as bytes and the launch thunks instantiated for their types
+    std::vector<unsigned char> hook_blob_;
+    int (*thunk_eval_)(void *, const void *, const void *, void *) = nullptr;
+    int (*thunk_solve_)(void *, const void *, const void *, void *) = nullptr;
+    bool hook_out_ = false, hooks_erased_ = false;
+    // hook sources (hipRTC)
+    struct Sources { bool set = false; std::string pre, f, obj, ineq, eq, out; bool has_ineq = false, has_eq = false, has_out = false; } src_;
     NLParameters prm_;
     bool have_prev_ = false;
     Result<Tnu> last_;
@@ -42,20 +64,40 @@ class NLMPC {
         const char *e = std::getenv("MPCX_DEVICE");
         return e ? std::atoi(e) : 0;
     }
-    void need() const
+    void need()
     {
-        if (!h_) throw std::runtime_error("NLMPC: call setModel() first (the system, cost and constraints are device functors)");
+        if (dirty_ || !h_) build();
     }
     void build()
     {
         if (h_) { mpcx_nlmpc_destroy(h_); h_ = nullptr; }
-        detail::check(mpcx_nlmpc_create(model_, ph_, ch_, ts_, params_.empty() ? nullptr : params_.data(), (int)params_.size(),
-                                        device(), &h_), "mpcx_nlmpc_create");
+        if (thunk_solve_) {
+            mpcx_nlmpc_custom c{};
+            c.nx = nx_; c.nu = nu_; c.ny = ny_; c.ph = ph_; c.ch = ch_; c.nineq = ineq_; c.neq_user = eq_;
+            c.has_output = hook_out_ ? 1 : 0; c.vector_hooks = 1;
+            c.hooks = hook_blob_.data(); c.hooks_bytes = (int)hook_blob_.size();
+            c.launch_evaluate = thunk_eval_; c.launch_solve = thunk_solve_; c.launch_ctx = nullptr;
+            detail::check(mpcx_nlmpc_create_custom(&c, ts_, device(), &h_), "mpcx_nlmpc_create_custom");
+        } else if (src_.set) {
+            mpcx_nlmpc_source q{nx_, nu_, ny_, ph_, ch_, ineq_, eq_, src_.pre.empty() ? nullptr : src_.pre.c_str(), src_.f.c_str(),
+                                src_.obj.c_str(), src_.has_ineq ? src_.ineq.c_str() : nullptr, src_.has_eq ? src_.eq.c_str() : nullptr,
+                                src_.has_out ? src_.out.c_str() : nullptr};
+            detail::check(mpcx_nlmpc_create_from_source(&q, ts_, device(), &h_), "mpcx_nlmpc_create_from_source");
+        } else if (model_ != 0) {
+            detail::check(mpcx_nlmpc_create(model_, ph_, ch_, ts_, params_.empty() ? nullptr : params_.data(), (int)params_.size(),
+                                            device(), &h_), "mpcx_nlmpc_create");
+        } else {
+            throw std::runtime_error("NLMPC: no system yet -- set the hooks (setStateSpaceFunction & co., setHooks, setHookSources) or "
+                                     "pick a built-in model (setModel)");
+        }
+        dirty_ = false;
         mpcx_nlmpc_dims d{};
         detail::check(mpcx_nlmpc_get_dims(h_, &d), "mpcx_nlmpc_get_dims");
-        if (d.nx != nx_ || d.nu != nu_ || d.nineq != ineq_)
+        if (d.nx != nx_ || d.nu != nu_ || d.nineq != ineq_ || d.neq_user != eq_)
             throw std::runtime_error("NLMPC: the model's dimensions do not match the template arguments");
         push_parameters();
+        if (!su_.empty()) detail::check(mpcx_nlmpc_set_input_scale(h_, su_.data()), "setInputScale");
+        if (!ss_.empty()) detail::check(mpcx_nlmpc_set_state_scale(h_, ss_.data()), "setStateScale");
         for (const auto &b : bounds_)
             (void)(b.state ? mpcx_nlmpc_set_state_bounds_slice(h_, b.lo.data(), b.hi.data(), b.a, b.b)
                            : mpcx_nlmpc_set_input_bounds_slice(h_, b.lo.data(), b.hi.data(), b.a, b.b));
@@ -67,11 +109,36 @@ class NLMPC {
                         prm_.absolute_ftol, prm_.absolute_xtol, prm_.hard_constraints ? 1 : 0};
         detail::check(mpcx_nlmpc_set_optimizer_parameters(h_, &q), "setOptimizerParameters");
     }
-    [[noreturn]] static void closures()
+    [[noreturn]] static void host_compiler()
     {
-        throw std::runtime_error("this controller's system, objective and constraint functions are device functors selected with "
-                                 "setModel(); host closures cannot run inside the kernel");
+        throw std::runtime_error("NLMPC: a closure can only become device code when this translation unit is compiled by hipcc; "
+                                 "with a host compiler pass the hook bodies as text (setHookSources) or pick a built-in model (setModel)");
     }
+#if defined(__HIPCC__)
+    static constexpr bool kStatic = Tnx >= 0 && Tnu >= 0 && Tny >= 0 && Tph >= 0 && Tch >= 0 && Tineq >= 0 && Teq >= 0;
+    using Erased = mpcx::ErasedHooks<(Tnx > 0 ? Tnx : 1), (Tnu > 0 ? Tnu : 1), (Tny > 0 ? Tny : 0), (Tph > 0 ? Tph : 1), (Tch > 0 ? Tch : 1),
+                                     (Tineq > 0 ? Tineq : 0), (Teq > 0 ? Teq : 0)>;
+    template <class Model> static int thunk_eval(void *ctx, const void *m, const void *b, void *s)
+    {
+        return mpcx::engine::launch_evaluate<Model>(ctx, static_cast<const mpcx::NlmpcDev *>(m), static_cast<const mpcx::NlmpcBatchDev *>(b), s);
+    }
+    template <class Model> static int thunk_solve(void *ctx, const void *m, const void *b, void *s)
+    {
+        return mpcx::engine::launch_solve<Model>(ctx, static_cast<const mpcx::NlmpcDev *>(m), static_cast<const mpcx::NlmpcSolveDev *>(b), s);
+    }
+    // one hook arrives: keep its closure bytes and the device address of its trampoline in the erased table
+    template <class Fn> bool set_erased(Fn &&fill)
+    {
+        static_assert(kStatic, "device hooks need compile-time dimensions (the hook signatures carry them)");
+        using Model = mpcx::HookModel<Tnx, Tnu, Tny, Tph, Tch, Tineq, Teq, Erased>;
+        if (hipSetDevice(device()) != hipSuccess) throw std::runtime_error("NLMPC: no usable HIP device");
+        if (!hooks_erased_) { hook_blob_.assign(sizeof(Erased), 0); new (hook_blob_.data()) Erased(); hooks_erased_ = true; hook_out_ = false; }
+        const bool ok = fill(*reinterpret_cast<Erased *>(hook_blob_.data()));
+        thunk_eval_ = &thunk_eval<Model>; thunk_solve_ = &thunk_solve<Model>;
+        src_.set = false; model_ = 0; dirty_ = true;
+        return ok;
+    }
+#endif
     bool bound(bool state, const double *lo, const double *hi, int n, int a, int b)
     {
         bounds_.push_back(Bound{state, std::vector<double>(lo, lo + n), std::vector<double>(hi, hi + n), a, b});
@@ -97,17 +164,24 @@ public:
     NLMPC &operator=(const NLMPC &) = delete;
     ~NLMPC() { if (h_) mpcx_nlmpc_destroy(h_); }
 
-    /// extension that replaces the closure setters: MPCX_MODEL_* and the constants its closures capture in the reference
+    /// extension: one of the systems built into the library, MPCX_MODEL_* and the constants its closures capture in the reference
     void setModel(int model_id, const std::vector<double> &params = {})
     {
-        if (eq_ != 0) throw std::runtime_error("NLMPC: user equality constraints are not available");
         model_ = model_id; params_ = params;
+        thunk_eval_ = nullptr; thunk_solve_ = nullptr; hooks_erased_ = false; src_.set = false;
         build();
+    }
+    /// extension: the hook bodies as C++ text, compiled at run time (parameter names and scope: mpcx_nlmpc_create_from_source)
+    void setHookSources(const std::string &state_fn, const std::string &objective_fn, const std::string &ineq_fn = "",
+                        const std::string &eq_fn = "", const std::string &output_fn = "", const std::string &preamble = "")
+    {
+        src_ = Sources{true, preamble, state_fn, objective_fn, ineq_fn, eq_fn, output_fn, !ineq_fn.empty(), !eq_fn.empty(), !output_fn.empty()};
+        thunk_eval_ = nullptr; thunk_solve_ = nullptr; hooks_erased_ = false; model_ = 0; dirty_ = true;
     }
     bool setDiscretizationSamplingTime(const double ts)                         // NLMPC.hpp:80-90
     {
         ts_ = ts;
-        if (h_) build();
+        dirty_ = true;
         return true;
     }
     void setOptimizerParameters(const Parameters &param)                       // NLMPC.hpp:97-101
@@ -117,13 +191,65 @@ public:
     }
     bool setLoggerLevel(Logger::LogLevel) { return true; }
     bool setLoggerPrefix(std::string) { return true; }
-    void setInputScale(const cvec<Tnu>) { throw std::runtime_error("input scaling is not available on the device functors"); }
-    void setStateScale(const cvec<Tnx>) { throw std::runtime_error("state scaling is not available on the device functors"); }
-    template <class F> bool setStateSpaceFunction(F &&, float = 1e-10f) { closures(); }     // NLMPC.hpp:139-157
-    template <class F> bool setOutputFunction(F &&) { closures(); }
-    template <class F> bool setObjectiveFunction(F &&) { closures(); }
-    template <class F> bool setIneqConFunction(F &&, float = 1e-10f) { closures(); }
-    template <class F> bool setEqConFunction(F &&, float = 1e-10f) { closures(); }
+    void setInputScale(const cvec<Tnu> scaling)                                // NLMPC.hpp:108 -> Mapping::setInputScaling
+    {
+        su_.assign(scaling.data(), scaling.data() + nu_);
+        if (h_ && !dirty_) detail::check(mpcx_nlmpc_set_input_scale(h_, su_.data()), "setInputScale");
+    }
+    void setStateScale(const cvec<Tnx> scaling)                                // NLMPC.hpp:123 -> Mapping::setStateScaling
+    {
+        ss_.assign(scaling.data(), scaling.data() + nx_);
+        if (h_ && !dirty_) detail::check(mpcx_nlmpc_set_state_scale(h_, ss_.data()), "setStateScale");
+    }
+#if defined(__HIPCC__)
+    // The reference's closure setters (NLMPC.hpp:139-281).  The tolerance arguments are accepted for source compatibility;
+    // feasibility is reported against the reference's defaults (1e-10, NLMPC.hpp:166,229,262).
+    template <class F> bool setStateSpaceFunction(F handle, float = 1e-10f)                // NLMPC.hpp:165
+    {
+        return set_erased([&](Erased &e) { mpcx::hookdetail::stash(e.cdyn, handle); return mpcx::hookdetail::resolve<F>(e.pdyn); });
+    }
+    template <class F> bool setOutputFunction(F handle)                                    // NLMPC.hpp:202
+    {
+        const bool ok = set_erased([&](Erased &e) { mpcx::hookdetail::stash(e.cout_, handle); return mpcx::hookdetail::resolve<F>(e.pout); });
+        hook_out_ = true;
+        return ok;
+    }
+    template <class F> bool setObjectiveFunction(F handle)                                 // NLMPC.hpp:139
+    {
+        return set_erased([&](Erased &e) { mpcx::hookdetail::stash(e.cobj, handle); return mpcx::hookdetail::resolve<F>(e.pobj); });
+    }
+    template <class F> bool setIneqConFunction(F handle, float = 1e-10f)                   // NLMPC.hpp:228
+    {
+        return set_erased([&](Erased &e) { mpcx::hookdetail::stash(e.cineq, handle); return mpcx::hookdetail::resolve<F>(e.pineq); });
+    }
+    template <class F> bool setEqConFunction(F handle, float = 1e-10f)                     // NLMPC.hpp:261
+    {
+        return set_erased([&](Erased &e) { mpcx::hookdetail::stash(e.ceq, handle); return mpcx::hookdetail::resolve<F>(e.peq); });
+    }
+    /// extension: all hooks at once -- their types are known together, every call is inlined into the kernels.  Pass
+    /// mpcx::NoHook{} for a hook the controller does not have.
+    template <class FDyn, class FObj, class FIneq = mpcx::NoHook, class FEq = mpcx::NoHook, class FOut = mpcx::NoHook>
+    bool setHooks(FDyn f, FObj obj, FIneq ineq = {}, FEq eq = {}, FOut out = {})
+    {
+        static_assert(kStatic, "device hooks need compile-time dimensions (the hook signatures carry them)");
+        using Set = mpcx::HookSet<FDyn, FObj, FIneq, FEq, FOut>;
+        using Model = mpcx::HookModel<Tnx, Tnu, Tny, Tph, Tch, Tineq, Teq, Set>;
+        static_assert(__is_trivially_copyable(Set), "hooks must capture trivially copyable values (by value)");
+        const Set set{f, obj, ineq, eq, out};
+        hook_blob_.assign(sizeof(Set), 0);
+        std::memcpy(hook_blob_.data(), &set, sizeof(Set));
+        hooks_erased_ = false; hook_out_ = !__is_same(FOut, mpcx::NoHook);
+        thunk_eval_ = &thunk_eval<Model>; thunk_solve_ = &thunk_solve<Model>;
+        src_.set = false; model_ = 0; dirty_ = true;
+        return true;
+    }
+#else
+    template <class F> bool setStateSpaceFunction(F &&, float = 1e-10f) { host_compiler(); }     // NLMPC.hpp:139-281
+    template <class F> bool setOutputFunction(F &&) { host_compiler(); }
+    template <class F> bool setObjectiveFunction(F &&) { host_compiler(); }
+    template <class F> bool setIneqConFunction(F &&, float = 1e-10f) { host_compiler(); }
+    template <class F> bool setEqConFunction(F &&, float = 1e-10f) { host_compiler(); }
+#endif
 
     bool setStateBounds(const cvec<Tnx> &lo, const cvec<Tnx> &hi, const HorizonSlice &s)    // NLMPC.hpp:346-358
     {
@@ -193,7 +319,7 @@ public:
         return R;
     }
     int optimizeBatch(const mpcx_nlmpc_batch &b, void *stream) { need(); return mpcx_nlmpc_solve_batch(h_, &b, stream); }
-    mpcx_nlmpc_t handle() { return h_; }
+    mpcx_nlmpc_t handle() { need(); return h_; }
 };
 
 }  // namespace mpc

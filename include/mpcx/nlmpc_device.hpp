@@ -1,12 +1,14 @@
-// POD views handed to the NLMPC kernels (nlmpc_kernels.hip).
+// POD views handed to the NLMPC kernels (mpcx/nlmpc_engine.hpp).  Shared by the library (zoo models, run-time compiled
+// hooks) and by a user's translation unit that instantiates the engine for its own hooks (mpcx/nlmpc_hooks.hpp): the
+// library owns every buffer these structs point to and fills them; the kernels only read the layout.
 #pragma once
 
-#include <cstdint>
 
 namespace mpcx {
 
 constexpr int kNlMaxWorking = 128;     // rows the QP sub-solver may hold active at once
 constexpr int kNlLdsWorking = 24;      // up to this many, their Schur complement is factored in LDS
+constexpr int kNlTrials = 8;           // step lengths the line search evaluates at a time
 
 // offsets (in doubles) into one instance's slice of the SQP workspace
 struct NlmpcWsLayout {
@@ -17,6 +19,9 @@ struct NlmpcWsLayout {
     int qn, qv, qs, qs2;                   // QP: normals and Hinv*normals of the working set, their Schur complement
     int scal;                           // scalars: [0] cost, [2..7] per-phase cycle counts
     int lamw;                           // right-hand side of the backward sweep for the dynamics multipliers
+    int hook;                           // vector-valued user hooks only: two column buffers [64 x rows] for the central
+                                        // differences, the line search's constraint values [kNlTrials x rows] and output
+                                        // trajectories [kNlTrials x (ph+1) x ny]
     int total;
 };
 
@@ -27,8 +32,13 @@ struct NlmpcDev {
     int nzu, nr;                // ch*nu, ch*nu + 1
     int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
     int lds_per_wave;           // doubles
+    int continuous;             // hook models: 1 = the state function is dx/dt (setDiscretizationSamplingTime was called)
+    int has_output;             // hook models: 1 = an output function was set (otherwise Y reads as zeros, Model.hpp:72-96)
+    int vector_hooks;           // 1 = user hooks with the reference's whole-vector signatures (sizes the hook workspace)
     double Ts;
-    const double *params;       // model parameters in HBM
+    const double *params;       // model parameters in HBM (zoo) or the hook closures (mpcx/nlmpc_hooks.hpp)
+    // Mapping scalings (Mapping.hpp:71-86): U = input_scale * z_u, X = z_x / state_scale; arrays of ones by default
+    const double *su, *ss;      // [nu], [nx]
     // box bounds on the decision vector (NLOptimizer::lb / ub): all of them, and the finite ones as sub-problem rows
     const double *zlb, *zub;    // [nz]
     int nbnd;
@@ -45,6 +55,8 @@ struct NlmpcBatchDev {
     double *cost, *grad;        // [B], [B x nz]
     double *ceq, *jeq;          // [B x ph*nx], [B x ph x nx x (2nx+nu)] blocks [dc/dx_i | dc/dx_{i+1} | dc/du_i]
     double *cineq, *jineq;      // [B x (nineq+nue)], [B x (nineq+nue) x nz] row-major: user inequalities, then user equalities
+    double *hook_ws;            // vector-valued user hooks: [B x hook scratch] (handle-owned), null otherwise
+    int hook_ld;
 };
 
 struct NlmpcSolveDev {
@@ -55,15 +67,28 @@ struct NlmpcSolveDev {
     int max_iter, hard;
     int keep_curvature;         // 1: start from the inverse BFGS matrix already in the workspace (receding-horizon extension)
     double tol_step, tol_con, ieq_tol, eq_tol;
+    // nlopt's stopping tolerances (NLOptimizer.hpp:135-138; <= 0: disabled, the reference's default)
+    double ftol_rel, ftol_abs, xtol_rel, xtol_abs;
     double *cmd, *cost, *z_out; // [B x nu], [B], [B x nz]
-    int32_t *status, *solver_status, *is_feasible, *iterations;
+    int *status, *solver_status, *is_feasible, *iterations;     // int32
     double *seq_state, *seq_input;      // [B x (ph+1) x nx], [B x (ph+1) x nu]
     double *seq_output;                 // [B x (ph+1) x ny]
+    double *mu_out;                     // [B x (nineq + nue + nbnd)] multipliers of the last sub-problem (0 = inactive)
 };
 
-int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq, int *nue);
-void nlmpc_plan(NlmpcDev &m);           // fills nzu, nr, lds_per_wave, ws from the dimensions
-int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream);
-int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream);
+// doubles of hook scratch per instance (NlmpcWsLayout::hook, NlmpcBatchDev::hook_ws): two column buffers [rows x 64], the
+// line search's constraint values [kNlTrials x rows] and its output trajectories [kNlTrials x (ph+1) x ny]
+inline int nlmpc_hook_scratch(const NlmpcDev &m)
+{
+    const int rows = m.nineq + m.nue;
+    return 2 * 64 * rows + kNlTrials * rows + kNlTrials * (m.ph + 1) * m.ny + 2;
+}
+
+// ---- host-side plumbing ---------------------------------------------------------------------------------------
+// How the library launches the two kernels of a controller.  Zoo models: thunks inside libmpcx.so.  User hooks compiled
+// in the user's translation unit (mpcx/nlmpc_hooks.hpp): thunks instantiated there and registered through
+// mpcx_nlmpc_create_custom (include/mpcx.h).  Both return 0, -2 (LDS budget) or -3 (launch error).
+typedef int (*nlmpc_launch_eval_fn)(void *ctx, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream);
+typedef int (*nlmpc_launch_solve_fn)(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream);
 
 }  // namespace mpcx

@@ -19,11 +19,15 @@
 //                               which (contiguous) constraints read row i.  Everything else differentiates to an exact
 //                               zero (also in the reference's finite differences) and is skipped; the second form lets
 //                               every lane walk its own few rows instead of the wavefront walking the union of them.
-// X and U are accessor objects (a perturbed or a shifted view of the trajectory in LDS), hence the templates.  A new
-// system is one more struct here plus one line in dispatch_model() (nlmpc_kernels.hip) and in mpcx_nlmpc_create.
+// X and U are accessor objects (a perturbed or a shifted view of the trajectory in LDS), hence the templates.  This is the
+// fast form: the declared structure lets the engine skip every structural zero.  Hooks with the reference's own
+// signatures (whole constraint vectors, Eigen-style matrices) go through mpcx/nlmpc_hooks.hpp instead -- compiled in the
+// user's translation unit or at run time from source -- and need no change to this file.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 
 namespace mpcx {
 namespace models {
@@ -57,6 +61,7 @@ struct NoOutput {
 };
 
 struct NoUserEq {
+    static constexpr bool VECTOR_HOOKS = false;        // component-wise constraint functors with declared structure (this file)
     __host__ __device__ static int neq_user(int) { return 0; }
     template <class XA, class UA>
     __device__ static double eq(int, const XA &, const UA &, int, const double *) { return 0.0; }
@@ -76,10 +81,15 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
     template <class XA, class UA>
     __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
     {
-        double s = 0;
+        // x.array().square().sum() + u.array().square().sum() with the coefficients in storage (column-major) order: the
+        // same arithmetic, term for term, as the reference example's lambda evaluated through mpcx/matrix.hpp
+        double sx = 0, su = 0;
+        for (int j = 0; j < NX; ++j)
 #pragma unroll 4
-        for (int i = 0; i <= ph; ++i) { s += X(i, 0) * X(i, 0) + X(i, 1) * X(i, 1); s += U(i, 0) * U(i, 0); }
-        return s;
+            for (int i = 0; i <= ph; ++i) sx += X(i, j) * X(i, j);
+#pragma unroll 4
+        for (int i = 0; i <= ph; ++i) su += U(i, 0) * U(i, 0);
+        return sx + su;
     }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
@@ -160,13 +170,14 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     template <class XA, class UA>
     __device__ static double cost(const XA &X, const UA &U, double, int ph, const double *)
     {
-        double s = 0;
+        double sx = 0, su = 0;                       // column-major order, as for VanDerPol above
+        for (int j = 0; j < NX; ++j)
 #pragma unroll 2
-        for (int i = 0; i <= ph; ++i) {
-            for (int j = 0; j < NX; ++j) s += X(i, j) * X(i, j);
-            for (int j = 0; j < NU; ++j) s += U(i, j) * U(i, j);
-        }
-        return s;
+            for (int i = 0; i <= ph; ++i) sx += X(i, j) * X(i, j);
+        for (int j = 0; j < NU; ++j)
+#pragma unroll 2
+            for (int i = 0; i <= ph; ++i) su += U(i, j) * U(i, j);
+        return sx + su;
     }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }

@@ -64,6 +64,8 @@ EXPORTS = [
     "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
     "mpcx_nlparams_default", "mpcx_nlmpc_set_optimizer_parameters", "mpcx_nlmpc_solve_batch", "mpcx_nlmpc_time_solve_batch", "mpcx_discretize_batch",
     "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice", "mpcx_nlmpc_solve_host",
+    "mpcx_nlmpc_create_custom", "mpcx_nlmpc_create_from_source", "mpcx_nlmpc_set_input_scale", "mpcx_nlmpc_set_state_scale",
+    "mpcx_comm_get_unique_id", "mpcx_comm_create", "mpcx_comm_destroy", "mpcx_comm_rank", "mpcx_comm_world", "mpcx_allgather_u",
 ]
 
 
@@ -78,11 +80,17 @@ class NlmpcBatch(C.Structure):
     _fields_ = [("batch", C.c_int), ("x0", C.c_void_p), ("u0", C.c_void_p), ("z_warm", C.c_void_p), ("cmd", C.c_void_p),
                 ("cost", C.c_void_p), ("status", C.c_void_p), ("solver_status", C.c_void_p), ("is_feasible", C.c_void_p),
                 ("iterations", C.c_void_p), ("z", C.c_void_p), ("seq_state", C.c_void_p), ("seq_input", C.c_void_p),
-                ("seq_output", C.c_void_p), ("warm_curvature", C.c_int)]
+                ("seq_output", C.c_void_p), ("warm_curvature", C.c_int), ("multipliers", C.c_void_p)]
 
 
 class NlmpcDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w", "neq_user", "ny")]
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w", "neq_user", "ny", "nbnd")]
+
+
+class NlmpcSource(C.Structure):
+    """mpcx_nlmpc_source: user hooks as C++ text (the bodies of the reference's lambdas), compiled at run time"""
+    _fields_ = ([(n, C.c_int) for n in ("nx", "nu", "ny", "ph", "ch", "nineq", "neq_user")] +
+                [(n, C.c_char_p) for n in ("preamble", "state_fn", "objective_fn", "ineq_fn", "eq_fn", "output_fn")])
 
 _lib = None
 
@@ -122,6 +130,15 @@ def lib():
         _lib.mpcx_nlmpc_set_optimizer_parameters.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_solve_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_time_solve_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.mpcx_nlmpc_create_from_source.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        _lib.mpcx_nlmpc_set_input_scale.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mpcx_nlmpc_set_state_scale.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mpcx_comm_get_unique_id.argtypes = [C.c_void_p]
+        _lib.mpcx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.mpcx_comm_destroy.argtypes = [C.c_void_p]
+        _lib.mpcx_comm_rank.argtypes = [C.c_void_p]
+        _lib.mpcx_comm_world.argtypes = [C.c_void_p]
+        _lib.mpcx_allgather_u.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
 
 

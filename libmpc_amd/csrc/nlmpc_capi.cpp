@@ -6,16 +6,32 @@
 #include <vector>
 
 #include "../../include/mpcx.h"
-#include "nlmpc_device.hpp"
+#include "mpcx/nlmpc_device.hpp"
 
 namespace mpcx {
 int capi_fail(int code, const std::string &msg);
+// zoo models (nlmpc_kernels.hip)
+int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq, int *nue);
+void nlmpc_plan_host(NlmpcDev &m);
+int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream);
+int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream);
+// run-time compiled hooks (nlmpc_jit.cpp)
+void nlmpc_jit_release(void *jit);
 }
 
 struct mpcx_nlmpc {
     mpcx::NlmpcDev dev{};
     int device = 0;
+    // how the two kernels are launched: the library's zoo, a user's translation unit, or a run-time compiled module
+    mpcx::nlmpc_launch_eval_fn launch_eval = mpcx::nlmpc_launch;
+    mpcx::nlmpc_launch_solve_fn launch_solve = mpcx::nlmpc_launch_solve;
+    void *launch_ctx = nullptr;
+    void *jit = nullptr;                 // run-time compiled module (nlmpc_jit.cpp), released with the handle
     double *params_d = nullptr;
+    double *scale_d = nullptr;           // input scaling [nu] | state scaling [nx] (Mapping.hpp:71-86), ones by default
+    std::vector<double> su, ss;
+    double *hook_ws = nullptr;           // scratch of mpcx_nlmpc_evaluate_batch for vector-valued hooks
+    size_t hook_cap = 0;
     double *ws = nullptr;
     size_t ws_cap = 0;          // instances
     int solved_batch = 0;       // batch size of the last solve whose state is still in the workspace (0: none)
@@ -25,6 +41,15 @@ struct mpcx_nlmpc {
     bool bounds_dirty = true;
     void *bnd_block = nullptr;  // one allocation: zlb | zub | bnd_val | bnd_sign | bnd_idx
 
+    int sync_scale()
+    {
+        std::vector<double> both(su);
+        both.insert(both.end(), ss.begin(), ss.end());
+        if (!scale_d && hipMalloc(reinterpret_cast<void **>(&scale_d), both.size() * sizeof(double)) != hipSuccess) return MPCX_E_DEVICE;
+        if (hipMemcpy(scale_d, both.data(), both.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return MPCX_E_DEVICE;
+        dev.su = scale_d; dev.ss = scale_d + su.size();
+        return MPCX_OK;
+    }
     int sync_bounds()
     {
         if (!bounds_dirty) return MPCX_OK;
@@ -53,7 +78,7 @@ struct mpcx_nlmpc {
         dev.zlb = d; dev.zub = d + nz; dev.bnd_val = dval; dev.bnd_sign = dsign; dev.bnd_idx = didx;
         if (nb != dev.nbnd) {                       // the workspace layout depends on the number of rows
             dev.nbnd = nb;
-            mpcx::nlmpc_plan(dev);
+            mpcx::nlmpc_plan_host(dev);
             if (ws) (void)hipFree(ws);
             ws = nullptr; ws_cap = 0; solved_batch = 0;
         }
@@ -68,6 +93,28 @@ void mpcx_nlparams_default(mpcx_nlparams *p)
 {
     if (!p) return;
     *p = mpcx_nlparams{100, 0.0, 0, -1.0, -1.0, -1.0, -1.0, 1};      // Types.hpp:108-143
+}
+
+// common tail of the three ways to create a controller: plan the workspace, default bounds and scalings
+static int finish_create(mpcx_nlmpc *h, mpcx_nlmpc_t *out)
+{
+    using mpcx::capi_fail;
+    mpcx::NlmpcDev &d = h->dev;
+    d.nbnd = 0;
+    mpcx::nlmpc_plan_host(d);
+    h->lb.assign(d.nz, -INFINITY); h->ub.assign(d.nz, INFINITY);
+    h->su.assign(d.nu, 1.0); h->ss.assign(d.nx, 1.0);
+    mpcx_nlparams_default(&h->prm);
+    if ((size_t)d.lds_per_wave * sizeof(double) > 64 * 1024) {
+        mpcx_nlmpc_destroy(h);
+        return capi_fail(MPCX_E_UNSUPPORTED, "horizon too long for the per-wave LDS slice");
+    }
+    if (h->sync_scale() != MPCX_OK) {
+        mpcx_nlmpc_destroy(h);
+        return capi_fail(MPCX_E_DEVICE, "could not upload the scalings");
+    }
+    *out = h;
+    return MPCX_OK;
 }
 
 int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *params, int n_params, int device,
@@ -90,26 +137,50 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed: no usable HIP device");
     auto *h = new mpcx_nlmpc;
     h->device = device;
-    mpcx_nlparams_default(&h->prm);
     if (hipMalloc(reinterpret_cast<void **>(&h->params_d), prm.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(h->params_d, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-        delete h;
+        mpcx_nlmpc_destroy(h);
         return capi_fail(MPCX_E_DEVICE, "could not upload the model parameters");
     }
     mpcx::NlmpcDev &d = h->dev;
     d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq; d.nue = nue; d.ny = ny;
     d.Ts = Ts;
     d.params = h->params_d;
-    d.nbnd = 0;
-    mpcx::nlmpc_plan(d);
-    h->lb.assign(d.nz, -INFINITY); h->ub.assign(d.nz, INFINITY);
-    if ((size_t)d.lds_per_wave * sizeof(double) > 64 * 1024) {
-        (void)hipFree(h->params_d);
-        delete h;
-        return capi_fail(MPCX_E_UNSUPPORTED, "horizon too long for the per-wave LDS slice");
+    return finish_create(h, out);
+}
+
+// shared by mpcx_nlmpc_create_custom and the run-time compiled path (nlmpc_jit.cpp)
+int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, void *jit, mpcx_nlmpc_t *out)
+{
+    using mpcx::capi_fail;
+    if (!c || !out) return capi_fail(MPCX_E_INVALID, "null argument");
+    if (c->nx < 1 || c->nu < 1 || c->ny < 0 || c->nineq < 0 || c->neq_user < 0) return capi_fail(MPCX_E_INVALID, "bad dimensions");
+    if (c->ph < 1 || c->ch < 1 || c->ch > c->ph) return capi_fail(MPCX_E_INVALID, "need 1 <= ch <= ph");
+    if (!c->launch_evaluate || !c->launch_solve) return capi_fail(MPCX_E_INVALID, "launch thunks are required");
+    if (c->hooks_bytes < 0 || (c->hooks_bytes > 0 && !c->hooks)) return capi_fail(MPCX_E_INVALID, "bad hook blob");
+    if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed: no usable HIP device");
+    auto *h = new mpcx_nlmpc;
+    h->device = device;
+    h->jit = jit;
+    const size_t nb = c->hooks_bytes > 0 ? (size_t)c->hooks_bytes : sizeof(double);
+    if (hipMalloc(reinterpret_cast<void **>(&h->params_d), nb) != hipSuccess ||
+        (c->hooks_bytes > 0 && hipMemcpy(h->params_d, c->hooks, nb, hipMemcpyHostToDevice) != hipSuccess)) {
+        mpcx_nlmpc_destroy(h);
+        return capi_fail(MPCX_E_DEVICE, "could not upload the hook closures");
     }
-    *out = h;
-    return MPCX_OK;
+    h->launch_eval = reinterpret_cast<mpcx::nlmpc_launch_eval_fn>(c->launch_evaluate);
+    h->launch_solve = reinterpret_cast<mpcx::nlmpc_launch_solve_fn>(c->launch_solve);
+    h->launch_ctx = c->launch_ctx;
+    mpcx::NlmpcDev &d = h->dev;
+    d.model_id = 0; d.nx = c->nx; d.nu = c->nu; d.ny = c->ny; d.ph = c->ph; d.ch = c->ch; d.nineq = c->nineq; d.nue = c->neq_user;
+    d.Ts = Ts; d.continuous = Ts > 0.0 ? 1 : 0; d.has_output = c->has_output ? 1 : 0; d.vector_hooks = c->vector_hooks ? 1 : 0;
+    d.params = h->params_d;
+    return finish_create(h, out);
+}
+
+int mpcx_nlmpc_create_custom(const mpcx_nlmpc_custom *c, double Ts, int device, mpcx_nlmpc_t *out)
+{
+    return mpcx_nlmpc_create_hooked(c, Ts, device, nullptr, out);
 }
 
 int mpcx_nlmpc_destroy(mpcx_nlmpc_t h)
@@ -117,6 +188,9 @@ int mpcx_nlmpc_destroy(mpcx_nlmpc_t h)
     if (!h) return MPCX_OK;
     (void)hipSetDevice(h->device);
     if (h->params_d) (void)hipFree(h->params_d);
+    if (h->scale_d) (void)hipFree(h->scale_d);
+    if (h->hook_ws) (void)hipFree(h->hook_ws);
+    if (h->jit) mpcx::nlmpc_jit_release(h->jit);
     if (h->ws) (void)hipFree(h->ws);
     if (h->bnd_block) (void)hipFree(h->bnd_block);
     delete h;
@@ -127,7 +201,9 @@ int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d)
 {
     if (!h || !d) return mpcx::capi_fail(MPCX_E_INVALID, "null argument");
     const mpcx::NlmpcDev &m = h->dev;
-    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue, m.ny};
+    int nb = 0;                                   // finite bounds = rows of the sub-problem after the user constraints
+    for (int k = 0; k < m.nz - 1; ++k) nb += (h->ub[k] < 1e30) + (h->lb[k] > -1e30);
+    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue, m.ny, nb};
     return MPCX_OK;
 }
 
@@ -166,6 +242,20 @@ int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const do
     return set_bounds(h, lo, hi, start, end, false);
 }
 
+static int set_scale(mpcx_nlmpc_t h, const double *s, bool state)
+{
+    using mpcx::capi_fail;
+    if (!h || !s) return capi_fail(MPCX_E_INVALID, "null argument");
+    std::vector<double> &dst = state ? h->ss : h->su;
+    for (size_t j = 0; j < dst.size(); ++j) if (!(s[j] != 0.0) || !std::isfinite(s[j])) return capi_fail(MPCX_E_INVALID, "scaling factors must be finite and non-zero");
+    dst.assign(s, s + dst.size());
+    if (hipSetDevice(h->device) != hipSuccess || h->sync_scale() != MPCX_OK) return capi_fail(MPCX_E_DEVICE, "could not upload the scalings");
+    h->solved_batch = 0;
+    return MPCX_OK;
+}
+int mpcx_nlmpc_set_input_scale(mpcx_nlmpc_t h, const double *scaling) { return set_scale(h, scaling, false); }
+int mpcx_nlmpc_set_state_scale(mpcx_nlmpc_t h, const double *scaling) { return set_scale(h, scaling, true); }
+
 int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const double *x0, double *cost, double *grad,
                               double *ceq, double *jeq, double *cineq, double *jineq, void *stream)
 {
@@ -175,8 +265,19 @@ int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const 
     if (batch == 0) return MPCX_OK;
     if (!z || !x0) return capi_fail(MPCX_E_INVALID, "z and x0 are required");
     if (hipSetDevice(h->device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
-    mpcx::NlmpcBatchDev b{batch, z, x0, cost, grad, ceq, jeq, cineq, jineq};
-    const int rc = mpcx::nlmpc_launch(h->dev, b, stream);
+    mpcx::NlmpcBatchDev b{batch, z, x0, cost, grad, ceq, jeq, cineq, jineq, nullptr, 0};
+    if (h->dev.vector_hooks) {
+        const int ld = mpcx::nlmpc_hook_scratch(h->dev);
+        if ((size_t)batch > h->hook_cap) {
+            if (h->hook_ws) (void)hipFree(h->hook_ws);
+            h->hook_ws = nullptr; h->hook_cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&h->hook_ws), (size_t)batch * ld * sizeof(double)) != hipSuccess)
+                return capi_fail(MPCX_E_DEVICE, "could not allocate the hook scratch");
+            h->hook_cap = batch;
+        }
+        b.hook_ws = h->hook_ws; b.hook_ld = ld;
+    }
+    const int rc = h->launch_eval(h->launch_ctx, &h->dev, &b, stream);
     if (rc != 0) return capi_fail(MPCX_E_DEVICE, "NLMPC kernel launch failed (" + std::to_string(rc) + ")");
     return MPCX_OK;
 }
@@ -200,8 +301,11 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     s = mpcx::NlmpcSolveDev{};
     s.batch = b->batch; s.x0 = b->x0; s.u0 = b->u0; s.z_warm = b->z_warm; s.ws = h->ws;
     s.max_iter = h->prm.maximum_iteration; s.hard = h->prm.hard_constraints ? 1 : 0;
-    s.tol_step = h->prm.relative_xtol > 0 ? h->prm.relative_xtol : 1e-6;
+    s.tol_step = 1e-6;
     s.tol_con = 1e-8; s.ieq_tol = 1e-10; s.eq_tol = 1e-10;
+    s.ftol_rel = h->prm.relative_ftol; s.ftol_abs = h->prm.absolute_ftol;        // NLOptimizer.hpp:135-138, <= 0: disabled
+    s.xtol_rel = h->prm.relative_xtol; s.xtol_abs = h->prm.absolute_xtol;
+    s.mu_out = b->multipliers;
     s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch) ? 1 : 0;
     h->solved_batch = b->batch;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
@@ -214,7 +318,7 @@ int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stre
     mpcx::NlmpcSolveDev s;
     const int rc = prepare_solve(h, b, s);
     if (rc != MPCX_OK) return rc > 0 ? MPCX_OK : rc;
-    const int lr = mpcx::nlmpc_launch_solve(h->dev, s, stream);
+    const int lr = h->launch_solve(h->launch_ctx, &h->dev, &s, stream);
     if (lr != 0) return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")");
     return MPCX_OK;
 }
@@ -274,7 +378,7 @@ int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void 
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipEventCreate failed");
     (void)hipEventRecord(e0, st);
     int lr = 0;
-    for (int i = 0; i < repeats && lr == 0; ++i) lr = mpcx::nlmpc_launch_solve(h->dev, s, stream);
+    for (int i = 0; i < repeats && lr == 0; ++i) lr = h->launch_solve(h->launch_ctx, &h->dev, &s, stream);
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;

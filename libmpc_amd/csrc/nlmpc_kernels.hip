@@ -1,1165 +1,15 @@
-// NLMPC kernels for gfx950, one instance per wavefront.
-//
-// (1) nlmpc_evaluate: what libmpc++ evaluates inside every NLopt SLSQP callback
-//     (reference include/mpc/NLMPC/NLOptimizer.hpp:760-997 -> Objective.hpp:91-265, Constraints.hpp:211-316,
-//     490-905, Mapping.hpp:174-211) for a batch of decision vectors:
-//       - unwrap z into (X, U, slack) with move blocking                       (Mapping::unwrapVector)
-//       - cost + forward-difference gradient, with the reference's step quirk  (Objective::computeGradient)
-//       - dynamics equalities (trapezoidal collocation or one-step) + central-difference blocks
-//                                                                              (getStateEqConstraints)
-//       - user inequalities + central-difference Jacobian                      (computeIneqJacobian)
-//       - user equalities + central-difference Jacobian, with their own step rules (computeEqJacobian)
-// (2) nlmpc_sqp: the optimisation NLOptimizer::run (NLOptimizer.hpp:412-638) hands to nlopt LD_SLSQP, as a
-//     sequential quadratic programme on the same transcription: the dynamics equalities are eliminated by a
-//     forward sweep over their block-bidiagonal Jacobian (condensing), the quadratic sub-problem lives in the
-//     move-blocked inputs (+ slack), its Hessian is a damped BFGS estimate kept in inverse form, it is solved by
-//     a dual active-set method (Goldfarb-Idnani, range-space form on that inverse), and the step is globalised by
-//     a backtracking search on an l1 merit function whose trial points are evaluated by the lanes in parallel.
-//
-// The user hooks of the reference are host std::function objects (IDimensionable.hpp:94-149) which a kernel
-// cannot call; here they are device functors compiled into the library (the reference's example systems),
-// selected by id.  Every finite-difference column is an independent re-evaluation of a whole-horizon function:
-// lanes own columns, the unwrapped trajectory sits in the wave's LDS slice and perturbations are applied on the
-// fly by the accessor.
+// The NLMPC engine (mpcx/nlmpc_engine.hpp) instantiated for the model zoo of mpcx/nlmpc_models.hpp: the reference's example
+// systems as component-wise device functors with declared constraint structure, selected by id (mpcx_nlmpc_create).
+// Hooks with the reference's own signatures do not pass through this file: they instantiate the same engine in the user's
+// translation unit (mpcx/nlmpc_hooks.hpp) or in a run-time compiled module (nlmpc_jit.cpp).
 #include <hip/hip_runtime.h>
 
-#include <cmath>
-
-#include "nlmpc_device.hpp"
-#include "nlmpc_models.hpp"
+#include "mpcx/nlmpc_engine.hpp"
 
 namespace mpcx {
 namespace {
 
 using namespace models;
-
-__device__ __forceinline__ void nl_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-    for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-
-// sum_j a[j * stride] * x[j]: the loads of a batch are issued together and waited for once -- the compiler does not
-// pipeline loads across the iterations of a plain loop, and every iteration would pay the full memory latency
-__device__ __forceinline__ double gdot(const double *__restrict__ a, size_t stride, const double *x, int n)
-{
-    constexpr int U = 8;
-    double s = 0;
-    int j = 0;
-    for (; j + U <= n; j += U) {
-        double v[U], w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = a[(size_t)(j + u) * stride];
-#pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = x[j + u];
-#pragma unroll
-        for (int u = 0; u < U; ++u) s = fma(v[u], w[u], s);
-    }
-    for (; j < n; ++j) s = fma(a[(size_t)j * stride], x[j], s);
-    return s;
-}
-// the same with both operands strided in memory
-__device__ __forceinline__ double gdot2(const double *__restrict__ a, size_t sa, const double *__restrict__ b, size_t sb, int n)
-{
-    constexpr int U = 8;
-    double s = 0;
-    int j = 0;
-    for (; j + U <= n; j += U) {
-        double v[U], w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { v[u] = a[(size_t)(j + u) * sa]; w[u] = b[(size_t)(j + u) * sb]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) s = fma(v[u], w[u], s);
-    }
-    for (; j < n; ++j) s = fma(a[(size_t)j * sa], b[(size_t)j * sb], s);
-    return s;
-}
-// largest value and the lowest lane-supplied index holding it
-__device__ __forceinline__ void wave_argmax(double &v, int &idx)
-{
-    for (int o = 32; o; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-}
-
-constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
-
-// Mapping::unwrapVector (scalings are 1 for the zoo models)
-template <class Mdl>
-__device__ __forceinline__ void unwrap(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, int lane)
-{
-    constexpr int NX = Mdl::NX, NU = Mdl::NU;
-    const int ph = M.ph, ch = M.ch;
-    for (int k = lane; k < (ph + 1) * NX; k += 64) {
-        const int i = k / NX, j = k - i * NX;
-        Xs[k] = i == 0 ? x0[j] : z[(i - 1) * NX + j];
-    }
-    for (int k = lane; k < (ph + 1) * NU; k += 64) {
-        const int i = k / NU, j = k - i * NU;
-        const int blk = min(min(i, ph - 1), ch - 1);          // first ch-1 moves one step each, the last one held
-        Us[k] = z[ph * NX + blk * NU + j];
-    }
-    nl_wave_sync();
-}
-
-// the transcription of one instance; any output may be null.  Xs/Us/Jm: this wave's LDS.
-template <class Mdl>
-__device__ void eval_instance(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, double *Jm, int lane,
-                              double *cost, double *grad, double *ceq, double *jeq, double *cineq, double *jineq, bool jin_fill = true)
-{
-    constexpr int NX = Mdl::NX, NU = Mdl::NU;
-    const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
-    const double dv = kDv;
-    const double *prm = M.params;
-    unwrap<Mdl>(M, z, x0, Xs, Us, lane);
-    const double e = z[nz - 1];
-    auto Xa = [&](int j) { const double v = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
-    auto Ua = [&](int j) { const double v = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
-    const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
-
-    // ---- Objective::evaluate + computeGradient
-    if (cost || grad) {
-        const double f0 = Mdl::cost(X0, U0, e, ph, prm);
-        if (lane == 0 && cost) *cost = f0;
-        if (grad) {
-            double *g = grad;
-            for (int k = lane; k < ph * NX; k += 64) {
-                const int i = k / NX, j = k - i * NX;
-                const double dx = dv * Xa(j);
-                const Pert Xp{Xs, NX, i + 1, -1, j, dx};
-                g[k] = (Mdl::cost(Xp, U0, e, ph, prm) - f0) / dx;
-            }
-            for (int k = lane; k < ph * NU; k += 64) {
-                const int i = k / NU, j = k - i * NU;
-                const double du = dv * Ua(j);
-                const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du};     // the last row moves with its copy
-                Jm[k] = (Mdl::cost(X0, Up, e, ph, prm) - f0) / du;
-            }
-            nl_wave_sync();
-            for (int k = lane; k < ch * NU; k += 64) {
-                const int bl = k / NU, j = k - bl * NU;
-                double s = 0;
-                for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
-                g[ph * NX + k] = s;                                        // Iz2u' * vec(Jmv)
-            }
-            if (lane == 0) {
-                const double de = fmax(dv, fabs(e)) * dv;
-                g[nz - 1] = (Mdl::cost(X0, U0, e + de, ph, prm) - Mdl::cost(X0, U0, e - de, ph, prm)) / (2 * de);
-            }
-            nl_wave_sync();
-        }
-    }
-
-    // ---- Constraints::getStateEqConstraints: value and the blocks [dc/dx_i | dc/dx_{i+1} | dc/du_i]
-    if (ceq || jeq) {
-        const double h = 0.5 * M.Ts;
-        const int W = 2 * NX + NU;
-        for (int k = lane; k < ph * (W + 1); k += 64) {
-            const int i = k / (W + 1), c = k - i * (W + 1);     // c = 0: value; 1..: one Jacobian column
-            double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
-            for (int a = 0; a < NX; ++a) { xk[a] = Xs[i * NX + a]; xk1[a] = Xs[(i + 1) * NX + a]; }
-            for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
-            if (c == 0) {
-                if (!ceq) continue;
-                double *cv = ceq + i * NX;
-                Mdl::f(fa, xk, uk, prm);
-                if (Mdl::CONTINUOUS) {
-                    Mdl::f(fb, xk1, uk, prm);
-                    for (int a = 0; a < NX; ++a) cv[a] = xk[a] + (h * (fa[a] + fb[a])) - xk1[a];
-                } else {
-                    for (int a = 0; a < NX; ++a) cv[a] = xk1[a] - fa[a];
-                }
-                continue;
-            }
-            if (!jeq) continue;
-            double *J = jeq + (size_t)i * NX * W;          // [NX x W] row-major block of step i
-            const int col = c - 1;
-            auto cdiff = [&](const double *xx, const double *uu, int v, bool isu, double *out) {
-                double xp[NX], up[NU], f1[NX], f2[NX];
-                for (int a = 0; a < NX; ++a) xp[a] = xx[a];
-                for (int a = 0; a < NU; ++a) up[a] = uu[a];
-                const double base = isu ? uu[v] : xx[v];
-                const double d = dv * fmax(fabs(base), 1.0);
-                if (isu) up[v] = base + d; else xp[v] = base + d;
-                Mdl::f(f1, xp, up, prm);
-                if (isu) up[v] = base - d; else xp[v] = base - d;
-                Mdl::f(f2, xp, up, prm);
-                for (int a = 0; a < NX; ++a) out[a] = (f1[a] - f2[a]) / (2 * d);
-            };
-            double dcol[NX];
-            if (col < NX) {                    // d c_i / d x_i  (not a decision variable for i = 0: kept for the caller to drop)
-                cdiff(xk, uk, col, false, dcol);
-                for (int a = 0; a < NX; ++a)
-                    J[a * W + col] = Mdl::CONTINUOUS ? ((a == col ? 1.0 : 0.0) + h * dcol[a]) : -dcol[a];
-            } else if (col < 2 * NX) {         // d c_i / d x_{i+1}
-                const int v = col - NX;
-                if (Mdl::CONTINUOUS) {
-                    cdiff(xk1, uk, v, false, dcol);
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? -1.0 : 0.0) + h * dcol[a];
-                } else {
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? 1.0 : 0.0);
-                }
-            } else {                           // d c_i / d u_i
-                const int v = col - 2 * NX;
-                cdiff(xk, uk, v, true, dcol);
-                if (Mdl::CONTINUOUS) {
-                    double d2[NX];
-                    cdiff(xk1, uk, v, true, d2);
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = h * (dcol[a] + d2[a]);
-                } else {
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = -dcol[a];
-                }
-            }
-        }
-    }
-
-    // ---- Constraints::evaluateIneq + computeIneqJacobian (dense [nineq x nz], row-major)
-    if (cineq)
-        for (int k = lane; k < nineq; k += 64) cineq[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
-    if (jineq) {
-        double *J = jineq;
-        for (int k = lane; k < nz; k += 64) {
-            if (k < ph * NX) {
-                const int i = k / NX, j = k - i * NX;
-                const double dx = dv * Xa(j);
-                const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
-                if (jin_fill) for (int r = 0; r < nineq; ++r) J[(size_t)r * nz + k] = 0.0;
-                int first, count;
-                Mdl::ineq_rows_of_x(i + 1, first, count);           // the lane's own rows: no divergence over the union of rows
-                for (int t = 0; t < count; ++t) {
-                    const int r = first + t;
-                    J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx);
-                }
-            } else if (k < nz - 1) {
-                const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
-                const double du = dv * Ua(j);
-                const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;       // the steps this block drives
-                if (jin_fill) for (int r = 0; r < nineq; ++r) J[(size_t)r * nz + k] = 0.0;
-                else
-                    for (int i = i_first; i <= i_last; ++i) {      // the entries that get contributions below start from zero
-                        int first, count;
-                        Mdl::ineq_rows_of_u(i, first, count);
-                        for (int t = 0; t < count; ++t) J[(size_t)(first + t) * nz + k] = 0.0;
-                    }
-                for (int i = i_first; i <= i_last; ++i) {          // every input row of the block on its own (no pairing here)
-                    int first, count;
-                    Mdl::ineq_rows_of_u(i, first, count);
-                    const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
-                    for (int t = 0; t < count; ++t) {
-                        const int r = first + t;
-                        J[(size_t)r * nz + k] += (Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du);
-                    }
-                }
-            } else {
-                const double de = fmax(dv, fabs(e)) * dv;
-                for (int r = 0; r < nineq; ++r) {
-                    if (!Mdl::INEQ_USES_SLACK) { if (jin_fill) J[(size_t)r * nz + k] = 0.0; continue; }
-                    J[(size_t)r * nz + k] = (Mdl::ineq(r, X0, U0, e + de, ph, prm) - Mdl::ineq(r, X0, U0, e - de, ph, prm)) / (2 * de);
-                }
-            }
-        }
-    }
-    // ---- Constraints::evaluateEq + computeEqJacobian (Constraints.hpp:365-442, 731-832): rows nineq.. of the same arrays.
-    // Steps: the perturbed element's own magnitude for the states, row ph-1's for every input step, last input row paired.
-    const int nue = M.nue;
-    if (nue && cineq)
-        for (int k = lane; k < nue; k += 64) cineq[nineq + k] = Mdl::eq(k, X0, U0, ph, prm);
-    if (nue && jineq) {
-        double *J = jineq + (size_t)nineq * nz;
-        for (int k = lane; k < nz; k += 64) {
-            if (k < ph * NX) {
-                const int i = k / NX, j = k - i * NX;
-                const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
-                const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
-                for (int r = 0; r < nue; ++r)
-                    J[(size_t)r * nz + k] = (Mdl::eq(r, Xp, U0, ph, prm) - Mdl::eq(r, Xm, U0, ph, prm)) / (2 * dx);
-            } else if (k < nz - 1) {
-                const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
-                const double du = dv * fmax(fabs(Us[(ph - 1) * NU + j]), 1.0);
-                const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;
-                for (int r = 0; r < nue; ++r) {
-                    double s = 0;
-                    for (int i = i_first; i <= i_last; ++i) {
-                        const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du}, Um{Us, NU, i, i == ph - 1 ? ph : -1, j, -du};
-                        s += (Mdl::eq(r, X0, Up, ph, prm) - Mdl::eq(r, X0, Um, ph, prm)) / (2 * du);
-                    }
-                    J[(size_t)r * nz + k] = s;
-                }
-            } else {
-                for (int r = 0; r < nue; ++r) J[(size_t)r * nz + k] = 0.0;
-            }
-        }
-    }
-    nl_wave_sync();
-}
-
-template <class Mdl>
-__global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const NlmpcBatchDev Bt)
-{
-    constexpr int NX = Mdl::NX, NU = Mdl::NU;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int ph = M.ph, nz = M.nz;
-    double *Xs = smem + (size_t)wave * M.lds_per_wave;  // (ph+1) x NX
-    double *Us = Xs + (ph + 1) * NX;                    // (ph+1) x NU
-    double *Jm = Us + (ph + 1) * NU;                    // ph x NU scratch (gradient wrt the input rows)
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb) {
-        auto at = [&](double *p, size_t stride) { return p ? p + (size_t)b * stride : nullptr; };
-        eval_instance<Mdl>(M, Bt.z + (size_t)b * nz, Bt.x0 + (size_t)b * NX, Xs, Us, Jm, lane, at(Bt.cost, 1), at(Bt.grad, nz),
-                           at(Bt.ceq, M.neq), at(Bt.jeq, (size_t)ph * NX * (2 * NX + NU)), at(Bt.cineq, M.nineq + M.nue),
-                           at(Bt.jineq, (size_t)(M.nineq + M.nue) * nz));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// SQP
-// ---------------------------------------------------------------------------------------------------
-// Dense symmetric positive definite solve: S [n x ld] (destroyed; LDS for small n, the workspace otherwise), rhs t ->
-// solution in t.  Lanes own rows (two each beyond 64).  n <= 128.
-__device__ bool spd_solve(double *S, int ld, double *t, int n, int lane)
-{
-    double dmax = 0.0;
-    for (int r = lane; r < n; r += 64) dmax = fmax(dmax, S[r * ld + r]);
-    dmax = wave_max(dmax);
-    bool ok = true;
-    for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
-        const double piv = S[k * ld + k];
-        ok &= piv > 1e-13 * dmax;
-        const double tk = t[k];
-        for (int r = lane; r < n; r += 64) {
-            if (r <= k) continue;
-            const double fct = S[r * ld + k] / piv;
-            for (int j = k + 1; j < n; ++j) S[r * ld + j] -= fct * S[k * ld + j];
-            t[r] -= fct * tk;
-        }
-        nl_wave_sync();
-    }
-    for (int k = n - 1; k >= 0; --k) {      // back substitution
-        if (lane == 0) t[k] /= S[k * ld + k];
-        nl_wave_sync();
-        const double tk = t[k];
-        for (int r = lane; r < k; r += 64) t[r] -= S[r * ld + k] * tk;
-        nl_wave_sync();
-    }
-    return ok;
-}
-
-template <class Mdl>
-__global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S)
-{
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KL = kNlLdsWorking;
-    const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
-    const int ph = M.ph, ch = M.ch, nz = M.nz, mi = M.nineq, m = M.nineq + M.nue, nzu = M.nzu, nr = M.nr, nxs = ph * NX;
-    // user rows: [0, mi) inequalities g <= 0, [mi, m) equalities h = 0; then the bounds
-    const int mt = m + M.nbnd;                           // sub-problem rows: user inequalities, then the finite bounds on z
-    const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
-    const int mld = (mt + 1) & ~1;
-    const double *prm = M.params;
-    double *Xs = smem + (size_t)wave * M.lds_per_wave;
-    double *Us = Xs + (ph + 1) * NX;
-    double *dXs = Us + (ph + 1) * NU;
-    double *dUs = dXs + (ph + 1) * NX;
-    double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
-    double *Sfac = Jm + ph * NU;                          // KL x (KL+1) copy of the working-set Schur complement for the solve
-    double *tq = Sfac + KL * (KL + 1);                    // KW
-    double *uq = tq + KW;                                 // KW  multipliers of the working set
-    double *wq = uq + KW;                                 // KW  row numbers (as doubles)
-    double *sgq = wq + KW;                                // KW  orientation of the row in the working set (+1; -1 for an equality entered from below)
-    double *aug = sgq + KW;                               // NX x 2NX
-    double *v0 = aug + NX * 2 * NX;                       // 4 vectors of nr
-    double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
-    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(v3 + nr);   // structure bits of d g / d x
-
-    for (int b = blockIdx.x * wpb + wave; b < S.batch; b += gridDim.x * wpb) {
-        double *w = S.ws + (size_t)b * M.ws.total;
-        double *z = w + M.ws.z, *d = w + M.ws.d, *g = w + M.ws.g, *c = w + M.ws.c, *jeq = w + M.ws.jeq, *gin = w + M.ws.gin,
-               *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
-               *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
-               *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal,
-               *lamw = w + M.ws.lamw;
-        const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
-
-        // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
-        if (S.z_warm) {
-            const double *zw = S.z_warm + (size_t)b * nz;
-            for (int k = lane; k < nxs; k += 64) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
-            for (int k = lane; k < nzu; k += 64) {
-                const int bl = k / NU, j = k - bl * NU;
-                const int step = min(bl + 1, ph - 1);                       // first step of the block, shifted by one
-                z[nxs + k] = zw[nxs + min(step, ch - 1) * NU + j];
-            }
-            if (lane == 0) z[nz - 1] = zw[nz - 1];
-        } else {
-            for (int k = lane; k < nxs; k += 64) z[k] = x0[k % NX];
-            for (int k = lane; k < nzu; k += 64) z[nxs + k] = u0[k % NU];
-            if (lane == 0) z[nz - 1] = 0.0;
-        }
-        if (!S.keep_curvature)                              // otherwise: the estimate the previous tick's solve left in the workspace
-            for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
-        for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
-        // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
-        for (int k = lane; k < nz; k += 64) {
-            const double lo = M.zlb[k], hi = M.zub[k];
-            if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
-        }
-        nl_wave_sync();
-
-        // user inequalities read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
-        // structure the model declares (the finite differences leave exact zeros everywhere else)
-        {
-            const int nchunk = (nxs + 63) >> 6;
-            for (int e0 = 0; e0 < m * nchunk; ++e0) {
-                const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
-                const unsigned long long bal = __ballot(col < nxs && (k < mi ? Mdl::ineq_reads_x(k, col / NX + 1) : Mdl::eq_reads_x(k - mi, col / NX + 1)));
-                if (lane == 0) fmask[e0] = bal;
-            }
-            nl_wave_sync();
-        }
-        double nu_pen = 0.0, a_prev = 0.0;
-        bool have_old = false;
-        int resets = 0;
-        int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
-        long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
-        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
-        int it = 0, code = 5;       // nlopt codes: 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
-        // One call site for the transcription (the solver has to stay inside the 64 KB instruction cache, and three inlined
-        // copies of it do not): every pass of the loop starts with the evaluation at the current point -- everything on the
-        // first pass and after a step, values only after the last, converged step.
-        bool first_eval = true, final_eval = false;
-        for (;;) {
-            if (!first_eval) lap(4);
-            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, lane, scal, final_eval ? nullptr : g, c, final_eval ? nullptr : jeq, gin,
-                               final_eval ? nullptr : jin, first_eval);     // structural zeros are written once
-            if (!first_eval) lap(5); else tstamp = __builtin_readcyclecounter();
-            first_eval = false;
-            if (final_eval || it >= S.max_iter) break;
-            // ---- condensing: inverses of E_i = dc_i/dx_{i+1} (identity for one-step models)
-            if (Mdl::CONTINUOUS) {
-                // Gauss-Jordan on [E | I] with one column per lane held in registers: the pivot column's entries reach the
-                // other lanes by shuffles, so a pivot step is NX shuffles and NX FMAs with no LDS traffic and no barrier; 2 NX
-                // lanes serve one step, the wavefront inverts 64 / (2 NX) steps at a time.  Partial pivoting as before.
-                constexpr int GW = 2 * NX, G = 64 / GW;
-                const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
-                for (int i0 = 0; i0 < ph; i0 += G) {
-                    const int i = i0 + g;
-                    const bool live = g < G && i < ph;
-                    double col[NX];
-#pragma unroll
-                    for (int a = 0; a < NX; ++a)
-                        col[a] = (live && cidx < NX) ? jeq[(size_t)i * NX * W + a * W + NX + cidx] : ((cidx < NX ? cidx : cidx - NX) == a ? 1.0 : 0.0);
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) {
-                        int pr = k;
-                        double best = fabs(col[k]);
-#pragma unroll
-                        for (int a = k + 1; a < NX; ++a) { const double v = fabs(col[a]); if (v > best) { best = v; pr = a; } }
-                        pr = __shfl(pr, base + k);                     // the pivot column's choice
-                        double cp = col[k];
-#pragma unroll
-                        for (int a = k + 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[k]; }
-                        col[k] = cp;                                    // rows k and pr swapped in every column
-                        const double piv = __shfl(col[k], base + k);
-                        double mlt[NX];
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) mlt[a] = __shfl(col[a], base + k);     // pivot column, before anyone updates
-                        const double cs = col[k] / piv;
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) col[a] = a == k ? cs : fma(-mlt[a], cs, col[a]);
-                    }
-                    if (live && cidx >= NX)
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) einv[(size_t)i * NX * NX + a * NX + (cidx - NX)] = col[a];
-                }
-                nl_wave_sync();
-            }
-            // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0.  A_i = dc_i/dx_i (and E_i^-1) are the same for
-            // every lane: they are staged in LDS, the next step's share already in flight while this step computes.
-            if constexpr (NX >= 8) {
-            for (int q0 = 0; q0 <= nzu; q0 += 64) {
-                    const int q = q0 + lane;
-                    const bool qlive = q <= nzu;
-                    const int bq = q / NU, jq = q - bq * NU;
-                    constexpr int NST = Mdl::CONTINUOUS ? 2 * NX * NX : NX * NX;     // staged doubles per step: A | Einv
-                    constexpr int PL = (NST + 63) / 64;
-                    double *As = aug, *Es = aug + NX * NX;
-                    double nxt[PL], rhs[NX], rhs_n[NX], v[NX], t[NX];
-                    auto fetch = [&](int i, double (&dst)[PL], double (&rh)[NX]) {
-                        const double *Jb = jeq + (size_t)i * NX * W;
-    #pragma unroll
-                        for (int u = 0; u < PL; ++u) {
-                            const int e = min(lane + 64 * u, NST - 1);
-                            dst[u] = e < NX * NX ? Jb[(e / NX) * W + e % NX] : einv[(size_t)i * NX * NX + (e - NX * NX)];
-                        }
-    #pragma unroll
-                        for (int a = 0; a < NX; ++a)
-                            rh[a] = !qlive ? 0.0 : (q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0));
-                    };
-    #pragma unroll
-                    for (int a = 0; a < NX; ++a) v[a] = 0.0;
-                    fetch(0, nxt, rhs_n);
-                    for (int i = 0; i < ph; ++i) {
-    #pragma unroll
-                        for (int u = 0; u < PL; ++u) if (lane + 64 * u < NST) aug[lane + 64 * u] = nxt[u];
-    #pragma unroll
-                        for (int a = 0; a < NX; ++a) rhs[a] = rhs_n[a];
-                        nl_wave_sync();
-                        if (i + 1 < ph) fetch(i + 1, nxt, rhs_n);
-    #pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double s2 = rhs[a];
-    #pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) s2 = fma(As[a * NX + bb], v[bb], s2);
-                            t[a] = s2;
-                        }
-                        if (Mdl::CONTINUOUS) {
-    #pragma unroll
-                            for (int a = 0; a < NX; ++a) {
-                                double s2 = 0;
-    #pragma unroll
-                                for (int bb = 0; bb < NX; ++bb) s2 = fma(Es[a * NX + bb], t[bb], s2);
-                                v[a] = -s2;
-                            }
-                        } else {
-    #pragma unroll
-                            for (int a = 0; a < NX; ++a) v[a] = -t[a];
-                        }
-                        if (qlive) {
-                            if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
-                            else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
-                        }
-                        nl_wave_sync();
-                    }
-                }
-            } else {
-                for (int q = lane; q <= nzu; q += 64) {
-                    // small blocks come straight from L2, the next step's already requested while this one computes (the
-                    // stores to Phi in between keep the compiler from moving the loads up by itself)
-                    double v[NX], t[NX], An[NX * NX], rn[NX], En[Mdl::CONTINUOUS ? NX * NX : 1];
-                    for (int a = 0; a < NX; ++a) v[a] = 0.0;
-                    const int bq = q / NU, jq = q - bq * NU;
-                    auto fetch = [&](int i) {
-                        const double *Jb = jeq + (size_t)i * NX * W;
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            rn[a] = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) An[a * NX + bb] = Jb[a * W + bb];
-                        }
-                        if (Mdl::CONTINUOUS) {
-                            const double *Ei = einv + (size_t)i * NX * NX;
-#pragma unroll
-                            for (int e2 = 0; e2 < NX * NX; ++e2) En[e2] = Ei[e2];
-                        }
-                    };
-                    fetch(0);
-                    for (int i = 0; i < ph; ++i) {
-                        double Ac[NX * NX], rc[NX], Ec[Mdl::CONTINUOUS ? NX * NX : 1];
-#pragma unroll
-                        for (int e2 = 0; e2 < NX * NX; ++e2) { Ac[e2] = An[e2]; if (Mdl::CONTINUOUS) Ec[e2] = En[e2]; }
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) rc[a] = rn[a];
-                        if (i + 1 < ph) fetch(i + 1);
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double s2 = rc[a];
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) s2 = fma(Ac[a * NX + bb], v[bb], s2);
-                            t[a] = s2;
-                        }
-                        if (Mdl::CONTINUOUS) {
-#pragma unroll
-                            for (int a = 0; a < NX; ++a) {
-                                double s2 = 0;
-#pragma unroll
-                                for (int bb = 0; bb < NX; ++bb) s2 = fma(Ec[a * NX + bb], t[bb], s2);
-                                v[a] = -s2;
-                            }
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < NX; ++a) v[a] = -t[a];
-                        }
-                        if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
-                        else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
-                    }
-                }
-            }
-            nl_wave_sync();
-            lap(0);
-            // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
-            for (int q = lane; q < nr; q += 64) {
-                if (q == nzu) { gr[q] = g[nz - 1]; continue; }
-                const double s = g[nxs + q] + gdot2(phi + q, nzu, g, 1, nxs);
-                gr[q] = s;
-            }
-            const int nchunk = (nxs + 63) >> 6;
-            nl_wave_sync();
-            for (int q = lane; q < nr; q += 64) {
-                const bool realq = q < nzu;
-                const size_t qq = realq ? q : 0, ucol = q == nzu ? nz - 1 : nxs + q;
-                if (nchunk <= 2) {
-                    // four rows at a time, up to four entries of each gathered first so that their loads are in flight together
-                    for (int k0 = 0; k0 < m; k0 += 4) {
-                        int c4[4][4];
-                        unsigned long long rest0[4], rest1[4];
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int k = min(k0 + rr, m - 1);
-                            unsigned long long m0 = fmask[k * nchunk], m1 = nchunk > 1 ? fmask[k * nchunk + 1] : 0ull;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                int cc = -1;
-                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; }
-                                else if (m1) { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
-                                c4[rr][u] = cc;
-                            }
-                            rest0[rr] = m0; rest1[rr] = m1;
-                        }
-                        double a0[4], jv[4][4], pv[4][4];
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const size_t k = min(k0 + rr, m - 1);
-                            a0[rr] = jin[k * nz + ucol];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const size_t cc = c4[rr][u] < 0 ? 0 : c4[rr][u];
-                                jv[rr][u] = jin[k * nz + cc];
-                                pv[rr][u] = phi[cc * nzu + qq];
-                            }
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            double acc = a0[rr];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) if (realq && c4[rr][u] >= 0) acc = fma(jv[rr][u], pv[rr][u], acc);
-                            const size_t k = min(k0 + rr, m - 1);
-                            unsigned long long m0 = rest0[rr], m1 = rest1[rr];
-                            while (realq && (m0 | m1)) {                   // rows with more than four entries
-                                int cc;
-                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; } else { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
-                                acc = fma(jin[k * nz + cc], phi[(size_t)cc * nzu + qq], acc);
-                            }
-                            if (k0 + rr < m) art[(size_t)q * mld + k0 + rr] = acc;
-                        }
-                    }
-                } else {
-                    for (int k = 0; k < m; ++k) {
-                        double acc = jin[(size_t)k * nz + ucol];
-                        if (realq)
-                            for (int cb = 0; cb < nchunk; ++cb) {
-                                unsigned long long mk = fmask[k * nchunk + cb];
-                                while (mk) {
-                                    const int row = cb * 64 + (int)__builtin_ctzll(mk);
-                                    mk &= mk - 1;
-                                    acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
-                                }
-                            }
-                        art[(size_t)q * mld + k] = acc;
-                    }
-                }
-            }
-            // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
-            for (int kb = 0; kb < M.nbnd; ++kb) {
-                const int zi = M.bnd_idx[kb];
-                const double sg = M.bnd_sign[kb];
-                for (int q = lane; q < nr; q += 64) {
-                    double v = 0.0;
-                    if (zi < nxs) v = q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0;
-                    else v = (q == zi - nxs) ? sg : 0.0;
-                    art[(size_t)q * mld + m + kb] = v;
-                }
-                if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - M.bnd_val[kb]);
-            }
-            for (int k = lane; k < m; k += 64) {
-                double s = gin[k];
-                for (int cb = 0; cb < nchunk; ++cb) {
-                    unsigned long long mk = fmask[k * nchunk + cb];
-                    while (mk) {
-                        const int row = cb * 64 + (int)__builtin_ctzll(mk);
-                        mk &= mk - 1;
-                        s += jin[(size_t)k * nz + row] * r[row];
-                    }
-                }
-                br[k] = s;
-            }
-            nl_wave_sync();
-            lap(1);
-            // ---- damped BFGS update of the inverse Hessian estimate (Powell), s = a p, y = change of the reduced Lagrangian gradient
-            if (have_old) {
-                double sBs = 0, sy = 0;
-                for (int q = lane; q < nq; q += 64) {
-                    double gl = gr[q];
-                    for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
-                    const double y = gl - glold[q], Bs = -a_prev * glold[q];
-                    v0[q] = y; v1[q] = Bs;
-                    sBs += sv[q] * Bs; sy += sv[q] * y;
-                }
-                sBs = wave_sum(sBs); sy = wave_sum(sy);
-                if (sy < 0.2 * sBs) {
-                    const double th = 0.8 * sBs / (sBs - sy);
-                    for (int q = lane; q < nq; q += 64) v0[q] = th * v0[q] + (1 - th) * v1[q];
-                    sy = th * sy + (1 - th) * sBs;
-                }
-                nl_wave_sync();
-                if (sy > 1e-300) {
-                    const double rho = 1.0 / sy;
-                    double yHy = 0;
-                    for (int q = lane; q < nq; q += 64) {
-                        const double s = gdot(hinv + q, nr, v0, nq);
-                        v2[q] = s; yHy += s * v0[q];
-                    }
-                    yHy = wave_sum(yHy);
-                    nl_wave_sync();
-                    const double cc = rho * rho * yHy + rho;
-                    for (int q = lane; q < nq; q += 64) v3[q] = sv[q];          // s next to Hy in LDS
-                    nl_wave_sync();
-                    for (int q = lane; q < nq; q += 64) {
-                        const double hyq = v2[q], sq = v3[q];
-                        int i = 0;
-                        for (; i + 8 <= nq; i += 8) {                           // eight loads, eight updates, eight stores
-                            double hv[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) hv[u] = hinv[(size_t)(i + u) * nr + q];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) hv[u] += -rho * (v3[i + u] * hyq + v2[i + u] * sq) + cc * v3[i + u] * sq;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) hinv[(size_t)(i + u) * nr + q] = hv[u];
-                        }
-                        for (; i < nq; ++i) hinv[(size_t)i * nr + q] += -rho * (v3[i] * hyq + v2[i] * sq) + cc * v3[i] * sq;
-                    }
-                }
-                nl_wave_sync();
-            }
-
-            lap(2);
-            // ---- sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0   (Goldfarb-Idnani, range-space form on B^-1)
-            double *xq = v0, *np_ = v1, *vv = v2, *zd = v3;
-            for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
-            nl_wave_sync();
-            int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
-            auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
-                const int last = nw - 1;
-                if (kdrop != last) {
-                    for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
-                    nl_wave_sync();
-                    for (int r = lane; r < nw; r += 64) Ssm[r * SLD + kdrop] = Ssm[r * SLD + last];
-                    nl_wave_sync();
-                    for (int r = lane; r < nw; r += 64) Ssm[kdrop * SLD + r] = Ssm[last * SLD + r];
-                    nl_wave_sync();
-                    if (lane == 0) { uq[kdrop] = uq[last]; wq[kdrop] = wq[last]; sgq[kdrop] = sgq[last]; }
-                }
-                --nw;
-                nl_wave_sync();
-            };
-            // One sweep over B^-1 serves the unconstrained minimiser x = -B^-1 gr and B^-1 n for three rows of the previous
-            // working set at a time (their normals parked in LDS): every product with B^-1 costs a full pass of loads, and
-            // the warm start needs one per row.
-            for (int t0 = 0; t0 == 0 || t0 < nw_keep; t0 += 3) {
-                const int nv = min(3, nw_keep - t0);
-                for (int u = 0; u < nv; ++u) {
-                    const int k = (int)wq[t0 + u];
-                    for (int q = lane; q < nq; q += 64) v1[u * nr + q] = sgq[t0 + u] * art[(size_t)q * mld + k];
-                }
-                nl_wave_sync();
-                for (int q = lane; q < nq; q += 64) {
-                    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                    const double *hq = hinv + q;
-                    int j = 0;
-                    for (; j + 8 <= nq; j += 8) {
-                        double h[8], gv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { h[u] = hq[(size_t)(j + u) * nr]; gv[u] = t0 == 0 ? gr[j + u] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            a0 = fma(h[u], gv[u], a0);
-                            a1 = fma(h[u], v1[j + u], a1); a2 = fma(h[u], v1[nr + j + u], a2); a3 = fma(h[u], v1[2 * nr + j + u], a3);
-                        }
-                    }
-                    for (; j < nq; ++j) {
-                        const double hv = hq[(size_t)j * nr];
-                        a0 = fma(hv, t0 == 0 ? gr[j] : 0.0, a0);
-                        a1 = fma(hv, v1[j], a1); a2 = fma(hv, v1[nr + j], a2); a3 = fma(hv, v1[2 * nr + j], a3);
-                    }
-                    if (t0 == 0) xq[q] = -a0;
-                    const double acc[3] = {a1, a2, a3};
-                    for (int u = 0; u < nv; ++u) { qn[(size_t)(t0 + u) * nr + q] = v1[u * nr + q]; qv[(size_t)(t0 + u) * nr + q] = acc[u]; }
-                }
-                nl_wave_sync();
-            }
-            // warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative --
-            // the minimiser on that set with u >= 0 is a valid state of the dual method
-            if (nw_keep > 0) {
-                nw = nw_keep;
-                for (int e2 = lane; e2 < nw * nw; e2 += 64) {
-                    const int a = e2 / nw, b2 = e2 - a * nw;
-                    const double s2 = gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
-                    Ssm[a * SLD + b2] = s2;
-                }
-                nl_wave_sync();
-                while (nw > 0) {
-                    if (nw <= 16 && nq <= 64) {
-                        for (int t0 = 0; t0 < nw; t0 += 8) {
-                            double part[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) part[u] = (t0 + u < nw && lane < nq) ? qn[(size_t)(t0 + u) * nr + lane] : 0.0;
-                            const double xl = lane < nq ? xq[lane] : 0.0;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const double sred = wave_sum(part[u] * xl);
-                                if (lane == 0 && t0 + u < nw) tq[t0 + u] = sgq[t0 + u] * br[(int)wq[t0 + u]] + sred;
-                            }
-                        }
-                    } else {
-                        for (int t = lane; t < nw; t += 64) {
-                            const double s2 = sgq[t] * br[(int)wq[t]] + gdot(qn + (size_t)t * nr, 1, xq, nq);
-                            tq[t] = s2;
-                        }
-                    }
-                    double *Sf = nw <= KL ? Sfac : Sbig;
-                    const int sfld = nw <= KL ? KL + 1 : SLD;
-                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
-                    nl_wave_sync();
-                    if (!spd_solve(Sf, sfld, tq, nw, lane)) { nw = 0; break; }      // dependent rows: start cold
-                    auto sheds = [&](int t) { const int k = (int)wq[t]; return tq[t] < 0.0 && !(k >= mi && k < m); };   // equalities stay
-                    int neg = -1;
-                    for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
-                    if (neg < 0) break;
-                    for (int t = nw - 1; t >= 0; --t) {
-                        if (sheds(t)) { const double tl = tq[nw - 1]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
-                    }
-                }
-                if (nw > 0) {
-                    for (int q = lane; q < nq; q += 64) {
-                        const double s2 = xq[q] - gdot(qv + q, nr, tq, nw);
-                        xq[q] = s2;
-                    }
-                    for (int r = lane; r < nw; r += 64) uq[r] = tq[r];
-                    nl_wave_sync();
-                }
-            }
-            for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
-                double vmax = -1e300; int pidx = 0x7fffffff;
-                for (int k = lane; k < mt; k += 64) {
-                    double s = br[k] + gdot(art + k, mld, xq, nq);
-                    if (k >= mi && k < m) s = fabs(s);                   // an equality is violated on either side
-                    bool inw = mu[k] == -1.0 && !(k >= mi && k < m);     // set aside (see below)
-                    for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
-                    if (!inw && s > vmax) { vmax = s; pidx = k; }
-                }
-                wave_argmax(vmax, pidx);
-                if (mt == 0 || vmax <= 1e-12) { qp_done = true; break; }   // primal feasible (well inside the reported 1e-10): optimal
-                if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
-                // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
-                const bool p_is_eq = pidx >= mi && pidx < m;
-                double sgn = 1.0;
-                if (p_is_eq) {
-                    double part = 0;
-                    for (int q = lane; q < nq; q += 64) part += art[(size_t)q * mld + pidx] * xq[q];
-                    sgn = br[pidx] + wave_sum(part) < 0.0 ? -1.0 : 1.0;
-                }
-                for (int q = lane; q < nq; q += 64) np_[q] = sgn * art[(size_t)q * mld + pidx];
-                nl_wave_sync();
-                double up = 0.0, sp = vmax;
-                bool added = false;
-                for (int inner = 0; inner <= KW + 1 && !added; ++inner) {
-                    for (int q = lane; q < nq; q += 64) {
-                        const double s = gdot(hinv + q, nr, np_, nq);
-                        vv[q] = s;
-                    }
-                    nl_wave_sync();
-                    // t = N_W v (also the new column of S), rr = S^-1 t
-                    if (nw <= 16 && nq <= 64) {
-                        // few rows: the lanes split each dot product (coalesced loads, all rows in flight, a butterfly per row)
-                        // instead of each walking one row on its own
-                        for (int t0 = 0; t0 < nw; t0 += 8) {
-                            double part[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) part[u] = (t0 + u < nw && lane < nq) ? qn[(size_t)(t0 + u) * nr + lane] : 0.0;
-                            const double vl = lane < nq ? vv[lane] : 0.0;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const double sred = wave_sum(part[u] * vl);
-                                if (lane == 0 && t0 + u < nw) tq[t0 + u] = sred;
-                            }
-                        }
-                    } else {
-                        for (int t = lane; t < nw; t += 64) {
-                            const double s = gdot(qn + (size_t)t * nr, 1, vv, nq);
-                            tq[t] = s;
-                        }
-                    }
-                    // small working sets factor in LDS, large ones in the workspace
-                    double *Sf = nw <= KL ? Sfac : Sbig;
-                    const int sfld = nw <= KL ? KL + 1 : SLD;
-                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
-                    nl_wave_sync();
-                    const double tcol = lane < nw ? tq[lane] : 0.0, tcol2 = lane + 64 < nw ? tq[lane + 64] : 0.0;   // keep N_W v: it becomes S[:, new]
-                    if (nw) spd_solve(Sf, sfld, tq, nw, lane);
-                    double zn = 0;
-                    for (int q = lane; q < nq; q += 64) {
-                        const double s = vv[q] - gdot(qv + q, nr, tq, nw);
-                        zd[q] = s; zn += s * np_[q];
-                    }
-                    zn = wave_sum(zn);
-                    double npn = 0;
-                    for (int q = lane; q < nq; q += 64) npn += np_[q] * np_[q];
-                    npn = wave_sum(npn);
-                    // dual ratio test
-                    double t1 = 1e300; int kdrop = -1;
-                    for (int t = 0; t < nw; ++t) {
-                        const double rr = tq[t];
-                        const int kt = (int)wq[t];
-                        if (rr > 1e-14 && !(kt >= mi && kt < m)) { const double tj = uq[t] / rr; if (tj < t1) { t1 = tj; kdrop = t; } }
-                    }
-                    const bool can_move = zn > 1e-13 * fmax(1.0, npn);
-                    const double t2 = can_move ? sp / zn : 1e300;
-                    const double tt = fmin(t1, t2);
-                    if (tt >= 1e300) {
-                        // no step: the row is a combination of working rows.  Violated by round-off only (a copy of an
-                        // active row): set it aside; violated for real: the linearised constraints are inconsistent.
-                        if (sp <= 1e-7 && !p_is_eq) { if (lane == 0) mu[pidx] = -1.0; nl_wave_sync(); added = true; break; }
-                        qp_ok = false; break;
-                    }
-                    nl_wave_sync();
-                    if (can_move) {
-                        for (int q = lane; q < nq; q += 64) xq[q] -= tt * zd[q];
-                        sp -= tt * zn;
-                    }
-                    for (int r = lane; r < nw; r += 64) uq[r] -= tt * tq[r];
-                    up += tt;
-                    nl_wave_sync();
-                    if (t2 <= t1) {                                     // full step: the row joins the working set
-                        for (int q = lane; q < nq; q += 64) { qn[(size_t)nw * nr + q] = np_[q]; qv[(size_t)nw * nr + q] = vv[q]; }
-                        if (lane < nw) { Ssm[lane * SLD + nw] = tcol; Ssm[nw * SLD + lane] = tcol; }
-                        if (lane + 64 < nw) { Ssm[(lane + 64) * SLD + nw] = tcol2; Ssm[nw * SLD + lane + 64] = tcol2; }
-                        double snn = 0;
-                        for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
-                        snn = wave_sum(snn);
-                        if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; sgq[nw] = sgn; }
-                        ++nw; added = true;
-                    } else {                                            // a multiplier hit zero: that row leaves, try again
-                        drop_row(kdrop);
-                    }
-                    nl_wave_sync();
-                }
-                if (!qp_ok) break;
-                if (!added) { qp_ok = false; break; }
-            }
-            if (!qp_ok || !qp_done) { code = qp_fail ? qp_fail : -1; break; }
-            for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
-            nl_wave_sync();
-            for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = sgq[t] * uq[t];
-            nw_keep = nw;
-            for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
-            nl_wave_sync();
-
-            lap(3);
-            // ---- full-space step d = [r + Phi p_u ; p]
-            double dmax = 0, cmax = 0, gd = 0;
-            for (int row = lane; row < nxs; row += 64) {
-                const double s = r[row] + gdot2(phi + (size_t)row * nzu, 1, p, 1, nzu);
-                d[row] = s;
-            }
-            for (int q = lane; q < nr; q += 64) d[nxs + q] = p[q];
-            nl_wave_sync();
-            for (int k = lane; k < nz; k += 64) { dmax = fmax(dmax, fabs(d[k])); gd += g[k] * d[k]; }
-            for (int k = lane; k < nxs; k += 64) cmax = fmax(cmax, fabs(c[k]));
-            dmax = wave_max(dmax); cmax = wave_max(cmax); gd = wave_sum(gd);
-            double zmax = 0;
-            for (int k = lane; k < nz; k += 64) zmax = fmax(zmax, fabs(z[k]));
-            zmax = wave_max(zmax);
-            for (int k = mi + lane; k < m; k += 64) cmax = fmax(cmax, fabs(gin[k]));     // user equalities count as defects
-            cmax = wave_max(cmax);
-            if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
-                // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
-                for (int k = lane; k < nz; k += 64) z[k] += d[k];
-                nl_wave_sync();
-                code = 4; ++it;
-                final_eval = true;
-                continue;
-            }
-
-            // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
-            for (int q = lane; q < nq; q += 64) {
-                double gl = gr[q];
-                for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
-                glold[q] = gl;
-            }
-            // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
-            // the weight of the l1 merit function has to dominate them and mu
-            for (int row = lane; row < nxs; row += 64) {
-                double s2 = g[row];
-                for (int t = 0; t < nw_keep; ++t) {                     // mu lives on the working set
-                    const int k = (int)wq[t];
-                    if (k < m) s2 += jin[(size_t)k * nz + row] * (sgq[t] * uq[t]);
-                    else if (M.bnd_idx[k - m] == row) s2 += M.bnd_sign[k - m] * uq[t];
-                }
-                lamw[row] = s2;
-            }
-            nl_wave_sync();
-            double lam_max = 0;
-            {
-                double *tl = aug, *ln = aug + NX;                  // t and lam_{i+1}
-                // the operands of step i-1 are requested before step i computes: the sweep is a chain of ph dependent steps and
-                // would otherwise pay a memory latency in each
-                double an[NX], en[NX], wn = 0.0;
-                auto fetch = [&](int i) {
-                    if (lane < NX) {
-                        wn = lamw[i * NX + lane];
-                        const double *Jb = jeq + (size_t)min(i + 1, ph - 1) * NX * W;
-#pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) an[bb] = i + 1 < ph ? Jb[bb * W + lane] : 0.0;
-                        if (Mdl::CONTINUOUS) {
-                            const double *Ei = einv + (size_t)i * NX * NX;
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) en[bb] = Ei[bb * NX + lane];
-                        }
-                    }
-                };
-                if (lane < NX) ln[lane] = 0.0;
-                fetch(ph - 1);
-                nl_wave_sync();
-                for (int i = ph - 1; i >= 0; --i) {
-                    double ac[NX], ec[NX];
-                    const double wc = wn;
-#pragma unroll
-                    for (int bb = 0; bb < NX; ++bb) { ac[bb] = an[bb]; ec[bb] = en[bb]; }
-                    if (i > 0) fetch(i - 1);
-                    if (lane < NX) {
-                        double s2 = wc;
-#pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) s2 = fma(ac[bb], ln[bb], s2);
-                        tl[lane] = s2;
-                    }
-                    nl_wave_sync();
-                    if (lane < NX) {
-                        double lam;
-                        if (Mdl::CONTINUOUS) {
-                            lam = 0;
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) lam = fma(-ec[bb], tl[bb], lam);
-                        } else {
-                            lam = -tl[lane];
-                        }
-                        ln[lane] = lam;
-                        lam_max = fmax(lam_max, fabs(lam));
-                    }
-                    nl_wave_sync();
-                }
-            }
-            for (int r = lane; r < nw_keep; r += 64) lam_max = fmax(lam_max, fabs(uq[r]));
-            lam_max = wave_max(lam_max);
-            if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
-            double viol = 0;
-            for (int k = lane; k < nxs; k += 64) viol += fabs(c[k]);
-            for (int k = lane; k < m; k += 64) viol += k < mi ? fmax(gin[k], 0.0) : fabs(gin[k]);
-            viol = wave_sum(viol);
-            const double phi0 = scal[0] + nu_pen * viol;
-            const double dphi = fmin(gd - nu_pen * viol, 0.0);
-
-            // ---- line search: lane l tries a = 2^-l on the l1 merit function
-            unwrap<Mdl>(M, z, x0, Xs, Us, lane);
-            for (int k = lane; k < (ph + 1) * NX; k += 64) { const int i = k / NX; dXs[k] = i == 0 ? 0.0 : d[k - NX]; }
-            for (int k = lane; k < (ph + 1) * NU; k += 64) {
-                const int i = k / NU, j = k - i * NU;
-                dUs[k] = d[nxs + min(min(i, ph - 1), ch - 1) * NU + j];
-            }
-            nl_wave_sync();
-            double a_step;
-            {
-                // eight step lengths at a time, eight lanes each: lane (g, part) evaluates every eighth defect and constraint of
-                // trial point a = 2^-(g + 8 round), the cost is one lane's (it is a black box over the whole horizon), a
-                // three-step butterfly adds the parts up.  Almost always the first round holds an acceptable length.
-                const int grp = lane >> 3, part = lane & 7;
-                unsigned long long bal = 0;
-                int round = 0;
-                for (; round < 5 && !bal; ++round) {
-                    const double al = ldexp(1.0, -(grp + 8 * round));
-                    const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
-                    const double et = z[nz - 1] + al * d[nz - 1];
-                    double mer = part == 0 ? Mdl::cost(XL, UL, et, ph, prm) : 0.0, vio = 0;
-                    const double h = 0.5 * M.Ts;
-                    for (int i = part; i < ph; i += 8) {
-                        double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
-                        for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
-                        for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
-                        Mdl::f(fa, xk, uk, prm);
-                        if (Mdl::CONTINUOUS) {
-                            Mdl::f(fb, xk1, uk, prm);
-                            for (int a = 0; a < NX; ++a) vio += fabs(xk[a] + (h * (fa[a] + fb[a])) - xk1[a]);
-                        } else {
-                            for (int a = 0; a < NX; ++a) vio += fabs(xk1[a] - fa[a]);
-                        }
-                    }
-                    for (int k = part; k < mi; k += 8) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
-                    for (int k = part; k < m - mi; k += 8) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
-                    mer += nu_pen * vio;
-                    mer += __shfl_xor(mer, 1); mer += __shfl_xor(mer, 2); mer += __shfl_xor(mer, 4);
-                    const bool ok = part == 0 && mer <= phi0 + 1e-4 * al * dphi;
-                    bal = __ballot(ok);
-                }
-                if (!bal) {                                         // no decrease left within 2^-40: the iteration has stalled
-                    if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
-                    if (resets >= 5) { code = -4; break; }
-                    // far from a solution: the curvature estimate has gone bad -- forget it and try a steepest-descent-like step
-                    ++resets;
-                    for (int k = lane; k < nr * nr; k += 64) hinv[k] = (k / nr == k % nr) ? 1.0 : 0.0;
-                    have_old = false;
-                    nl_wave_sync();
-                    ++it;
-                    continue;
-                }
-                a_step = ldexp(1.0, -((int)__builtin_ctzll(bal) / 8 + 8 * (round - 1)));
-            }
-            for (int q = lane; q < nr; q += 64) sv[q] = a_step * p[q];
-            for (int k = lane; k < nz; k += 64) z[k] += a_step * d[k];
-            a_prev = a_step; have_old = true;
-            nl_wave_sync();
-            ++it;
-        }
-        if (lane == 0) for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k];
-
-        // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
-        double gmax = -1e300;
-        double hmax = 0.0;
-        for (int k = lane; k < m; k += 64) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
-        gmax = wave_max(gmax); hmax = wave_max(hmax);
-        unwrap<Mdl>(M, z, x0, Xs, Us, lane);
-        const bool failed = code < 0;
-        if (S.cmd) for (int j = lane; j < NU; j += 64) S.cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
-        if (S.z_out) for (int k = lane; k < nz; k += 64) S.z_out[(size_t)b * nz + k] = z[k];
-        if (S.seq_state) for (int k = lane; k < (ph + 1) * NX; k += 64) S.seq_state[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
-        if (S.seq_input) for (int k = lane; k < (ph + 1) * NU; k += 64) S.seq_input[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
-        if (S.seq_output)                                   // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
-            for (int i = lane; i <= ph; i += 64) {
-                double y[Mdl::NY];
-                for (int a = 0; a < Mdl::NY; ++a) y[a] = 0.0;
-                if (Mdl::HAS_OUTPUT && !failed) Mdl::out(y, Xs + i * NX, Us + i * NU, prm);
-                for (int a = 0; a < Mdl::NY; ++a) S.seq_output[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
-            }
-        if (lane == 0) {
-            if (S.cost) S.cost[b] = failed ? INFINITY : scal[0];
-            if (S.solver_status) S.solver_status[b] = code;
-            if (S.status) S.status[b] = code == 4 ? 0 : (code == 5 ? 1 : 3);         // SUCCESS / MAX_ITERATION / ERROR
-            if (S.is_feasible) S.is_feasible[b] = ((mi == 0 || gmax <= S.ieq_tol) && hmax <= S.eq_tol) ? 1 : 0;    // Constraints.hpp:157-202
-            if (S.iterations) S.iterations[b] = it;
-        }
-        nl_wave_sync();
-    }
-}
 
 template <class F>
 int dispatch_model(int model_id, F &&fn)
@@ -1185,68 +35,16 @@ int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq
     });
 }
 
-void nlmpc_plan(NlmpcDev &m)
+void nlmpc_plan_host(NlmpcDev &m) { engine::nlmpc_plan(m); }
+
+int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream)
 {
-    const int nx = m.nx, nu = m.nu, ph = m.ph;
-    m.nzu = m.ch * nu; m.nr = m.nzu + 1;
-    m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
-    // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
-    m.kw = min(kNlMaxWorking, max(kNlLdsWorking, min(m.nineq + m.nue + m.nbnd, m.nr)));
-    const int KW = m.kw;
-    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + kNlLdsWorking * (kNlLdsWorking + 1) + 4 * KW + nx * 2 * nx + 4 * m.nr +
-                      (m.nineq + m.nue) * ((ph * nx + 63) / 64) + 1) & ~1;
-    int o = 0;
-    auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
-    NlmpcWsLayout &w = m.ws;
-    const int mtot = m.nineq + m.nue + m.nbnd;
-    const int mld = (mtot + 1) & ~1;
-    w.z = take(m.nz); w.d = take(m.nz); w.g = take(m.nz); w.c = take(m.neq); w.jeq = take(ph * nx * (2 * nx + nu));
-    w.gin = take(m.nineq + m.nue); w.jin = take((m.nineq + m.nue) * m.nz);
-    w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
-    w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(mtot);
-    w.hinv = take(m.nr * m.nr); w.mu = take(mtot); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
-    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
-    w.lamw = take(m.neq);
-    w.total = o;
+    return dispatch_model(m->model_id, [&](auto mdl) { return engine::launch_evaluate<decltype(mdl)>(nullptr, m, b, stream); });
 }
 
-static int waves_per_block(const NlmpcDev &m)
+int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
-    int wpb = (int)((64 * 1024) / (m.lds_per_wave * sizeof(double)));
-    return wpb > 4 ? 4 : wpb;
-}
-
-int nlmpc_launch(const NlmpcDev &m, const NlmpcBatchDev &b, void *stream)
-{
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int wpb = waves_per_block(m);
-    if (wpb < 1) return -2;
-    int blocks = (b.batch + wpb - 1) / wpb;
-    if (blocks > 4096) blocks = 4096;
-    const size_t lds = (size_t)wpb * m.lds_per_wave * sizeof(double);
-    const int rc = dispatch_model(m.model_id, [&](auto mdl) {
-        using Mdl = decltype(mdl);
-        hipLaunchKernelGGL(nlmpc_evaluate<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, m, b);
-        return 0;
-    });
-    if (rc) return rc;
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-int nlmpc_launch_solve(const NlmpcDev &m, const NlmpcSolveDev &b, void *stream)
-{
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int wpb = waves_per_block(m);
-    if (wpb < 1) return -2;
-    int blocks = (b.batch + wpb - 1) / wpb;
-    const size_t lds = (size_t)wpb * m.lds_per_wave * sizeof(double);
-    const int rc = dispatch_model(m.model_id, [&](auto mdl) {
-        using Mdl = decltype(mdl);
-        hipLaunchKernelGGL(nlmpc_sqp<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, m, b);
-        return 0;
-    });
-    if (rc) return rc;
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return dispatch_model(m->model_id, [&](auto mdl) { return engine::launch_solve<decltype(mdl)>(nullptr, m, b, stream); });
 }
 
 }  // namespace mpcx

@@ -4,8 +4,13 @@
 `NLOptimizer<>` stand (include/mpc/NLMPC/NLOptimizer.hpp:760-997): given decision vectors it
 returns the cost and its gradient, the dynamics equalities with their Jacobian blocks and the user
 inequalities with theirs -- for a whole batch in one kernel launch through the C ABI
-(`mpcx_nlmpc_*`, include/mpcx.h).  The system/cost/constraint hooks are the library's built-in
-device functors (the reference's example systems); arbitrary host callables cannot run in a kernel.
+(`mpcx_nlmpc_*`, include/mpcx.h).
+
+The system / cost / constraint hooks are device code: either one of the reference's example systems built
+into the library (`model=VANDERPOL` ...), or **user hooks given as C++ text** -- the bodies of the lambdas one
+would hand to `setStateSpaceFunction`, `setObjectiveFunction`, `setIneqConFunction`, `setEqConFunction`,
+`setOutputFunction` in the reference (NLMPC.hpp:139-281) -- compiled at run time for gfx950 (hipRTC,
+`mpcx_nlmpc_create_from_source`).  A Python callable cannot run inside a kernel, its C++ spelling can.
 No CPU fallback.
 """
 from __future__ import annotations
@@ -40,10 +45,50 @@ class NLMPCEvaluator:
         check(self._lib.mpcx_nlmpc_create(int(model), int(ph), int(ch), float(Ts),
                                           None if prm is None else prm.ctypes.data, 0 if prm is None else prm.size,
                                           int(device), C.byref(self._h)))
+        self._read_dims()
+
+    @classmethod
+    def from_sources(cls, nx, nu, ny, ph, ch, ineq, eq, Ts, *, state_fn, objective_fn, ineq_fn=None, eq_fn=None, output_fn=None,
+                     preamble=None, device=0):
+        """A controller whose hooks are the C++ bodies of the reference's lambdas (NLMPC.hpp:139-281), compiled at run time.
+
+        Parameter names inside the bodies: state_fn (dx, x, u, step); objective_fn (x, y, u, e) -> return the cost;
+        ineq_fn (in_con, x, y, u, e); eq_fn (eq_con, x, u); output_fn (y, x, u, step).  Types are the reference's
+        (mpc::cvec<n>, mpc::mat<ph+1, n>), and num_states, num_inputs, num_output, pred_hor, ctrl_hor, ineq_c, eq_c are in
+        scope.  Ts > 0: state_fn is dx/dt (setDiscretizationSamplingTime(Ts)); Ts <= 0: it returns x(k+1)."""
+        self = cls.__new__(cls)
+        self._lib = _capi.lib()
+        self._h = C.c_void_p()
+        self.device = device
+        enc = lambda t: None if t is None else t.encode()
+        src = _capi.NlmpcSource(int(nx), int(nu), int(ny), int(ph), int(ch), int(ineq), int(eq), enc(preamble), enc(state_fn),
+                                enc(objective_fn), enc(ineq_fn), enc(eq_fn), enc(output_fn))
+        check(self._lib.mpcx_nlmpc_create_from_source(C.byref(src), float(Ts), int(device), C.byref(self._h)))
+        self._read_dims()
+        return self
+
+    def _read_dims(self):
         d = _capi.NlmpcDims()
         check(self._lib.mpcx_nlmpc_get_dims(self._h, C.byref(d)))
         self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w, self.neq_user, self.ny = (
             d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w, d.neq_user, d.ny)
+
+    @property
+    def nbnd(self):
+        """finite state / input bounds: the rows after the user constraints in `multipliers`"""
+        d = _capi.NlmpcDims()
+        check(self._lib.mpcx_nlmpc_get_dims(self._h, C.byref(d)))
+        return d.nbnd
+
+    def setInputScale(self, scaling):
+        """NLMPC::setInputScale (NLMPC.hpp:108): the hooks see U = scaling * z_u"""
+        v = np.ascontiguousarray(scaling, dtype=np.float64).reshape(self.nu)
+        check(self._lib.mpcx_nlmpc_set_input_scale(self._h, v.ctypes.data))
+
+    def setStateScale(self, scaling):
+        """NLMPC::setStateScale (NLMPC.hpp:123): the hooks see X = [x0; z_x] / scaling"""
+        v = np.ascontiguousarray(scaling, dtype=np.float64).reshape(self.nx)
+        check(self._lib.mpcx_nlmpc_set_state_scale(self._h, v.ctypes.data))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -82,10 +127,11 @@ class NLMPCEvaluator:
 
 
 class NLMPC(NLMPCEvaluator):
-    """Batched counterpart of `mpc::NLMPC<>` (reference include/mpc/NLMPC.hpp) for the built-in systems: the hooks
-    the reference takes as closures (`setStateSpaceFunction`, `setObjectiveFunction`, `setIneqConFunction`,
-    NLMPC.hpp:139-280) are fixed by `model`; `setOptimizerParameters` and `optimize` keep their meaning, and
-    `optimizeBatch` runs B instances of NLOptimizer::run (NLOptimizer.hpp:412-638) in one kernel launch."""
+    """Batched counterpart of `mpc::NLMPC<>` (reference include/mpc/NLMPC.hpp).  The hooks the reference takes as
+    closures (`setStateSpaceFunction`, `setObjectiveFunction`, `setIneqConFunction`, ..., NLMPC.hpp:139-280) are either
+    those of a built-in `model` or C++ text given to `NLMPC.from_sources(...)`; `setOptimizerParameters`, the bound and
+    scale setters and `optimize` keep their meaning, and `optimizeBatch` runs B instances of NLOptimizer::run
+    (NLOptimizer.hpp:412-638) in one kernel launch."""
 
     def setOptimizerParameters(self, p):
         check(self._lib.mpcx_nlmpc_set_optimizer_parameters(self._h, C.byref(p)))
@@ -113,11 +159,11 @@ class NLMPC(NLMPCEvaluator):
         raise RuntimeError("Output constraints cannot be set for this type of MPC")        # NLMPC.hpp:318-325
 
     def _closures_are_fixed(self, *_a, **_k):
-        raise RuntimeError("the system, objective and constraint functions of this controller are the built-in device "
-                           "functors of its model; host callables cannot run inside the kernel")
+        raise RuntimeError("a Python callable cannot run inside the kernel: give the hook bodies as C++ text to "
+                           "NLMPC.from_sources(...), or use a built-in model")
     setStateSpaceFunction = setObjectiveFunction = setIneqConFunction = setEqConFunction = setOutputFunction = _closures_are_fixed
 
-    def make_batch(self, x0, u0, z_warm=None, sequences=False, warm_curvature=False):
+    def make_batch(self, x0, u0, z_warm=None, sequences=False, warm_curvature=False, multipliers=False):
         import torch
         dev = torch.device("cuda", self.device)
         x0 = x0.to(dev, torch.float64).contiguous(); u0 = u0.to(dev, torch.float64).contiguous()
@@ -129,6 +175,8 @@ class NLMPC(NLMPCEvaluator):
         if sequences:
             out["seq_state"] = f(self.ph + 1, self.nx); out["seq_input"] = f(self.ph + 1, self.nu)
             out["seq_output"] = f(self.ph + 1, self.ny)
+        if multipliers:
+            out["multipliers"] = f(self.nineq + self.neq_user + self.nbnd)
         zw = None if z_warm is None else z_warm.to(dev, torch.float64).contiguous()
         b = _capi.NlmpcBatch(batch=B, x0=x0.data_ptr(), u0=u0.data_ptr(), z_warm=None if zw is None else zw.data_ptr(),
                              **{k: v.data_ptr() for k, v in out.items()})
@@ -136,9 +184,9 @@ class NLMPC(NLMPCEvaluator):
         out["_keep"] = (x0, u0, zw)
         return b, out
 
-    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None, warm_curvature=False):
+    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None, warm_curvature=False, multipliers=False):
         import torch
-        b, out = self.make_batch(x0, u0, z_warm, sequences, warm_curvature)
+        b, out = self.make_batch(x0, u0, z_warm, sequences, warm_curvature, multipliers)
         s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if stream is None else stream
         check(self._lib.mpcx_nlmpc_solve_batch(self._h, C.byref(b), s))
         return out
@@ -163,7 +211,7 @@ class NLMPC(NLMPCEvaluator):
         return r
 
     _WS_FIELDS = ("z", "d", "g", "c", "jeq", "gin", "jin", "r", "phi", "einv", "gr", "art", "br", "hinv", "mu", "glold", "s", "p",
-                  "qn", "qv", "qs", "qs2", "scal", "lamw", "total")
+                  "qn", "qv", "qs", "qs2", "scal", "lamw", "hook", "total")
 
     def debug_workspace(self, instance):
         """testing aid: the SQP workspace of one instance after the last solve, as a dict of numpy arrays"""
