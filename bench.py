@@ -1,13 +1,22 @@
-"""bench.py -- MPC solves/sec on the reference's quadrotor LMPC (N=20), batch 4096 per GPU.
+"""bench.py -- MPC solves/sec of the batched solve path on MI355X.
 
-One "step" = one pass of the hot path (batched LOptimizer::run) over one batch of synthetic
-instances already resident in HBM.  N>1: one process per GPU (torch.distributed / RCCL),
-each rank solves its own shard, then one all-gather of u* over xGMI; weak scaling.
-Prints ONE JSON line on rank 0.
+Default workload: BASELINE.json's headline, the reference's quadrotor LMPC (N=20), batch 4096 per GPU.  One "step" = one
+pass of the hot path (batched LOptimizer::run / NLOptimizer::run) over one batch of synthetic instances already resident
+in HBM.  N>1: one process per GPU; each rank solves its own shard, then one RCCL all-gather of u* over xGMI issued through
+the C ABI (mpcx_allgather_u) on the solve stream; weak scaling.  Prints ONE JSON line on rank 0.
+
+  python bench.py                               # config 2: quadrotor LMPC N=20, 4096 instances, 1 GPU
+  python bench.py --gpus 8                      # spawns 8 ranks itself (torch.distributed.run); the driver may also
+                                                # launch the ranks, then RANK/WORLD_SIZE come from the environment
+  python bench.py --config 4 --gpus 8           # quadrotor N=50, 32768 per GPU (262144 on 8), 8 MiB all-gather
+  python bench.py --workload ugv|osc8|vanderpol|osc6   # the NLMPC configs (3, 5, 1) under the same contract
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,6 +28,21 @@ import torch
 
 PEAK_FP64_TFLOPS = 78.6      # MI355X FP64 vector == FP64 matrix peak; see DESIGN.md
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+CONFIGS = {1: ("vanderpol", 4096), 2: ("lmpc", 4096), 3: ("ugv", 4096), 4: ("lmpc50", 32768), 5: ("osc8", 1024)}
+
+
+def kernel_source_hash():
+    """what the committed PMC profiles are stamped with: a digest of every source the device code is built from"""
+    h = hashlib.sha256()
+    files = []
+    for d, pat in (("libmpc_amd/csrc", (".hip", ".hpp", ".cpp")), ("include/mpcx", (".hpp",))):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if f.endswith(pat):
+                files.append(os.path.join(ROOT, d, f))
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _usable_cores():
@@ -53,78 +77,162 @@ def _cpu_worker(job):
     return done, time.perf_counter() - t0
 
 
+def _nl_cpu_worker(job):
+    """NLMPC CPU baseline: the oracle (numpy callbacks + scipy SLSQP) on a few instances of the batch"""
+    name, x0, u0, budget = job
+    from oracle import nlmpc_numpy as ref
+    m = dict(ugv=lambda: ref.ugv(30, 30), vanderpol=lambda: ref.vanderpol(10, 5, 0.1), osc6=lambda: ref.oscillators(6, 20, 10),
+             osc8=lambda: ref.oscillators(8, 30, 15))[name]()
+    done, t0 = 0, time.perf_counter()
+    for i in range(x0.shape[0]):
+        m.solve(x0[i], u0[i], max_iter=150, hard=(name != "ugv"))
+        done += 1
+        if time.perf_counter() - t0 > budget:
+            break
+    return done, time.perf_counter() - t0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _traffic(dom, tag):
+    """HBM bytes of the dominant kernel per launch, from the committed rocprofv3 --pmc summary of this command
+    (tools/pmc_profile.sh).  The summary is stamped with the digest of the kernel sources it was measured on; a stale one is
+    refused rather than quoted."""
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)))
+    if not cand:
+        return None, None, "no PMC summary committed for this workload"
+    pm = json.load(open(cand[-1]))
+    if pm.get("kernel_source_hash") != kernel_source_hash():
+        return None, os.path.basename(cand[-1]), "PMC summary is stale: kernel sources changed since it was measured"
+    try:
+        # KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+        return (2.0 * pm["FETCH_SIZE"][dom]["mean"] + pm["WRITE_SIZE"][dom]["mean"]) * 1024.0, os.path.basename(cand[-1]), None
+    except KeyError:
+        return None, os.path.basename(cand[-1]), "kernel %s not in the PMC summary" % dom
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config number (1..5)")
+    ap.add_argument("--workload", default=None, choices=["lmpc", "lmpc50", "ugv", "osc8", "osc6", "vanderpol"],
+                    help="lmpc = quadrotor LMPC N=20 (config 2, the default); lmpc50 = N=50 (config 4); the others are NLMPC")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=None, help="LMPC prediction horizon (overrides the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the timed steps rotate over (each with its own controller handle, workspace and outputs); "
                          "1 = strictly serial steps (default: what `value`, the roofline and the rocprof trace refer to)")
     ap.add_argument("--pipeline-streams", type=int, default=3,
                     help="extra leg after the timed region: the same steps rotated over this many streams, reported as "
-                         "`pipelined_value` (0 = skip)")
+                         "`pipelined` (0 = skip)")
     args = ap.parse_args()
+    workload, batch = CONFIGS[args.config] if args.config else ("lmpc", 4096)
+    if args.workload:
+        workload = args.workload
+        batch = {"lmpc": 4096, "lmpc50": 32768, "ugv": 4096, "osc8": 1024, "osc6": 1024, "vanderpol": 4096}[workload]
+    if args.batch:
+        batch = args.batch
+    nl = workload not in ("lmpc", "lmpc50")
+    steps = args.steps if args.steps is not None else (200 if not nl else {"vanderpol": 50, "ugv": 5, "osc6": 5, "osc8": 3}[workload])
+    warmup = args.warmup if args.warmup is not None else (20 if not nl else 1)
 
+    # ---- ranks: the driver starts them (RANK / WORLD_SIZE in the environment) or we do
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    # MPCX_FORCE_DIST=1: take the RCCL path (process group, all-gather, barriers) even with one rank -- a single-GPU box can
+    # MPCX_FORCE_DIST=1: take the RCCL path (communicator, all-gather, barriers) even with one rank -- a single-GPU box can
     # then exercise the code the multi-GPU launches run
     use_dist = world > 1 or os.environ.get("MPCX_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    gather = None
+    if use_dist:
+        from libmpc_amd.distributed import ControlGather
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # rendezvous, barriers, the time reduction
+            assert dist.get_world_size() == args.gpus
+        gather = ControlGather(local, rank, world)           # the data-path collective: RCCL behind the C ABI
+        assert gather.world == world
 
-    from libmpc_amd.distributed import allgather_controls
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B = batch
+    if nl:
+        run_nlmpc(args, workload, B, steps, warmup, world, rank, local, dev, gather, barrier)
+    else:
+        ph = args.horizon if args.horizon else (50 if workload == "lmpc50" else 20)
+        run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrier)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def timed(step, steps, warmup, barrier, world, dev):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrier):
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
 
-    B, ph = args.batch, args.horizon
     x0, u0, yref = quadrotor_batch(B, first=rank * B)
     ns = max(1, args.streams)
     lanes = []
     for k in range(ns):
         c_k = quadrotor_lmpc(ph, device=local)
         b_k, r_k, keep_k = c_k.make_batch(x0, u0, yref=yref)
-        lanes.append((c_k, b_k, r_k, keep_k, torch.cuda.current_stream(local) if ns == 1 else torch.cuda.Stream(device=dev)))
-    ctl, batch, res, keep, stream = lanes[0]
+        all_k = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if gather else None
+        lanes.append((c_k, b_k, r_k, keep_k, torch.cuda.current_stream(local) if ns == 1 else torch.cuda.Stream(device=dev), all_k))
+    ctl, batch, res, keep, stream, _ = lanes[0]
     info = ctl.info()
     counter = [0]
 
     def step():
-        c_k, b_k, r_k, _, s_k = lanes[counter[0] % ns]
+        c_k, b_k, r_k, _, s_k, all_k = lanes[counter[0] % ns]
         counter[0] += 1
         with torch.cuda.stream(s_k):
             c_k.launch(b_k, s_k)
-            if use_dist:
-                return allgather_controls(r_k.cmd, force=True)
+            if gather:
+                return gather.allgather(r_k.cmd, out=all_k, stream=s_k.cuda_stream)     # same stream: starts when the solve retires
         return r_k.cmd
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(step, steps, warmup, barrier, world, dev)
 
     # extra leg: consecutive batches are independent, so a serving loop keeps several in flight -- the tail of one launch
     # (it lasts as long as its slowest instance) overlaps the start of the next.  Not `value`: reported beside it.
@@ -139,16 +247,16 @@ def main():
             pl[i % len(pl)][0].launch(pl[i % len(pl)][1], pl[i % len(pl)][4])
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             c_k, b_k, _, _, s_k = pl[i % len(pl)]
             c_k.launch(b_k, s_k)
         torch.cuda.synchronize()
-        pipelined = {"value": B * args.steps / (time.perf_counter() - tp0), "unit": "solves/s", "streams": len(pl),
+        pipelined = {"value": B * steps / (time.perf_counter() - tp0), "unit": "solves/s", "streams": len(pl),
                      "note": "same steps, independent handles and buffers per stream, launches overlap"}
 
     # per-step latency distribution (host-synchronised single steps), outside the timed region
     lat = []
-    for _ in range(min(50, max(5, args.steps))):
+    for _ in range(min(50, max(5, steps))):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step()
@@ -156,98 +264,189 @@ def main():
         lat.append(time.perf_counter() - t1)
     lat_p50 = float(np.median(lat)) * 1e3
 
-    if rank == 0:
-        # per-kernel average launch duration, HIP events on the launch stream (each kernel timed alone)
-        import ctypes as C
-        reps = max(10, min(args.steps, 100))
-        ms3 = (C.c_float * 3)()
-        ctl._lib.mpcx_lmpc_debug_time_kernels(ctl._h, C.byref(batch), C.c_void_p(stream.cuda_stream), reps, ms3)
-        all_ms = ctl.time_launches(batch, reps, stream)
-        torch.cuda.synchronize()
-        iters = res.iterations.cpu().numpy().astype(np.float64)
-        rounds = res.polish_rounds.cpu().numpy().astype(np.float64)
-        na = res.active_count.cpu().numpy().astype(np.float64)
-        status = res.status.cpu().numpy()
-        nz, mg = float(info["nz"]), float(info["mg"])
-        nin = 12 + 4 + 12 + 1
-        # algorithmic flops: what the arithmetic needs, not what padding executes
-        fl_assemble = B * (2.0 * (nz + mg + nin + nin) * nin + 2.0 * (nz + mg) * nz)
-        fl_polish = float((rounds * (na ** 3 / 3.0 + 2.0 * na ** 2 + 2.0 * na * (nz + mg) + 8.0 * (nz + mg))).sum()
-                          + B * (2.0 * nz * nz + 2.0 * nz))
-        fl_admm = float(iters.sum() * info["flops_per_admm_iter"])
-        kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve": (ms3[1], fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
-        dom = max(kern, key=lambda k: kern[k][0])
-        kern_ms, flops = kern[dom]
-        bytes_alg = float(B) * (8.0 * (12 + 4 + 12) + 8.0 * 4 + 8.0 + 16.0)   # x0,u0,yref in; cmd,cost,4 ints out
-        ach_tf = flops / (kern_ms * 1e-3) / 1e12
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from
-        # the two rocprofv3 --pmc passes of this same command whose per-kernel means are committed under profiles/
-        # (tools/pmc_summary.py).  KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-            if cand and B == 4096 and ph == 20:
-                pm = json.load(open(cand[-1]))
-                traffic = (2.0 * pm["FETCH_SIZE"][dom]["mean"] + pm["WRITE_SIZE"][dom]["mean"]) * 1024.0
-                traffic_src = os.path.basename(cand[-1])
-        except Exception:
-            traffic = None
-        roof = {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": dom, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops,
-                "note": "f64 path, latency/issue-bound small dense factorisations; peak = FP64 vector = FP64 MFMA peak",
-                "kernels_ms": {k: round(v[0], 5) for k, v in kern.items()}, "all_kernels_ms": all_ms,
-                "all_kernels_achieved_TFLOPs": (fl_assemble + fl_polish + fl_admm) / (all_ms * 1e-3) / 1e12,
-                "mean_polish_rounds": float(rounds.mean()), "mean_active_set": float(na.mean()),
-                "mean_admm_iters": float(iters.mean()),
-                "hbm_achieved_GBs": bytes_alg / (all_ms * 1e-3) / 1e9,
-                "hbm_frac": bytes_alg / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "algorithmic_bytes_per_launch": bytes_alg}
-        cpu = None
-        if world == 1 and args.cpu_seconds > 0:
-            # (i) one thread, every instance in turn -> per-solve latency and single-core rate; (ii) all host
-            # cores, instances split over worker processes -> the node's CPU rate (`value`, `cores`)
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from helpers import quadrotor_oracle
-            o = quadrotor_oracle(ph)
-            probe = o.solve_batch_constref(x0[:32], u0[:32], yref[:32])
-            per = probe["seconds"] / 32
-            n1 = int(max(32, min(B, 0.4 * args.cpu_seconds / per)))
-            rr = o.solve_batch_constref(x0[:n1], u0[:n1], yref[:n1])
-            ps = np.sort(rr["per_solve_seconds"])
-            ncores = _usable_cores()
-            import multiprocessing as mp
-            per_core = max(8, min(64, B // ncores))
-            budget = 0.5 * args.cpu_seconds
-            with mp.get_context("fork").Pool(ncores) as pool:
-                chunks = [(ph, x0[(i * per_core) % B:][:per_core], u0[(i * per_core) % B:][:per_core], yref[(i * per_core) % B:][:per_core], budget)
-                          for i in range(ncores)]
-                res_cpu = pool.map(_cpu_worker, chunks)
-            done = sum(r[0] for r in res_cpu)
-            t_all = max(r[1] for r in res_cpu)         # workers run concurrently: the slowest one closes the interval
-            cpu = {"value": done / t_all, "unit": "solves/s", "cores": ncores, "kind": "port",
-                   "sample": f"{done} solves in {t_all:.1f} s: {ncores} worker processes (one per host core), each repeating its own "
-                             f"{per_core} instances of the same batch, set-up per solve as LOptimizer::run; single-thread "
-                             f"figures from the first {n1} instances",
-                   "single_thread_value": n1 / rr["seconds"],
-                   "p50_ms": float(ps[len(ps) // 2] * 1e3), "p99_ms": float(ps[int(len(ps) * 0.99) - 1] * 1e3)}
-        total = world * B * args.steps
-        out = {"metric": "MPC solves/sec (whole node) + p50 solve latency, quadrotor LMPC N=%d batch=%d" % (ph, B),
-               "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "quadrotor_ex.cpp LMPC nx=12 nu=4 ny=12 ph=ch=%d, batch %d per GPU, "
-                                      "SplitMix64 x0/u0/yref (SURVEY 8d), maximum_iteration=250" % (ph, B),
-                          "parallelism": "batch-sharded x%d, all-gather of u*" % world if world > 1 else "single GPU",
-                          "streams": ns},
-               "p50_step_latency_ms": lat_p50,
-               "pipelined": pipelined,
-               "solved_fraction": float((status == 0).mean()),
-               "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+    if rank != 0:
+        return
+    # per-kernel average launch duration, HIP events on the launch stream (each kernel timed alone)
+    import ctypes as C
+    reps = max(10, min(steps, 100))
+    ms3 = (C.c_float * 3)()
+    ctl._lib.mpcx_lmpc_debug_time_kernels(ctl._h, C.byref(batch), C.c_void_p(stream.cuda_stream), reps, ms3)
+    all_ms = ctl.time_launches(batch, reps, stream)
+    torch.cuda.synchronize()
+    iters = res.iterations.cpu().numpy().astype(np.float64)
+    rounds = res.polish_rounds.cpu().numpy().astype(np.float64)
+    na = res.active_count.cpu().numpy().astype(np.float64)
+    status = res.status.cpu().numpy()
+    nz, mg = float(info["nz"]), float(info["mg"])
+    nin = 12 + 4 + 12 + 1
+    # algorithmic flops: what the arithmetic needs, not what padding executes
+    fl_assemble = B * (2.0 * (nz + mg + nin + nin) * nin + 2.0 * (nz + mg) * nz)
+    fl_polish = float((rounds * (na ** 3 / 3.0 + 2.0 * na ** 2 + 2.0 * na * (nz + mg) + 8.0 * (nz + mg))).sum() + B * 4.0 * nz)
+    fl_admm = float(iters.sum() * info["flops_per_admm_iter"])
+    kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve": (ms3[1], fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
+    dom = max(kern, key=lambda k: kern[k][0])
+    kern_ms, flops = kern[dom]
+    bytes_alg = float(B) * (8.0 * (12 + 4 + 12) + 8.0 * 4 + 8.0 + 16.0)   # x0,u0,yref in; cmd,cost,4 ints out
+    ach_tf = flops / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_src, traffic_note = _traffic(dom, "lmpc%d_b%d" % (ph, B))
+    roof = {"bound": "mfma", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+            "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
+            "kernel": dom, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops,
+            "note": "f64 path, latency/issue-bound small dense factorisations; peak = FP64 vector = FP64 MFMA peak",
+            "kernels_ms": {k: round(v[0], 5) for k, v in kern.items()}, "all_kernels_ms": all_ms,
+            "all_kernels_achieved_TFLOPs": (fl_assemble + fl_polish + fl_admm) / (all_ms * 1e-3) / 1e12,
+            "mean_polish_rounds": float(rounds.mean()), "mean_active_set": float(na.mean()),
+            "mean_admm_iters": float(iters.mean()),
+            "hbm_achieved_GBs": bytes_alg / (all_ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_alg / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "algorithmic_bytes_per_launch": bytes_alg, "kernel_source_hash": kernel_source_hash()}
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        # (i) one thread, every instance in turn -> per-solve latency and single-core rate; (ii) all host
+        # cores, instances split over worker processes -> the node's CPU rate (`value`, `cores`)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import quadrotor_oracle
+        o = quadrotor_oracle(ph)
+        probe = o.solve_batch_constref(x0[:32], u0[:32], yref[:32])
+        per = probe["seconds"] / 32
+        n1 = int(max(32, min(B, 0.4 * args.cpu_seconds / per)))
+        rr = o.solve_batch_constref(x0[:n1], u0[:n1], yref[:n1])
+        ps = np.sort(rr["per_solve_seconds"])
+        ncores = _usable_cores()
+        import multiprocessing as mp
+        per_core = max(8, min(64, B // ncores))
+        budget = 0.5 * args.cpu_seconds
+        with mp.get_context("fork").Pool(ncores) as pool:
+            chunks = [(ph, x0[(i * per_core) % B:][:per_core], u0[(i * per_core) % B:][:per_core], yref[(i * per_core) % B:][:per_core], budget)
+                      for i in range(ncores)]
+            res_cpu = pool.map(_cpu_worker, chunks)
+        done = sum(r[0] for r in res_cpu)
+        t_all = max(r[1] for r in res_cpu)         # workers run concurrently: the slowest one closes the interval
+        cpu = {"value": done / t_all, "unit": "solves/s", "cores": ncores, "kind": "port",
+               "sample": f"{done} solves in {t_all:.1f} s: {ncores} worker processes (one per host core), each repeating its own "
+                         f"{per_core} instances of the same batch, set-up per solve as LOptimizer::run; single-thread "
+                         f"figures from the first {n1} instances",
+               "single_thread_value": n1 / rr["seconds"],
+               "p50_ms": float(ps[len(ps) // 2] * 1e3), "p99_ms": float(ps[int(len(ps) * 0.99) - 1] * 1e3)}
+    total = world * B * steps
+    out = {"metric": "MPC solves/sec (whole node) + p50 solve latency, quadrotor LMPC N=%d batch=%d" % (ph, B),
+           "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "quadrotor_ex.cpp LMPC nx=12 nu=4 ny=12 ph=ch=%d, batch %d per GPU, "
+                                  "SplitMix64 x0/u0/yref (SURVEY 8d), maximum_iteration=250" % (ph, B),
+                      "parallelism": ("batch-sharded x%d, RCCL all-gather of u* (%d x 4 doubles) through mpcx_allgather_u"
+                                      % (world, world * B)) if gather else "single GPU",
+                      "rccl_ranks": gather.world if gather else 0, "streams": ns},
+           "p50_step_latency_ms": lat_p50,
+           "pipelined": pipelined,
+           "solved_fraction": float((status == 0).mean()),
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def nl_make(name, B, first=0, device=0):
+    """the synthetic batches of SURVEY.md 8(d) configs 1, 3, 5 (same generator as tools/nlmpc_bench.py); `first` offsets
+    the stream so that every rank solves different instances"""
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS6, OSCILLATORS8, UGV, VANDERPOL
+    rng = np.random.default_rng(first)
+    if name == "ugv":
+        c = NLMPC(UGV, 30, 30, 0.1, device=device)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=150, hard_constraints=0))
+        x0 = np.zeros((B, 4)); x0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    elif name == "vanderpol":
+        c = NLMPC(VANDERPOL, 10, 5, 0.1, device=device)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+        x0 = rng.uniform(-1, 1, size=(B, 2))
+    else:
+        n = int(name[3:])
+        c = NLMPC(OSCILLATORS6 if n == 6 else OSCILLATORS8, 20 if n == 6 else 30, 10 if n == 6 else 15, 0.1, device=device)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+        x0 = rng.uniform(-0.1, 0.1, size=(B, 2 * n)); x0[:, 0] += 1.0
+    return c, x0, np.zeros((B, c.nu))
+
+
+def nl_flops(c, name, it, nact):
+    """algorithmic flops of the SQP solves of one batch: per iteration the transcription's function
+    evaluations, the condensing sweep, the reduction, the BFGS update and the dual active-set steps the final active set needs"""
+    nx, nu, ph, ch, nz = c.nx, c.nu, c.ph, c.ch, c.nz
+    nzu = ch * nu; nq = nzu + 1; nxs = ph * nx
+    ct = name != "ugv"
+    f_f = {"vanderpol": 8.0, "ugv": 16.0}.get(name, 6.0 * nu + 2.0 * nu * nu)        # one vector-field call
+    f_cost = (ph + 1) * (2.0 * nx + 2.0 * nu)                                          # one cost call
+    f_ineq = 4.0 if name == "ugv" else 1.0                                             # one constraint component
+    ev = f_cost * (ph * (nx + nu) + 3) + f_f * ph * (1 + ct) * (1 + 2 * (nx + nu)) + f_ineq * c.nineq * 3
+    cond = ph * (nzu + 1) * 2.0 * nx * nx * (1 + ct) + (ph * 2.0 * nx ** 3 if ct else 0.0)
+    red = 2.0 * nxs * nzu + 2.0 * c.nineq * nzu
+    bfgs = 8.0 * nq * nq
+    qp = 2.0 * nq * nq + nact * (2.0 * nq * nq + 4.0 * nq * nact)
+    ls = 8 * (f_cost + f_f * ph * (1 + ct) + f_ineq * c.nineq)
+    return float((it * (ev + cond + red + bfgs + ls) + it * qp).sum())
+
+
+def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, barrier):
+    c, x0, u0 = nl_make(name, B, first=rank * 7919, device=local)
+    x0t, u0t = torch.from_numpy(x0), torch.from_numpy(u0)
+    b, out = c.make_batch(x0t, u0t, multipliers=True)
+    stream = torch.cuda.current_stream(local)
+    all_u = torch.empty((world * B, c.nu), dtype=torch.float64, device=dev) if gather else None
+    import ctypes as C
+    from libmpc_amd._capi import check
+
+    def step():
+        check(c._lib.mpcx_nlmpc_solve_batch(c._h, C.byref(b), stream.cuda_stream))
+        if gather:
+            gather.allgather(out["cmd"], out=all_u, stream=stream.cuda_stream)
+
+    dt = timed(step, steps, warmup, barrier, world, dev)
+    if rank != 0:
+        return
+    kern_ms = c.time_launches(b, max(1, min(steps, 5)), stream.cuda_stream)       # HIP events on the launch stream
+    torch.cuda.synchronize()
+    st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy().astype(np.float64)
+    nact = (out["multipliers"].cpu().numpy() != 0).sum(axis=1).astype(np.float64)
+    flops = nl_flops(c, name, it, nact)
+    bytes_alg = float(B) * 8.0 * (c.nx + c.nu + c.nu + 1 + 2)
+    ach = flops / (kern_ms * 1e-3) / 1e12
+    dom = "nlmpc_sqp"
+    traffic, traffic_src, traffic_note = _traffic(dom, "%s_b%d" % (name, B))
+    roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+            "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
+            "kernel": dom, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops,
+            "note": "f64 SQP, one instance per wavefront, latency-bound dependent iterations; flop model in DESIGN.md section 6",
+            "mean_iterations": float(it.mean()), "max_iterations": int(it.max()), "mean_active_rows": float(nact.mean()),
+            "hbm_achieved_GBs": bytes_alg / (kern_ms * 1e-3) / 1e9, "hbm_frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "algorithmic_bytes_per_launch": bytes_alg, "workspace_bytes_per_instance": int(c.debug_workspace_bytes()),
+            "kernel_source_hash": kernel_source_hash()}
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        ncores = _usable_cores()
+        per = {"vanderpol": 64, "ugv": 2, "osc6": 1, "osc8": 1}[name]
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(ncores) as pool:
+            res_cpu = pool.map(_nl_cpu_worker, [(name, x0[(i * per) % B:][:per], u0[(i * per) % B:][:per], args.cpu_seconds) for i in range(ncores)])
+        done = sum(r[0] for r in res_cpu); t_all = max(r[1] for r in res_cpu)
+        cpu = {"value": done / t_all, "unit": "solves/s", "cores": ncores, "kind": "port",
+               "sample": f"{done} solves in {t_all:.1f} s: {ncores} worker processes, each its own {per} instance(s) of the same "
+                         f"batch; oracle = numpy restatement of the reference's callbacks + scipy SLSQP (Kraft's code, what "
+                         f"NLopt's LD_SLSQP translates)"}
+    label = {"vanderpol": "vanderpol_ex.cpp NLMPC nx=2 nu=1 ph=10 ch=5 (config 1)",
+             "ugv": "ugv_ex.cpp NLMPC nx=4 nu=2 ph=ch=30, soft constraints (config 3)",
+             "osc6": "networked_oscillators_ex.cpp NLMPC 6 oscillators nx=12 nu=6 ph=20 ch=10 (the reference example)",
+             "osc8": "networked_oscillators_ex.cpp NLMPC 8 oscillators nx=16 nu=8 ph=30 ch=15 (config 5)"}[name]
+    o = {"metric": "MPC solves/sec (whole node), %s batch=%d" % (name, B), "value": world * B * steps / dt, "unit": "solves/s",
+         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+         "config": {"workload": label + ", batch %d per GPU, cold starts" % B,
+                    "parallelism": ("batch-sharded x%d, RCCL all-gather of u* through mpcx_allgather_u" % world) if gather else "single GPU",
+                    "rccl_ranks": gather.world if gather else 0},
+         "solved_fraction": float(np.isin(st, (3, 4)).mean()),
+         "solver_status_counts": {int(k): int((st == k).sum()) for k in np.unique(st)},
+         "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(o))
 
 
 if __name__ == "__main__":

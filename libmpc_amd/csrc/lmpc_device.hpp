@@ -27,7 +27,7 @@ struct LmpcDev {
     int has_dist, n_fixed;
     // solver parameters
     int max_iter, polish, check_every, polish_rounds0, polish_rounds;
-    int use_quad;                                // 1: four-instances-per-wavefront polish kernel where it applies
+    int cost_direct;                             // 1: cost from its definition (regularised Hessian), 0: from the multipliers
     int strict_infeasible;                       // 1: report INFEASIBLE / NaN; 0: behave as the reference does
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
     // per-wave LDS carve (in doubles)

@@ -23,6 +23,7 @@
 // element 0), so the compiler keeps many of them in flight.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <type_traits>
@@ -365,7 +366,13 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
             st2(ws + ldz + ldy + ldg + r, ug[2 * c], ug[2 * c + 1]);
         }
     }
-    if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, infeasible0 ? 1.0 : 0.0);
+    // the record carries c0 + f't0 / 2: with f = -H t0 the cost at w = t0 - Y[:, A] lambda is that constant plus
+    // lambda' (N_A t0 - b_A) / 2 (lmpc_solve), and the solve kernel needs neither f nor H
+    double ft = 0;
+#pragma unroll
+    for (int s = 0; s < NZS; ++s) ft = fma(f[s], t0[s], ft);
+    ft = wave_sum(ft);
+    if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0 + 0.5 * ft, infeasible0 ? 1.0 : 0.0);
     wave_sync();
 }
 
@@ -507,6 +514,14 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             for (; kb < nz4; ++kb)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
             unsigned nv = 0;
+            if (16 * t < M.nz16) {              // rows of t0: f't0 / 2 joins the cost constant (f of row 4k + kq sits in Bf[k][lane])
+                double ftp = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ftp = fma(acc[r], Bf[(4 * t + r) * 64 + lane], ftp);
+                ftp += __shfl_xor(ftp, 16, 64);
+                ftp += __shfl_xor(ftp, 32, 64);
+                if (kq == 0) atomicAdd(&c0s[j], 0.5 * ftp);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
@@ -586,9 +601,13 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int c = 0; c < CPZ; ++c) {
         const int e = 128 * c + 2 * lane;
         const int eo = e < ldz ? e : 0;
-        const d2 vf = ld2(ws + eo), vt = ld2(ws + ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
+        const d2 vt = ld2(ws + ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
         const bool ok = e < ldz;
-        f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
+        f[2 * c] = 0.0; f[2 * c + 1] = 0.0;
+        if constexpr (ADMM) {                   // the polish-only kernel needs neither f nor H (see the cost below)
+            const d2 vf = ld2(ws + eo);
+            f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
+        }
         t0[2 * c] = ok ? vt.x : 0.0; t0[2 * c + 1] = ok ? vt.y : 0.0;
         lw[2 * c] = ok ? vl.x : -INF; lw[2 * c + 1] = ok ? vl.y : -INF;
         uw[2 * c] = ok ? vu.x : INF; uw[2 * c + 1] = ok ? vu.y : INF;
@@ -1225,14 +1244,29 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     wave_sync();
     if (infeasible) {
         cost = 1e30;
+    } else if (!ADMM && polished && !M.cost_direct) {
+        // w = t0 - Y[:, A] lambda with f = -H t0:  w'Hw/2 + f'w = lambda'(N_A t0 - b_A)/2 + f't0/2, and the record's constant
+        // already holds c0 + f't0/2 -- no pass over H, no f (the factorisation just solved S lambda = N_A t0 - b_A)
+        double j = 0;
+        if (lane < na_last) j = 0.5 * lam[lane] * (nt0[wsidx[lane]] - wsb[lane]);
+        cost = wave_sum(j) + c0;
     } else {
-        double hw[NZS];
+        // any other point (ADMM iterate, regularised Hessian): the definition.  The record's constant carries f't0/2: take it out
+        double hw[NZS], fl[NZS];
 #pragma unroll
-        for (int s = 0; s < NZS; ++s) hw[s] = 0;
+        for (int s = 0; s < NZS; ++s) { hw[s] = 0; fl[s] = f[s]; }
+        if constexpr (!ADMM) {
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                const d2 vf = ld2(ws + (e < ldz ? e : 0));
+                fl[2 * c] = e < ldz ? vf.x : 0.0; fl[2 * c + 1] = e < ldz ? vf.y : 0.0;
+            }
+        }
         matvec_acc<CPZ>(GP(H), ldz, ldz, nz, stage, hw, lane);
         double j = 0;
 #pragma unroll
-        for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + f[s]);
+        for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + fl[s]) - 0.5 * fl[s] * t0[s];
         cost = wave_sum(j) + c0;
     }
 #pragma unroll
@@ -1432,438 +1466,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
 }
 
 
-// =====================================================================================
-// solve, quad form: four instances per wavefront (16 lanes each), polish only
-// =====================================================================================
-// The active-set rounds are long dependent chains in which a working set of ~6 rows keeps at
-// most 16 lanes busy.  Here a wavefront carries four instances, one per DPP row of 16 lanes:
-// the same instruction stream factors four Schur complements at once (lane t of a row owns row
-// t; the pivot column is broadcast inside each row with v_mov_b32_dpp row_newbcast, which costs
-// no LDS round trip), fetches four sets of Y rows, verifies four KKT systems.  Vectors use one
-// unified index q (variables [0,ldz), constraint rows [ldz,ldy)); lane t owns q = 32c+2t, +1.
-// Leaves cost (-> lmpc_cost_mfma) and anything it cannot finish (-> lmpc_solve_admm) to others.
-template <int K> __device__ __forceinline__ double rowbcast(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_max16(double v)
-{
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-template <int K, int CAP> struct FactorStep {
-    // one elimination step of the in-register LDL' (rows owned by lanes, four systems at once)
-    static __device__ __forceinline__ void run(double (&Sr)[CAP], const int t, const int nag, const int namax,
-                                               const double dgi, double &mydinv, int &dep)
-    {
-        if (K < namax) {
-            const bool valid = K < nag && dep < 0;
-            const double dk = rowbcast<K>(Sr[K]);
-            const double d0 = rowbcast<K>(dgi);
-            const bool isdep = valid && !(dk > 1e-11 * d0);
-            if (isdep) dep = K;
-            const double rinv = (valid && !isdep) ? 1.0 / dk : 0.0;
-            if (t == K && valid && !isdep) mydinv = rinv;
-            const double lik = Sr[K] * rinv;
-            elim<K + 1>(Sr, t, namax, lik);
-            if (t > K && valid && !isdep) Sr[K] = lik;
-        }
-        FactorStep<K + 1, CAP>::run(Sr, t, nag, namax, dgi, mydinv, dep);
-    }
-    template <int J> static __device__ __forceinline__ void elim(double (&Sr)[CAP], const int t, const int namax, const double lik)
-    {
-        if constexpr (J < CAP) {
-            if (J < namax) {
-                const double tjk = rowbcast<J>(Sr[K]);
-                if (t >= J) Sr[J] = fma(-lik, tjk, Sr[J]);
-            }
-            elim<J + 1>(Sr, t, namax, lik);
-        }
-    }
-};
-template <int CAP> struct FactorStep<CAP, CAP> {
-    static __device__ __forceinline__ void run(double (&)[CAP], int, int, int, double, double &, int &) {}
-};
-template <int K, int CAP> struct FwdStep {
-    static __device__ __forceinline__ void run(const double (&Sr)[CAP], double &y, const int t, const int namax)
-    {
-        if (K < namax) { const double yk = rowbcast<K>(y); if (t > K) y = fma(-Sr[K], yk, y); }
-        FwdStep<K + 1, CAP>::run(Sr, y, t, namax);
-    }
-};
-template <int CAP> struct FwdStep<CAP, CAP> { static __device__ __forceinline__ void run(const double (&)[CAP], double &, int, int) {} };
-template <int K, int CAP> struct BwdStep {
-    static __device__ __forceinline__ void run(const double (&Sr)[CAP], double &y, const int t, const int namax)
-    {
-        if (K < namax) { const double xk = rowbcast<K>(y); if (t < K) y = fma(-Sr[K], xk, y); }
-        if constexpr (K > 0) BwdStep<K - 1, CAP>::run(Sr, y, t, namax);
-    }
-};
-
-template <int CE>
-__global__ __launch_bounds__(256, 2) void lmpc_solve_quad(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
-{
-    constexpr int NS = 2 * CE, QL = 32 * CE, CAP = kRegCap;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, t = lane & 15;
-    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, nz = M.nz, mg = M.mg, nu = M.nu;
-    const double INF = __builtin_huge_val();
-    // LDS slice of this (wave, row): nt0[QL] | lam[CAP] | wsb[CAP] | T[CAP*CAP] | wsidx[CAP] (ints)
-    constexpr int PER = QL + 2 * CAP + CAP * CAP + CAP / 2;
-    double *base = smem + (size_t)(wave * 4 + g) * PER;
-    double *nt0 = base, *lam = nt0 + QL, *wsb = lam + CAP, *T = wsb + CAP;
-    int *wsidx = reinterpret_cast<int *>(T + CAP * CAP);
-    const gdp gY = GP(Y);
-    const unsigned tmask = (1u << t) - 1u;
-    const double ptol = 1e-8;
-
-    for (int b0 = (blockIdx.x * 4 + wave) * 4; b0 < Bt.batch; b0 += gridDim.x * 16) {
-        const int bq = b0 + g;
-        const bool live = bq < Bt.batch;
-        const int bc = live ? bq : Bt.batch - 1;
-        gdw ws = glw(wsbase) + (size_t)bc * M.wsld;
-        const gdp wsr = gl((const double *)wsbase) + (size_t)bc * M.wsld;
-        const double flag0 = wsr[ldz + ldy + 2 * ldg + 1];
-        bool done = !live || flag0 != 0.0;      // anything unusual goes to the fallback kernel
-        bool solved = false;
-
-        double lo[NS], hi[NS], nw[NS];
-        int act[NS], pos[NS];
-        bool eq[NS];
-#pragma unroll
-        for (int c = 0; c < CE; ++c) {
-            const int q = 32 * c + 2 * t;
-            d2 vl, vh, vt;
-            vl.x = vl.y = -INF; vh.x = vh.y = INF; vt.x = vt.y = 0.0;
-            if (q < ldz) { vl = ld2(GP(lw) + q); vh = ld2(GP(uw) + q); vt = ld2(wsr + ldz + q); }
-            else if (q < ldy) { vl = ld2(wsr + ldz + ldy + (q - ldz)); vh = ld2(wsr + ldz + ldy + ldg + (q - ldz)); vt = ld2(wsr + ldz + q); }
-            lo[2 * c] = vl.x; lo[2 * c + 1] = vl.y; hi[2 * c] = vh.x; hi[2 * c + 1] = vh.y;
-            nw[2 * c] = vt.x; nw[2 * c + 1] = vt.y;
-            *reinterpret_cast<double2 *>(nt0 + q) = make_double2(vt.x, vt.y);
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int q = 32 * (s >> 1) + 2 * t + (s & 1);
-            const bool real = (q < nz) || (q >= ldz && q < ldz + mg);
-            eq[s] = real && (lo[s] == hi[s]);
-            act[s] = !real ? 0 : (eq[s] ? 1 : (nw[s] < lo[s] - ptol * fmax(1.0, fabs(lo[s])) ? -1 : (nw[s] > hi[s] + ptol * fmax(1.0, fabs(hi[s])) ? 1 : 0)));
-            pos[s] = 0;
-            if (!real) { lo[s] = -INF; hi[s] = INF; }
-        }
-        wave_sync();
-
-        int nag = 0, rounds = 0;
-        double dtol = 0;
-        const int hybrid_rounds = M.polish_rounds0 < 10 ? M.polish_rounds0 : 10;
-        const int max_rounds = hybrid_rounds > 0 ? hybrid_rounds + 24 : 0;
-        for (int rd = 0; rd < max_rounds; ++rd) {
-            if (!wave_any(!done)) break;
-            if (!done) ++rounds;
-            // ---- working set of each row
-            nag = 0;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int q = 32 * (s >> 1) + 2 * t + (s & 1);
-                const bool a = act[s] != 0 && !(done && !solved);   // a solved row keeps reproducing its solution
-                const unsigned m16 = (unsigned)(__ballot(a) >> (16 * g)) & 0xFFFFu;
-                const int p = nag + __popc(m16 & tmask);
-                pos[s] = p;
-                if (a && p < CAP) { wsidx[p] = q; wsb[p] = act[s] < 0 ? lo[s] : hi[s]; }
-                nag += __popc(m16);
-            }
-            if (nag > CAP) { done = true; nag = 0; }        // too large for this kernel: fallback
-            int namax = max(nag, __shfl_xor(nag, 16, 64));
-            namax = max(namax, __shfl_xor(namax, 32, 64));
-            namax = __builtin_amdgcn_readfirstlane(namax);
-            wave_sync();
-            int dep = -1;
-            double y = 0.0;
-            if (namax > 0) {
-                const int qi = nag > 0 ? wsidx[t < nag ? t : 0] : 0;
-                double Sr[CAP];
-#pragma unroll
-                for (int c = 0; c < CAP; ++c) {
-                    const int qc = nag > 0 ? wsidx[c < nag ? c : 0] : 0;
-                    Sr[c] = gY[(size_t)qi * ldy + qc];
-                }
-                y = (t < nag) ? nt0[qi] - wsb[t] : 0.0;
-                double dgi = 1.0, mydinv = 1.0;
-#pragma unroll
-                for (int c = 0; c < CAP; ++c) if (t == c) dgi = Sr[c];
-                FactorStep<0, CAP>::run(Sr, t, nag, namax, dgi, mydinv, dep);
-                FwdStep<0, CAP>::run(Sr, y, t, namax);
-                y *= mydinv;
-#pragma unroll
-                for (int c = 0; c < CAP; ++c)
-                    if (c < t && t < nag) T[t * CAP + c] = Sr[c];
-                wave_sync();
-#pragma unroll
-                for (int k = 0; k < CAP; ++k) {
-                    const bool ok = k > t && k < nag;
-                    const double v = T[(ok ? k : 0) * CAP + (ok ? t : 0)];
-                    Sr[k] = ok ? v : 0.0;
-                }
-                BwdStep<CAP - 1, CAP>::run(Sr, y, t, namax);
-                if (t < nag) lam[t] = y;
-                wave_sync();
-            }
-            const bool isdep = dep >= 0;
-            if (isdep) {
-                // linearly dependent working set: drop the offending row, redo the round
-                const int qd = wsidx[dep < nag ? dep : 0];
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (32 * (s >> 1) + 2 * t + (s & 1) == qd) act[s] = 0;
-            }
-            // ---- w = t0 - Y[:, A] lambda  (rows of the four working sets fetched side by side)
-            double lmax = 0.0;
-#pragma unroll
-            for (int c = 0; c < CE; ++c) {
-                const double2 v = *reinterpret_cast<const double2 *>(nt0 + 32 * c + 2 * t);
-                nw[2 * c] = v.x; nw[2 * c + 1] = v.y;
-            }
-            for (int a0 = 0; a0 < namax; a0 += 2) {
-                double la[2];
-                d2 mv[2][CE];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool ok = a0 + u < nag;
-                    la[u] = ok ? lam[a0 + u] : 0.0;
-                    const int qa = ok ? wsidx[a0 + u] : 0;          // rows past a row's working set: row 0, weight 0
-                    const gdp row = gY + (size_t)qa * ldy;
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) {
-                        const int q = 32 * c + 2 * t;
-                        mv[u][c] = ld2(row + (q < ldy ? q : 0));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    lmax = fmax(lmax, fabs(la[u]));
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) {
-                        nw[2 * c] = fma(-la[u], mv[u][c].x, nw[2 * c]);
-                        nw[2 * c + 1] = fma(-la[u], mv[u][c].y, nw[2 * c + 1]);
-                    }
-                }
-            }
-            lmax = row_max16(lmax);
-            dtol = 1e-9 * lmax + 1e-300;
-            // ---- verify / repair, per row of 16 lanes
-            bool nanv = false, drop = false, add = false;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) nanv |= !(nw[s] == nw[s]);
-            if (!done && !isdep) {
-                if (rd < hybrid_rounds) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        if (act[s] != 0 && !eq[s]) {
-                            const double l = lam[pos[s]];
-                            if ((act[s] < 0 && l > dtol) || (act[s] > 0 && l < -dtol)) { act[s] = 0; drop = true; }
-                        }
-                    const bool anydrop = ((unsigned)(__ballot(drop) >> (16 * g)) & 0xFFFFu) != 0u;
-                    drop = anydrop;
-                    if (!anydrop) {
-#pragma unroll
-                        for (int s = 0; s < NS; ++s)
-                            if (act[s] == 0) {
-                                if (nw[s] < lo[s] - ptol * fmax(1.0, fabs(lo[s]))) { act[s] = -1; add = true; }
-                                else if (nw[s] > hi[s] + ptol * fmax(1.0, fabs(hi[s]))) { act[s] = 1; add = true; }
-                            }
-                    }
-                } else {
-                    // late rounds: one exchange per round (the simultaneous rule cycles on a few
-                    // instances in a thousand; this one does not)
-                    double bestv = 0.0; int bests = -1;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        if (act[s] != 0 && !eq[s]) {
-                            const double l = lam[pos[s]];
-                            const double bad = act[s] < 0 ? l : -l;
-                            if (bad > dtol && bad > bestv) { bestv = bad; bests = s; }
-                        }
-                    double mx = row_max16(bestv);
-                    if (mx > 0.0) {
-                        const unsigned m16 = (unsigned)(__ballot(bestv == mx && bests >= 0) >> (16 * g)) & 0xFFFFu;
-                        if (t == __ffs(m16) - 1) {
-#pragma unroll
-                            for (int s = 0; s < NS; ++s) if (bests == s) act[s] = 0;
-                        }
-                        drop = true;
-                    } else {
-                        int side = 0;
-                        bestv = 0.0; bests = -1;
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            const int q = 32 * (s >> 1) + 2 * t + (s & 1);
-                            if (act[s] == 0) {
-                                const double vl = lo[s] - ptol * fmax(1.0, fabs(lo[s])) - nw[s];
-                                const double vu = nw[s] - hi[s] - ptol * fmax(1.0, fabs(hi[s]));
-                                const double v = fmax(vl, vu);
-                                if (v > 0.0) {
-                                    const double nv = v * rsqrt(gY[(size_t)(q < ldy ? q : 0) * ldy + (q < ldy ? q : 0)]);
-                                    if (nv > bestv) { bestv = nv; bests = s; side = vl > vu ? -1 : 1; }
-                                }
-                            }
-                        }
-                        mx = row_max16(bestv);
-                        if (mx > 0.0) {
-                            const unsigned m16 = (unsigned)(__ballot(bestv == mx && bests >= 0) >> (16 * g)) & 0xFFFFu;
-                            if (t == __ffs(m16) - 1) {
-#pragma unroll
-                                for (int s = 0; s < NS; ++s) if (bests == s) act[s] = side;
-                            }
-                            add = true;
-                        }
-                    }
-                }
-            }
-            const bool rownan = ((unsigned)(__ballot(nanv) >> (16 * g)) & 0xFFFFu) != 0u;
-            const bool rowchg = ((unsigned)(__ballot(drop || add) >> (16 * g)) & 0xFFFFu) != 0u;
-            if (!done && !isdep) {
-                if (rownan) done = true;                       // fallback
-                else if (!rowchg) { done = true; solved = true; }
-            }
-            wave_sync();
-        }
-
-        // ---- file the result of each solved row
-        if (solved) {
-#pragma unroll
-            for (int c = 0; c < CE; ++c) {
-                const int q = 32 * c + 2 * t;
-                if (q < ldz) {
-                    const double a0 = q < nz ? nw[2 * c] : 0.0, a1 = q + 1 < nz ? nw[2 * c + 1] : 0.0;
-                    st2(ws + ldz + q, a0, a1);                 // w replaces t0 in the workspace (cost kernel reads it)
-                    if (q < nu) glw(Bt.cmd)[(size_t)bq * nu + q] = a0;
-                    if (q + 1 < nu) glw(Bt.cmd)[(size_t)bq * nu + q + 1] = a1;
-                }
-            }
-            if (t == 0) {
-                ws[ldz + ldy + 2 * ldg + 1] = 3.0;              // solved, cost pending
-                if (Bt.solver_status) glw(Bt.solver_status)[bq] = 1;
-                if (Bt.status) glw(Bt.status)[bq] = 0;
-                if (Bt.is_feasible) glw(Bt.is_feasible)[bq] = 1;
-                if (Bt.iterations) glw(Bt.iterations)[bq] = 0;
-                if (Bt.polish_rounds) glw(Bt.polish_rounds)[bq] = rounds;
-                if (Bt.active_count) glw(Bt.active_count)[bq] = nag;
-            }
-        }
-        if (Bt.active_lower && Bt.active_upper) {
-            wave_sync();
-            unsigned *bl = reinterpret_cast<unsigned *>(T);
-            unsigned *bu = bl + M.active_words;
-            for (int wd = t; wd < 2 * M.active_words; wd += 16) bl[wd] = 0u;
-            wave_sync();
-            if (solved) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int q = 32 * (s >> 1) + 2 * t + (s & 1);
-                    if (act[s] == 0) continue;
-                    const double l = lam[pos[s]];
-                    if (!(fabs(l) > dtol)) continue;
-                    const int side = l < 0 ? -1 : 1;
-                    if (q < nz) {
-                        for (int p = GP(boxrow_ptr)[q]; p < GP(boxrow_ptr)[q + 1]; ++p) {
-                            const int rr = GP(boxrow_ref)[p];
-                            if (side < 0 && GP(boxrow_lo)[p] == lo[s]) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
-                            if (side > 0 && GP(boxrow_hi)[p] == hi[s]) atomicOr(&bu[rr >> 5], 1u << (rr & 31));
-                        }
-                    } else {
-                        const int rr = GP(g_refrow)[q - ldz];
-                        if (side < 0) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
-                        else atomicOr(&bu[rr >> 5], 1u << (rr & 31));
-                    }
-                }
-            }
-            wave_sync();
-            if (solved)
-                for (int wd = t; wd < M.active_words; wd += 16) {
-                    glw(Bt.active_lower)[(size_t)bq * M.active_words + wd] = bl[wd];
-                    glw(Bt.active_upper)[(size_t)bq * M.active_words + wd] = bu[wd];
-                }
-        }
-        wave_sync();
-    }
-}
-
-// cost = 0.5 w'Hw + f'w + c0 for the instances lmpc_solve_quad marked "cost pending": H*W on the
-// f64 MFMA pipe, 16 instances per workgroup (same operand chaining as lmpc_assemble_mfma)
-__global__ __launch_bounds__(256) void lmpc_cost_mfma(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
-    const int ldz = M.ldz, ldy = M.ldy, ldg = M.ldg, nz4 = M.nz16 >> 2, ntile = M.nz16 >> 4;
-    double *Bw = smem;                              // [nz4][64]
-    double *cs = Bw + (size_t)nz4 * 64;             // [16]
-    const gdp H = GP(H);
-    for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
-        const int bj = b0 + j;
-        const bool live = bj < Bt.batch;
-        const int bc = live ? bj : Bt.batch - 1;
-        const gdp wsr = gl((const double *)wsbase) + (size_t)bc * M.wsld;
-        const bool pending = live && wsr[ldz + ldy + 2 * ldg + 1] == 3.0;
-        for (int kb = wave; kb < nz4; kb += 4) {
-            const int k = 4 * kb + kq;
-            Bw[kb * 64 + lane] = (pending && k < M.nz) ? wsr[ldz + k] : 0.0;
-        }
-        if (threadIdx.x < 16) cs[threadIdx.x] = 0.0;
-        __syncthreads();
-        double part = 0.0;
-        for (int tl = wave; tl < ntile; tl += 4) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const int rowa = 16 * tl + j;
-            const gdp Ht = H + (rowa < ldz ? rowa : 0);
-            int kb = 0;
-            for (; kb + 4 <= nz4; kb += 4) {
-                double a[4], bq[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int col = 4 * (kb + u) + kq;
-                    a[u] = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = Bw[(kb + u) * 64 + lane];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
-            }
-            for (; kb < nz4; ++kb) {
-                const int col = 4 * kb + kq;
-                const double a = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bw[kb * 64 + lane], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * tl + 4 * r + kq;
-                const double w = Bw[(4 * tl + r) * 64 + lane];
-                const double fr = (pending && row < M.nz) ? wsr[row] : 0.0;
-                part = fma(w, 0.5 * acc[r] + fr, part);
-            }
-        }
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (kq == 0) atomicAdd(&cs[j], part);
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            const int bb = b0 + threadIdx.x;
-            if (bb < Bt.batch) {
-                gdw wst = glw(wsbase) + (size_t)bb * M.wsld + ldz + ldy + 2 * ldg;
-                if (wst[1] == 3.0) {
-                    if (Bt.cost) glw(Bt.cost)[bb] = cs[threadIdx.x] + wst[0];
-                    wst[1] = 2.0;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 template <int CPZ, int CPG>
 int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which, int fast)
 {
@@ -1872,13 +1474,19 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
     auto k2 = lmpc_solve<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
-    static size_t configured = 0;
-    if (lds > configured) {
+    // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
+    // two handles on different GPUs cannot skip or tear the update)
+    static std::atomic<size_t> configured[64];
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    devid &= 63;
+    if (lds > configured[devid].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
-        configured = lds;
+        size_t prev = configured[devid].load(std::memory_order_relaxed);
+        while (prev < lds && !configured[devid].compare_exchange_weak(prev, lds, std::memory_order_release)) {}
     }
     int blocks = (b.batch + kWavesPerBlock - 1) / kWavesPerBlock;
     const int cap = 256 * 8;
@@ -1897,30 +1505,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         }
     }
     if (which & 2) {
-        // four instances per wavefront when the problem is small enough and no sequences are asked for
-        const bool quad_ok = m.polish && m.ldy <= 256 && !(b.seq_state || b.seq_input || b.seq_output) && !b.dbg_cycles && m.use_quad;
-        if (quad_ok) {
-            const int ce = m.ldy <= 96 ? 3 : (m.ldy <= 160 ? 5 : 8);
-            const size_t per = (size_t)(32 * ce + 2 * kRegCap + kRegCap * kRegCap + kRegCap / 2);
-            size_t ldsq = 16 * per * sizeof(double);
-            const size_t need_bits = (size_t)(2 * m.active_words + 1) / 2;
-            if (need_bits > (size_t)kRegCap * kRegCap) return -2;
-            int blocksq = (b.batch + 15) / 16;
-            if (blocksq > 2048) blocksq = 2048;
-            static bool quad_attr = false;
-            if (!quad_attr) {
-                const int big = 160 * 1024;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_quad<3>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_quad<5>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_quad<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big);
-                quad_attr = true;
-            }
-            if (ce == 3) hipLaunchKernelGGL(lmpc_solve_quad<3>, dim3(blocksq), dim3(256), ldsq, stream, m_dev, b, ws);
-            else if (ce == 5) hipLaunchKernelGGL(lmpc_solve_quad<5>, dim3(blocksq), dim3(256), ldsq, stream, m_dev, b, ws);
-            else hipLaunchKernelGGL(lmpc_solve_quad<8>, dim3(blocksq), dim3(256), ldsq, stream, m_dev, b, ws);
-            const size_t ldsc = ((size_t)(m.nz16 / 4) * 64 + 16) * sizeof(double);
-            hipLaunchKernelGGL(lmpc_cost_mfma, dim3(blocksq), dim3(256), ldsc, stream, m_dev, b, ws);
-        } else {
+        {
             hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
         }
     }

@@ -44,7 +44,6 @@ struct mpcx_lmpc {
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
-    bool use_quad = false;              // measured slower than one-instance-per-wave at B = 4096 (1 wave per SIMD)         // testing aid: route every batch through the generic assemble kernel
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     int *queues = nullptr;              // dispatch queues: kLmpcQueues counters, then kLmpcQueues lists of ws_cap instances
     size_t ws_cap = 0;                  // instances
@@ -370,7 +369,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.n_fixed = (int)o.fixed_rows.size();
     D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
     D.strict_infeasible = h->strict_infeasible ? 1 : 0;
-    D.use_quad = h->use_quad ? 1 : 0;
+    D.cost_direct = o.h_regularised ? 1 : 0;
     D.check_every = h->dbg_check_every; D.polish_rounds0 = h->dbg_rounds0; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
@@ -642,15 +641,6 @@ int mpcx_lmpc_debug_set_rounds(mpcx_lmpc_t h, int rounds0, int check_every)
 {
     CHECK_H(h);
     h->dbg_rounds0 = rounds0; h->dbg_check_every = check_every;
-    h->dirty = true;
-    return MPCX_OK;
-}
-
-/* testing aid: 0 = never use the four-instances-per-wavefront solve kernel */
-int mpcx_lmpc_debug_use_quad(mpcx_lmpc_t h, int on)
-{
-    CHECK_H(h);
-    h->use_quad = on != 0;
     h->dirty = true;
     return MPCX_OK;
 }

@@ -36,6 +36,7 @@ struct mpcx_nlmpc {
     size_t ws_cap = 0;          // instances
     int solved_batch = 0;       // batch size of the last solve whose state is still in the workspace (0: none)
     mpcx_nlparams prm{};
+    double tol_step = 1e-6, tol_con = 1e-8;      // own convergence test (mpcx_nlmpc_debug_set_tolerances: experiment knob)
     // NLOptimizer::lb / ub (NLOptimizer.hpp:346-404): bounds on the decision vector, host copy + device tables
     std::vector<double> lb, ub;
     bool bounds_dirty = true;
@@ -301,8 +302,8 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     s = mpcx::NlmpcSolveDev{};
     s.batch = b->batch; s.x0 = b->x0; s.u0 = b->u0; s.z_warm = b->z_warm; s.ws = h->ws;
     s.max_iter = h->prm.maximum_iteration; s.hard = h->prm.hard_constraints ? 1 : 0;
-    s.tol_step = 1e-6;
-    s.tol_con = 1e-8; s.ieq_tol = 1e-10; s.eq_tol = 1e-10;
+    s.tol_step = h->tol_step;
+    s.tol_con = h->tol_con; s.ieq_tol = 1e-10; s.eq_tol = 1e-10;
     s.ftol_rel = h->prm.relative_ftol; s.ftol_abs = h->prm.absolute_ftol;        // NLOptimizer.hpp:135-138, <= 0: disabled
     s.xtol_rel = h->prm.relative_xtol; s.xtol_abs = h->prm.absolute_xtol;
     s.mu_out = b->multipliers;
@@ -407,6 +408,14 @@ extern "C" int mpcx_discretize_batch(int device, int nx, int nu, int batch, cons
     if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
     const int rc = mpcx::c2d_launch(nx, nu, batch, A, B, Ts, ts_per_instance ? 1 : 0, Ad, Bd, stream);
     if (rc != 0) return capi_fail(MPCX_E_DEVICE, "discretisation kernel launch failed");
+    return MPCX_OK;
+}
+
+// Experiment knob (not part of include/mpcx.h): the step / defect thresholds of the solver's own convergence test
+extern "C" int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_con)
+{
+    if (!h || !(tol_step > 0) || !(tol_con > 0)) return mpcx::capi_fail(MPCX_E_INVALID, "bad tolerances");
+    h->tol_step = tol_step; h->tol_con = tol_con;
     return MPCX_OK;
 }
 

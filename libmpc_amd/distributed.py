@@ -3,9 +3,17 @@
 Instances are independent (the reference solves one controller at a time and has no
 coupling between controllers), so the batch shards as contiguous slices with no
 collective on the data path; the only exchange is one all-gather of the optimal
-controls u* (B x nu doubles) after the solve -- RCCL over xGMI when the process group
-is "nccl", gloo in the CPU tests."""
+controls u* (B x nu doubles) after the solve.
+
+On the GPU that all-gather goes through the C ABI (`mpcx_comm_*` / `mpcx_allgather_u`,
+include/mpcx.h): RCCL's ncclAllGather over xGMI, enqueued on the stream the solve kernels
+were launched on -- the same entry point a C++ host uses.  `ControlGather` wraps it; the
+only thing it borrows from torch.distributed is the rendezvous (the 128-byte RCCL id
+travels from rank 0 to the others through the process group's store).  CPU tensors (the
+gloo tests) take torch's own all_gather."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -20,24 +28,73 @@ def shard_range(total: int, rank: int, world: int):
     return lo, hi
 
 
-def allgather_controls(cmd_local: torch.Tensor, total: int | None = None, group=None, force: bool = False) -> torch.Tensor:
+class ControlGather:
+    """One RCCL communicator per process, behind the C ABI.  `rank`/`world` default to the
+    initialised torch.distributed group, which is then also used to ship the RCCL id; a
+    single-rank communicator needs no process group at all."""
+
+    def __init__(self, device: int, rank: int | None = None, world: int | None = None, group=None):
+        from . import _capi
+        self._lib = _capi.lib()
+        self._check = _capi.check
+        if rank is None or world is None:
+            if dist.is_initialized():
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, world = 0, 1
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            self._check(self._lib.mpcx_comm_get_unique_id(ident))
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)      # rendezvous only: 128 bytes through the store
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        self._check(self._lib.mpcx_comm_create(self.device, self.rank, self.world, ident, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.mpcx_comm_destroy(self._h)
+            self._h = None
+
+    def allgather(self, cmd_local: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """cmd_local [n, nu] (cuda, fp64, the same n on every rank) -> [world * n, nu], enqueued on `stream`
+        (default: torch's current stream on the communicator's device)."""
+        assert cmd_local.is_cuda and cmd_local.dtype == torch.float64 and cmd_local.is_contiguous()
+        n, nu = cmd_local.shape
+        if out is None:
+            out = torch.empty((self.world * n, nu), dtype=torch.float64, device=cmd_local.device)
+        s = torch.cuda.current_stream(cmd_local.device).cuda_stream if stream is None else stream
+        self._check(self._lib.mpcx_allgather_u(self._h, cmd_local.data_ptr(), int(n), int(nu), out.data_ptr(), C.c_void_p(s)))
+        return out
+
+
+def allgather_controls(cmd_local: torch.Tensor, total: int | None = None, group=None, force: bool = False,
+                       gather: ControlGather | None = None) -> torch.Tensor:
     """All-gather the per-rank optimal controls into [total, nu] on every rank.
 
-    Equal shards use one all_gather_into_tensor (a single RCCL ring collective);
-    ragged shards are padded to the largest shard and trimmed afterwards."""
-    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-        return cmd_local           # force: run the collective even on a single rank (exercises the RCCL path)
-    world = dist.get_world_size(group)
+    Equal shards use one all-gather (RCCL through `gather` for CUDA tensors, torch's
+    collective otherwise); ragged shards are padded to the largest shard and trimmed
+    afterwards."""
+    if gather is None and (not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force)):
+        return cmd_local           # force: run the collective even on a single rank (exercises the path)
+    world = gather.world if gather is not None else dist.get_world_size(group)
     n_local, nu = cmd_local.shape
-    if total is None or total == n_local * world:
-        out = torch.empty((world * n_local, nu), dtype=cmd_local.dtype, device=cmd_local.device)
-        dist.all_gather_into_tensor(out, cmd_local.contiguous(), group=group)
+
+    def collect(block):
+        if gather is not None and block.is_cuda:
+            return gather.allgather(block.contiguous())
+        out = torch.empty((world * block.shape[0], nu), dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(out, block.contiguous(), group=group)
         return out
+
+    if total is None or total == n_local * world:
+        return collect(cmd_local)
     sizes = [shard_range(total, r, world) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((nmax, nu), dtype=cmd_local.dtype, device=cmd_local.device)
     pad[:n_local] = cmd_local
-    out = torch.empty((world * nmax, nu), dtype=cmd_local.dtype, device=cmd_local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    out = collect(pad)
     parts = [out[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, dim=0)

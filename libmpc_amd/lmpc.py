@@ -294,10 +294,6 @@ class LMPC:
         """testing aid: route every batch through the generic (roll-out) assemble kernel"""
         check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))
 
-    def debug_use_quad(self, on=True):
-        """testing aid: allow / forbid the four-instances-per-wavefront solve kernel"""
-        check(self._lib.mpcx_lmpc_debug_use_quad(self._h, int(bool(on))))
-
     # -- the hot path ------------------------------------------------------------------
     def _torch(self):
         import torch

@@ -213,6 +213,12 @@ class NLMPC(NLMPCEvaluator):
     _WS_FIELDS = ("z", "d", "g", "c", "jeq", "gin", "jin", "r", "phi", "einv", "gr", "art", "br", "hinv", "mu", "glold", "s", "p",
                   "qn", "qv", "qs", "qs2", "scal", "lamw", "hook", "total")
 
+    def debug_workspace_bytes(self):
+        """size of one instance's SQP workspace in HBM"""
+        fn = self._lib.mpcx_nlmpc_debug_get_ws
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        return 8 * check(fn(self._h, 0, None, 0, None, 0))
+
     def debug_workspace(self, instance):
         """testing aid: the SQP workspace of one instance after the last solve, as a dict of numpy arrays"""
         n = len(self._WS_FIELDS)

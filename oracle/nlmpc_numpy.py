@@ -232,7 +232,8 @@ class NlmpcRef:
         from scipy.optimize import minimize
         nx, nu, ph, ch = self.nx, self.nu, self.ph, self.ch
         self.x0 = np.asarray(x0, float)
-        z0 = np.concatenate([np.tile(self.x0 * self.state_scaling, ph), np.tile(np.asarray(u0, float) / self.input_scaling, ch), [0.0]])
+        # cold start (NLOptimizer.hpp:431-451): x0 and u0 replicated as they are -- no scaling applied to the guess
+        z0 = np.concatenate([np.tile(self.x0, ph), np.tile(np.asarray(u0, float), ch), [0.0]])
         lo = np.full(self.nz, -np.inf); hi = np.full(self.nz, np.inf)
         if lb_x is not None:
             lo[:ph * nx] = np.tile(lb_x, ph); hi[:ph * nx] = np.tile(ub_x, ph)

@@ -180,7 +180,8 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
     pairs = {"mpcx_dims": _capi.Dims, "mpcx_lparams": _capi.LParams, "mpcx_lmpc_batch": _capi.Batch, "mpcx_lmpc_info": _capi.Info,
-             "mpcx_nlmpc_dims": _capi.NlmpcDims, "mpcx_nlparams": _capi.NLParams, "mpcx_nlmpc_batch": _capi.NlmpcBatch}
+             "mpcx_nlmpc_dims": _capi.NlmpcDims, "mpcx_nlparams": _capi.NLParams, "mpcx_nlmpc_batch": _capi.NlmpcBatch,
+             "mpcx_nlmpc_source": _capi.NlmpcSource}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpcx.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')

@@ -348,3 +348,170 @@ def test_receding_horizon_with_carried_curvature_reaches_the_same_optimum():
         dx = torch.stack([(1 - x[:, 1] ** 2) * x[:, 0] - x[:, 1] + u[:, 0], x[:, 0]], dim=1)
         x = x + 0.1 * dx
     assert it_w[0] == it_c[0] and sum(it_w[1:]) < 0.8 * sum(it_c[1:]), (it_w, it_c)
+
+
+# ---- oracle-independent optimality check, mapping scalings, nlopt's tolerances ------------------------------------------
+def _kkt_report(m, z, x0, mu, hard, nbnd_rows=None):
+    """KKT residuals of the RESTATED problem (oracle callbacks) at z with the kernel's inequality / equality / bound
+    multipliers mu; the dynamics multipliers are the least-squares ones.  Returns (stationarity relative to |grad|_inf,
+    primal violation, worst complementarity product, most negative inequality multiplier)."""
+    m.x0 = np.asarray(x0, float)
+    f, g = m.objective(z)
+    c, Jc = m.state_eq(z)
+    nfree = m.nz - 1 if hard else m.nz               # slack pinned at zero under hard constraints (NLOptimizer.hpp:182-186)
+    rhs = g.copy()
+    viol = np.abs(c).max()
+    comp, neg, k = 0.0, 0.0, 0
+    if m.ineq_fun is not None:
+        gi, Ji = m.user_ineq(z)
+        mi = mu[k:k + gi.size]; k += gi.size
+        rhs += Ji.T @ mi
+        viol = max(viol, gi.max())
+        comp = max(comp, np.abs(mi * gi).max()); neg = min(neg, mi.min())
+    if m.eq_fun is not None:
+        h, Jh = m.user_eq(z)
+        mh = mu[k:k + h.size]; k += h.size
+        rhs += Jh.T @ mh
+        viol = max(viol, np.abs(h).max())
+    if nbnd_rows is not None:
+        for (idx, sign), mb in zip(nbnd_rows, mu[k:]):
+            rhs[idx] += sign * mb
+            neg = min(neg, mb)
+    lam = np.linalg.lstsq(Jc[:, :nfree].T, -rhs[:nfree], rcond=None)[0]
+    stat = np.abs(rhs[:nfree] + Jc[:, :nfree].T @ lam).max() / max(1.0, np.abs(g).max())
+    return stat, viol, comp, neg
+
+
+@pytest.mark.parametrize("name,kw,B,hard,iters", [("vanderpol", dict(ph=10, ch=5, Ts=0.1), 64, True, 200),
+                                                   ("ugv", dict(ph=30, ch=30), 24, False, 150),
+                                                   ("osc6", dict(ph=20, ch=10, Ts=0.1), 4, True, 200)])
+def test_gpu_solution_satisfies_the_restated_kkt_conditions(name, kw, B, hard, iters):
+    """Independent of where scipy's SLSQP stops: stationarity (with the kernel's own multipliers), complementarity,
+    dual and primal feasibility of the oracle's restatement of the reference problem at the point the GPU returns."""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV, OSCILLATORS6
+    rng = np.random.default_rng(41)
+    m = dict(vanderpol=lambda: ref.vanderpol(**kw), ugv=lambda: ref.ugv(**kw), osc6=lambda: ref.oscillators(N=6, **kw))[name]()
+    c = NLMPC(dict(vanderpol=VANDERPOL, ugv=UGV, osc6=OSCILLATORS6)[name], kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+    c.setOptimizerParameters(NLParameters(maximum_iteration=iters, hard_constraints=int(hard)))
+    X0 = np.zeros((B, m.nx)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    if name == "osc6":
+        X0 = rng.uniform(-0.1, 0.1, size=(B, m.nx)); X0[:, 0] += 1.0
+    U0 = np.zeros((B, m.nu))
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), multipliers=True)
+    torch.cuda.synchronize()
+    z = r["z"].cpu().numpy(); mu = r["multipliers"].cpu().numpy(); st = r["solver_status"].cpu().numpy()
+    worst = np.zeros(4)
+    checked = 0
+    for b in range(B):
+        if st[b] not in (3, 4):
+            continue
+        stat, viol, comp, neg = _kkt_report(m, z[b], X0[b], mu[b], hard)
+        worst = np.maximum(worst, [stat, viol, comp, -neg])
+        checked += 1
+    print("KKT %s: stationarity %.2e  violation %.2e  complementarity %.2e  most negative multiplier %.2e  (%d of %d instances)"
+          % (name, worst[0], worst[1], worst[2], -worst[3], checked, B))
+    assert checked >= 0.95 * B
+    assert worst[0] <= 2e-5, worst            # forward-difference gradients: noise ~1.5e-8 |f| / step in the residual
+    assert worst[1] <= 1e-7 and worst[2] <= 1e-6 and worst[3] <= 1e-9, worst
+
+
+def test_active_set_matches_the_oracle_optimum():
+    """bit-exact active-set indices: the user inequalities with a non-zero multiplier are the ones the oracle's optimum holds
+    at their bound (Van der Pol: u_i <= 0.5 active on the first moves for starts that need full effort)"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL
+    kw = dict(ph=10, ch=5, Ts=0.1)
+    m = ref.vanderpol(**kw)
+    c = NLMPC(VANDERPOL, 10, 5, 0.1)
+    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+    X0 = np.array([[0.0, 1.0], [-0.9, -0.9], [0.8, -0.5], [-0.6, 0.9], [0.1, 0.1], [-1.0, 0.3]])
+    U0 = np.zeros((6, 1))
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), multipliers=True)
+    torch.cuda.synchronize()
+    mu = r["multipliers"].cpu().numpy()
+    some_active = 0
+    for b in range(6):
+        o = m.solve(X0[b], U0[b], max_iter=1000)
+        if not o["success"]:
+            continue
+        g = m.user_ineq(o["z"])[0]
+        # move blocking repeats the last block's constraint: rows 4..10 are copies, the kernel keeps one of them in the set
+        act_ref = {min(int(k), 4) for k in np.nonzero(g > -1e-7)[0]}
+        act_gpu = {min(int(k), 4) for k in np.nonzero(mu[b] > 0)[0]}
+        assert act_gpu == act_ref, (b, act_gpu, act_ref)
+        some_active += bool(act_ref)
+    assert some_active >= 2
+
+
+def test_transcription_with_mapping_scalings_matches_oracle():
+    """NLMPC::setInputScale / setStateScale (NLMPC.hpp:108,123): Mapping.hpp:174-211,221-257 and what the reference does
+    and does not propagate into the derivatives (Objective.hpp:107-144, Constraints.hpp:269-284, 515-517, 565-571, 607-608)"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPCEvaluator, VANDERPOL, UGV
+    for name, kw, su, ss in [("vanderpol", dict(ph=10, ch=5, Ts=0.1), [2.0], [0.5, 4.0]),
+                             ("ugv", dict(ph=12, ch=4), [3.0, 0.25], [2.0, 0.5, 1.5, 8.0])]:
+        m = ref.vanderpol(**kw) if name == "vanderpol" else ref.ugv(**kw)
+        ev = NLMPCEvaluator(VANDERPOL if name == "vanderpol" else UGV, kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+        ev.setInputScale(su); ev.setStateScale(ss)
+        m.set_scaling(su, ss)
+        rng = np.random.default_rng(9)
+        B = 5
+        Z = rng.normal(size=(B, m.nz)); Z[:, -1] = rng.normal(scale=0.1, size=B); X0 = rng.normal(size=(B, m.nx))
+        out = ev.evaluate(torch.from_numpy(Z), torch.from_numpy(X0))
+        torch.cuda.synchronize()
+        Jd = ev.dense_eq_jacobian(out["jeq"])
+        o = {k: v.cpu().numpy() for k, v in out.items()}
+        for b in range(B):
+            m.x0 = X0[b]
+            f0, g = m.objective(Z[b]); c, J = m.state_eq(Z[b]); gi, Ji = m.user_ineq(Z[b])
+            assert abs(o["cost"][b] - f0) <= 1e-12 * max(1.0, abs(f0))
+            np.testing.assert_allclose(o["ceq"][b], c, rtol=0, atol=1e-13 * max(1.0, np.abs(c).max()))
+            np.testing.assert_allclose(o["cineq"][b], gi, rtol=0, atol=1e-13)
+            np.testing.assert_allclose(o["grad"][b], g, rtol=1e-9, atol=64 * np.finfo(float).eps * max(1.0, abs(f0)) / ref.DV)
+            np.testing.assert_allclose(Jd[b], J, rtol=1e-9, atol=1e-6)
+            np.testing.assert_allclose(o["jineq"][b], Ji, rtol=1e-9, atol=1e-6)
+
+
+def test_nlopt_stopping_tolerances_stop_early_with_their_codes():
+    """NLParameters::relative_ftol / absolute_ftol / relative_xtol / absolute_xtol (NLOptimizer.hpp:135-138): disabled (-1) the
+    solve runs to its own convergence test (XTOL_REACHED = 4); a loose ftol stops earlier with FTOL_REACHED = 3 at nearly the
+    same cost; a loose xtol stops earlier with 4; all map to SUCCESS (NLOptimizer.hpp:729-750)"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL
+    rng = np.random.default_rng(3)
+    B = 64
+    x0 = torch.from_numpy(rng.uniform(-1, 1, size=(B, 2))); u0 = torch.zeros(B, 1, dtype=torch.float64)
+    res = {}
+    for key, prm in [("none", {}), ("ftol_rel", dict(relative_ftol=1e-4)), ("ftol_abs", dict(absolute_ftol=1e-3)),
+                     ("xtol_rel", dict(relative_xtol=1e-2)), ("xtol_abs", dict(absolute_xtol=1e-2))]:
+        c = NLMPC(VANDERPOL, 10, 5, 0.1)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=200, **prm))
+        r = c.optimizeBatch(x0, u0)
+        torch.cuda.synchronize()
+        res[key] = {k: r[k].cpu().numpy() for k in ("status", "solver_status", "iterations", "cost")}
+    base = res["none"]
+    assert (base["solver_status"] == 4).mean() > 0.9
+    for key, code in [("ftol_rel", 3), ("ftol_abs", 3), ("xtol_rel", 4), ("xtol_abs", 4)]:
+        r = res[key]
+        assert (r["status"] == 0).mean() > 0.9, key
+        assert np.isin(r["solver_status"], (code, 4)).mean() > 0.9, (key, np.unique(r["solver_status"]))
+        if code == 3:
+            assert (r["solver_status"] == 3).mean() > 0.5, (key, np.unique(r["solver_status"], return_counts=True))
+        assert r["iterations"].mean() < base["iterations"].mean(), (key, r["iterations"].mean(), base["iterations"].mean())
+        ok = (r["status"] == 0) & (base["status"] == 0)
+        assert np.abs(r["cost"][ok] - base["cost"][ok]).max() <= 2e-2 * np.maximum(1.0, base["cost"][ok]).max(), key
+
+
+def test_control_gather_single_rank_through_the_c_abi():
+    """mpcx_comm_* / mpcx_allgather_u: a one-rank RCCL communicator gathers a block onto itself on the caller's stream"""
+    import torch
+    from libmpc_amd.distributed import ControlGather, allgather_controls
+    g = ControlGather(0, 0, 1)
+    a = torch.arange(4096 * 4, dtype=torch.float64, device="cuda").reshape(4096, 4)
+    out = g.allgather(a)
+    torch.cuda.synchronize()
+    assert out.shape == (4096, 4) and torch.equal(out, a)
+    out2 = allgather_controls(a, gather=g)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, a)

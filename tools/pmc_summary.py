@@ -1,10 +1,14 @@
-"""Per-kernel mean of one rocprofv3 --pmc counter from the csv output (counter_collection.csv) as JSON."""
+"""Per-kernel mean of rocprofv3 --pmc counters from the csv output (counter_collection.csv) as JSON, stamped with the digest
+of the kernel sources the numbers were measured on (bench.py refuses a summary whose stamp does not match the tree)."""
 import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def summarise(directory):
@@ -21,7 +25,8 @@ def summarise(directory):
 
 
 if __name__ == "__main__":
-    res = {}
+    from bench import kernel_source_hash
+    res = {"kernel_source_hash": kernel_source_hash(), "unit": "KB per launch (FETCH_SIZE as reported: double it on gfx950)"}
     for d in sys.argv[1:]:
         res.update(summarise(d))
     print(json.dumps(res, indent=1))
