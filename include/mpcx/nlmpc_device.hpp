@@ -38,7 +38,8 @@ struct NlmpcDev {
     double Ts;
     const double *params;       // model parameters in HBM (zoo) or the hook closures (mpcx/nlmpc_hooks.hpp)
     // Mapping scalings (Mapping.hpp:71-86): U = input_scale * z_u, X = z_x / state_scale; arrays of ones by default
-    const double *su, *ss;      // [nu], [nx]
+    const double *su, *ss, *iss; // [nu], [nx], [nx] = 1 / ss
+    int scaled;                 // 0: every factor is 1, the kernels skip them
     // box bounds on the decision vector (NLOptimizer::lb / ub): all of them, and the finite ones as sub-problem rows
     const double *zlb, *zub;    // [nz]
     int nbnd;

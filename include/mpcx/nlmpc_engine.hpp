@@ -103,6 +103,17 @@ __device__ __forceinline__ void wave_argmax(double &v, int &idx)
 
 constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
 
+// Mapping scalings (Mapping.hpp:71-86).  Identity unless NLMPC::setInputScale / setStateScale were called: then nothing is
+// loaded or multiplied (the branch is wave-uniform); otherwise divisions go through the reciprocals the host prepared.
+struct Scale {
+    const double *su, *ss, *iss;
+    bool on;
+    __device__ __forceinline__ explicit Scale(const NlmpcDev &M) : su(M.su), ss(M.ss), iss(M.iss), on(M.scaled != 0) {}
+    __device__ __forceinline__ double by_su(double v, int j) const { return on ? v * su[j] : v; }
+    __device__ __forceinline__ double by_ss(double v, int j) const { return on ? v * ss[j] : v; }
+    __device__ __forceinline__ double over_ss(double v, int j) const { return on ? v * iss[j] : v; }
+};
+
 // zoo models fix the kind of transcription at compile time; hook models may be either (setDiscretizationSamplingTime)
 template <class Mdl> __device__ __forceinline__ bool is_ct(const NlmpcDev &M)
 {
@@ -124,14 +135,15 @@ __device__ __forceinline__ void unwrap(const NlmpcDev &M, const double *z, const
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int ph = M.ph, ch = M.ch;
+    const Scale sc(M);
     for (int k = lane; k < (ph + 1) * NX; k += 64) {
         const int i = k / NX, j = k - i * NX;
-        Xs[k] = (i == 0 ? x0[j] : z[(i - 1) * NX + j]) / M.ss[j];
+        Xs[k] = sc.over_ss(i == 0 ? x0[j] : z[(i - 1) * NX + j], j);
     }
     for (int k = lane; k < (ph + 1) * NU; k += 64) {
         const int i = k / NU, j = k - i * NU;
         const int blk = min(min(i, ph - 1), ch - 1);          // first ch-1 moves one step each, the last one held
-        Us[k] = M.su[j] * z[ph * NX + blk * NU + j];
+        Us[k] = sc.by_su(z[ph * NX + blk * NU + j], j);
     }
     nl_wave_sync();
 }
@@ -212,7 +224,7 @@ __device__ __forceinline__ void hook_cost_grad(const NlmpcDev &M, const double *
         const int bl = k / NU, j = k - bl * NU;
         double s = 0;
         for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
-        g[ph * NX + k] = M.su[j] * s;                                         // Iz2u' * vec(Jmv)
+        g[ph * NX + k] = Scale(M).by_su(s, j);                                // Iz2u' * vec(Jmv)
     }
     if (lane == 0) {
         const double de = fmax(dv, fabs(e)) * dv;
@@ -235,6 +247,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
     const double dv = kDv, e = z[nz - 1];
     const double *prm = M.params;
     const bool ho = M.has_output != 0;
+    const Scale sc(M);
     auto Xa = [&](int j) { const double v = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
     auto Ua = [&](int j) { const double v = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return v > 1.0 ? v : 1.0; };
     const MX X0 = MX::trajectory(Xs);
@@ -262,7 +275,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
                     Mdl::ineq_all(o, Xp, Yp, U0, e, prm);
                 }
                 // computeIneqJacobian multiplies the state columns by the state scaling (Constraints.hpp:269-284)
-                for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = (cA[r * 64] - cB[r * 64]) / (2 * dx) * M.ss[j];
+                for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
             }
             if constexpr (NE > 0) {
                 const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
@@ -271,7 +284,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
                     VE o = VE::output((sgn ? cB : cA) + (size_t)64 * NI, 64);
                     Mdl::eq_all(o, Xp, U0, prm);
                 }
-                for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = (cA[r * 64] - cB[r * 64]) / (2 * dx) * M.ss[j];
+                for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
             }
         } else if (k < nz - 1) {
             const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
@@ -303,7 +316,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
                     for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] += (cA[r * 64] - cB[r * 64]) / (2 * du);
                 }
             }
-            for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] *= M.su[j];      // glueJacobian: Jmanvar * Iz2u
+            if (sc.on) for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] *= sc.su[j];      // glueJacobian: Jmanvar * Iz2u
         } else {
             const double de = fmax(dv, fabs(e)) * dv;
             if constexpr (NI > 0) {
@@ -329,7 +342,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
     const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
     const double dv = kDv;
     const double *prm = M.params;
-    const double *su = M.su, *ss = M.ss;
+    const Scale sc(M);
     const bool CT = is_ct<Mdl>(M);
     unwrap<Mdl>(M, z, x0, Xs, Us, lane);
     hook_base_outputs<Mdl>(M, Xs, Us, Ys, lane);
@@ -363,7 +376,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 const int bl = k / NU, j = k - bl * NU;
                 double s = 0;
                 for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
-                g[ph * NX + k] = su[j] * s;                                 // Iz2u' * vec(Jmv)
+                g[ph * NX + k] = sc.by_su(s, j);                            // Iz2u' * vec(Jmv)
             }
             if (lane == 0) {
                 const double de = fmax(dv, fabs(e)) * dv;
@@ -389,9 +402,9 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 call_f<Mdl>(fa, xk, uk, prm, i);
                 if (CT) {
                     call_f<Mdl>(fb, xk1, uk, prm, i);
-                    for (int a = 0; a < NX; ++a) cv[a] = (xk[a] + (h * (fa[a] + fb[a])) - xk1[a]) / ss[a];
+                    for (int a = 0; a < NX; ++a) cv[a] = sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a);
                 } else {
-                    for (int a = 0; a < NX; ++a) cv[a] = (xk1[a] - fa[a]) / ss[a];
+                    for (int a = 0; a < NX; ++a) cv[a] = sc.over_ss(xk1[a] - fa[a], a);
                 }
                 continue;
             }
@@ -414,14 +427,14 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
             if (col < NX) {                    // d c_i / d x_i  (not a decision variable for i = 0: kept for the caller to drop)
                 cdiff(xk, uk, col, false, dcol);
                 for (int a = 0; a < NX; ++a) {
-                    const double sa = dcol[a] * ss[col] / ss[a];
+                    const double sa = sc.over_ss(sc.by_ss(dcol[a], col), a);
                     J[a * W + col] = CT ? ((a == col ? 1.0 : 0.0) + h * sa) : -sa;
                 }
             } else if (col < 2 * NX) {         // d c_i / d x_{i+1}
                 const int v = col - NX;
                 if (CT) {
                     cdiff(xk1, uk, v, false, dcol);
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? -1.0 : 0.0) + h * (dcol[a] * ss[v] / ss[a]);
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss(dcol[a], v), a);
                 } else {
                     for (int a = 0; a < NX; ++a) J[a * W + col] = (a == v ? 1.0 : 0.0);
                 }
@@ -431,9 +444,9 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 if (CT) {
                     double d2[NX];
                     cdiff(xk1, uk, v, true, d2);
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = h * ((dcol[a] + d2[a]) / ss[a]) * su[v];
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = sc.by_su(h * sc.over_ss(dcol[a] + d2[a], a), v);
                 } else {
-                    for (int a = 0; a < NX; ++a) J[a * W + col] = -(dcol[a] / ss[a]) * su[v];
+                    for (int a = 0; a < NX; ++a) J[a * W + col] = sc.by_su(-sc.over_ss(dcol[a], a), v);
                 }
             }
         }
@@ -460,7 +473,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 for (int t = 0; t < count; ++t) {
                     const int r = first + t;
                     // the state columns are multiplied by the state scaling (Constraints.hpp:269-284)
-                    J[(size_t)r * nz + k] = (Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx) * ss[j];
+                    J[(size_t)r * nz + k] = sc.by_ss((Mdl::ineq(r, Xp, U0, e, ph, prm) - Mdl::ineq(r, Xm, U0, e, ph, prm)) / (2 * dx), j);
                 }
             } else if (k < nz - 1) {
                 const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
@@ -479,7 +492,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                     const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
                     for (int t = 0; t < count; ++t) {
                         const int r = first + t;
-                        J[(size_t)r * nz + k] += su[j] * ((Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du));
+                        J[(size_t)r * nz + k] += sc.by_su((Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du), j);
                     }
                 }
             } else {
@@ -504,7 +517,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
                 const Pert Xp{Xs, NX, i + 1, -1, j, dx}, Xm{Xs, NX, i + 1, -1, j, -dx};
                 for (int r = 0; r < nue; ++r)
-                    J[(size_t)r * nz + k] = (Mdl::eq(r, Xp, U0, ph, prm) - Mdl::eq(r, Xm, U0, ph, prm)) / (2 * dx) * ss[j];
+                    J[(size_t)r * nz + k] = sc.by_ss((Mdl::eq(r, Xp, U0, ph, prm) - Mdl::eq(r, Xm, U0, ph, prm)) / (2 * dx), j);
             } else if (k < nz - 1) {
                 const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
                 const double du = dv * fmax(fabs(Us[(ph - 1) * NU + j]), 1.0);
@@ -515,7 +528,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                         const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du}, Um{Us, NU, i, i == ph - 1 ? ph : -1, j, -du};
                         s += (Mdl::eq(r, X0, Up, ph, prm) - Mdl::eq(r, X0, Um, ph, prm)) / (2 * du);
                     }
-                    J[(size_t)r * nz + k] = su[j] * s;
+                    J[(size_t)r * nz + k] = sc.by_su(s, j);
                 }
             } else {
                 for (int r = 0; r < nue; ++r) J[(size_t)r * nz + k] = 0.0;
@@ -595,7 +608,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
     const int mld = (mt + 1) & ~1;
     const double *prm = M.params;
-    const double *su = M.su, *ss = M.ss;
+    const Scale sc(M);
     double *Xs = smem + (size_t)wave * M.lds_per_wave;
     double *Us = Xs + (ph + 1) * NX;
     double *dXs = Us + (ph + 1) * NU;
@@ -1322,10 +1335,10 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 
             // ---- line search: lane l tries a = 2^-l on the l1 merit function
             unwrap<Mdl>(M, z, x0, Xs, Us, lane);
-            for (int k = lane; k < (ph + 1) * NX; k += 64) { const int i = k / NX; dXs[k] = i == 0 ? 0.0 : d[k - NX] / ss[k - i * NX]; }
+            for (int k = lane; k < (ph + 1) * NX; k += 64) { const int i = k / NX; dXs[k] = i == 0 ? 0.0 : sc.over_ss(d[k - NX], k - i * NX); }
             for (int k = lane; k < (ph + 1) * NU; k += 64) {
                 const int i = k / NU, j = k - i * NU;
-                dUs[k] = su[j] * d[nxs + min(min(i, ph - 1), ch - 1) * NU + j];
+                dUs[k] = sc.by_su(d[nxs + min(min(i, ph - 1), ch - 1) * NU + j], j);
             }
             nl_wave_sync();
             double a_step;
@@ -1381,9 +1394,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                         call_f<Mdl>(fa, xk, uk, prm, i);
                         if (CT) {
                             call_f<Mdl>(fb, xk1, uk, prm, i);
-                            for (int a = 0; a < NX; ++a) vio += fabs((xk[a] + (h * (fa[a] + fb[a])) - xk1[a]) / ss[a]);
+                            for (int a = 0; a < NX; ++a) vio += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
                         } else {
-                            for (int a = 0; a < NX; ++a) vio += fabs((xk1[a] - fa[a]) / ss[a]);
+                            for (int a = 0; a < NX; ++a) vio += fabs(sc.over_ss(xk1[a] - fa[a], a));
                         }
                     }
                     mer += nu_pen * vio;
@@ -1451,8 +1464,12 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     }
 }
 
+// Register budget: the per-lane state arrays grow with the state dimension (a dozen vectors of NX doubles are live in the
+// sweeps and the finite differences), while the LDS slice of such a system already limits a CU to 3-6 wavefronts.  Large
+// systems therefore get the whole register file of a SIMD (512 VGPRs, one wavefront per SIMD) instead of spilling.
+template <class Mdl> constexpr int kSqpWavesPerSimd = Mdl::NX >= 12 ? 1 : 2;
 template <class Mdl>
-__global__ __launch_bounds__(256, 2) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl>(M, S); }
+__global__ __launch_bounds__(256, kSqpWavesPerSimd<Mdl>) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl>(M, S); }
 
 // ---- host side: workspace plan and launchers -----------------------------------------------------------------------
 #if !defined(__HIPCC_RTC__)

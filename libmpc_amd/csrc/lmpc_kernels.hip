@@ -38,7 +38,7 @@ namespace {
 #define MPCX_WAVES_PER_BLOCK 2
 #endif
 constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
-constexpr int kFallbackChunk = 8;
+constexpr int kFallbackChunk = 64;      // instances one wavefront of the fallback kernel screens (one flag per lane)
 constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
 constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
 // a working set with all signs right grows by the rows violated by at least this fraction of the largest violation: adding
@@ -416,10 +416,10 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
     const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, nz = M.nz, mg = M.mg;
     double *Bv = smem;                               // [kin4][64]   vin as MFMA B operands
     double *Bf = Bv + (size_t)kin4 * 64;             // [nz4][64]    f as MFMA B operands
-    double *c0s = Bf + (size_t)nz4 * 64;             // [16]
-    unsigned *bad = reinterpret_cast<unsigned *>(c0s + 16);   // [16]
+    double *c0s = Bf + (size_t)nz4 * 64;             // [4][16]: one slot per wavefront and instance, added up in wave order
+    unsigned *bad = reinterpret_cast<unsigned *>(c0s + 64);   // [16]
     unsigned *nviol = bad + 16;                                // [16] rows violated at the unconstrained optimum
-    double *offs = c0s + 16 + 32;                              // [ldg][16] row offsets (only when the queue is built)
+    double *offs = c0s + 64 + 32;                              // [ldg][16] row offsets (only when the queue is built)
     const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
 
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             else if (k == M.ione) v = 1.0;
             Bv[kb * 64 + lane] = v;
         }
-        if (threadIdx.x < 16) { c0s[threadIdx.x] = 0.0; bad[threadIdx.x] = 0u; nviol[threadIdx.x] = 0u; }
+        if (threadIdx.x < 16) { bad[threadIdx.x] = 0u; nviol[threadIdx.x] = 0u; }
         __syncthreads();
 
         gdw wsj = glw(wsbase) + (size_t)bc * M.wsld;
@@ -491,9 +491,6 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             }
         }
         // per-instance reductions over the four k-quarters of the wave, then over the waves
-        c0p += __shfl_xor(c0p, 16, 64);
-        c0p += __shfl_xor(c0p, 32, 64);
-        if (kq == 0) atomicAdd(&c0s[j], c0p);
         if (badl) atomicOr(&bad[j], 1u);
         __syncthreads();
 
@@ -515,12 +512,8 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
             unsigned nv = 0;
             if (16 * t < M.nz16) {              // rows of t0: f't0 / 2 joins the cost constant (f of row 4k + kq sits in Bf[k][lane])
-                double ftp = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ftp = fma(acc[r], Bf[(4 * t + r) * 64 + lane], ftp);
-                ftp += __shfl_xor(ftp, 16, 64);
-                ftp += __shfl_xor(ftp, 32, 64);
-                if (kq == 0) atomicAdd(&c0s[j], 0.5 * ftp);
+                for (int r = 0; r < 4; ++r) c0p = fma(0.5 * acc[r], Bf[(4 * t + r) * 64 + lane], c0p);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -535,10 +528,14 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             }
             if (Bt.qcnt && nv) atomicAdd(&nviol[j], nv);
         }
+        // this wavefront's share of the cost constant of instance j (no atomics: the sum must not depend on arrival order)
+        c0p += __shfl_xor(c0p, 16, 64);
+        c0p += __shfl_xor(c0p, 32, 64);
+        if (kq == 0) c0s[wave * 16 + j] = c0p;
         __syncthreads();
         if (threadIdx.x < 16 && b0 + (int)threadIdx.x < Bt.batch) {
             gdw wst = glw(wsbase) + (size_t)(b0 + threadIdx.x) * M.wsld + ldz + ldy + 2 * ldg;
-            wst[0] = c0s[threadIdx.x];
+            wst[0] = ((c0s[threadIdx.x] + c0s[16 + threadIdx.x]) + c0s[32 + threadIdx.x]) + c0s[48 + threadIdx.x];
             wst[1] = bad[threadIdx.x] ? 1.0 : 0.0;
         }
         if (Bt.qcnt) {
@@ -1496,7 +1493,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         // the counters are cleared by the last kernel of a full launch; partial launches (profiling) clear them here
         if (b.qcnt && which != 7) (void)hipMemsetAsync(b.qcnt, 0, kQueues * sizeof(int), stream);
         if (fast >= 0) {
-            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 16 + 32 + (b.qcnt ? (size_t)m.ldg * 16 : 0)) * sizeof(double);
+            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 64 + 32 + (b.qcnt ? (size_t)m.ldg * 16 : 0)) * sizeof(double);
             int blocks1 = (b.batch + 15) / 16;
             if (blocks1 > 4096) blocks1 = 4096;
             hipLaunchKernelGGL(lmpc_assemble_mfma, dim3(blocks1), dim3(256), lds1, stream, m_dev, b, ws, fast);

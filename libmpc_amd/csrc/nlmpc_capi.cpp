@@ -46,9 +46,12 @@ struct mpcx_nlmpc {
     {
         std::vector<double> both(su);
         both.insert(both.end(), ss.begin(), ss.end());
+        bool any = false;
+        for (double v : both) any |= v != 1.0;
+        for (double v : ss) both.push_back(1.0 / v);
         if (!scale_d && hipMalloc(reinterpret_cast<void **>(&scale_d), both.size() * sizeof(double)) != hipSuccess) return MPCX_E_DEVICE;
         if (hipMemcpy(scale_d, both.data(), both.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return MPCX_E_DEVICE;
-        dev.su = scale_d; dev.ss = scale_d + su.size();
+        dev.su = scale_d; dev.ss = scale_d + su.size(); dev.iss = dev.ss + ss.size(); dev.scaled = any ? 1 : 0;
         return MPCX_OK;
     }
     int sync_bounds()

@@ -138,12 +138,16 @@ static int solve()
     for (int b = 0; b < 3; ++b) {
         std::printf("instance %d  zoo %.17g  setters %.17g  setHooks %.17g  sources %.17g\n", b, rz.cmd[b], re.cmd[b], rf.cmd[b], rj.cmd[b]);
         CHECK(re.status[b] == 0 && rf.status[b] == 0 && rj.status[b] == 0);
-        const double tol = 1e-9 * std::fmax(1.0, std::fabs(rz.cmd[b]));
-        CHECK(std::fabs(re.cmd[b] - rz.cmd[b]) <= tol && std::fabs(rf.cmd[b] - rz.cmd[b]) <= tol && std::fabs(rj.cmd[b] - rz.cmd[b]) <= tol);
+        // the three routes run the same source through the same engine: bit for bit the same answer
+        CHECK(re.cmd[b] == rf.cmd[b] && re.cmd[b] == rj.cmd[b] && re.cost[b] == rf.cost[b] && re.cost[b] == rj.cost[b]);
+        // the built-in model spells the same functions by hand: the compiler may contract its products differently, and one
+        // ulp in the cost is 1e-8 in a forward-difference gradient -- the optimum agrees to that noise, not to the bit
+        const double tol = 2e-6 * std::fmax(1.0, std::fabs(rz.cmd[b]));
+        CHECK(std::fabs(re.cmd[b] - rz.cmd[b]) <= tol);
         CHECK(std::fabs(re.cost[b] - rz.cost[b]) <= 1e-9 * std::fabs(rz.cost[b]));
-        identical += (re.cmd[b] == rz.cmd[b]) + (rf.cmd[b] == rz.cmd[b]) + (rj.cmd[b] == rz.cmd[b]);
+        identical += (re.cmd[b] == rz.cmd[b]);
     }
-    std::printf("bit-identical to the built-in model: %d of 9 commands\n", identical);
+    std::printf("bit-identical to the built-in model: %d of 3 commands\n", identical);
 
     // the example's closed loop through the reference's setters
     int steps = 0; double first_cmd = 0;

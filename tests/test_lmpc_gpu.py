@@ -38,7 +38,7 @@ def test_reference_known_answer_n10():
 @pytest.mark.parametrize("path", ["mfma-assemble", "generic-assemble"])
 @pytest.mark.parametrize("ph,B", [(10, 64), (20, 256), (50, 32)])
 def test_parity_with_oracle(ph, B, path):
-    c, (x0, u0, yref), r = _solve_gpu(ph, B, generic=path == "generic-assemble", quad=path == "quad-solve")
+    c, (x0, u0, yref), r = _solve_gpu(ph, B, generic=path == "generic-assemble")
     o = quadrotor_oracle(ph)
     ref = o.solve_batch_constref(x0, u0, yref, want_active=True)
     cmd = r.cmd.cpu().numpy(); cost = r.cost.cpu().numpy()
