@@ -366,13 +366,7 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
             st2(ws + ldz + ldy + ldg + r, ug[2 * c], ug[2 * c + 1]);
         }
     }
-    // the record carries c0 + f't0 / 2: with f = -H t0 the cost at w = t0 - Y[:, A] lambda is that constant plus
-    // lambda' (N_A t0 - b_A) / 2 (lmpc_solve), and the solve kernel needs neither f nor H
-    double ft = 0;
-#pragma unroll
-    for (int s = 0; s < NZS; ++s) ft = fma(f[s], t0[s], ft);
-    ft = wave_sum(ft);
-    if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0 + 0.5 * ft, infeasible0 ? 1.0 : 0.0);
+    if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, infeasible0 ? 1.0 : 0.0);
     wave_sync();
 }
 
@@ -511,10 +505,6 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             for (; kb < nz4; ++kb)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
             unsigned nv = 0;
-            if (16 * t < M.nz16) {              // rows of t0: f't0 / 2 joins the cost constant (f of row 4k + kq sits in Bf[k][lane])
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c0p = fma(0.5 * acc[r], Bf[(4 * t + r) * 64 + lane], c0p);
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
@@ -600,11 +590,8 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         const int eo = e < ldz ? e : 0;
         const d2 vt = ld2(ws + ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
         const bool ok = e < ldz;
-        f[2 * c] = 0.0; f[2 * c + 1] = 0.0;
-        if constexpr (ADMM) {                   // the polish-only kernel needs neither f nor H (see the cost below)
-            const d2 vf = ld2(ws + eo);
-            f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
-        }
+        const d2 vf = ld2(ws + eo);
+        f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
         t0[2 * c] = ok ? vt.x : 0.0; t0[2 * c + 1] = ok ? vt.y : 0.0;
         lw[2 * c] = ok ? vl.x : -INF; lw[2 * c + 1] = ok ? vl.y : -INF;
         uw[2 * c] = ok ? vu.x : INF; uw[2 * c + 1] = ok ? vu.y : INF;
@@ -1242,28 +1229,23 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     if (infeasible) {
         cost = 1e30;
     } else if (!ADMM && polished && !M.cost_direct) {
-        // w = t0 - Y[:, A] lambda with f = -H t0:  w'Hw/2 + f'w = lambda'(N_A t0 - b_A)/2 + f't0/2, and the record's constant
-        // already holds c0 + f't0/2 -- no pass over H, no f (the factorisation just solved S lambda = N_A t0 - b_A)
+        // At the verified point H w + f + N_A' lambda = 0 and N_A w = b_A, hence w'Hw/2 + f'w = (f'w - lambda'b_A)/2: no pass
+        // over H (the single largest read of an instance: nz x nz doubles), and the products involve the bounded solution w,
+        // not the possibly huge unconstrained optimum
         double j = 0;
-        if (lane < na_last) j = 0.5 * lam[lane] * (nt0[wsidx[lane]] - wsb[lane]);
-        cost = wave_sum(j) + c0;
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) j = fma(f[s], w[s], j);
+        if (lane < na_last) j = fma(-lam[lane], wsb[lane], j);
+        cost = 0.5 * wave_sum(j) + c0;
     } else {
-        // any other point (ADMM iterate, regularised Hessian): the definition.  The record's constant carries f't0/2: take it out
-        double hw[NZS], fl[NZS];
+        // any other point (ADMM iterate, regularised Hessian): the definition
+        double hw[NZS];
 #pragma unroll
-        for (int s = 0; s < NZS; ++s) { hw[s] = 0; fl[s] = f[s]; }
-        if constexpr (!ADMM) {
-#pragma unroll
-            for (int c = 0; c < CPZ; ++c) {
-                const int e = 128 * c + 2 * lane;
-                const d2 vf = ld2(ws + (e < ldz ? e : 0));
-                fl[2 * c] = e < ldz ? vf.x : 0.0; fl[2 * c + 1] = e < ldz ? vf.y : 0.0;
-            }
-        }
+        for (int s = 0; s < NZS; ++s) hw[s] = 0;
         matvec_acc<CPZ>(GP(H), ldz, ldz, nz, stage, hw, lane);
         double j = 0;
 #pragma unroll
-        for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + fl[s]) - 0.5 * fl[s] * t0[s];
+        for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + f[s]);
         cost = wave_sum(j) + c0;
     }
 #pragma unroll

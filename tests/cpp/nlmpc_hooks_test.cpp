@@ -177,7 +177,7 @@ static int solve()
         ht.setEqConFunction([=] __device__(mpc::cvec<2> &eq_con, const mpc::mat<pred_hor + 1, num_states> &x, const mpc::mat<pred_hor + 1, num_inputs> &)
                             { eq_con(0) = x(pred_hor, 0); eq_con(1) = x(pred_hor, 1); });
     }
-    mpc::cvec<num_states> x0; x0(0) = 0.3; x0(1) = 0.4;
+    mpc::cvec<num_states> x0; x0(0) = 0.1; x0(1) = 0.1;
     mpc::cvec<num_inputs> u0; u0(0) = 0.0;
     auto a = zt.optimize(x0, u0), bq = ht.optimize(x0, u0);
     std::printf("terminal constraint: zoo cmd %.12f status %d, hooks cmd %.12f status %d\n", a.cmd(0), (int)a.status, bq.cmd(0), (int)bq.status);
