@@ -315,6 +315,19 @@ std::string LmpcController::condense(Condensed &o) const
     }
     Mat Hinv = spd_inverse_from_chol(L);
     o.flops_setup += 2.0 * nz * nz * nz / 3.0 + 2.0 * nz * nz * nz;
+    // how well the computed inverse inverts: || H Hinv - I ||_max.  The solve kernel may take the optimal cost from the
+    // stationarity identity (no pass over H) only while this is negligible; long horizons (N = 50: cond(H) ~ 8e8) are not
+    {
+        double worst = 0;
+        for (int i = 0; i < nz; i++)
+            for (int j = 0; j < nz; j++) {
+                double acc = i == j ? -1.0 : 0.0;
+                for (int k = 0; k < nz; k++) acc += H(i, k) * Hinv(k, j);
+                worst = std::max(worst, std::fabs(acc));
+            }
+        o.inverse_residual = worst;
+        o.flops_setup += 2.0 * nz * nz * nz;
+    }
 
     // dual Hessian Y = N Hinv N', N = [I; G]
     Mat G(std::max(mg, 1), nz);

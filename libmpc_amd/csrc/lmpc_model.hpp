@@ -57,6 +57,7 @@ struct Condensed {
     int nf = 0, nz = 0, mg = 0, ldz = 0, ldg = 0, ldy = 0;
     int n_ref = 0, m_ref = 0, neq_ref = 0, active_words = 0;
     bool has_dist = false, h_regularised = false;
+    double inverse_residual = 0;                 // || H Hinv - I ||_max of the computed inverse
     std::vector<double> H, Kinv, Gr, Gc, Y;      // padded, see lmpc_device.hpp
     std::vector<double> lw, uw, rho_b;           // [ldz]
     std::vector<double> lg0, ug0, rho_g;         // [ldg]

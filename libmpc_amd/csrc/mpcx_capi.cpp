@@ -369,7 +369,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.n_fixed = (int)o.fixed_rows.size();
     D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
     D.strict_infeasible = h->strict_infeasible ? 1 : 0;
-    D.cost_direct = o.h_regularised ? 1 : 0;
+    D.cost_direct = (o.h_regularised || o.inverse_residual > 1e-9) ? 1 : 0;
     D.check_every = h->dbg_check_every; D.polish_rounds0 = h->dbg_rounds0; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;

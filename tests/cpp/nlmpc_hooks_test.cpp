@@ -180,7 +180,8 @@ static int solve()
     mpc::cvec<num_states> x0; x0(0) = 0.1; x0(1) = 0.1;
     mpc::cvec<num_inputs> u0; u0(0) = 0.0;
     auto a = zt.optimize(x0, u0), bq = ht.optimize(x0, u0);
-    std::printf("terminal constraint: zoo cmd %.12f status %d, hooks cmd %.12f status %d\n", a.cmd(0), (int)a.status, bq.cmd(0), (int)bq.status);
+    std::printf("terminal constraint: zoo cmd %.12f status %d (%d), hooks cmd %.12f status %d (%d)\n", a.cmd(0), (int)a.status, a.solver_status,
+                bq.cmd(0), (int)bq.status, bq.solver_status);
     CHECK(a.status == mpc::ResultStatus::SUCCESS && bq.status == mpc::ResultStatus::SUCCESS);
     CHECK(std::fabs(a.cmd(0) - bq.cmd(0)) <= 1e-7 * std::fmax(1.0, std::fabs(a.cmd(0))));
     auto sq = ht.getOptimalSequence();

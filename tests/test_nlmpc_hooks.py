@@ -138,6 +138,40 @@ def test_hooks_from_sources_match_the_builtin_model(name):
 
 
 @pytest.mark.gpu
+def test_hooks_with_user_equalities_and_an_output_function_match_the_builtin_model():
+    """setEqConFunction and setOutputFunction as sources: Van der Pol with the terminal equality x(ph) = 0, the cost written
+    on the outputs y = x (Model::getOutput is re-run inside every perturbation, Model.hpp:72-96)"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL_TERMINAL
+    zoo = NLMPC(VANDERPOL_TERMINAL, 10, 5, 0.1)
+    usr = NLMPC.from_sources(2, 1, 2, 10, 5, 11, 2, 0.1, state_fn=VDP["state_fn"], ineq_fn=VDP["ineq_fn"],
+                             output_fn="y(0) = x(0); y(1) = x(1);",
+                             objective_fn="return y.array().square().sum() + u.array().square().sum();",
+                             eq_fn="eq_con(0) = x(pred_hor, 0); eq_con(1) = x(pred_hor, 1);")
+    assert usr.neq_user == 2
+    rng = np.random.default_rng(8)
+    B = 6
+    Z = torch.from_numpy(rng.normal(size=(B, zoo.nz))); X0 = torch.from_numpy(rng.normal(size=(B, 2)))
+    a = zoo.evaluate(Z, X0); b = usr.evaluate(Z, X0)
+    torch.cuda.synchronize()
+    for k in ("cost", "grad", "ceq", "jeq", "cineq", "jineq"):
+        np.testing.assert_allclose(b[k].cpu().numpy(), a[k].cpu().numpy(), rtol=1e-9, atol=1e-6 if k.startswith("j") or k == "grad" else 1e-12, err_msg=k)
+    for c in (zoo, usr):
+        c.setOptimizerParameters(NLParameters(maximum_iteration=300))
+    x0 = rng.uniform(-0.12, 0.12, size=(B, 2)); x0[0] = [0.1, 0.1]
+    u0 = np.zeros((B, 1))
+    ra = zoo.optimizeBatch(torch.from_numpy(x0), torch.from_numpy(u0), sequences=True)
+    rb = usr.optimizeBatch(torch.from_numpy(x0), torch.from_numpy(u0), sequences=True)
+    torch.cuda.synchronize()
+    sa, sb = ra["solver_status"].cpu().numpy(), rb["solver_status"].cpu().numpy()
+    assert (ra["status"].cpu().numpy() == 0).all(), sa
+    assert (rb["status"].cpu().numpy() == 0).all(), sb
+    np.testing.assert_allclose(rb["cmd"].cpu().numpy(), ra["cmd"].cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(rb["seq_output"].cpu().numpy(), rb["seq_state"].cpu().numpy(), rtol=0, atol=0)
+    assert np.abs(rb["seq_state"].cpu().numpy()[:, 10]).max() <= 1e-9
+
+
+@pytest.mark.gpu
 def test_python_callables_are_refused_with_a_pointer_to_sources():
     from libmpc_amd.nlmpc import NLMPC, VANDERPOL
     c = NLMPC(VANDERPOL, 10, 5, 0.1)
