@@ -132,6 +132,12 @@ class NLMPC {
         static_assert(kStatic, "device hooks need compile-time dimensions (the hook signatures carry them)");
         using Model = mpcx::HookModel<Tnx, Tnu, Tny, Tph, Tch, Tineq, Teq, Erased>;
         if (hipSetDevice(device()) != hipSuccess) throw std::runtime_error("NLMPC: no usable HIP device");
+        // Hooks reached through function pointers run on the kernel's dynamic stack: the runtime sizes a lane's scratch as
+        // max(the kernel's own frame, hipLimitStackSize), so the limit has to cover the kernel's frame (a few KiB of spills
+        // and the matrix views handed to the hooks by reference) PLUS the frames of the hooks themselves.
+        size_t stack = 0;
+        const size_t want = 16384 + 4 * sizeof(mpc::mat<(Tph > 0 ? Tph : 1) + 1, (Tnx > Tnu ? (Tnx > Tny ? Tnx : Tny) : (Tnu > Tny ? Tnu : Tny))>);
+        if (hipDeviceGetLimit(&stack, hipLimitStackSize) == hipSuccess && stack < want) (void)hipDeviceSetLimit(hipLimitStackSize, want);
         if (!hooks_erased_) { hook_blob_.assign(sizeof(Erased), 0); new (hook_blob_.data()) Erased(); hooks_erased_ = true; hook_out_ = false; }
         const bool ok = fill(*reinterpret_cast<Erased *>(hook_blob_.data()));
         thunk_eval_ = &thunk_eval<Model>; thunk_solve_ = &thunk_solve<Model>;

@@ -170,7 +170,13 @@ __device__ __forceinline__ void hook_base_outputs(const NlmpcDev &M, const doubl
 {
     if constexpr (Mdl::VECTOR_HOOKS) {
         if (M.has_output) {
-            for (int i = lane; i <= M.ph; i += 64) hook_out_row<Mdl>(Ys + i * Mdl::NY, Xs, Us, i, -1, 0.0, -1, 0.0, M.params);
+            // every lane makes the call (surplus lanes redo row ph): no divergence around a hook that may sit behind a pointer
+            for (int i0 = 0; i0 <= M.ph; i0 += 64) {
+                const int i = min(i0 + lane, M.ph);
+                double yr[Mdl::NY > 0 ? Mdl::NY : 1];
+                hook_out_row<Mdl>(yr, Xs, Us, i, -1, 0.0, -1, 0.0, M.params);
+                if (i0 + lane <= M.ph) for (int a = 0; a < Mdl::NY; ++a) Ys[i * Mdl::NY + a] = yr[a];
+            }
             nl_wave_sync();
         }
     }
@@ -196,16 +202,24 @@ __device__ __forceinline__ void hook_cost_grad(const NlmpcDev &M, const double *
     if (lane == 0 && cost) *cost = f0;
     if (!grad) return;
     double *g = grad;
-    for (int k = lane; k < ph * NX; k += 64) {
+    // Every lane runs the same number of passes and makes the same calls in each (a surplus lane repeats the last column and
+    // keeps the result to itself): a hook may sit behind a function pointer, and call sites inside control flow that differs
+    // between lanes are where that goes wrong.
+    for (int k0 = 0; k0 < ph * NX; k0 += 64) {
+        const bool live = k0 + lane < ph * NX;
+        const int k = live ? k0 + lane : ph * NX - 1;
         const int i = k / NX, j = k - i * NX;
         const double dx = dv * Xa(j);
         MX Xp = MX::trajectory(Xs); Xp.perturb(i + 1, -1, j, dx);
         MY Yp = Y0;
         double yo1[NYA];
         if (ho) { hook_out_row<Mdl>(yo1, Xs, Us, i + 1, j, dx, -1, 0.0, prm); Yp.perturb(i + 1, -1, -1, 0.0).replace_rows(yo1, nullptr); }
-        g[k] = (Mdl::cost(Xp, Yp, U0, e, prm) - f0) / dx;
+        const double fp = Mdl::cost(Xp, Yp, U0, e, prm);
+        if (live) g[k] = (fp - f0) / dx;
     }
-    for (int k = lane; k < ph * NU; k += 64) {
+    for (int k0 = 0; k0 < ph * NU; k0 += 64) {
+        const bool live = k0 + lane < ph * NU;
+        const int k = live ? k0 + lane : ph * NU - 1;
         const int i = k / NU, j = k - i * NU;
         const double du = dv * Ua(j);
         const int pair = i == ph - 1 ? ph : -1;                               // the last row moves with its copy
@@ -214,10 +228,11 @@ __device__ __forceinline__ void hook_cost_grad(const NlmpcDev &M, const double *
         double yo1[NYA], yo2[NYA];
         if (ho) {
             hook_out_row<Mdl>(yo1, Xs, Us, i, -1, 0.0, j, du, prm);
-            if (pair >= 0) hook_out_row<Mdl>(yo2, Xs, Us, ph, -1, 0.0, j, du, prm);
+            hook_out_row<Mdl>(yo2, Xs, Us, ph, -1, 0.0, j, du, prm);           // used only by the paired last row
             Yp.perturb(i, pair, -1, 0.0).replace_rows(yo1, pair >= 0 ? yo2 : nullptr);
         }
-        Jm[k] = (Mdl::cost(X0, Yp, Up, e, prm) - f0) / du;
+        const double fp = Mdl::cost(X0, Yp, Up, e, prm);
+        if (live) Jm[k] = (fp - f0) / du;
     }
     nl_wave_sync();
     for (int k = lane; k < ch * NU; k += 64) {
@@ -226,9 +241,10 @@ __device__ __forceinline__ void hook_cost_grad(const NlmpcDev &M, const double *
         for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
         g[ph * NX + k] = Scale(M).by_su(s, j);                                // Iz2u' * vec(Jmv)
     }
-    if (lane == 0) {
+    {
         const double de = fmax(dv, fabs(e)) * dv;
-        g[nz - 1] = (Mdl::cost(X0, Y0, U0, e + de, prm) - Mdl::cost(X0, Y0, U0, e - de, prm)) / (2 * de);
+        const double ge = (Mdl::cost(X0, Y0, U0, e + de, prm) - Mdl::cost(X0, Y0, U0, e - de, prm)) / (2 * de);
+        if (lane == 0) g[nz - 1] = ge;
     }
     nl_wave_sync();
 }
@@ -253,81 +269,94 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
     const MX X0 = MX::trajectory(Xs);
     const MU U0 = MU::trajectory(Us);
     const MY Y0 = ho ? MY::trajectory(Ys) : MY::zeros_view();
-    if (cineq) {
-        if constexpr (NI > 0) if (lane == 0) { VI o = VI::output(cineq, 1); Mdl::ineq_all(o, X0, Y0, U0, e, prm); }
-        if constexpr (NE > 0) if (lane == (NI > 0 ? 1 : 0)) { VE o = VE::output(cineq + NI, 1); Mdl::eq_all(o, X0, U0, prm); }
-    }
-    if (!jineq) { nl_wave_sync(); return; }
     double *J = jineq;
     double *cA = hk + lane, *cB = hk + (size_t)64 * m + lane;                  // element r at [r * 64]
-    for (int k = lane; k < nz; k += 64) {
-        if (k < ph * NX) {
-            const int i = k / NX, j = k - i * NX;
-            if constexpr (NI > 0) {
-                const double dx = dv * Xa(j);
-                for (int sgn = 0; sgn < 2; ++sgn) {
-                    const double d = sgn ? -dx : dx;
-                    MX Xp = MX::trajectory(Xs); Xp.perturb(i + 1, -1, j, d);
-                    MY Yp = Y0;
-                    double yo1[NYA];
-                    if (ho) { hook_out_row<Mdl>(yo1, Xs, Us, i + 1, j, d, -1, 0.0, prm); Yp.perturb(i + 1, -1, -1, 0.0).replace_rows(yo1, nullptr); }
-                    VI o = VI::output(sgn ? cB : cA, 64);
-                    Mdl::ineq_all(o, Xp, Yp, U0, e, prm);
-                }
-                // computeIneqJacobian multiplies the state columns by the state scaling (Constraints.hpp:269-284)
-                for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
+    // values: every lane evaluates the vectors into its own column buffer (same calls in every lane, see hook_cost_grad),
+    // lane 0 files them
+    if (cineq) {
+        if constexpr (NI > 0) { VI o = VI::output(cA, 64); Mdl::ineq_all(o, X0, Y0, U0, e, prm); }
+        if constexpr (NE > 0) { VE o = VE::output(cA + (size_t)64 * NI, 64); Mdl::eq_all(o, X0, U0, prm); }
+        if (lane == 0) for (int r = 0; r < m; ++r) cineq[r] = cA[r * 64];
+    }
+    if (!jineq) { nl_wave_sync(); return; }
+    // state columns
+    for (int k0 = 0; k0 < ph * NX; k0 += 64) {
+        const bool live = k0 + lane < ph * NX;
+        const int k = live ? k0 + lane : ph * NX - 1;
+        const int i = k / NX, j = k - i * NX;
+        if constexpr (NI > 0) {
+            const double dx = dv * Xa(j);
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const double d = sgn ? -dx : dx;
+                MX Xp = MX::trajectory(Xs); Xp.perturb(i + 1, -1, j, d);
+                MY Yp = Y0;
+                double yo1[NYA];
+                if (ho) { hook_out_row<Mdl>(yo1, Xs, Us, i + 1, j, d, -1, 0.0, prm); Yp.perturb(i + 1, -1, -1, 0.0).replace_rows(yo1, nullptr); }
+                VI o = VI::output(sgn ? cB : cA, 64);
+                Mdl::ineq_all(o, Xp, Yp, U0, e, prm);
             }
-            if constexpr (NE > 0) {
-                const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
-                for (int sgn = 0; sgn < 2; ++sgn) {
-                    MX Xp = MX::trajectory(Xs); Xp.perturb(i + 1, -1, j, sgn ? -dx : dx);
-                    VE o = VE::output((sgn ? cB : cA) + (size_t)64 * NI, 64);
-                    Mdl::eq_all(o, Xp, U0, prm);
-                }
-                for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
+            // computeIneqJacobian multiplies the state columns by the state scaling (Constraints.hpp:269-284)
+            if (live) for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
+        }
+        if constexpr (NE > 0) {
+            const double dx = dv * fmax(fabs(Xs[(i + 1) * NX + j]), 1.0);
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                MX Xp = MX::trajectory(Xs); Xp.perturb(i + 1, -1, j, sgn ? -dx : dx);
+                VE o = VE::output((sgn ? cB : cA) + (size_t)64 * NI, 64);
+                Mdl::eq_all(o, Xp, U0, prm);
             }
-        } else if (k < nz - 1) {
-            const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
-            const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;       // the steps this block drives
-            for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] = 0.0;
+            if (live) for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = sc.by_ss((cA[r * 64] - cB[r * 64]) / (2 * dx), j);
+        }
+    }
+    // input columns: block bl drives the steps i_first..i_last; the passes over the steps are the same for every lane (the
+    // longest block), a lane whose block is shorter repeats its last step and drops the result
+    const int span_max = ph - ch + 1;
+    for (int q0 = 0; q0 < ch * NU; q0 += 64) {
+        const bool live = q0 + lane < ch * NU;
+        const int q = live ? q0 + lane : ch * NU - 1;
+        const int bl = q / NU, j = q - bl * NU, k = ph * NX + q;
+        const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;           // the steps this block drives
+        if (live) for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] = 0.0;
+        for (int t = 0; t < span_max; ++t) {
+            const bool step_live = live && i_first + t <= i_last;
+            const int i = min(i_first + t, i_last);
             if constexpr (NI > 0) {
                 const double du = dv * Ua(j);
-                for (int i = i_first; i <= i_last; ++i) {                      // every input row of the block on its own (no pairing here)
-                    for (int sgn = 0; sgn < 2; ++sgn) {
-                        const double d = sgn ? -du : du;
-                        MU Up = MU::trajectory(Us); Up.perturb(i, -1, j, d);
-                        MY Yp = Y0;
-                        double yo1[NYA];
-                        if (ho) { hook_out_row<Mdl>(yo1, Xs, Us, i, -1, 0.0, j, d, prm); Yp.perturb(i, -1, -1, 0.0).replace_rows(yo1, nullptr); }
-                        VI o = VI::output(sgn ? cB : cA, 64);
-                        Mdl::ineq_all(o, X0, Yp, Up, e, prm);
-                    }
-                    for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] += (cA[r * 64] - cB[r * 64]) / (2 * du);
+                for (int sgn = 0; sgn < 2; ++sgn) {                            // every input row of the block on its own (no pairing here)
+                    const double d = sgn ? -du : du;
+                    MU Up = MU::trajectory(Us); Up.perturb(i, -1, j, d);
+                    MY Yp = Y0;
+                    double yo1[NYA];
+                    if (ho) { hook_out_row<Mdl>(yo1, Xs, Us, i, -1, 0.0, j, d, prm); Yp.perturb(i, -1, -1, 0.0).replace_rows(yo1, nullptr); }
+                    VI o = VI::output(sgn ? cB : cA, 64);
+                    Mdl::ineq_all(o, X0, Yp, Up, e, prm);
                 }
+                if (step_live) for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] += (cA[r * 64] - cB[r * 64]) / (2 * du);
             }
             if constexpr (NE > 0) {
                 const double du = dv * fmax(fabs(Us[(ph - 1) * NU + j]), 1.0);  // row ph-1's magnitude for every step (Constraints.hpp:780,806)
-                for (int i = i_first; i <= i_last; ++i) {
-                    for (int sgn = 0; sgn < 2; ++sgn) {
-                        MU Up = MU::trajectory(Us); Up.perturb(i, i == ph - 1 ? ph : -1, j, sgn ? -du : du);
-                        VE o = VE::output((sgn ? cB : cA) + (size_t)64 * NI, 64);
-                        Mdl::eq_all(o, X0, Up, prm);
-                    }
-                    for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] += (cA[r * 64] - cB[r * 64]) / (2 * du);
-                }
-            }
-            if (sc.on) for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] *= sc.su[j];      // glueJacobian: Jmanvar * Iz2u
-        } else {
-            const double de = fmax(dv, fabs(e)) * dv;
-            if constexpr (NI > 0) {
                 for (int sgn = 0; sgn < 2; ++sgn) {
-                    VI o = VI::output(sgn ? cB : cA, 64);
-                    Mdl::ineq_all(o, X0, Y0, U0, sgn ? e - de : e + de, prm);
+                    MU Up = MU::trajectory(Us); Up.perturb(i, i == ph - 1 ? ph : -1, j, sgn ? -du : du);
+                    VE o = VE::output((sgn ? cB : cA) + (size_t)64 * NI, 64);
+                    Mdl::eq_all(o, X0, Up, prm);
                 }
-                for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = (cA[r * 64] - cB[r * 64]) / (2 * de);
+                if (step_live) for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] += (cA[r * 64] - cB[r * 64]) / (2 * du);
             }
-            for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = 0.0;
         }
+        if (live && sc.on) for (int r = 0; r < m; ++r) J[(size_t)r * nz + k] *= sc.su[j];      // glueJacobian: Jmanvar * Iz2u
+    }
+    // slack column (every lane computes it, lane 0 files it)
+    {
+        const int k = nz - 1;
+        const double de = fmax(dv, fabs(e)) * dv;
+        if constexpr (NI > 0) {
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                VI o = VI::output(sgn ? cB : cA, 64);
+                Mdl::ineq_all(o, X0, Y0, U0, sgn ? e - de : e + de, prm);
+            }
+            if (lane == 0) for (int r = 0; r < NI; ++r) J[(size_t)r * nz + k] = (cA[r * 64] - cB[r * 64]) / (2 * de);
+        }
+        if (lane == 0) for (int r = NI; r < m; ++r) J[(size_t)r * nz + k] = 0.0;
     }
     nl_wave_sync();
 }
@@ -1366,19 +1395,26 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                         MY YV = MY::zeros_view();
                         if (M.has_output) {
                             double *yt = ytr + (size_t)grp * (ph + 1) * NY;
-                            for (int i = part; i <= ph; i += 8) {
-                                double xr[NX], ur[NU];
+                            // every lane makes the same number of calls (a hook may sit behind a function pointer: keep the
+                            // call sites out of loops whose trip count differs between lanes); surplus lanes redo row ph
+                            for (int i0 = 0; i0 <= ph; i0 += 8) {
+                                const int i = min(i0 + part, ph);
+                                double xr[NX], ur[NU], yr[NY > 0 ? NY : 1];
                                 for (int a = 0; a < NX; ++a) xr[a] = XL(i, a);
                                 for (int a = 0; a < NU; ++a) ur[a] = UL(i, a);
-                                Mdl::out(yt + i * NY, xr, ur, prm, (unsigned)i);
+                                Mdl::out(yr, xr, ur, prm, (unsigned)i);
+                                if (i0 + part <= ph) for (int a = 0; a < NY; ++a) yt[i * NY + a] = yr[a];
                             }
                             nl_wave_sync();
                             YV = MY::trajectory(yt);
                         }
                         double *gl = lsb + (size_t)grp * m;
-                        if (part == 0) mer = Mdl::cost(XV, YV, UV, et, prm);
-                        if constexpr (NI > 0) if (part == 1) { VI o = VI::output(gl, 1); Mdl::ineq_all(o, XV, YV, UV, et, prm); }
-                        if constexpr (NE > 0) if (part == 2) { VE o = VE::output(gl + NI, 1); Mdl::eq_all(o, XV, UV, prm); }
+                        // the eight lanes of a trial point make the same calls (they store the same values to the same place):
+                        // no hook call sits in control flow that differs between lanes
+                        const double ct = Mdl::cost(XV, YV, UV, et, prm);
+                        if (part == 0) mer = ct;
+                        if constexpr (NI > 0) { VI o = VI::output(gl, 1); Mdl::ineq_all(o, XV, YV, UV, et, prm); }
+                        if constexpr (NE > 0) { VE o = VE::output(gl + NI, 1); Mdl::eq_all(o, XV, UV, prm); }
                         nl_wave_sync();
                         for (int k = part; k < m; k += 8) vio += k < mi ? fmax(gl[k], 0.0) : fabs(gl[k]);
                     } else {
@@ -1387,17 +1423,20 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                         for (int k = part; k < m - mi; k += 8) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
                     }
                     const double h = 0.5 * M.Ts;
-                    for (int i = part; i < ph; i += 8) {
-                        double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
+                    for (int i0 = 0; i0 < ph; i0 += 8) {              // same trip count in every lane; a surplus lane redoes step ph-1
+                        const bool live = i0 + part < ph;
+                        const int i = live ? i0 + part : ph - 1;
+                        double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX], v = 0;
                         for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
                         for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
                         call_f<Mdl>(fa, xk, uk, prm, i);
                         if (CT) {
                             call_f<Mdl>(fb, xk1, uk, prm, i);
-                            for (int a = 0; a < NX; ++a) vio += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
+                            for (int a = 0; a < NX; ++a) v += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
                         } else {
-                            for (int a = 0; a < NX; ++a) vio += fabs(sc.over_ss(xk1[a] - fa[a], a));
+                            for (int a = 0; a < NX; ++a) v += fabs(sc.over_ss(xk1[a] - fa[a], a));
                         }
+                        if (live) vio += v;
                     }
                     mer += nu_pen * vio;
                     mer += __shfl_xor(mer, 1); mer += __shfl_xor(mer, 2); mer += __shfl_xor(mer, 4);

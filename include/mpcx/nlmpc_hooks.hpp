@@ -30,6 +30,7 @@ struct NoHook {};      // an unset hook: no outputs / zero cost / no rows
 
 template <class FDyn, class FObj, class FIneq = NoHook, class FEq = NoHook, class FOut = NoHook>
 struct HookSet {
+    static constexpr bool kErased = false;
     FDyn fdyn; FObj fobj; FIneq fineq; FEq feq; FOut fout;
     template <class VX, class VU> __device__ void f(VX &dx, const VX &x, const VU &u, const unsigned &s) const { fdyn(dx, x, u, s); }
     template <class MX, class MY, class MU> __device__ double obj(const MX &X, const MY &Y, const MU &U, const double &e) const
@@ -101,6 +102,7 @@ constexpr int kHookClosureBytes = 192;
 
 template <int NX, int NU, int NY, int PH, int CH, int NI, int NE>
 struct ErasedHooks {
+    static constexpr bool kErased = true;
     using MatX = mpc::mat<PH + 1, NX>;
     using MatU = mpc::mat<PH + 1, NU>;
     using MatY = mpc::mat<PH + 1, NY>;
