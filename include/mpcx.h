@@ -172,7 +172,16 @@ int mpcx_lmpc_set_strict_infeasibility(mpcx_lmpc_t h, int on);
 int mpcx_lmpc_setup(mpcx_lmpc_t h);
 /* Batched LOptimizer::run on `stream` (a hipStream_t, NULL = default stream).
  * Asynchronous with respect to the host; outputs are valid once the stream
- * has been synchronised. */
+ * has been synchronised.
+ * Concurrency: a handle owns ONE per-instance workspace and ONE set of dispatch queues.  Launches of the
+ * same handle on the same stream are ordered and safe; two launches of the same handle in flight on
+ * DIFFERENT streams race on them (instances could be dropped or solved twice).  Overlap batches by giving
+ * each stream its own handle (set-up cost is per handle and paid once), as bench.py's pipelined leg does.
+ * maximum_iteration: the main iteration here is OSQP's polish step repeated until the KKT conditions verify
+ * (DESIGN.md 4.3); it needs no ADMM iterations, so LParameters::maximum_iteration only bounds the ADMM
+ * fallback that takes over when the polish does not verify (or when polish = 0).  `iterations[]` reports
+ * the ADMM iterations actually spent (0 on the polish path), `polish_rounds[]` the active-set rounds.  A QP the
+ * reference would leave MAX_ITER_REACHED and un-polished comes back here as the exact optimum with SUCCESS. */
 int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream);
 /* Same launch, timed with HIP events recorded on `stream` around `repeats`
  * back-to-back launches; returns the mean kernel time in milliseconds. */

@@ -598,4 +598,41 @@ void LmpcController::build_fast_maps(Condensed &o) const
         for (int r = 0; r < o.ldy; r++) o.Ym[(size_t)q * o.ldy16 + r] = -o.Y[(size_t)q * o.ldy + r];
 }
 
+void LmpcController::refresh_fast_maps(Condensed &o) const
+{
+    const int nx = d.nx, nu = d.nu, ny = d.ny, ph = d.ph;
+    const int offg = o.nz16, offs = offg + o.mg16, offq = offs + o.ns16;
+    const int nin = nx + nu + ny;
+    auto col_of = [&](int k) { return k < nx ? k : (k < nx + nu ? o.nxp + (k - nx) : o.nxp + o.nup + (k - nx - nu)); };
+    Mat zero_y(ny, ph);
+    for (int variant = 0; variant < 2; variant++) {
+        std::vector<double> &M = o.MA[variant];
+        auto eval = [&](const std::vector<double> &v, AsmOut &out) {
+            Mat yR = variant == 0 ? yRef : zero_y;
+            if (variant == 1)
+                for (int k = 0; k < ph; k++)
+                    for (int a = 0; a < ny; a++) yR(a, k) = v[nx + nu + a];
+            assemble_host(o, v.data(), v.data() + nx, yR, uRef, duRef, dMeas, out);
+        };
+        auto put = [&](int row, int col, double val) { M[(size_t)col * o.rowsA + row] = val; };
+        auto get = [&](int row, int col) { return M[(size_t)col * o.rowsA + row]; };
+        const int nprobe = variant == 0 ? nx + nu : nin;
+        std::vector<double> v(nin, 0.0);
+        AsmOut base; eval(v, base);
+        for (int r = 0; r < o.nz; r++) put(r, o.ione, base.f[r]);
+        for (int r = 0; r < o.mg; r++) put(offg + r, o.ione, base.goff[r]);
+        for (int r = 0; r < o.ns; r++) put(offs + r, o.ione, base.sval[r]);
+        const double c = base.c0;
+        put(offq + o.ione, o.ione, 2.0 * c);
+        for (int k = 0; k < nprobe; k++) {
+            // c0(e_k) = c + b_k + A_kk / 2 with A_kk kept from the full build
+            v.assign(nin, 0.0); v[k] = 1.0;
+            AsmOut e1; eval(v, e1);
+            const int ck = col_of(k);
+            const double bk = e1.c0 - c - 0.5 * get(offq + ck, ck);
+            put(offq + ck, o.ione, bk); put(offq + o.ione, ck, bk);
+        }
+    }
+}
+
 }  // namespace mpcx

@@ -121,6 +121,9 @@ struct LmpcController {
     void assemble_host(const Condensed &o, const double *x0, const double *u0, const Mat &yR, const Mat &uR,
                        const Mat &dR, const Mat &dM, AsmOut &out) const;
     void build_fast_maps(Condensed &o) const;
+    // the same after a change of references / exogenous inputs only: the constant column (and the linear part of the cost
+    // form) of both maps; the quadratic part does not depend on them
+    void refresh_fast_maps(Condensed &o) const;
 };
 
 }  // namespace mpcx

@@ -34,7 +34,8 @@ struct mpcx_lmpc {
     mpcx::LmpcController ctl;
     int device = 0;
     bool host_only = false;
-    bool dirty = true;
+    bool dirty = true;                  // controller changed: condense again, rebuild the device-resident model
+    bool refs_dirty = false;            // only references / exogenous inputs changed: refresh what depends on them, in place
     mpcx::Condensed cond;
     mpcx::LmpcDev dev{};
     mpcx::LmpcDev *dev_d = nullptr;     // the same struct, resident in HBM for the kernel
@@ -44,6 +45,11 @@ struct mpcx_lmpc {
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
+    // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
+    double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
+    size_t stage_cap = 0;               // instances
+    int warm_batch = 0;                 // batch size whose active sets are in stage_act (0: none)
+    int n_full_setups = 0, n_ref_refreshes = 0;      // how often each kind of set-up ran (mpcx_lmpc_debug_setup_counts)
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     int *queues = nullptr;              // dispatch queues: kLmpcQueues counters, then kLmpcQueues lists of ws_cap instances
     size_t ws_cap = 0;                  // instances
@@ -56,6 +62,20 @@ struct mpcx_lmpc {
         if (ws) (void)hipFree(ws);
         if (queues) (void)hipFree(queues);
         ws = nullptr; queues = nullptr; ws_cap = 0;
+        warm_batch = 0;                 // row numbering may have changed with the model
+    }
+    void release_staging()
+    {
+        if (stage_d) (void)hipFree(stage_d);
+        if (stage_i) (void)hipFree(stage_i);
+        if (stage_act) (void)hipFree(stage_act);
+        stage_d = nullptr; stage_i = nullptr; stage_act = nullptr; stage_cap = 0; warm_batch = 0;
+    }
+    // copy into a buffer this handle already owns on the device (same size as at set-up)
+    template <typename T>
+    bool reup(const T *dst, const std::vector<T> &v)
+    {
+        return v.empty() || hipMemcpy(const_cast<T *>(dst), v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
     }
     template <typename T>
     const T *up(const std::vector<T> &v, int &rc)
@@ -105,7 +125,7 @@ int mpcx_lmpc_create(const mpcx_dims *d, int device, mpcx_lmpc_t *out)
 int mpcx_lmpc_destroy(mpcx_lmpc_t h)
 {
     if (!h) return MPCX_OK;
-    if (!h->host_only) { (void)hipSetDevice(h->device); h->release(); }
+    if (!h->host_only) { (void)hipSetDevice(h->device); h->release(); h->release_staging(); }
     delete h;
     return MPCX_OK;
 }
@@ -286,7 +306,7 @@ int mpcx_lmpc_set_references(mpcx_lmpc_t h, const double *yref, const double *ur
     std::memcpy(c.yRef.a.data(), yref, sizeof(double) * c.yRef.a.size());
     std::memcpy(c.uRef.a.data(), uref, sizeof(double) * c.uRef.a.size());
     std::memcpy(c.duRef.a.data(), duref, sizeof(double) * c.duRef.a.size());
-    h->dirty = true;
+    h->refs_dirty = true;        // the time-invariant terms stay (the reference's setReferences does not rebuild them either)
     return MPCX_OK;
 }
 int mpcx_lmpc_set_references_slice(mpcx_lmpc_t h, const double *yref, const double *uref, const double *duref, int start, int end)
@@ -302,7 +322,7 @@ int mpcx_lmpc_set_references_slice(mpcx_lmpc_t h, const double *yref, const doub
         std::memcpy(c.uRef.col(i), uref, sizeof(double) * c.d.nu);
         std::memcpy(c.duRef.col(i), duref, sizeof(double) * c.d.nu);
     }
-    h->dirty = true;
+    h->refs_dirty = true;        // the time-invariant terms stay (the reference's setReferences does not rebuild them either)
     return MPCX_OK;
 }
 int mpcx_lmpc_set_exogenous_inputs(mpcx_lmpc_t h, const double *dmeas)
@@ -313,7 +333,7 @@ int mpcx_lmpc_set_exogenous_inputs(mpcx_lmpc_t h, const double *dmeas)
         if (!dmeas) return fail(MPCX_E_INVALID, "null matrix");
         std::memcpy(c.dMeas.a.data(), dmeas, sizeof(double) * c.dMeas.a.size());
     }
-    h->dirty = true;
+    h->refs_dirty = true;        // the time-invariant terms stay (the reference's setReferences does not rebuild them either)
     return MPCX_OK;
 }
 int mpcx_lmpc_set_exogenous_inputs_slice(mpcx_lmpc_t h, const double *dmeas, int start, int end)
@@ -322,12 +342,13 @@ int mpcx_lmpc_set_exogenous_inputs_slice(mpcx_lmpc_t h, const double *dmeas, int
     auto &c = h->ctl;
     int s = start, e = end;
     if (start == -1 && end == -1) { s = 0; e = c.d.ph; }
-    else if (!c.pred_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The prediction horizon slice is out of bounds");
+    // the reference validates this slice against the CONTROL horizon (LMPC.hpp:571, isControlHorizonSliceValid)
+    else if (!c.ctrl_slice_valid(start, end)) return fail(MPCX_E_INVALID, "The control horizon slice is out of bounds");
     if (c.d.ndu > 0) {
         if (!dmeas) return fail(MPCX_E_INVALID, "null vector");
         for (int i = s; i < e; i++) std::memcpy(c.dMeas.col(i), dmeas, sizeof(double) * c.d.ndu);
     }
-    h->dirty = true;
+    h->refs_dirty = true;        // the time-invariant terms stay (the reference's setReferences does not rebuild them either)
     return MPCX_OK;
 }
 
@@ -350,10 +371,30 @@ int mpcx_lmpc_set_strict_infeasibility(mpcx_lmpc_t h, int on)
     return MPCX_OK;
 }
 
+// References / exogenous inputs changed and nothing else: the condensed matrices, their factors, the workspace and the
+// queues stay where they are; what depends on the references -- the shared reference arrays and the constant column of the
+// stacked maps of the MFMA assemble kernel -- is recomputed on the host (one roll-out per input component) and copied over
+// the device arrays in place.
+static int refresh_references(mpcx_lmpc_t h)
+{
+    const auto &c = h->ctl;
+    h->ctl.refresh_fast_maps(h->cond);
+    h->refs_dirty = false;
+    ++h->n_ref_refreshes;
+    if (h->host_only) return MPCX_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    const mpcx::LmpcDev &D = h->dev;
+    const bool ok = h->reup(D.yref_s, c.yRef.a) && h->reup(D.uref_s, c.uRef.a) && h->reup(D.duref_s, c.duRef.a) &&
+                    h->reup(D.dmeas_s, c.dMeas.a) && h->reup(D.MA0, h->cond.MA[0]) && h->reup(D.MA1, h->cond.MA[1]);
+    return ok ? MPCX_OK : fail(MPCX_E_DEVICE, "device upload failed");
+}
+
 int mpcx_lmpc_setup(mpcx_lmpc_t h)
 {
     CHECK_H(h);
-    if (!h->dirty) return MPCX_OK;
+    if (!h->dirty) return h->refs_dirty ? refresh_references(h) : MPCX_OK;
+    h->refs_dirty = false;
+    ++h->n_full_setups;
     std::string msg = h->ctl.condense(h->cond);
     if (!msg.empty()) return fail(msg == "state-space model not set" ? MPCX_E_STATE : MPCX_E_NUMERIC, msg);
     const auto &c = h->ctl;
@@ -501,41 +542,58 @@ int mpcx_lmpc_solve_host(mpcx_lmpc_t h, int batch, const double *x0, const doubl
     if (batch < 0 || (batch > 0 && (!x0 || !u0 || !cmd))) return fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
     if (h->host_only) return fail(MPCX_E_DEVICE, "host-only handle: the solve path needs a HIP device, there is no CPU fallback");
     if (batch == 0) return MPCX_OK;
+    int rc = mpcx_lmpc_setup(h);                 // active_words below comes from the condensed model
+    if (rc != MPCX_OK) return rc;
     if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
     const auto &d = h->ctl.d;
-    const size_t B = (size_t)batch, n1 = (size_t)d.ph + 1;
-    const size_t nd = B * (d.nx + d.nu + d.nu + 1 + n1 * (d.nx + d.ny + d.nu));
-    double *dbuf = nullptr; int32_t *ibuf = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&dbuf), nd * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ibuf), B * 4 * sizeof(int32_t)) != hipSuccess) {
-        if (dbuf) (void)hipFree(dbuf);
-        return fail(MPCX_E_DEVICE, "staging allocation failed");
+    const size_t B = (size_t)batch, n1 = (size_t)d.ph + 1, aw = (size_t)h->dev.active_words;
+    const size_t per = d.nx + d.nu + d.nu + 1 + n1 * (d.nx + d.ny + d.nu);
+    if (B > h->stage_cap) {                       // staging buffers live in the handle: no allocation in the steady state
+        h->release_staging();
+        if (hipMalloc(reinterpret_cast<void **>(&h->stage_d), B * per * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&h->stage_i), B * 4 * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&h->stage_act), B * 4 * aw * sizeof(uint32_t)) != hipSuccess) {
+            h->release_staging();
+            return fail(MPCX_E_DEVICE, "staging allocation failed");
+        }
+        h->stage_cap = B;
     }
-    double *dx0 = dbuf, *du0 = dx0 + B * d.nx, *dcmd = du0 + B * d.nu, *dcost = dcmd + B * d.nu;
+    double *dx0 = h->stage_d, *du0 = dx0 + B * d.nx, *dcmd = du0 + B * d.nu, *dcost = dcmd + B * d.nu;
     double *dss = dcost + B, *dso = dss + B * n1 * d.nx, *dsi = dso + B * n1 * d.ny;
-    (void)hipMemcpy(dx0, x0, B * d.nx * sizeof(double), hipMemcpyHostToDevice);
-    (void)hipMemcpy(du0, u0, B * d.nu * sizeof(double), hipMemcpyHostToDevice);
+    int32_t *ibuf = h->stage_i;
+    if (hipMemcpy(dx0, x0, B * d.nx * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(du0, u0, B * d.nu * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MPCX_E_DEVICE, "copy of x0 / u0 to the device failed");
     mpcx_lmpc_batch b{};
     b.batch = batch; b.x0 = dx0; b.u0 = du0;
     b.cmd = dcmd; b.cost = dcost;
     b.status = ibuf; b.solver_status = ibuf + B; b.is_feasible = ibuf + 2 * B; b.iterations = ibuf + 3 * B;
     const bool want_seq = seq_state || seq_output || seq_input;
     if (want_seq) { b.seq_state = dss; b.seq_output = dso; b.seq_input = dsi; }
-    int rc = mpcx_lmpc_solve_batch(h, &b, nullptr);
-    if (rc == MPCX_OK) {
-        if (hipDeviceSynchronize() != hipSuccess) rc = fail(MPCX_E_DEVICE, "kernel execution failed");
+    // LParameters::enable_warm_start (LOptimizer.hpp:268-281, LMPC.hpp:677-722): the reference re-uses the previous call's
+    // primal / dual pair; what carries over here is the previous call's active set, shifted one step (receding horizon).
+    // Two pairs of bitmaps alternate between "previous" and "current".
+    if (h->ctl.prm.enable_warm_start) {
+        uint32_t *cur = h->stage_act, *prev = h->stage_act + 2 * B * aw;
+        if (h->warm_batch == batch) {
+            if (hipMemcpy(prev, cur, 2 * B * aw * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess)
+                return fail(MPCX_E_DEVICE, "device copy failed");
+            b.warm_active_lower = prev; b.warm_active_upper = prev + B * aw; b.warm_shift = 1;
+        }
+        b.active_lower = cur; b.active_upper = cur + B * aw;
     }
+    rc = mpcx_lmpc_solve_batch(h, &b, nullptr);
+    if (rc == MPCX_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(MPCX_E_DEVICE, "kernel execution failed");
+    h->warm_batch = (rc == MPCX_OK && h->ctl.prm.enable_warm_start) ? batch : 0;
     if (rc == MPCX_OK) {
-        (void)hipMemcpy(cmd, dcmd, B * d.nu * sizeof(double), hipMemcpyDeviceToHost);
-        if (cost) (void)hipMemcpy(cost, dcost, B * sizeof(double), hipMemcpyDeviceToHost);
-        if (status) (void)hipMemcpy(status, ibuf, B * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (solver_status) (void)hipMemcpy(solver_status, ibuf + B, B * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (is_feasible) (void)hipMemcpy(is_feasible, ibuf + 2 * B, B * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (seq_state) (void)hipMemcpy(seq_state, dss, B * n1 * d.nx * sizeof(double), hipMemcpyDeviceToHost);
-        if (seq_output) (void)hipMemcpy(seq_output, dso, B * n1 * d.ny * sizeof(double), hipMemcpyDeviceToHost);
-        if (seq_input) (void)hipMemcpy(seq_input, dsi, B * n1 * d.nu * sizeof(double), hipMemcpyDeviceToHost);
+        bool ok = true;
+        auto back = [&](void *dst, const void *src, size_t bytes) { if (dst) ok = ok && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+        back(cmd, dcmd, B * d.nu * sizeof(double)); back(cost, dcost, B * sizeof(double));
+        back(status, ibuf, B * sizeof(int32_t)); back(solver_status, ibuf + B, B * sizeof(int32_t)); back(is_feasible, ibuf + 2 * B, B * sizeof(int32_t));
+        back(seq_state, dss, B * n1 * d.nx * sizeof(double)); back(seq_output, dso, B * n1 * d.ny * sizeof(double));
+        back(seq_input, dsi, B * n1 * d.nu * sizeof(double));
+        if (!ok) rc = fail(MPCX_E_DEVICE, "copy of the results to the host failed");
     }
-    (void)hipFree(dbuf); (void)hipFree(ibuf);
     return rc;
 }
 
@@ -616,6 +674,15 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
     }
     if (B.qcnt) (void)hipMemsetAsync(B.qcnt, 0, mpcx::kLmpcQueues * sizeof(int), s);     // full launches expect empty queues
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MPCX_OK;
+}
+
+/* testing aid: how many full set-ups (condensing + device rebuild) and how many reference-only refreshes have run */
+int mpcx_lmpc_debug_setup_counts(mpcx_lmpc_t h, int *full, int *refs)
+{
+    CHECK_H(h);
+    if (full) *full = h->n_full_setups;
+    if (refs) *refs = h->n_ref_refreshes;
     return MPCX_OK;
 }
 

@@ -382,10 +382,22 @@ class LMPC:
         keep = (x0, u0, yr, ur, dr, de, wl, wu)
         return b, res, keep
 
-    def launch(self, batch, stream=None):
-        """One asynchronous kernel launch for a descriptor built by make_batch()."""
+    def launch(self, batch, stream=None, keep=None):
+        """One asynchronous kernel launch for a descriptor built by make_batch().
+
+        A handle owns one workspace and one set of dispatch queues: keep ONE launch of a controller in flight at a time
+        (launches on the same stream are ordered; for overlapping batches use one controller per stream, as bench.py
+        does).  make_batch() fills its tensors on torch's current stream: a different launch stream first waits for it,
+        and `keep` (the tensors the descriptor points at) is tied to the launch stream so that the caching allocator
+        does not recycle them while the kernels still read them."""
         torch, _ = self._torch()
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        s = stream if stream is not None else cur
+        if s.cuda_stream != cur.cuda_stream:
+            s.wait_stream(cur)
+            for t in (keep or ()):
+                if t is not None:
+                    t.record_stream(s)
         check(self._lib.mpcx_lmpc_solve_batch(self._h, C.byref(batch), C.c_void_p(s.cuda_stream)))
 
     def time_launches(self, batch, repeats, stream=None):
@@ -402,8 +414,8 @@ class LMPC:
         previous control tick (solved with want_active=True) -- its active sets seed the working sets; warm_shift=True
         looks each row up one horizon step later (receding horizon)."""
         b, res, keep = self.make_batch(x0, lastU, yref, uref, duref, dmeas, want_active or warm is not None, want_sequence, warm, warm_shift)
-        self.launch(b, stream)
-        self._keep = keep
+        self.launch(b, stream, keep)
+        res._inputs = keep                     # the inputs live as long as the result that was computed from them
         return res
 
     def optimize(self, x0, lastU) -> Result:

@@ -136,6 +136,26 @@ void quadrotor_case(Controller &optsolver, bool solve)
     REQUIRE(R.batch == B && (int)R.cmd.size() == B * 4);
     REQUIRE(std::fabs(R.cmd[1] - res.cmd(1)) < 1e-12);
     for (int b = 0; b < B; ++b) REQUIRE(R.status[b] == 0);
+
+    // LParameters::enable_warm_start through optimize() (LMPC.hpp:677-722): the next tick starts from the previous tick's
+    // active set; the results are those of a cold solve
+    {
+        mpc::LParameters pw;
+        pw.maximum_iteration = 250;
+        pw.enable_warm_start = true;
+        optsolver.setOptimizerParameters(pw);
+        mpc::cvec<Tnx> xa(12, 1), xb(12, 1);
+        xa(2) = 0.05; xb(2) = 0.06; xb(8) = 0.02;
+        auto w1 = optsolver.optimize(xa, zu);
+        auto w2 = optsolver.optimize(xb, w1.cmd);            // warm: carries the active set of w1
+        mpc::LParameters pc;
+        pc.maximum_iteration = 250;
+        optsolver.setOptimizerParameters(pc);
+        auto c2 = optsolver.optimize(xb, w1.cmd);            // cold
+        REQUIRE(w2.status == mpc::ResultStatus::SUCCESS && c2.status == mpc::ResultStatus::SUCCESS);
+        for (int i = 0; i < 4; ++i) REQUIRE(std::fabs(w2.cmd(i) - c2.cmd(i)) <= 1e-9 * std::fmax(1.0, std::fabs(c2.cmd(i))));
+        REQUIRE(std::fabs(w2.cost - c2.cost) <= 1e-9 * std::fmax(1.0, std::fabs(c2.cost)));
+    }
 }
 
 int main(int argc, char **argv)

@@ -111,7 +111,7 @@ class OracleFrontEnd:
             self.dMeas[:] = d
             return True
         s = (0, self.ph) if self._unset(slice) else slice
-        if not self._pred_ok(s):
+        if not self._unset(slice) and not self._ctrl_ok(s):       # LMPC.hpp:571: control-horizon validity
             return False
         for i in range(s[0], s[1]):
             self.dMeas[:, i] = d

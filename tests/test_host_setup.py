@@ -61,7 +61,10 @@ def test_slice_validation_and_return_values():
     assert c.setReferences(np.zeros((ny, ph)), np.zeros((nu, ph)), np.zeros((nu, ph)))
     assert c.setReferences(np.zeros(ny), np.zeros(nu), np.zeros(nu), (0, ph))
     assert c.setExogenousInputs(np.zeros((ndu, ph)))
-    assert c.setExogenousInputs(np.zeros(ndu), (0, ph))
+    # the reference validates this slice against the CONTROL horizon (LMPC.hpp:571: isControlHorizonSliceValid)
+    assert c.setExogenousInputs(np.zeros(ndu), (0, ch))
+    assert c.setExogenousInputs(np.zeros(ndu), (-1, -1))
+    assert c.setExogenousInputs(np.zeros(ndu), (0, ph)) == (ph <= ch)
     with pytest.raises(ValueError):
         c.setStateSpaceModel(np.eye(nx + 1), np.ones((nx, nu)), np.ones((ny, nx)))
 
@@ -199,3 +202,27 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         assert int(parts[1]) == C.sizeof(cls), parts[0]
         offs = [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(p) for p in parts[2:]] == offs, parts[0]
+
+
+def test_reference_setters_do_not_rebuild_the_controller():
+    """LMPC::setReferences / setExogenousInputs leave the time-invariant terms alone in the reference (LOptimizer.hpp:130-181 only
+    stores the matrices); here they trigger a reference-only refresh, never the condensing"""
+    import ctypes as C
+    from libmpc_amd.workloads import quadrotor_lmpc
+    c = quadrotor_lmpc(10, device=-1)
+    c.info()
+    full, refs = C.c_int(), C.c_int()
+    lib = c._lib
+    lib.mpcx_lmpc_debug_setup_counts(c._h, C.byref(full), C.byref(refs))
+    assert (full.value, refs.value) == (1, 0)
+    yref = np.zeros(12); yref[2] = 0.7
+    for k in range(3):
+        assert c.setReferences(yref * (k + 1), np.zeros(4), np.zeros(4), (0, 10))
+        assert c.setExogenousInputs(np.zeros(4), (-1, -1))
+        c.info()
+    lib.mpcx_lmpc_debug_setup_counts(c._h, C.byref(full), C.byref(refs))
+    assert (full.value, refs.value) == (1, 3)
+    c.setInputBounds([-1.0] * 4, [1.0] * 4, (0, 10))          # a real change of the controller does rebuild
+    c.info()
+    lib.mpcx_lmpc_debug_setup_counts(c._h, C.byref(full), C.byref(refs))
+    assert full.value == 2

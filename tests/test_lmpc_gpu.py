@@ -334,3 +334,25 @@ def test_single_instance_front_end_warm_start_and_stats():
     np.testing.assert_allclose(ro.cmd, rc.cmd, rtol=1e-9, atol=1e-12)
     warm.resetStats()
     assert warm.getExecutionStats().numberOfSolutions == 0
+
+
+def test_reference_refresh_gives_the_results_of_a_fresh_controller():
+    """setReferences / setExogenousInputs between solves: the in-place refresh of the reference-dependent device data must give
+    exactly what a controller built with those references from the start gives (shared and per-instance reference paths)"""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    B = 96
+    x0, u0, yref_b = quadrotor_batch(B)
+    a = quadrotor_lmpc(20, device=0)
+    r0 = a.optimizeBatch(x0, u0)                          # first solve with the example's references
+    torch.cuda.synchronize()
+    yr = np.zeros(12); yr[2] = 0.6; yr[9] = 0.05
+    ur = np.full(4, 0.02)
+    assert a.setReferences(yr, ur, np.zeros(4), (0, 20))
+    b = quadrotor_lmpc(20, device=0)
+    assert b.setReferences(yr, ur, np.zeros(4), (0, 20))
+    for kw in (dict(), dict(yref=yref_b)):
+        ra = a.optimizeBatch(x0, u0, **kw); rb = b.optimizeBatch(x0, u0, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(ra.cmd, rb.cmd) and torch.equal(ra.cost, rb.cost) and torch.equal(ra.status, rb.status)
+    assert not torch.equal(r0.cmd, ra.cmd)
