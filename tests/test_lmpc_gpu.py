@@ -354,5 +354,9 @@ def test_reference_refresh_gives_the_results_of_a_fresh_controller():
     for kw in (dict(), dict(yref=yref_b)):
         ra = a.optimizeBatch(x0, u0, **kw); rb = b.optimizeBatch(x0, u0, **kw)
         torch.cuda.synchronize()
-        assert torch.equal(ra.cmd, rb.cmd) and torch.equal(ra.cost, rb.cost) and torch.equal(ra.status, rb.status)
+        # equal up to round-off: the kept linear columns of the assemble maps were tabulated as differences around the OLD
+        # references, those of the fresh controller around the new ones -- the same numbers to the last bit or two
+        assert torch.equal(ra.status, rb.status)
+        np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=1e-10, atol=1e-10)
     assert not torch.equal(r0.cmd, ra.cmd)
