@@ -51,6 +51,9 @@ struct LmpcDev {
     // stacked maps of the MFMA assemble kernel (see Condensed in lmpc_model.hpp)
     int kin, nxp, nup, nyp, ione, nz16, mg16, ns, ns16, kq16, rowsA, ldy16;
     const double *MA0, *MA1, *Ym, *slo, *shi;
+    // composed maps of the fused solve kernel: rows [t0; gt0 (ldy) | goff (ldg) | f (ldz) | feasibility rows (nsp) | Qc vin (kin)]
+    int rowsF, nsp, fused_ok;
+    const double *MF0, *MF1;
 };
 
 struct LmpcBatchDev {
@@ -70,6 +73,7 @@ struct LmpcBatchDev {
     int warm_shift;
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
+    int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 

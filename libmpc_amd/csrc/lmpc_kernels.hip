@@ -555,9 +555,70 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
 }
 
 // =====================================================================================
+// the record of one instance without the workspace: ProblemBuilder::get as ONE mat-vec
+// =====================================================================================
+// Everything the solve needs of an instance -- f, t0 = -Hinv f, G t0, the row offsets, the feasibility rows and the cost
+// constant -- is MF * vin with vin = [x0 | lastU | yref | 1] (lmpc_model.cpp: compose_fused_maps).  The wavefront computes it
+// into its own LDS slice, in the layout of the workspace record (f | t0 | gt0 | lg | ug | c0, flag), and solve_one reads it
+// from there: no assemble kernel, no 2.7 KB per instance written to HBM and read back.  MF streams from L2 (87 KB at N = 20).
+constexpr int kCpFused = 3;            // rows of MF per lane pair: up to 384
+__device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane, double *stage, double *rec)
+{
+    const int nx = M.nx, nu = M.nu, ny = M.ny, kin = M.kin;
+    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, rowsF = M.rowsF;
+    const int variant = Bt.fused - 1;
+    // vin: the same k -> (x0 | lastU | yref | 1) map as lmpc_assemble_mfma
+    if (lane < kin) {
+        const int k = lane;
+        double v = 0.0;
+        if (k < M.nxp) { if (k < nx) v = gl(Bt.x0)[(size_t)b * nx + k]; }
+        else if (k < M.nxp + M.nup) { const int c = k - M.nxp; if (c < nu) v = gl(Bt.u0)[(size_t)b * nu + c]; }
+        else if (k < M.ione) { const int c = k - M.nxp - M.nup; if (variant && c < ny) v = gl(Bt.yref)[(size_t)b * Bt.yref_bs + c]; }
+        else if (k == M.ione) v = 1.0;
+        stage[k] = v;
+    }
+    wave_sync();
+    double acc[2 * kCpFused];
+#pragma unroll
+    for (int s = 0; s < 2 * kCpFused; ++s) acc[s] = 0.0;
+    matvec_acc<kCpFused>(gl(variant ? M.MF1 : M.MF0), rowsF, rowsF, kin, stage, acc, lane);
+    const int r_goff = ldy, r_f = r_goff + ldg, r_s = r_f + ldz, r_q = r_s + M.nsp;
+    double c0p = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < kCpFused; ++c) {
+        const int e = 128 * c + 2 * lane;          // block boundaries are even: a pair never straddles two blocks
+        if (e >= rowsF) continue;
+        const double a0 = acc[2 * c], a1 = acc[2 * c + 1];
+        if (e < r_goff) {                          // t0 | gt0
+            *reinterpret_cast<double2 *>(rec + ldz + e) = make_double2(a0, a1);
+        } else if (e < r_f) {                      // row offsets -> bounds of this instance
+            const int r = e - r_goff;
+            const d2 l0 = ld2(GP(lg0) + r), u0 = ld2(GP(ug0) + r);
+            *reinterpret_cast<double2 *>(rec + ldz + ldy + r) = make_double2(l0.x - a0, l0.y - a1);
+            *reinterpret_cast<double2 *>(rec + ldz + ldy + ldg + r) = make_double2(u0.x - a0, u0.y - a1);
+        } else if (e < r_s) {                      // linear term
+            *reinterpret_cast<double2 *>(rec + (e - r_f)) = make_double2(a0, a1);
+        } else if (e < r_q) {                      // rows that do not see the inputs: pure feasibility conditions on (x0, lastU)
+            const int r = e - r_s;
+            if (r < M.ns) bad |= violates(a0, GP(slo)[r], GP(shi)[r], M.eps_abs, M.eps_rel);
+            if (r + 1 < M.ns) bad |= violates(a1, GP(slo)[r + 1], GP(shi)[r + 1], M.eps_abs, M.eps_rel);
+        } else {                                   // cost constant: vin' Qc vin / 2
+            const int k = e - r_q;
+            c0p = fma(0.5 * stage[k], a0, c0p);
+            c0p = fma(0.5 * stage[k + 1], a1, c0p);
+        }
+    }
+    c0p = wave_sum(c0p);
+    const bool anybad = wave_any(bad);
+    if (lane == 0) *reinterpret_cast<double2 *>(rec + ldz + ldy + 2 * ldg) = make_double2(c0p, anybad ? 1.0 : 0.0);
+    wave_sync();
+}
+
+// =====================================================================================
 // solve: one instance per wavefront
 // =====================================================================================
-template <int CPZ, int CPG, bool ADMM>
+template <int CPZ, int CPG, bool ADMM, bool FUSED = false>
 __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
                           double *stage, double *nt0, double *arena, gdw ws)
 {
@@ -581,16 +642,22 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 8) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
     stamp();
 
-    // ---- load the assembled problem
+    // ---- load the assembled problem: from the workspace record the assemble kernel left, or from the one this wavefront just
+    // computed into its LDS slice (same layout)
+    if constexpr (FUSED) fused_record(M, Bt, b, lane, stage, arena);
+    auto rec2 = [&](int at) -> d2 {
+        if constexpr (FUSED) { const double2 v = *reinterpret_cast<const double2 *>(arena + at); d2 r; r.x = v.x; r.y = v.y; return r; }
+        else return ld2(ws + at);
+    };
     double f[NZS], lw[NZS], uw[NZS], rb[NZS], t0[NZS];
     bool eqb[NZS];
 #pragma unroll
     for (int c = 0; c < CPZ; ++c) {
         const int e = 128 * c + 2 * lane;
         const int eo = e < ldz ? e : 0;
-        const d2 vt = ld2(ws + ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
+        const d2 vt = rec2(ldz + eo), vl = ld2(GP(lw) + eo), vu = ld2(GP(uw) + eo), vr = ld2(GP(rho_b) + eo);
         const bool ok = e < ldz;
-        const d2 vf = ld2(ws + eo);
+        const d2 vf = rec2(eo);
         f[2 * c] = ok ? vf.x : 0.0; f[2 * c + 1] = ok ? vf.y : 0.0;
         t0[2 * c] = ok ? vt.x : 0.0; t0[2 * c + 1] = ok ? vt.y : 0.0;
         lw[2 * c] = ok ? vl.x : -INF; lw[2 * c + 1] = ok ? vl.y : -INF;
@@ -603,7 +670,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int c = 0; c < CPG; ++c) {
         const int r = 128 * c + 2 * lane;
         const int ro = r < ldg ? r : 0;
-        const d2 vt = ld2(ws + 2 * ldz + ro), vl = ld2(ws + ldz + ldy + ro), vu = ld2(ws + ldz + ldy + ldg + ro), vr = ld2(GP(rho_g) + ro);
+        const d2 vt = rec2(2 * ldz + ro), vl = rec2(ldz + ldy + ro), vu = rec2(ldz + ldy + ldg + ro), vr = ld2(GP(rho_g) + ro);
         const d2 l0 = ld2(GP(lg0) + ro), u0 = ld2(GP(ug0) + ro);
         const bool ok = r < ldg;
         gt0[2 * c] = ok ? vt.x : 0.0; gt0[2 * c + 1] = ok ? vt.y : 0.0;
@@ -614,7 +681,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     }
 #pragma unroll
     for (int s = 0; s < NZS; ++s) eqb[s] = (lw[s] == uw[s]);
-    const d2 tail = ld2(ws + ldz + ldy + 2 * ldg);
+    const d2 tail = rec2(ldz + ldy + 2 * ldg);
     const double c0 = tail.x;
     // A violated step-0 / input-independent row makes the QP infeasible.  The reference never
     // reports that (OSQP's certificate test yields NaN on libmpc++'s true infinities): it runs
@@ -624,6 +691,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     const bool fixed_violation = tail.y == 1.0;
     const bool infeasible0 = fixed_violation && M.strict_infeasible;
     if (ADMM && tail.y == 2.0) return;          // already solved by the polish-only kernel
+    if constexpr (FUSED) wave_sync();           // the record has been read: its LDS is the polish arena from here on
     stage_store<CPZ>(nt0, t0, ldz, lane);
     stage_store<CPG>(nt0 + ldz, gt0, ldg, lane);
     wave_sync();
@@ -1176,7 +1244,27 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     int solver_status = -10;
     if (!infeasible) {
         if (M.polish && !ADMM) { solved = polish(M.polish_rounds0); polished = solved; }
-        if (!ADMM && !solved) return;                 // left for the fallback kernel (flag stays 0)
+        if (!ADMM && !solved) {                       // left for the fallback kernel (flag stays 0 / 1)
+            if constexpr (FUSED) {
+                // the fallback reads the workspace record: file the one this wavefront computed (a handful of instances in a thousand)
+#pragma unroll
+                for (int c = 0; c < CPZ; ++c) {
+                    const int e = 128 * c + 2 * lane;
+                    if (e < ldz) { st2(ws + e, f[2 * c], f[2 * c + 1]); st2(ws + ldz + e, t0[2 * c], t0[2 * c + 1]); }
+                }
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) {
+                    const int r = 128 * c + 2 * lane;
+                    if (r < ldg) {
+                        st2(ws + ldz + ldz + r, gt0[2 * c], gt0[2 * c + 1]);
+                        st2(ws + ldz + ldy + r, lg[2 * c], lg[2 * c + 1]);
+                        st2(ws + ldz + ldy + ldg + r, ug[2 * c], ug[2 * c + 1]);
+                    }
+                }
+                if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, tail.y);
+            }
+            return;
+        }
         while (ADMM && !solved && iters < M.max_iter) {
             const int nblk = min(M.check_every, M.max_iter - iters);
             for (int k = 0; k < nblk; ++k) admm_iter();
@@ -1408,6 +1496,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_so
     }
 }
 
+// The same with the record computed in place (no assemble kernel, no workspace traffic): instances in batch order
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve_fused(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *stage = smem + (size_t)wave * M.lds_per_wave;
+    double *nt0 = stage + M.stage_len;
+    double *arena = nt0 + M.ldy;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+        solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+}
+
 // Fallback for the instances the polish-only kernel left unsolved (a handful in a thousand, or
 // everything when polish is switched off): ADMM iterations, then polish again.
 template <int CPZ, int CPG>
@@ -1453,6 +1556,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
     auto k2 = lmpc_solve<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
+    auto k4 = lmpc_solve_fused<CPZ, CPG>;
     // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
     // two handles on different GPUs cannot skip or tear the update)
     static std::atomic<size_t> configured[64];
@@ -1462,7 +1566,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (lds > configured[devid].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         size_t prev = configured[devid].load(std::memory_order_relaxed);
         while (prev < lds && !configured[devid].compare_exchange_weak(prev, lds, std::memory_order_release)) {}
@@ -1471,7 +1576,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const int cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (which & 1) {
+    const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
+    if ((which & 1) && !fused) {
         // the counters are cleared by the last kernel of a full launch; partial launches (profiling) clear them here
         if (b.qcnt && which != 7) (void)hipMemsetAsync(b.qcnt, 0, kQueues * sizeof(int), stream);
         if (fast >= 0) {
@@ -1484,9 +1590,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         }
     }
     if (which & 2) {
-        {
-            hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
-        }
+        if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
     }
     if (which & 4) {
         LmpcBatchDev b3 = b;

@@ -596,6 +596,36 @@ void LmpcController::build_fast_maps(Condensed &o) const
     o.Ym.assign((size_t)o.ldy16 * o.nz16, 0.0);
     for (int q = 0; q < o.nz; q++)
         for (int r = 0; r < o.ldy; r++) o.Ym[(size_t)q * o.ldy16 + r] = -o.Y[(size_t)q * o.ldy + r];
+    compose_fused_maps(o);
+}
+
+// [t0; gt0] = (-Y[:, :nz]) f and f = MA_f vin: compose the two products once per controller, so that a wavefront gets the whole
+// record of its instance from one mat-vec with the 32-odd inputs (lmpc_solve_fused) instead of reading it back from HBM
+void LmpcController::compose_fused_maps(Condensed &o) const
+{
+    const int offg = o.nz16, offs = offg + o.mg16, offq = offs + o.ns16;
+    o.nsp = (o.ns + 1) / 2 * 2;
+    o.rowsF = o.ldy + o.ldg + o.ldz + o.nsp + o.kin;
+    const int r_goff = o.ldy, r_f = r_goff + o.ldg, r_s = r_f + o.ldz, r_q = r_s + o.nsp;
+    for (int variant = 0; variant < 2; variant++) {
+        const std::vector<double> &M = o.MA[variant];
+        std::vector<double> &F = o.MF[variant];
+        F.assign((size_t)o.rowsF * o.kin, 0.0);
+        for (int c = 0; c < o.kin; c++) {
+            const double *mc = &M[(size_t)c * o.rowsA];
+            double *fc = &F[(size_t)c * o.rowsF];
+            for (int q = 0; q < o.nz; q++) {
+                const double fq = mc[q];
+                if (fq == 0.0) continue;
+                const double *yq = &o.Ym[(size_t)q * o.ldy16];
+                for (int r = 0; r < o.ldy; r++) fc[r] += yq[r] * fq;
+            }
+            for (int r = 0; r < o.mg; r++) fc[r_goff + r] = mc[offg + r];
+            for (int r = 0; r < o.nz; r++) fc[r_f + r] = mc[r];
+            for (int r = 0; r < o.ns; r++) fc[r_s + r] = mc[offs + r];
+            for (int r = 0; r < o.kin; r++) fc[r_q + r] = mc[offq + r];
+        }
+    }
 }
 
 void LmpcController::refresh_fast_maps(Condensed &o) const
@@ -633,6 +663,7 @@ void LmpcController::refresh_fast_maps(Condensed &o) const
             put(offq + ck, o.ione, bk); put(offq + o.ione, ck, bk);
         }
     }
+    compose_fused_maps(o);
 }
 
 }  // namespace mpcx

@@ -77,6 +77,10 @@ struct Condensed {
     std::vector<double> MA[2];                   // [0]: shared yref, [1]: per-instance constant yref; rowsA x kin, column-major
     std::vector<double> slo, shi;                // [ns16] bounds of the feasibility rows
     std::vector<double> Ym;                      // -Y[:, 0:nz], ldy16 x nz16 column-major (tile padded)
+    // ---- the same maps composed for the fused solve kernel: everything lmpc_solve needs of an instance is MF * vin, rows
+    // [t0 ; gt0 (ldy) | goff (ldg) | f (ldz) | feasibility rows (nsp) | Qc vin (kin)], rowsF x kin column-major
+    int rowsF = 0, nsp = 0;
+    std::vector<double> MF[2];
 };
 
 struct AsmOut {
@@ -124,6 +128,7 @@ struct LmpcController {
     // the same after a change of references / exogenous inputs only: the constant column (and the linear part of the cost
     // form) of both maps; the quadratic part does not depend on them
     void refresh_fast_maps(Condensed &o) const;
+    void compose_fused_maps(Condensed &o) const;
 };
 
 }  // namespace mpcx

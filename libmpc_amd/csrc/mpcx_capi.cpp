@@ -45,6 +45,7 @@ struct mpcx_lmpc {
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
+    bool use_fused = true;              // one kernel computes the instance's record and solves it (where the dimensions allow)
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
     double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
     size_t stage_cap = 0;               // instances
@@ -385,7 +386,8 @@ static int refresh_references(mpcx_lmpc_t h)
     if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
     const mpcx::LmpcDev &D = h->dev;
     const bool ok = h->reup(D.yref_s, c.yRef.a) && h->reup(D.uref_s, c.uRef.a) && h->reup(D.duref_s, c.duRef.a) &&
-                    h->reup(D.dmeas_s, c.dMeas.a) && h->reup(D.MA0, h->cond.MA[0]) && h->reup(D.MA1, h->cond.MA[1]);
+                    h->reup(D.dmeas_s, c.dMeas.a) && h->reup(D.MA0, h->cond.MA[0]) && h->reup(D.MA1, h->cond.MA[1]) &&
+                    h->reup(D.MF0, h->cond.MF[0]) && h->reup(D.MF1, h->cond.MF[1]);
     return ok ? MPCX_OK : fail(MPCX_E_DEVICE, "device upload failed");
 }
 
@@ -451,6 +453,9 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.kin = o.kin; D.nxp = o.nxp; D.nup = o.nup; D.nyp = o.nyp; D.ione = o.ione;
     D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
     D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
+    D.MF0 = h->up(o.MF[0], rc); D.MF1 = h->up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
+    // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
+    D.fused_ok = (h->use_fused && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384) ? 1 : 0;
     D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
@@ -527,7 +532,8 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) B.fused = fast + 1;
+    else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
@@ -659,7 +665,8 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) B.fused = fast + 1;
+    else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -691,6 +698,15 @@ int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);
     h->use_queues = on != 0;
+    return MPCX_OK;
+}
+
+/* testing aid: 0 = keep the assemble step a kernel of its own (record through the workspace) even where the fused kernel applies */
+int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->use_fused = on != 0;
+    h->dirty = true;
     return MPCX_OK;
 }
 

@@ -294,6 +294,10 @@ class LMPC:
         """testing aid: route every batch through the generic (roll-out) assemble kernel"""
         check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))
 
+    def debug_use_fused(self, on=True):
+        """testing aid: False keeps the assemble step a kernel of its own even where the fused solve kernel applies"""
+        check(self._lib.mpcx_lmpc_debug_use_fused(self._h, int(bool(on))))
+
     # -- the hot path ------------------------------------------------------------------
     def _torch(self):
         import torch

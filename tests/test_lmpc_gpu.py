@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 RTOL_CMD = 1e-5
 
 
-def _solve_gpu(ph, B, generic=False, **kw):
+def _solve_gpu(ph, B, generic=False, fused=True, **kw):
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
     c = quadrotor_lmpc(ph, device=0)
     c.debug_force_generic(generic)
+    c.debug_use_fused(fused)
     x0, u0, yref = quadrotor_batch(B)
     r = c.optimizeBatch(x0, u0, yref=yref, want_active=True, **kw)
     import torch
@@ -35,10 +36,10 @@ def test_reference_known_answer_n10():
     assert abs(float(r.cost[0]) - (-40.983485979)) < 1e-6
 
 
-@pytest.mark.parametrize("path", ["mfma-assemble", "generic-assemble"])
+@pytest.mark.parametrize("path", ["fused", "mfma-assemble", "generic-assemble"])
 @pytest.mark.parametrize("ph,B", [(10, 64), (20, 256), (50, 32)])
 def test_parity_with_oracle(ph, B, path):
-    c, (x0, u0, yref), r = _solve_gpu(ph, B, generic=path == "generic-assemble")
+    c, (x0, u0, yref), r = _solve_gpu(ph, B, generic=path == "generic-assemble", fused=path == "fused")
     o = quadrotor_oracle(ph)
     ref = o.solve_batch_constref(x0, u0, yref, want_active=True)
     cmd = r.cmd.cpu().numpy(); cost = r.cost.cpu().numpy()
