@@ -74,6 +74,7 @@ struct LmpcBatchDev {
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
     int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1
+    int *pcounter;                                // work counter of the persistent fused kernel (null: one instance per launched wavefront)
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
 

@@ -562,7 +562,8 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
 // into its own LDS slice, in the layout of the workspace record (f | t0 | gt0 | lg | ug | c0, flag), and solve_one reads it
 // from there: no assemble kernel, no 2.7 KB per instance written to HBM and read back.  MF streams from L2 (87 KB at N = 20).
 constexpr int kCpFused = 3;            // rows of MF per lane pair: up to 384
-__device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane, double *stage, double *rec)
+__device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane, double *stage, double *rec,
+                                          const double *mf_lds)
 {
     const int nx = M.nx, nu = M.nu, ny = M.ny, kin = M.kin;
     const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, rowsF = M.rowsF;
@@ -581,7 +582,36 @@ __device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &
     double acc[2 * kCpFused];
 #pragma unroll
     for (int s = 0; s < 2 * kCpFused; ++s) acc[s] = 0.0;
-    matvec_acc<kCpFused>(gl(variant ? M.MF1 : M.MF0), rowsF, rowsF, kin, stage, acc, lane);
+    if (mf_lds) {
+        // the composed map sits in this workgroup's LDS (lmpc_solve_persistent loaded it once): sixteen-byte reads, lanes on
+        // consecutive rows (no bank conflicts), four columns in flight
+        int off[kCpFused];
+#pragma unroll
+        for (int c = 0; c < kCpFused; ++c) { const int e = 128 * c + 2 * lane; off[c] = e < rowsF ? e : 0; }
+        for (int j = 0; j < kin; j += 4) {
+            double2 m[4][kCpFused];
+            double xj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *col = mf_lds + (size_t)(j + u) * rowsF;
+#pragma unroll
+                for (int c = 0; c < kCpFused; ++c) m[u][c] = *reinterpret_cast<const double2 *>(col + off[c]);
+                xj[u] = stage[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < kCpFused; ++c) {
+                    acc[2 * c] = fma(m[u][c].x, xj[u], acc[2 * c]);
+                    acc[2 * c + 1] = fma(m[u][c].y, xj[u], acc[2 * c + 1]);
+                }
+            }
+        }
+    } else {
+        // from L2, two columns per batch: the stream is bandwidth-bound there -- every wavefront of the launch reads the same
+        // 87 KB -- and deeper batches only made the burst worse (146 us against 122 us for the launch at the benchmark batch)
+        matvec_acc<kCpFused>(gl(variant ? M.MF1 : M.MF0), rowsF, rowsF, kin, stage, acc, lane);
+    }
     const int r_goff = ldy, r_f = r_goff + ldg, r_s = r_f + ldz, r_q = r_s + M.nsp;
     double c0p = 0.0;
     bool bad = false;
@@ -620,7 +650,7 @@ __device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &
 // =====================================================================================
 template <int CPZ, int CPG, bool ADMM, bool FUSED = false>
 __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
-                          double *stage, double *nt0, double *arena, gdw ws)
+                          double *stage, double *nt0, double *arena, gdw ws, const double *mf_lds = nullptr)
 {
     constexpr int NZS = 2 * CPZ, NGS = 2 * CPG;
     const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
@@ -644,7 +674,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 
     // ---- load the assembled problem: from the workspace record the assemble kernel left, or from the one this wavefront just
     // computed into its LDS slice (same layout)
-    if constexpr (FUSED) fused_record(M, Bt, b, lane, stage, arena);
+    if constexpr (FUSED) fused_record(M, Bt, b, lane, stage, arena, mf_lds);
     auto rec2 = [&](int at) -> d2 {
         if constexpr (FUSED) { const double2 v = *reinterpret_cast<const double2 *>(arena + at); d2 r; r.x = v.x; r.y = v.y; return r; }
         else return ld2(ws + at);
@@ -1511,6 +1541,38 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_so
         solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
 }
 
+// The fused form as a persistent kernel: one workgroup of eight wavefronts per CU loads the composed map into LDS once
+// (87.5 KB at N = 20; together with the eight per-wave slices that is 157 of the 160 KB of a CU), then every wavefront pulls
+// instances from a device counter until the batch is exhausted -- the record of an instance costs one pass over LDS instead of
+// a round trip through HBM, nobody waits for a neighbour, and an early finisher simply takes the next instance.
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(512, MPCX_SOLVE_WAVES) void lmpc_solve_persistent(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase,
+                                                                                int *counter)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nmf = M.rowsF * M.kin;                  // even
+    {
+        const gdp src = gl(Bt.fused == 2 ? M.MF1 : M.MF0);
+        for (int k = 2 * (int)threadIdx.x; k < nmf; k += 2 * (int)blockDim.x) {
+            const d2 v = ld2(src + k);
+            *reinterpret_cast<double2 *>(smem + k) = make_double2(v.x, v.y);
+        }
+    }
+    __syncthreads();
+    double *stage = smem + nmf + (size_t)wave * M.lds_per_wave;
+    double *nt0 = stage + M.stage_len;
+    double *arena = nt0 + M.ldy;
+    for (;;) {
+        int b = 0;
+        if (lane == 0) b = atomicAdd(counter, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= Bt.batch) break;
+        solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld, smem);
+    }
+}
+
 // Fallback for the instances the polish-only kernel left unsolved (a handful in a thousand, or
 // everything when polish is switched off): ADMM iterations, then polish again.
 template <int CPZ, int CPG>
@@ -1557,6 +1619,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     auto k2 = lmpc_solve<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
     auto k4 = lmpc_solve_fused<CPZ, CPG>;
+    auto k5 = lmpc_solve_persistent<CPZ, CPG>;
     // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
     // two handles on different GPUs cannot skip or tear the update)
     static std::atomic<size_t> configured[64];
@@ -1590,7 +1653,20 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         }
     }
     if (which & 2) {
-        if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        // persistent form: the composed map and eight per-wave slices must fit one CU's LDS, and the batch must be worth the
+        // 87 KB prologue of every workgroup
+        const size_t ldsp = ((size_t)m.rowsF * m.kin + 8 * (size_t)m.lds_per_wave) * sizeof(double);
+        if (fused && b.pcounter && ldsp <= 160 * 1024 && b.batch >= 1024) {
+            static std::atomic<int> pconf[64];
+            if (!pconf[devid].load(std::memory_order_acquire)) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+                pconf[devid].store(1, std::memory_order_release);
+            }
+            (void)hipMemsetAsync(b.pcounter, 0, sizeof(int), stream);
+            int wgs = (b.batch + 7) / 8;
+            if (wgs > 256) wgs = 256;
+            hipLaunchKernelGGL(k5, dim3(wgs), dim3(512), ldsp, stream, m_dev, b, ws, b.pcounter);
+        } else if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
         else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
     }
     if (which & 4) {

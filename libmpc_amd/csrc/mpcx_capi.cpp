@@ -45,7 +45,10 @@ struct mpcx_lmpc {
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
-    bool use_fused = true;              // one kernel computes the instance's record and solves it (where the dimensions allow)
+    // One kernel computes the instance's record and solves it (no workspace hand-off: 3 MB instead of 25 MB of HBM traffic per
+    // 4096-instance launch) -- but every wavefront then streams the composed map from L2 and the hardest-first dispatch order is
+    // lost: 0.128 ms per step against 0.097 ms with the two kernels at the benchmark batch.  Off by default; mpcx_lmpc_set_fused.
+    bool use_fused = false;
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
     double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
     size_t stage_cap = 0;               // instances
@@ -532,7 +535,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) B.fused = fast + 1;
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) { B.fused = fast + 1; B.pcounter = h->queues; }
     else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
@@ -665,7 +668,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) B.fused = fast + 1;
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) { B.fused = fast + 1; B.pcounter = h->queues; }
     else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
@@ -701,7 +704,8 @@ int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
     return MPCX_OK;
 }
 
-/* testing aid: 0 = keep the assemble step a kernel of its own (record through the workspace) even where the fused kernel applies */
+/* extension (no reference counterpart): 1 = where the dimensions allow, compute each instance's record inside the solve kernel
+ * instead of handing it over through the HBM workspace (least memory traffic; slower at large batches) */
 int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);

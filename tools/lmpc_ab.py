@@ -1,0 +1,36 @@
+"""A/B on the GPU box: the two-kernel LMPC path (assemble -> workspace -> solve) against the fused forms (record computed inside
+the solve kernel; persistent with the composed map in LDS at large batches).  Prints ms per step, per-kernel times and the largest
+difference of the results."""
+import ctypes as C
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+x0, u0, yref = quadrotor_batch(B)
+ref = None
+for fused in (0, 1, 0, 1):
+    c = quadrotor_lmpc(20, device=0)
+    c.debug_use_fused(bool(fused))
+    b, r, keep = c.make_batch(x0, u0, yref=yref)
+    s = torch.cuda.current_stream(0)
+    for _ in range(30):
+        c.launch(b, s)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(300):
+        c.launch(b, s)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 300 * 1e3
+    ms3 = (C.c_float * 3)()
+    c._lib.mpcx_lmpc_debug_time_kernels(c._h, C.byref(b), C.c_void_p(s.cuda_stream), 100, ms3)
+    c.launch(b, s); torch.cuda.synchronize()
+    out = (r.cmd.cpu().numpy().copy(), r.cost.cpu().numpy().copy(), r.status.cpu().numpy().copy())
+    if ref is None:
+        ref = out
+    dcmd = np.abs(out[0] - ref[0]).max(); dcost = np.abs(out[1] - ref[1]).max() / np.abs(ref[1]).max()
+    print("fused", fused, "batch", B, "ms/step %.4f" % dt, "kernels", [round(v, 4) for v in ms3], "rounds mean %.2f max %d" %
+          (r.polish_rounds.float().mean().item(), r.polish_rounds.max().item()), "solved", (r.status == 0).float().mean().item(),
+          "max|dcmd| %.2e rel dcost %.2e status equal %s" % (dcmd, dcost, np.array_equal(out[2], ref[2])))
