@@ -1564,12 +1564,17 @@ __global__ __launch_bounds__(512, MPCX_SOLVE_WAVES) void lmpc_solve_persistent(c
     double *stage = smem + nmf + (size_t)wave * M.lds_per_wave;
     double *nt0 = stage + M.stage_len;
     double *arena = nt0 + M.ldy;
-    for (;;) {
-        int b = 0;
-        if (lane == 0) b = atomicAdd(counter, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (b >= Bt.batch) break;
+    // The first instance of a wavefront is its own number; the rest of the batch is handed out by eight counters (one per
+    // residue of the workgroup number, i.e. per XCD under the usual placement), each over every eighth instance: a single
+    // device-scope counter serves about 88 pulls per microsecond, which 2048 wavefronts starting together would queue on.
+    const int nwaves = gridDim.x * 8, shard = blockIdx.x & 7;
+    int b = blockIdx.x * 8 + wave;
+    while (b < Bt.batch) {
         solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld, smem);
+        int n = 0;
+        if (lane == 0) n = atomicAdd(counter + shard, 1);
+        n = __builtin_amdgcn_readfirstlane(n);
+        b = nwaves + shard + 8 * n;
     }
 }
 
@@ -1662,7 +1667,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
                 pconf[devid].store(1, std::memory_order_release);
             }
-            (void)hipMemsetAsync(b.pcounter, 0, sizeof(int), stream);
+            (void)hipMemsetAsync(b.pcounter, 0, 8 * sizeof(int), stream);
             int wgs = (b.batch + 7) / 8;
             if (wgs > 256) wgs = 256;
             hipLaunchKernelGGL(k5, dim3(wgs), dim3(512), ldsp, stream, m_dev, b, ws, b.pcounter);

@@ -45,10 +45,12 @@ struct mpcx_lmpc {
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
-    // One kernel computes the instance's record and solves it (no workspace hand-off: 3 MB instead of 25 MB of HBM traffic per
-    // 4096-instance launch) -- but every wavefront then streams the composed map from L2 and the hardest-first dispatch order is
-    // lost: 0.128 ms per step against 0.097 ms with the two kernels at the benchmark batch.  Off by default; mpcx_lmpc_set_fused.
-    bool use_fused = false;
+    // Fused forms (lmpc_solve_fused / lmpc_solve_persistent): the instance's record is computed inside the solve kernel instead of
+    // being handed over through the HBM workspace (3 MB instead of 25 MB of traffic per 4096 instances), but the hardest-first
+    // dispatch order of the two-kernel path is lost -- worth 22 us of its 70 us at 4096 instances, nothing at large batches.
+    // Measured (quadrotor N = 20, ms per step, two kernels / fused): 4096: 0.097 / 0.125; 16384: 0.309 / 0.300; 65536: 1.10 / 1.00.
+    // -1 = automatic (fused from 16384 instances on), 0 = never, 1 = wherever the dimensions allow (mpcx_lmpc_debug_use_fused)
+    int use_fused = -1;
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
     double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
     size_t stage_cap = 0;               // instances
@@ -458,7 +460,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
     D.MF0 = h->up(o.MF[0], rc); D.MF1 = h->up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
-    D.fused_ok = (h->use_fused && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384) ? 1 : 0;
+    D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384) ? 1 : 0;
     D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
@@ -535,7 +537,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) { B.fused = fast + 1; B.pcounter = h->queues; }
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
     else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
@@ -668,7 +670,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles) { B.fused = fast + 1; B.pcounter = h->queues; }
+    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
     else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
@@ -704,12 +706,12 @@ int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
     return MPCX_OK;
 }
 
-/* extension (no reference counterpart): 1 = where the dimensions allow, compute each instance's record inside the solve kernel
- * instead of handing it over through the HBM workspace (least memory traffic; slower at large batches) */
+/* experiment / testing knob: 1 = wherever the dimensions allow, compute each instance's record inside the solve kernel instead of
+ * handing it over through the HBM workspace; 0 = never; -1 = automatic (the default: from 16384 instances on) */
 int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);
-    h->use_fused = on != 0;
+    h->use_fused = on < 0 ? -1 : (on != 0);
     h->dirty = true;
     return MPCX_OK;
 }

@@ -295,8 +295,8 @@ class LMPC:
         check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))
 
     def debug_use_fused(self, on=True):
-        """testing aid: False keeps the assemble step a kernel of its own even where the fused solve kernel applies"""
-        check(self._lib.mpcx_lmpc_debug_use_fused(self._h, int(bool(on))))
+        """experiment knob: True = fused solve kernel wherever the dimensions allow, False = never, None = automatic (default)"""
+        check(self._lib.mpcx_lmpc_debug_use_fused(self._h, -1 if on is None else int(bool(on))))
 
     # -- the hot path ------------------------------------------------------------------
     def _torch(self):
