@@ -15,8 +15,12 @@
 
 namespace mpcx {
 
-constexpr int kLmpcQueues = 256;        // dispatch queues: 4 difficulty classes (initially violated rows / 4) x 64 ways
-constexpr int kLmpcQueueWays = 64;
+#ifndef MPCX_QUEUE_KEYS
+#define MPCX_QUEUE_KEYS 4               // difficulty classes of the dispatch order ...
+#define MPCX_QUEUE_SHIFT 2              // ... class = min(rows violated at the unconstrained optimum >> shift, classes - 1)
+#endif
+constexpr int kLmpcQueueWays = 64;      // sub-queues per class (spreads the device-scope atomics)
+constexpr int kLmpcQueues = MPCX_QUEUE_KEYS * kLmpcQueueWays;
 constexpr int kMaxActive = 28;          // working-set capacity of the in-kernel polish
 constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
 

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             // ways (the way is the workgroup's, which spreads the device-scope atomics: one per class and workgroup).
             int *cls = reinterpret_cast<int *>(nviol + 16), *cbase = cls + 16;
             const int way = blockIdx.x & (kQueueWays - 1);
-            if (threadIdx.x < 16) cls[threadIdx.x] = b0 + (int)threadIdx.x < Bt.batch ? min((int)nviol[threadIdx.x] >> 2, kQueueKeys - 1) : -1;
+            if (threadIdx.x < 16) cls[threadIdx.x] = b0 + (int)threadIdx.x < Bt.batch ? min((int)nviol[threadIdx.x] >> MPCX_QUEUE_SHIFT, kQueueKeys - 1) : -1;
             __syncthreads();
             if (threadIdx.x < kQueueKeys) {
                 int n = 0;
