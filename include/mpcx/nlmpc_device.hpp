@@ -7,8 +7,9 @@
 namespace mpcx {
 
 constexpr int kNlMaxWorking = 128;     // rows the QP sub-solver may hold active at once
-constexpr int kNlLdsWorking = 24;      // up to this many, their Schur complement is factored in LDS
+constexpr int kNlLdsWorking = 24;      // the LDS slice holds the factor of a working set of at least this many rows
 constexpr int kNlTrials = 8;           // step lengths the line search evaluates at a time
+constexpr int kNlSparse = 4;           // sub-problem rows with at most this many entries are also kept as (index, value) lists
 
 // offsets (in doubles) into one instance's slice of the SQP workspace
 struct NlmpcWsLayout {
@@ -22,6 +23,7 @@ struct NlmpcWsLayout {
     int hook;                           // vector-valued user hooks only: two column buffers [64 x rows] for the central
                                         // differences, the line search's constraint values [kNlTrials x rows] and output
                                         // trajectories [kNlTrials x (ph+1) x ny]
+    int sp;                             // sparse form of the sub-problem's rows: values [rows x kNlSparse], indices (int), counts (int)
     int total;
 };
 
@@ -31,6 +33,7 @@ struct NlmpcDev {
     int nue;                    // user equalities: rows nineq .. nineq+nue-1 of the user constraint arrays
     int nzu, nr;                // ch*nu, ch*nu + 1
     int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
+    int nl;                     // rows of the working set whose factor fits the LDS slice (beyond: factored in the workspace)
     int lds_per_wave;           // doubles
     int continuous;             // hook models: 1 = the state function is dx/dt (setDiscretizationSamplingTime was called)
     int has_output;             // hook models: 1 = an output function was set (otherwise Y reads as zeros, Model.hpp:72-96)

@@ -34,6 +34,10 @@
 
 #include "nlmpc_device.hpp"
 #include "nlmpc_models.hpp"
+#if !defined(__HIPCC_RTC__)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace mpcx {
 namespace engine {
@@ -622,10 +626,83 @@ __device__ inline bool spd_solve(double *S, int ld, double *t, int n, int lane)
     return ok;
 }
 
+// The working set's Schur complement S = L L' as a packed lower-triangular factor in LDS (row r at r (r + 1) / 2), with
+// 1 / L_rr beside it.  A vector of up to 128 elements lives in two registers per lane (element e on lane e & 63).  Every
+// step of a substitution is one broadcast from a register and one multiply-add per lane; the operands of step k + 1 are
+// requested before step k computes, so the chain pays arithmetic latency only.
+__device__ __forceinline__ double read_lane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// L y = t on the leading n rows; t in (t0, t1), y returned in the same registers
+__device__ __forceinline__ void chol_forward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+{
+    const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
+    auto at0 = [&](int k) { return (lane > k && lane < n) ? o0 + k : 0; };
+    auto at1 = [&](int k) { return (lane + 64 > k && lane + 64 < n) ? o1 + k : 0; };
+    double a0 = Lp[at0(0)], a1 = Lp[at1(0)], id = invd[0];
+    for (int k = 0; k < n; ++k) {
+        const int kn = min(k + 1, n - 1);
+        const double a0n = Lp[at0(kn)], a1n = Lp[at1(kn)], idn = invd[kn];
+        const double yk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * id;
+        if (lane == k) t0 = yk;
+        if (lane + 64 == k) t1 = yk;
+        if (lane > k && lane < n) t0 = fma(-a0, yk, t0);
+        if (lane + 64 > k && lane + 64 < n) t1 = fma(-a1, yk, t1);
+        a0 = a0n; a1 = a1n; id = idn;
+    }
+}
+// L' x = y on the leading n rows
+__device__ __forceinline__ void chol_backward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+{
+    auto at0 = [&](int k) { return lane < k ? k * (k + 1) / 2 + lane : 0; };
+    auto at1 = [&](int k) { return lane + 64 < k ? k * (k + 1) / 2 + lane + 64 : 0; };
+    double a0 = Lp[at0(n - 1)], a1 = Lp[at1(n - 1)], id = invd[n - 1];
+    for (int k = n - 1; k >= 0; --k) {
+        const int kn = max(k - 1, 0);
+        const double a0n = Lp[at0(kn)], a1n = Lp[at1(kn)], idn = invd[kn];
+        const double xk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * id;
+        if (lane == k) t0 = xk;
+        if (lane + 64 == k) t1 = xk;
+        if (lane < k) t0 = fma(-a0, xk, t0);
+        if (lane + 64 < k) t1 = fma(-a1, xk, t1);
+        a0 = a0n; a1 = a1n; id = idn;
+    }
+}
+// row n of the factor from y = L^-1 (column n of S) and S_nn; false: the row depends on the ones above
+__device__ __forceinline__ bool chol_append(double *Lp, double *invd, int n, double y0, double y1, double snn, double dmax, int lane)
+{
+    const int on = n * (n + 1) / 2;
+    if (lane < n) Lp[on + lane] = y0;
+    if (lane + 64 < n) Lp[on + lane + 64] = y1;
+    const double d2 = snn - wave_sum((lane < n ? y0 * y0 : 0.0) + (lane + 64 < n ? y1 * y1 : 0.0));
+    const bool ok = d2 > 1e-13 * dmax;
+    const double dd = sqrt(ok ? d2 : 1e-13 * dmax + 1e-300);
+    if (lane == 0) { Lp[on + n] = dd; invd[n] = 1.0 / dd; }
+    nl_wave_sync();
+    return ok;
+}
+// the factor of the leading n x n block of S (global memory, row stride ld), row by row
+__device__ __attribute__((noinline)) bool chol_factor(double *Lp, double *invd, const double *Sg, int ld, int n, int lane)
+{
+    double dmax = 0.0;
+    for (int r = lane; r < n; r += 64) dmax = fmax(dmax, Sg[r * ld + r]);
+    dmax = wave_max(dmax);
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+        double t0 = lane < i ? Sg[i * ld + lane] : 0.0, t1 = lane + 64 < i ? Sg[i * ld + lane + 64] : 0.0;
+        const double sii = Sg[i * ld + i];
+        if (i) chol_forward(Lp, invd, i, t0, t1, lane);
+        ok &= chol_append(Lp, invd, i, t0, t1, sii, dmax, lane);
+    }
+    return ok;
+}
+
 template <class Mdl>
 __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev &S)
 {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU, KL = kNlLdsWorking;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU;
     constexpr bool MAYBE_CT = Mdl::CONTINUOUS;            // hook models: true, the run-time flag decides
     const bool CT = is_ct<Mdl>(M);
     const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
@@ -640,19 +717,22 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     const Scale sc(M);
     double *Xs = smem + (size_t)wave * M.lds_per_wave;
     double *Us = Xs + (ph + 1) * NX;
-    double *dXs = Us + (ph + 1) * NU;
-    double *dUs = dXs + (ph + 1) * NX;
-    double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
-    double *Ys = Jm + ph * NU;                            // (ph+1) x NY, hook models with an output function only (else empty)
-    double *Sfac = Ys + ((Mdl::VECTOR_HOOKS && M.has_output) ? (ph + 1) * Mdl::NY : 0);   // KL x (KL+1) copy of the working-set Schur complement for the solve
-    double *tq = Sfac + KL * (KL + 1);                    // KW
+    double *Ys = Us + (ph + 1) * NU;                      // (ph+1) x NY, hook models with an output function only (else empty)
+    double *tq = Ys + ((Mdl::VECTOR_HOOKS && M.has_output) ? (ph + 1) * Mdl::NY : 0);   // KW
     double *uq = tq + KW;                                 // KW  multipliers of the working set
     double *wq = uq + KW;                                 // KW  row numbers (as doubles)
     double *sgq = wq + KW;                                // KW  orientation of the row in the working set (+1; -1 for an equality entered from below)
-    double *aug = sgq + KW;                               // NX x 2NX
-    double *v0 = aug + NX * 2 * NX;                       // 4 vectors of nr
+    double *invd = sgq + KW;                              // KW  reciprocal diagonal of the working set's factor
+    double *v0 = invd + KW;                               // 4 vectors of nr
     double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
-    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(v3 + nr);   // structure bits of d g / d x
+    // the rest of the slice is the step (dXs, dUs), the transcription's scratch (Jm) and the condensing's (aug); none of
+    // them lives across the sub-problem, whose factor Lp takes the whole tail: rows 0 .. NL-1 of the working set
+    double *dXs = v3 + nr;
+    double *dUs = dXs + (ph + 1) * NX;
+    double *Jm = dUs + (ph + 1) * NU;                     // ph x NU
+    double *aug = Jm + ph * NU;                           // NX x 2NX
+    double *Lp = dXs;
+    const int NL = M.nl;
 
     for (int b = blockIdx.x * wpb + wave; b < S.batch; b += gridDim.x * wpb) {
         double *w = S.ws + (size_t)b * M.ws.total;
@@ -660,7 +740,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                *jin = w + M.ws.jin, *r = w + M.ws.r, *phi = w + M.ws.phi, *einv = w + M.ws.einv, *gr = w + M.ws.gr,
                *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
                *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal,
-               *lamw = w + M.ws.lamw, *hk = w + M.ws.hook;
+               *lamw = w + M.ws.lamw, *hk = w + M.ws.hook, *spv = w + M.ws.sp;
+        int *spi = reinterpret_cast<int *>(spv + (size_t)mt * kNlSparse), *spn = spi + (size_t)mt * kNlSparse;   // sparse rows of the sub-problem
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
@@ -688,22 +769,29 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         }
         nl_wave_sync();
 
-        // user inequalities read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
+        // user constraints read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
         // structure the model declares (the finite differences leave exact zeros everywhere else)
+        auto structure_word = [&](int e0, int nchunk) {
+            const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
+            return __ballot(col < nxs && (k < mi ? Mdl::ineq_reads_x(k, col / NX + 1) : Mdl::eq_reads_x(k - mi, col / NX + 1)));
+        };
+        // Phi = d x / d p (the condensed sensitivities, [ph nx x ch nu]) is only needed where a row of the sub-problem reads a
+        // state: a user constraint that does, or a bound on a state.  Without such rows the reduced gradient comes from one
+        // backward sweep, the state step from one forward sweep, and Phi is never formed.
+        bool needs_phi;
         {
             const int nchunk = (nxs + 63) >> 6;
-            for (int e0 = 0; e0 < m * nchunk; ++e0) {
-                const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
-                const unsigned long long bal = __ballot(col < nxs && (k < mi ? Mdl::ineq_reads_x(k, col / NX + 1) : Mdl::eq_reads_x(k - mi, col / NX + 1)));
-                if (lane == 0) fmask[e0] = bal;
-            }
-            nl_wave_sync();
+            bool any = false;
+            for (int e0 = 0; e0 < m * nchunk && !any; ++e0) any = structure_word(e0, nchunk) != 0ull;
+            for (int kb = lane; kb < M.nbnd; kb += 64) any |= M.bnd_idx[kb] < nxs;
+            needs_phi = __ballot(any) != 0ull;
         }
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
         int resets = 0;
         int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
         long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
+        long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // sub-problem statistics (debug_workspace): steps, inner passes, rows at the end (sum, max), rows kept, rows shed at the warm start, cycles of the warm start, cycles of the factorisations
         auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         double f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;       // the last accepted step, for nlopt's stopping rules
         bool stepped = false;
@@ -780,10 +868,12 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             }
             // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0.  A_i = dc_i/dx_i (and E_i^-1) are the same for
             // every lane: they are staged in LDS, the next step's share already in flight while this step computes.
+            // mode 0: every column (Phi and r); 1: r alone; 2: the state step r + Phi p itself (into d), p applied on the way
+            auto sweep = [&](const int mode) {
             if constexpr (NX >= 8) {
-            for (int q0 = 0; q0 <= nzu; q0 += 64) {
+            for (int q0 = mode == 0 ? 0 : (nzu & ~63); q0 <= nzu; q0 += 64) {
                     const int q = q0 + lane;
-                    const bool qlive = q <= nzu;
+                    const bool qlive = mode == 0 ? q <= nzu : q == nzu;
                     const int bq = q / NU, jq = q - bq * NU;
                     constexpr int NST = MAYBE_CT ? 2 * NX * NX : NX * NX;     // staged doubles per step: A | Einv
                     constexpr int PL = (NST + 63) / 64;
@@ -799,6 +889,13 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     #pragma unroll
                         for (int a = 0; a < NX; ++a)
                             rh[a] = !qlive ? 0.0 : (q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0));
+                        if (mode == 2 && q == nzu) {
+                            const double *pb = p + min(i, ch - 1) * NU;
+    #pragma unroll
+                            for (int a = 0; a < NX; ++a)
+    #pragma unroll
+                                for (int j = 0; j < NU; ++j) rh[a] = fma(Jb[a * W + 2 * NX + j], pb[j], rh[a]);
+                        }
                     };
     #pragma unroll
                     for (int a = 0; a < NX; ++a) v[a] = 0.0;
@@ -830,7 +927,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                             for (int a = 0; a < NX; ++a) v[a] = -t[a];
                         }
                         if (qlive) {
-                            if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
+                            if (q == nzu) for (int a = 0; a < NX; ++a) (mode == 2 ? d : r)[i * NX + a] = v[a];
                             else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
                         }
                         nl_wave_sync();
@@ -838,6 +935,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 }
             } else {
                 for (int q = lane; q <= nzu; q += 64) {
+                    if (mode != 0 && q != nzu) continue;
                     // small blocks come straight from L2, the next step's already requested while this one computes (the
                     // stores to Phi in between keep the compiler from moving the loads up by itself)
                     double v[NX], t[NX], An[NX * NX], rn[NX], En[MAYBE_CT ? NX * NX : 1];
@@ -848,6 +946,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 #pragma unroll
                         for (int a = 0; a < NX; ++a) {
                             rn[a] = q == nzu ? c[i * NX + a] : (min(i, ch - 1) == bq ? Jb[a * W + 2 * NX + jq] : 0.0);
+                            if (mode == 2 && q == nzu)
+#pragma unroll
+                                for (int j = 0; j < NU; ++j) rn[a] = fma(Jb[a * W + 2 * NX + j], p[min(i, ch - 1) * NU + j], rn[a]);
 #pragma unroll
                             for (int bb = 0; bb < NX; ++bb) An[a * NX + bb] = Jb[a * W + bb];
                         }
@@ -884,108 +985,263 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 #pragma unroll
                             for (int a = 0; a < NX; ++a) v[a] = -t[a];
                         }
-                        if (q == nzu) for (int a = 0; a < NX; ++a) r[i * NX + a] = v[a];
+                        if (q == nzu) for (int a = 0; a < NX; ++a) (mode == 2 ? d : r)[i * NX + a] = v[a];
                         else for (int a = 0; a < NX; ++a) phi[(size_t)(i * NX + a) * nzu + q] = v[a];
                     }
                 }
             }
             nl_wave_sync();
+            };
+            sweep(needs_phi ? 0 : 1);
             lap(0);
-            // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
-            for (int q = lane; q < nr; q += 64) {
-                if (q == nzu) { gr[q] = g[nz - 1]; continue; }
-                const double s = g[nxs + q] + gdot2(phi + q, nzu, g, 1, nxs);
-                gr[q] = s;
-            }
-            const int nchunk = (nxs + 63) >> 6;
-            nl_wave_sync();
-            for (int q = lane; q < nr; q += 64) {
-                const bool realq = q < nzu;
-                const size_t qq = realq ? q : 0, ucol = q == nzu ? nz - 1 : nxs + q;
-                if (nchunk <= 2) {
-                    // four rows at a time, up to four entries of each gathered first so that their loads are in flight together
-                    for (int k0 = 0; k0 < m; k0 += 4) {
-                        int c4[4][4];
-                        unsigned long long rest0[4], rest1[4];
+            // Jx' lam = -lamw by a backward sweep over the blocks (Jx: the block-bidiagonal Jacobian of the dynamics defects wrt
+            // the states); returns this lane's share of max |lam|, optionally leaves lam in lamw
+            auto backsolve = [&](const bool store) {
+            double lam_max = 0;
+            {
+                double *tl = aug, *ln = aug + NX;                  // t and lam_{i+1}
+                // the operands of step i-1 are requested before step i computes: the sweep is a chain of ph dependent steps and
+                // would otherwise pay a memory latency in each
+                double an[NX], en[NX], wn = 0.0;
+                auto fetch = [&](int i) {
+                    if (lane < NX) {
+                        wn = lamw[i * NX + lane];
+                        const double *Jb = jeq + (size_t)min(i + 1, ph - 1) * NX * W;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int k = min(k0 + rr, m - 1);
-                            unsigned long long m0 = fmask[k * nchunk], m1 = nchunk > 1 ? fmask[k * nchunk + 1] : 0ull;
+                        for (int bb = 0; bb < NX; ++bb) an[bb] = i + 1 < ph ? Jb[bb * W + lane] : 0.0;
+                        if (CT) {
+                            const double *Ei = einv + (size_t)i * NX * NX;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                int cc = -1;
-                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; }
-                                else if (m1) { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
-                                c4[rr][u] = cc;
-                            }
-                            rest0[rr] = m0; rest1[rr] = m1;
-                        }
-                        double a0[4], jv[4][4], pv[4][4];
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const size_t k = min(k0 + rr, m - 1);
-                            a0[rr] = jin[k * nz + ucol];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const size_t cc = c4[rr][u] < 0 ? 0 : c4[rr][u];
-                                jv[rr][u] = jin[k * nz + cc];
-                                pv[rr][u] = phi[cc * nzu + qq];
-                            }
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            double acc = a0[rr];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) if (realq && c4[rr][u] >= 0) acc = fma(jv[rr][u], pv[rr][u], acc);
-                            const size_t k = min(k0 + rr, m - 1);
-                            unsigned long long m0 = rest0[rr], m1 = rest1[rr];
-                            while (realq && (m0 | m1)) {                   // rows with more than four entries
-                                int cc;
-                                if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; } else { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
-                                acc = fma(jin[k * nz + cc], phi[(size_t)cc * nzu + qq], acc);
-                            }
-                            if (k0 + rr < m) art[(size_t)q * mld + k0 + rr] = acc;
+                            for (int bb = 0; bb < NX; ++bb) en[bb] = Ei[bb * NX + lane];
                         }
                     }
-                } else {
-                    for (int k = 0; k < m; ++k) {
-                        double acc = jin[(size_t)k * nz + ucol];
-                        if (realq)
-                            for (int cb = 0; cb < nchunk; ++cb) {
-                                unsigned long long mk = fmask[k * nchunk + cb];
-                                while (mk) {
-                                    const int row = cb * 64 + (int)__builtin_ctzll(mk);
-                                    mk &= mk - 1;
-                                    acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
+                };
+                if (lane < NX) ln[lane] = 0.0;
+                fetch(ph - 1);
+                nl_wave_sync();
+                for (int i = ph - 1; i >= 0; --i) {
+                    double ac[NX], ec[NX];
+                    const double wc = wn;
+#pragma unroll
+                    for (int bb = 0; bb < NX; ++bb) { ac[bb] = an[bb]; ec[bb] = en[bb]; }
+                    if (i > 0) fetch(i - 1);
+                    if (lane < NX) {
+                        double s2 = wc;
+#pragma unroll
+                        for (int bb = 0; bb < NX; ++bb) s2 = fma(ac[bb], ln[bb], s2);
+                        tl[lane] = s2;
+                    }
+                    nl_wave_sync();
+                    if (lane < NX) {
+                        double lam;
+                        if (CT) {
+                            lam = 0;
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) lam = fma(-ec[bb], tl[bb], lam);
+                        } else {
+                            lam = -tl[lane];
+                        }
+                        ln[lane] = lam;
+                        if (store) lamw[i * NX + lane] = lam;
+                        lam_max = fmax(lam_max, fabs(lam));
+                    }
+                    nl_wave_sync();
+                }
+            }
+            nl_wave_sync();
+            return lam_max;
+            };
+            double lam_dyn = 0;                                         // this lane's share of the largest dynamics multiplier (sweep below)
+            if (needs_phi) {
+                // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
+                for (int q = lane; q < nr; q += 64) {
+                    if (q == nzu) { gr[q] = g[nz - 1]; continue; }
+                    const double s = g[nxs + q] + gdot2(phi + q, nzu, g, 1, nxs);
+                    gr[q] = s;
+                }
+                const int nchunk = (nxs + 63) >> 6;
+                // the structure words, in the part of the LDS slice that is idle between the condensing and the sub-problem
+                unsigned long long *fmask = reinterpret_cast<unsigned long long *>(dXs);
+                for (int e0 = 0; e0 < m * nchunk; ++e0) {
+                    const unsigned long long bal = structure_word(e0, nchunk);
+                    if (lane == 0) fmask[e0] = bal;
+                }
+                nl_wave_sync();
+                for (int q = lane; q < nr; q += 64) {
+                    const bool realq = q < nzu;
+                    const size_t qq = realq ? q : 0, ucol = q == nzu ? nz - 1 : nxs + q;
+                    if (nchunk <= 2) {
+                        // four rows at a time, up to four entries of each gathered first so that their loads are in flight together
+                        for (int k0 = 0; k0 < m; k0 += 4) {
+                            int c4[4][4];
+                            unsigned long long rest0[4], rest1[4];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int k = min(k0 + rr, m - 1);
+                                unsigned long long m0 = fmask[k * nchunk], m1 = nchunk > 1 ? fmask[k * nchunk + 1] : 0ull;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    int cc = -1;
+                                    if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; }
+                                    else if (m1) { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
+                                    c4[rr][u] = cc;
+                                }
+                                rest0[rr] = m0; rest1[rr] = m1;
+                            }
+                            double a0[4], jv[4][4], pv[4][4];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const size_t k = min(k0 + rr, m - 1);
+                                a0[rr] = jin[k * nz + ucol];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const size_t cc = c4[rr][u] < 0 ? 0 : c4[rr][u];
+                                    jv[rr][u] = jin[k * nz + cc];
+                                    pv[rr][u] = phi[cc * nzu + qq];
                                 }
                             }
-                        art[(size_t)q * mld + k] = acc;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                double acc = a0[rr];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if (realq && c4[rr][u] >= 0) acc = fma(jv[rr][u], pv[rr][u], acc);
+                                const size_t k = min(k0 + rr, m - 1);
+                                unsigned long long m0 = rest0[rr], m1 = rest1[rr];
+                                while (realq && (m0 | m1)) {                   // rows with more than four entries
+                                    int cc;
+                                    if (m0) { cc = (int)__builtin_ctzll(m0); m0 &= m0 - 1; } else { cc = 64 + (int)__builtin_ctzll(m1); m1 &= m1 - 1; }
+                                    acc = fma(jin[k * nz + cc], phi[(size_t)cc * nzu + qq], acc);
+                                }
+                                if (k0 + rr < m) art[(size_t)q * mld + k0 + rr] = acc;
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < m; ++k) {
+                            double acc = jin[(size_t)k * nz + ucol];
+                            if (realq)
+                                for (int cb = 0; cb < nchunk; ++cb) {
+                                    unsigned long long mk = fmask[k * nchunk + cb];
+                                    while (mk) {
+                                        const int row = cb * 64 + (int)__builtin_ctzll(mk);
+                                        mk &= mk - 1;
+                                        acc += jin[(size_t)k * nz + row] * phi[(size_t)row * nzu + q];
+                                    }
+                                }
+                            art[(size_t)q * mld + k] = acc;
+                        }
                     }
                 }
-            }
-            // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
-            for (int kb = 0; kb < M.nbnd; ++kb) {
-                const int zi = M.bnd_idx[kb];
-                const double sg = M.bnd_sign[kb];
+                // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
+                for (int kb = 0; kb < M.nbnd; ++kb) {
+                    const int zi = M.bnd_idx[kb];
+                    const double sg = M.bnd_sign[kb];
+                    for (int q = lane; q < nr; q += 64) {
+                        double v = 0.0;
+                        if (zi < nxs) v = q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0;
+                        else v = (q == zi - nxs) ? sg : 0.0;
+                        art[(size_t)q * mld + m + kb] = v;
+                    }
+                    if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - M.bnd_val[kb]);
+                }
+                for (int k = lane; k < m; k += 64) {
+                    double s = gin[k];
+                    for (int cb = 0; cb < nchunk; ++cb) {
+                        unsigned long long mk = fmask[k * nchunk + cb];
+                        while (mk) {
+                            const int row = cb * 64 + (int)__builtin_ctzll(mk);
+                            mk &= mk - 1;
+                            s += jin[(size_t)k * nz + row] * r[row];
+                        }
+                    }
+                    br[k] = s;
+                }
+                nl_wave_sync();
+                // Rows with at most kNlSparse entries (a bound on an input, a constraint on a single input, ...) are also kept as
+                // (index, value) lists: for those the sub-problem reads neither their column of art nor a full pass of B^-1.
+                // Found numerically (the finite differences leave exact zeros), lanes = rows, so the scan of art is coalesced.
+                for (int k0 = 0; k0 < mt; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool live = k < mt;
+                    int cnt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                    const double *ak = art + (live ? k : 0);
+                    for (int q0 = 0; q0 < nq; q0 += 8) {
+                        double av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) av[u] = ak[(size_t)min(q0 + u, nq - 1) * mld];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (q0 + u < nq && av[u] != 0.0) {
+                                if (cnt == 0) { i0 = q0 + u; e0 = av[u]; } else if (cnt == 1) { i1 = q0 + u; e1 = av[u]; }
+                                else if (cnt == 2) { i2 = q0 + u; e2 = av[u]; } else if (cnt == 3) { i3 = q0 + u; e3 = av[u]; }
+                                ++cnt;
+                            }
+                        }
+                    }
+                    if (live) {
+                        const bool sp = cnt <= kNlSparse;
+                        spn[k] = sp ? cnt : -1;
+                        spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
+                        spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
+                    }
+                }
+            } else {
+                // no row reads a state.  Reduced gradient gr = g_u + Ju' lam with Jx' lam = -g_x: one backward sweep.
+                for (int row = lane; row < nxs; row += 64) lamw[row] = g[row];
+                nl_wave_sync();
+                lam_dyn = backsolve(true);
                 for (int q = lane; q < nr; q += 64) {
-                    double v = 0.0;
-                    if (zi < nxs) v = q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0;
-                    else v = (q == zi - nxs) ? sg : 0.0;
-                    art[(size_t)q * mld + m + kb] = v;
+                    if (q == nzu) { gr[q] = g[nz - 1]; continue; }
+                    const int bq = q / NU, jq = q - bq * NU;
+                    double s = g[nxs + q];
+                    for (int i = bq; i < (bq == ch - 1 ? ph : bq + 1); ++i) {
+                        const double *Jb = jeq + (size_t)i * NX * W + 2 * NX + jq;
+                        double bv[NX], lv[NX];
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) { bv[a] = Jb[a * W]; lv[a] = lamw[i * NX + a]; }
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) s = fma(bv[a], lv[a], s);
+                    }
+                    gr[q] = s;
                 }
-                if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - M.bnd_val[kb]);
-            }
-            for (int k = lane; k < m; k += 64) {
-                double s = gin[k];
-                for (int cb = 0; cb < nchunk; ++cb) {
-                    unsigned long long mk = fmask[k * nchunk + cb];
-                    while (mk) {
-                        const int row = cb * 64 + (int)__builtin_ctzll(mk);
-                        mk &= mk - 1;
-                        s += jin[(size_t)k * nz + row] * r[row];
+                // The rows of the sub-problem are the rows of the user Jacobian's input part (and the slack column) as they are:
+                // one lane scans one row, and only a row with more than kNlSparse entries is copied into art at all.
+                for (int k0 = 0; k0 < m; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool live = k < m;
+                    const double *jr = jin + (size_t)(live ? k : 0) * nz;
+                    int cnt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                    for (int q0 = 0; q0 < nq; q0 += 8) {
+                        double av[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int q = min(q0 + u, nq - 1); av[u] = jr[q == nzu ? nz - 1 : nxs + q]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (q0 + u < nq && av[u] != 0.0) {
+                                if (cnt == 0) { i0 = q0 + u; e0 = av[u]; } else if (cnt == 1) { i1 = q0 + u; e1 = av[u]; }
+                                else if (cnt == 2) { i2 = q0 + u; e2 = av[u]; } else if (cnt == 3) { i3 = q0 + u; e3 = av[u]; }
+                                ++cnt;
+                            }
+                        }
+                    }
+                    const bool sp = cnt <= kNlSparse;
+                    if (live) {
+                        spn[k] = sp ? cnt : -1;
+                        spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
+                        spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
+                        br[k] = gin[k];
+                        if (!sp) for (int q = 0; q < nr; ++q) art[(size_t)q * mld + k] = jr[q == nzu ? nz - 1 : nxs + q];
                     }
                 }
-                br[k] = s;
+                for (int kb = lane; kb < M.nbnd; kb += 64) {              // bounds on inputs: one entry each
+                    const int zi = M.bnd_idx[kb], k = m + kb;
+                    const double sg = M.bnd_sign[kb];
+                    spn[k] = 1;
+                    spi[k * kNlSparse] = zi - nxs; spi[k * kNlSparse + 1] = 0; spi[k * kNlSparse + 2] = 0; spi[k * kNlSparse + 3] = 0;
+                    spv[k * kNlSparse] = sg; spv[k * kNlSparse + 1] = 0.0; spv[k * kNlSparse + 2] = 0.0; spv[k * kNlSparse + 3] = 0.0;
+                    br[k] = sg * (z[zi] - M.bnd_val[kb]);
+                }
             }
             nl_wave_sync();
             lap(1);
@@ -994,7 +1250,12 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 double sBs = 0, sy = 0;
                 for (int q = lane; q < nq; q += 64) {
                     double gl = gr[q];
-                    for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
+                    for (int t = 0; t < nw_keep; ++t) {
+                        const int k = (int)wq[t], cn = spn[k];
+                        const double ml = sgq[t] * uq[t];
+                        if (cn < 0) gl += art[(size_t)q * mld + k] * ml;
+                        else for (int j = 0; j < cn; ++j) if (spi[k * kNlSparse + j] == q) gl += spv[k * kNlSparse + j] * ml;
+                    }
                     const double y = gl - glold[q], Bs = -a_prev * glold[q];
                     v0[q] = y; v1[q] = Bs;
                     sBs += sv[q] * Bs; sy += sv[q] * y;
@@ -1042,8 +1303,38 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             for (int k = lane; k < mt; k += 64) mu[k] = 0.0;
             nl_wave_sync();
             int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
+            int ndense_w = 0;                                           // working rows that are not in the sparse form
+            auto sp_dot = [&](int k, const double *x) {                 // (column k of art)' x for a row in the sparse form
+                const double *v = spv + (size_t)k * kNlSparse; const int *ix = spi + (size_t)k * kNlSparse;
+                return fma(v[3], x[ix[3]], fma(v[2], x[ix[2]], fma(v[1], x[ix[1]], v[0] * x[ix[0]])));
+            };
+            int nfac = 0, nfail = 0;
+            int fac_n = 0;                                              // rows the factor in LDS stands for (-1: stale)
+            double y0 = 0, y1 = 0;                                      // L^-1 t of the last solve: the factor's next row if the entering row joins
+            // tq <- S^-1 tq over the working set: the LDS factor (brought up to date if rows left) up to NL rows, beyond
+            // that an elimination in the workspace
+            auto solve_ws = [&]() -> bool {
+                if (nw <= NL) {
+                    bool ok = true;
+                    if (fac_n != nw) { ok = chol_factor(Lp, invd, Ssm, SLD, nw, lane); fac_n = ok ? nw : -1; ++nfac; nfail += !ok; }
+                    double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
+                    chol_forward(Lp, invd, nw, t0, t1, lane);
+                    y0 = t0; y1 = t1;
+                    chol_backward(Lp, invd, nw, t0, t1, lane);
+                    if (lane < nw) tq[lane] = t0;
+                    if (lane + 64 < nw) tq[lane + 64] = t1;
+                    nl_wave_sync();
+                    return ok;
+                }
+                fac_n = -1;
+                for (int e2 = lane; e2 < nw * nw; e2 += 64) Sbig[(e2 / nw) * SLD + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
+                nl_wave_sync();
+                return spd_solve(Sbig, SLD, tq, nw, lane);
+            };
             auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
                 const int last = nw - 1;
+                if (spn[(int)wq[kdrop]] < 0) --ndense_w;
+                fac_n = -1;
                 if (kdrop != last) {
                     for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
                     nl_wave_sync();
@@ -1059,13 +1350,46 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // One sweep over B^-1 serves the unconstrained minimiser x = -B^-1 gr and B^-1 n for three rows of the previous
             // working set at a time (their normals parked in LDS): every product with B^-1 costs a full pass of loads, and
             // the warm start needs one per row.
-            for (int t0 = 0; t0 == 0 || t0 < nw_keep; t0 += 3) {
-                const int nv = min(3, nw_keep - t0);
-                for (int u = 0; u < nv; ++u) {
-                    const int k = (int)wq[t0 + u];
-                    for (int q = lane; q < nq; q += 64) v1[u * nr + q] = sgq[t0 + u] * art[(size_t)q * mld + k];
+            // A row in the sparse form needs no sweep: B^-1 n is a combination of a few columns of B^-1.
+            for (int t = 0; t < nw_keep; ++t) {
+                const int k = (int)wq[t], cn = spn[k];
+                if (cn < 0) continue;
+                const double sg = sgq[t];
+                for (int q = lane; q < nq; q += 64) {
+                    double nvl = 0, hv = 0;
+                    for (int j = 0; j < cn; ++j) {
+                        const int ix = spi[k * kNlSparse + j];
+                        const double v = sg * spv[k * kNlSparse + j];
+                        if (ix == q) nvl += v;
+                        hv = fma(hinv[(size_t)ix * nr + q], v, hv);
+                    }
+                    qn[(size_t)t * nr + q] = nvl; qv[(size_t)t * nr + q] = hv;
+                }
+            }
+            int cur = 0;
+            for (bool first = true; first || cur < nw_keep; first = false) {
+                int slot[3] = {0, 0, 0}, nv = 0;
+                while (cur < nw_keep && nv < 3) {
+                    if (spn[(int)wq[cur]] < 0) { if (nv == 0) slot[0] = cur; else if (nv == 1) slot[1] = cur; else slot[2] = cur; ++nv; }
+                    ++cur;
+                }
+                if (!first && nv == 0) break;
+                ndense_w += nv;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (u >= nv) continue;
+                    const int k = (int)wq[slot[u]];
+                    for (int q = lane; q < nq; q += 64) v1[u * nr + q] = sgq[slot[u]] * art[(size_t)q * mld + k];
                 }
                 nl_wave_sync();
+                if (nv == 0) {                                         // x = -B^-1 gr alone
+                    for (int q = lane; q < nq; q += 64) {
+                        const double s = gdot(hinv + q, nr, gr, nq);
+                        xq[q] = -s;
+                    }
+                    nl_wave_sync();
+                    continue;
+                }
                 for (int q = lane; q < nq; q += 64) {
                     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                     const double *hq = hinv + q;
@@ -1073,7 +1397,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     for (; j + 8 <= nq; j += 8) {
                         double h[8], gv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { h[u] = hq[(size_t)(j + u) * nr]; gv[u] = t0 == 0 ? gr[j + u] : 0.0; }
+                        for (int u = 0; u < 8; ++u) { h[u] = hq[(size_t)(j + u) * nr]; gv[u] = first ? gr[j + u] : 0.0; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             a0 = fma(h[u], gv[u], a0);
@@ -1082,27 +1406,34 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     for (; j < nq; ++j) {
                         const double hv = hq[(size_t)j * nr];
-                        a0 = fma(hv, t0 == 0 ? gr[j] : 0.0, a0);
+                        a0 = fma(hv, first ? gr[j] : 0.0, a0);
                         a1 = fma(hv, v1[j], a1); a2 = fma(hv, v1[nr + j], a2); a3 = fma(hv, v1[2 * nr + j], a3);
                     }
-                    if (t0 == 0) xq[q] = -a0;
+                    if (first) xq[q] = -a0;
                     const double acc[3] = {a1, a2, a3};
-                    for (int u = 0; u < nv; ++u) { qn[(size_t)(t0 + u) * nr + q] = v1[u * nr + q]; qv[(size_t)(t0 + u) * nr + q] = acc[u]; }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+                        if (u < nv) { qn[(size_t)slot[u] * nr + q] = v1[u * nr + q]; qv[(size_t)slot[u] * nr + q] = acc[u]; }
                 }
                 nl_wave_sync();
             }
             // warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative --
             // the minimiser on that set with u >= 0 is a valid state of the dual method
+            const long long tw0 = __builtin_readcyclecounter();
+            qst[4] += nw_keep;
             if (nw_keep > 0) {
                 nw = nw_keep;
                 for (int e2 = lane; e2 < nw * nw; e2 += 64) {
                     const int a = e2 / nw, b2 = e2 - a * nw;
-                    const double s2 = gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
+                    const int ka = (int)wq[a];
+                    const double s2 = spn[ka] >= 0 ? sgq[a] * sp_dot(ka, qv + (size_t)b2 * nr) : gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
                     Ssm[a * SLD + b2] = s2;
                 }
                 nl_wave_sync();
                 while (nw > 0) {
-                    if (nw <= 16 && nq <= 64) {
+                    if (ndense_w == 0) {
+                        for (int t = lane; t < nw; t += 64) { const int k = (int)wq[t]; tq[t] = sgq[t] * br[k] + sgq[t] * sp_dot(k, xq); }
+                    } else if (nw <= 16 && nq <= 64) {
                         for (int t0 = 0; t0 < nw; t0 += 8) {
                             double part[8];
 #pragma unroll
@@ -1120,17 +1451,14 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                             tq[t] = s2;
                         }
                     }
-                    double *Sf = nw <= KL ? Sfac : Sbig;
-                    const int sfld = nw <= KL ? KL + 1 : SLD;
-                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
                     nl_wave_sync();
-                    if (!spd_solve(Sf, sfld, tq, nw, lane)) { nw = 0; break; }      // dependent rows: start cold
+                    if (!solve_ws()) { nw = 0; break; }                              // dependent rows: start cold
                     auto sheds = [&](int t) { const int k = (int)wq[t]; return tq[t] < 0.0 && !(k >= mi && k < m); };   // equalities stay
                     int neg = -1;
                     for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
                     if (neg < 0) break;
                     for (int t = nw - 1; t >= 0; --t) {
-                        if (sheds(t)) { const double tl = tq[nw - 1]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
+                        if (sheds(t)) { const double tl = tq[nw - 1]; ++qst[5]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
                     }
                 }
                 if (nw > 0) {
@@ -1142,10 +1470,13 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     nl_wave_sync();
                 }
             }
+            if (nw == 0) { fac_n = 0; ndense_w = 0; }
+            qst[6] += __builtin_readcyclecounter() - tw0;
             for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
+                ++qst[0];
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < mt; k += 64) {
-                    double s = br[k] + gdot(art + k, mld, xq, nq);
+                    double s = br[k] + (spn[k] >= 0 ? sp_dot(k, xq) : gdot(art + k, mld, xq, nq));
                     if (k >= mi && k < m) s = fabs(s);                   // an equality is violated on either side
                     bool inw = mu[k] == -1.0 && !(k >= mi && k < m);     // set aside (see below)
                     for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
@@ -1156,24 +1487,42 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
                 // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
                 const bool p_is_eq = pidx >= mi && pidx < m;
+                const int pcn = spn[pidx];
                 double sgn = 1.0;
                 if (p_is_eq) {
                     double part = 0;
-                    for (int q = lane; q < nq; q += 64) part += art[(size_t)q * mld + pidx] * xq[q];
+                    if (pcn >= 0) part = lane == 0 ? sp_dot(pidx, xq) : 0.0;
+                    else for (int q = lane; q < nq; q += 64) part += art[(size_t)q * mld + pidx] * xq[q];
                     sgn = br[pidx] + wave_sum(part) < 0.0 ? -1.0 : 1.0;
                 }
-                for (int q = lane; q < nq; q += 64) np_[q] = sgn * art[(size_t)q * mld + pidx];
-                nl_wave_sync();
-                double up = 0.0, sp = vmax;
-                bool added = false;
-                for (int inner = 0; inner <= KW + 1 && !added; ++inner) {
+                // the normal n of the entering row and v = B^-1 n (they stay as they are while rows leave to make room)
+                if (pcn >= 0) {
+                    for (int q = lane; q < nq; q += 64) {
+                        double nvl = 0, hv = 0;
+                        for (int j = 0; j < pcn; ++j) {
+                            const int ix = spi[pidx * kNlSparse + j];
+                            const double v = sgn * spv[pidx * kNlSparse + j];
+                            if (ix == q) nvl += v;
+                            hv = fma(hinv[(size_t)ix * nr + q], v, hv);
+                        }
+                        np_[q] = nvl; vv[q] = hv;
+                    }
+                } else {
+                    for (int q = lane; q < nq; q += 64) np_[q] = sgn * art[(size_t)q * mld + pidx];
+                    nl_wave_sync();
                     for (int q = lane; q < nq; q += 64) {
                         const double s = gdot(hinv + q, nr, np_, nq);
                         vv[q] = s;
                     }
-                    nl_wave_sync();
+                }
+                nl_wave_sync();
+                double up = 0.0, sp = vmax;
+                bool added = false;
+                for (int inner = 0; inner <= KW + 1 && !added; ++inner) {
                     // t = N_W v (also the new column of S), rr = S^-1 t
-                    if (nw <= 16 && nq <= 64) {
+                    if (ndense_w == 0) {
+                        for (int t = lane; t < nw; t += 64) tq[t] = sgq[t] * sp_dot((int)wq[t], vv);
+                    } else if (nw <= 16 && nq <= 64) {
                         // few rows: the lanes split each dot product (coalesced loads, all rows in flight, a butterfly per row)
                         // instead of each walking one row on its own
                         for (int t0 = 0; t0 < nw; t0 += 8) {
@@ -1193,13 +1542,12 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                             tq[t] = s;
                         }
                     }
-                    // small working sets factor in LDS, large ones in the workspace
-                    double *Sf = nw <= KL ? Sfac : Sbig;
-                    const int sfld = nw <= KL ? KL + 1 : SLD;
-                    for (int e2 = lane; e2 < nw * nw; e2 += 64) Sf[(e2 / nw) * sfld + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
                     nl_wave_sync();
                     const double tcol = lane < nw ? tq[lane] : 0.0, tcol2 = lane + 64 < nw ? tq[lane + 64] : 0.0;   // keep N_W v: it becomes S[:, new]
-                    if (nw) spd_solve(Sf, sfld, tq, nw, lane);
+                    ++qst[1];
+                    const long long tf0 = __builtin_readcyclecounter();
+                    if (nw) solve_ws();
+                    qst[7] += __builtin_readcyclecounter() - tf0;
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
                         const double s = vv[q] - gdot(qv + q, nr, tq, nw);
@@ -1241,7 +1589,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                         for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
                         snn = wave_sum(snn);
                         if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; sgq[nw] = sgn; }
+                        if (fac_n == nw && nw < NL) { chol_append(Lp, invd, nw, y0, y1, snn, snn, lane); fac_n = nw + 1; } else fac_n = -1;
                         ++nw; added = true;
+                        if (pcn < 0) ++ndense_w;
                     } else {                                            // a multiplier hit zero: that row leaves, try again
                         drop_row(kdrop);
                     }
@@ -1255,15 +1605,21 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = sgq[t] * uq[t];
             nw_keep = nw;
+            qst[2] += nw; qst[3] = nw > qst[3] ? nw : qst[3];
+            qst[4] += 1000000ll * nfac + 1000000000ll * nfail;
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
 
             lap(3);
             // ---- full-space step d = [r + Phi p_u ; p]
             double dmax = 0, cmax = 0, gd = 0;
-            for (int row = lane; row < nxs; row += 64) {
-                const double s = r[row] + gdot2(phi + (size_t)row * nzu, 1, p, 1, nzu);
-                d[row] = s;
+            if (needs_phi) {
+                for (int row = lane; row < nxs; row += 64) {
+                    const double s = r[row] + gdot2(phi + (size_t)row * nzu, 1, p, 1, nzu);
+                    d[row] = s;
+                }
+            } else {
+                sweep(2);
             }
             for (int q = lane; q < nr; q += 64) d[nxs + q] = p[q];
             nl_wave_sync();
@@ -1287,12 +1643,17 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
             for (int q = lane; q < nq; q += 64) {
                 double gl = gr[q];
-                for (int t = 0; t < nw_keep; ++t) gl += art[(size_t)q * mld + (int)wq[t]] * (sgq[t] * uq[t]);
+                for (int t = 0; t < nw_keep; ++t) {
+                    const int k = (int)wq[t], cn = spn[k];
+                    const double ml = sgq[t] * uq[t];
+                    if (cn < 0) gl += art[(size_t)q * mld + k] * ml;
+                    else for (int j = 0; j < cn; ++j) if (spi[k * kNlSparse + j] == q) gl += spv[k * kNlSparse + j] * ml;
+                }
                 glold[q] = gl;
             }
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
             // the weight of the l1 merit function has to dominate them and mu
-            for (int row = lane; row < nxs; row += 64) {
+            for (int row = lane; needs_phi && row < nxs; row += 64) {        // (no row reads a state otherwise: the sweep of the reduction stands)
                 double s2 = g[row];
                 for (int t = 0; t < nw_keep; ++t) {                     // mu lives on the working set
                     const int k = (int)wq[t];
@@ -1302,56 +1663,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 lamw[row] = s2;
             }
             nl_wave_sync();
-            double lam_max = 0;
-            {
-                double *tl = aug, *ln = aug + NX;                  // t and lam_{i+1}
-                // the operands of step i-1 are requested before step i computes: the sweep is a chain of ph dependent steps and
-                // would otherwise pay a memory latency in each
-                double an[NX], en[NX], wn = 0.0;
-                auto fetch = [&](int i) {
-                    if (lane < NX) {
-                        wn = lamw[i * NX + lane];
-                        const double *Jb = jeq + (size_t)min(i + 1, ph - 1) * NX * W;
-#pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) an[bb] = i + 1 < ph ? Jb[bb * W + lane] : 0.0;
-                        if (CT) {
-                            const double *Ei = einv + (size_t)i * NX * NX;
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) en[bb] = Ei[bb * NX + lane];
-                        }
-                    }
-                };
-                if (lane < NX) ln[lane] = 0.0;
-                fetch(ph - 1);
-                nl_wave_sync();
-                for (int i = ph - 1; i >= 0; --i) {
-                    double ac[NX], ec[NX];
-                    const double wc = wn;
-#pragma unroll
-                    for (int bb = 0; bb < NX; ++bb) { ac[bb] = an[bb]; ec[bb] = en[bb]; }
-                    if (i > 0) fetch(i - 1);
-                    if (lane < NX) {
-                        double s2 = wc;
-#pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) s2 = fma(ac[bb], ln[bb], s2);
-                        tl[lane] = s2;
-                    }
-                    nl_wave_sync();
-                    if (lane < NX) {
-                        double lam;
-                        if (CT) {
-                            lam = 0;
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) lam = fma(-ec[bb], tl[bb], lam);
-                        } else {
-                            lam = -tl[lane];
-                        }
-                        ln[lane] = lam;
-                        lam_max = fmax(lam_max, fabs(lam));
-                    }
-                    nl_wave_sync();
-                }
-            }
+            double lam_max = needs_phi ? backsolve(false) : lam_dyn;
             for (int r = lane; r < nw_keep; r += 64) lam_max = fmax(lam_max, fabs(uq[r]));
             lam_max = wave_max(lam_max);
             if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
@@ -1469,7 +1781,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             ++it;
         }
-        if (lane == 0) for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k];
+        if (lane == 0) { for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k]; for (int k = 0; k < 8; ++k) scal[8 + k] = (double)qst[k]; }
 
         // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
         double gmax = -1e300;
@@ -1524,8 +1836,19 @@ inline void nlmpc_plan(NlmpcDev &m)
     m.kw = imin(kNlMaxWorking, imax(kNlLdsWorking, imin(m.nineq + m.nue + m.nbnd, m.nr)));
     const int KW = m.kw;
     const int ylds = (m.vector_hooks && m.has_output) ? (ph + 1) * m.ny : 0;
-    m.lds_per_wave = (2 * (ph + 1) * (nx + nu) + ph * nu + ylds + kNlLdsWorking * (kNlLdsWorking + 1) + 4 * KW + nx * 2 * nx + 4 * m.nr +
-                      (m.nineq + m.nue) * ((ph * nx + 63) / 64) + 1) & ~1;
+    // LDS slice of a wavefront: trajectories, working-set vectors and four vectors of the sub-problem stay; the tail holds
+    // the step, the transcription's and the condensing's scratch, and during the sub-problem the packed factor of the
+    // working set's Schur complement -- as many rows (nl) as fit while the CU keeps its wavefronts: 39 KB where a SIMD runs
+    // one (nx >= 12; four blocks of one share 160 KB), 16 KB where it runs two (two blocks of four)
+    const int fixed = (ph + 1) * (nx + nu) + ylds + 5 * KW + 4 * m.nr;
+    const int tail_min = imax(imax((ph + 1) * (nx + nu) + ph * nu + 2 * nx * nx, kNlLdsWorking * (kNlLdsWorking + 1) / 2),
+                              (m.nineq + m.nue) * ((ph * nx + 63) / 64));           // (the structure words of the reduction live there too)
+    int cap = nx >= 12 ? 4992 : 2048;
+    if (const char *e = getenv("MPCX_DEBUG_LDS_CAP")) cap = atoi(e);          // testing aid
+    const int tail = imax(tail_min, imin(KW * (KW + 1) / 2, cap - fixed));
+    m.nl = 0;
+    while (m.nl < KW && (m.nl + 1) * (m.nl + 2) / 2 <= tail) ++m.nl;
+    m.lds_per_wave = (fixed + tail + 1) & ~1;
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
@@ -1536,16 +1859,18 @@ inline void nlmpc_plan(NlmpcDev &m)
     w.r = take(m.neq); w.phi = take(m.neq * m.nzu); w.einv = take(ph * nx * nx);
     w.gr = take(m.nr); w.art = take(m.nr * mld); w.br = take(mtot);
     w.hinv = take(m.nr * m.nr); w.mu = take(mtot); w.glold = take(m.nr); w.s = take(m.nr); w.p = take(m.nr);
-    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(8);
+    w.qn = take(KW * m.nr); w.qv = take(KW * m.nr); w.qs = take(KW * (KW + 1)); w.qs2 = take(KW * (KW + 1)); w.scal = take(16);
     w.lamw = take(m.neq);
     w.hook = take(m.vector_hooks ? nlmpc_hook_scratch(m) : 0);
+    w.sp = take(mtot * kNlSparse + (mtot * kNlSparse + mtot + 1) / 2);
     w.total = o;
 }
 
 inline int nlmpc_waves_per_block(const NlmpcDev &m)
 {
-    int wpb = (int)((64 * 1024) / (m.lds_per_wave * sizeof(double)));
-    return wpb > 4 ? 4 : wpb;
+    // a power of two, so that the blocks of a CU (160 KB of LDS) leave no slice unused
+    const size_t bytes = m.lds_per_wave * sizeof(double);
+    return bytes <= 16 * 1024 ? 4 : bytes <= 32 * 1024 ? 2 : bytes <= 64 * 1024 ? 1 : 0;
 }
 
 template <class Mdl>
@@ -1569,6 +1894,11 @@ int launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream
     if (wpb < 1) return -2;
     const int blocks = (b->batch + wpb - 1) / wpb;
     const size_t lds = (size_t)wpb * m->lds_per_wave * sizeof(double);
+    if (getenv("MPCX_DEBUG_OCCUPANCY")) {                     // testing aid: resident blocks per CU as the runtime sees them
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl>, wpb * 64, lds);
+        fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d\n", blocks, wpb, lds, nb);
+    }
     hipLaunchKernelGGL(nlmpc_sqp<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -211,7 +211,7 @@ class NLMPC(NLMPCEvaluator):
         return r
 
     _WS_FIELDS = ("z", "d", "g", "c", "jeq", "gin", "jin", "r", "phi", "einv", "gr", "art", "br", "hinv", "mu", "glold", "s", "p",
-                  "qn", "qv", "qs", "qs2", "scal", "lamw", "hook", "total")
+                  "qn", "qv", "qs", "qs2", "scal", "lamw", "hook", "sp", "total")
 
     def debug_workspace_bytes(self):
         """size of one instance's SQP workspace in HBM"""

@@ -13,10 +13,16 @@ c, x0, u0 = make(name, B)
 r = c.optimizeBatch(x0, u0); torch.cuda.synchronize()
 it = r["iterations"].cpu().numpy()
 acc = np.zeros(6)
+qst = np.zeros(8)
 for i in range(0, B, max(1, B // 16)):
-    acc += c.debug_workspace(i)["scal"][2:8]
+    sc = c.debug_workspace(i)["scal"]
+    acc += sc[2:8]
+    qst += sc[8:16] / max(1, it[i])
+qst /= len(range(0, B, max(1, B // 16)))
 names = ["condense", "reduce(gr,Ar,br)", "bfgs", "qp", "step+linesearch", "evaluate"]
 tot = acc.sum()
 for n, v in zip(names, acc):
     print("%-18s %5.1f %%" % (n, 100 * v / tot))
 print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
+print("sub-problem, per SQP iteration: steps %.1f, inner passes %.1f, rows at the end %.1f (max %d over the solve), rows kept %.1f, shed at the warm start %.1f,"
+      " warm-start cycles %.0f, factorisation cycles %.0f" % (qst[0], qst[1], qst[2], int(qst[3] * it.mean()), qst[4], qst[5], qst[6], qst[7]))
