@@ -596,70 +596,117 @@ __global__ __launch_bounds__(256) void nlmpc_evaluate(const NlmpcDev M, const Nl
 // ---------------------------------------------------------------------------------------------------
 // SQP
 // ---------------------------------------------------------------------------------------------------
-// Dense symmetric positive definite solve: S [n x ld] (destroyed; LDS for small n, the workspace otherwise), rhs t ->
-// solution in t.  Lanes own rows (two each beyond 64).  n <= 128.
-__device__ inline bool spd_solve(double *S, int ld, double *t, int n, int lane)
-{
-    double dmax = 0.0;
-    for (int r = lane; r < n; r += 64) dmax = fmax(dmax, S[r * ld + r]);
-    dmax = wave_max(dmax);
-    bool ok = true;
-    for (int k = 0; k < n; ++k) {           // elimination, lanes = rows below the pivot
-        const double piv = S[k * ld + k];
-        ok &= piv > 1e-13 * dmax;
-        const double tk = t[k];
-        for (int r = lane; r < n; r += 64) {
-            if (r <= k) continue;
-            const double fct = S[r * ld + k] / piv;
-            for (int j = k + 1; j < n; ++j) S[r * ld + j] -= fct * S[k * ld + j];
-            t[r] -= fct * tk;
-        }
-        nl_wave_sync();
-    }
-    for (int k = n - 1; k >= 0; --k) {      // back substitution
-        if (lane == 0) t[k] /= S[k * ld + k];
-        nl_wave_sync();
-        const double tk = t[k];
-        for (int r = lane; r < k; r += 64) t[r] -= S[r * ld + k] * tk;
-        nl_wave_sync();
-    }
-    return ok;
-}
-
-// The working set's Schur complement S = L L' as a packed lower-triangular factor in LDS (row r at r (r + 1) / 2), with
-// 1 / L_rr beside it.  A vector of up to 128 elements lives in two registers per lane (element e on lane e & 63).  Every
-// step of a substitution is one broadcast from a register and one multiply-add per lane; the operands of step k + 1 are
-// requested before step k computes, so the chain pays arithmetic latency only.
+// The working set's Schur complement S = L L' as a Cholesky factor held on two levels: rows 0 .. NL-1 packed in LDS (row r at
+// r (r + 1) / 2), rows NL .. in the workspace (row r at (r - NL) * ldg), 1 / L_rr of every row in LDS.  A vector of up to 128
+// elements lives in two registers per lane (element e on lane e & 63).  Every step of a substitution is one broadcast from
+// a register and one multiply-add per lane; over the LDS rows the operands of step k + 1 are requested before step k
+// computes, over the workspace rows eight steps' operands are requested together, so the chain pays arithmetic latency
+// (plus one memory latency per eight workspace rows).  Working sets beyond NL rows are the exception (the first iterations
+// of a cold start); the LDS slice is sized for the rule.
+struct Factor {
+    double *Lp, *invd, *yb;      // LDS: packed rows, reciprocal diagonal [KW], a vector [KW]
+    double *Lg;                  // workspace rows
+    int NL, ldg;
+};
 __device__ __forceinline__ double read_lane(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
 // L y = t on the leading n rows; t in (t0, t1), y returned in the same registers
-__device__ __forceinline__ void chol_forward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+template <bool TWO>
+__device__ __forceinline__ void chol_forward(const Factor &F, int n, double &t0, double &t1, int lane)
 {
-    const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
-    auto at0 = [&](int k) { return (lane > k && lane < n) ? o0 + k : 0; };
-    auto at1 = [&](int k) { return (lane + 64 > k && lane + 64 < n) ? o1 + k : 0; };
-    double a0 = Lp[at0(0)], a1 = Lp[at1(0)], id = invd[0];
-    for (int k = 0; k < n; ++k) {
-        const int kn = min(k + 1, n - 1);
-        const double a0n = Lp[at0(kn)], a1n = Lp[at1(kn)], idn = invd[kn];
-        const double yk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * id;
-        if (lane == k) t0 = yk;
-        if (lane + 64 == k) t1 = yk;
-        if (lane > k && lane < n) t0 = fma(-a0, yk, t0);
-        if (lane + 64 > k && lane + 64 < n) t1 = fma(-a1, yk, t1);
-        a0 = a0n; a1 = a1n; id = idn;
+    const double *Lp = F.Lp, *invd = F.invd;
+    const int nl = min(n, F.NL);
+    {
+        const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
+        auto at0 = [&](int k) { return (lane > k && lane < nl) ? o0 + k : 0; };
+        auto at1 = [&](int k) { return (lane + 64 > k && lane + 64 < nl) ? o1 + k : 0; };
+        double a0 = Lp[at0(0)], a1 = Lp[at1(0)], id = invd[0];
+        for (int k = 0; k < nl; ++k) {
+            const int kn = min(k + 1, nl - 1);
+            const double a0n = Lp[at0(kn)], a1n = Lp[at1(kn)], idn = invd[kn];
+            const double yk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * id;
+            if (lane == k) t0 = yk;
+            if (lane + 64 == k) t1 = yk;
+            if (lane > k && lane < nl) t0 = fma(-a0, yk, t0);
+            if (lane + 64 > k && lane + 64 < nl) t1 = fma(-a1, yk, t1);
+            a0 = a0n; a1 = a1n; id = idn;
+        }
+    }
+    if (!TWO || n <= F.NL) return;
+    // workspace rows: first their part against y_0 .. y_{NL-1} (one dot product per row, each lane walks its own row) ...
+    const int NL = F.NL;
+    if (lane < NL) F.yb[lane] = t0;
+    if (lane + 64 < NL) F.yb[lane + 64] = t1;
+    nl_wave_sync();
+    const bool g0 = lane >= NL && lane < n, g1 = lane + 64 >= NL && lane + 64 < n;
+    const double *r0 = F.Lg + (size_t)(g0 ? lane - NL : 0) * F.ldg, *r1 = F.Lg + (size_t)(g1 ? lane + 64 - NL : 0) * F.ldg;
+    if (g0) { const double s = gdot(r0, 1, F.yb, NL); t0 -= s; }
+    if (g1) { const double s = gdot(r1, 1, F.yb, NL); t1 -= s; }
+    // ... then the triangle among themselves
+    for (int kb = NL; kb < n; kb += 8) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(kb + u, n - 1);
+            a0[u] = (g0 && lane > k) ? r0[k] : 0.0;
+            a1[u] = (g1 && lane + 64 > k) ? r1[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kb + u;
+            if (k < n) {
+                const double yk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * invd[k];
+                if (lane == k) t0 = yk;
+                if (lane + 64 == k) t1 = yk;
+                t0 = fma(-a0[u], yk, t0);
+                t1 = fma(-a1[u], yk, t1);
+            }
+        }
     }
 }
 // L' x = y on the leading n rows
-__device__ __forceinline__ void chol_backward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+template <bool TWO>
+__device__ __forceinline__ void chol_backward(const Factor &F, int n, double &t0, double &t1, int lane)
 {
+    const double *Lp = F.Lp, *invd = F.invd;
+    const int NL = F.NL, nl = min(n, NL);
+    if (TWO && n > NL) {
+        // workspace rows, last first: the triangle among themselves ...
+        for (int kb = n - 1; kb >= NL; kb -= 8) {
+            double a0[8], a1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = max(kb - u, NL);
+                const double *rk = F.Lg + (size_t)(k - NL) * F.ldg;
+                a0[u] = (lane >= NL && lane < k) ? rk[lane] : 0.0;
+                a1[u] = (lane + 64 >= NL && lane + 64 < k) ? rk[lane + 64] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = kb - u;
+                if (k >= NL) {
+                    const double xk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * invd[k];
+                    if (lane == k) t0 = xk;
+                    if (lane + 64 == k) t1 = xk;
+                    t0 = fma(-a0[u], xk, t0);
+                    t1 = fma(-a1[u], xk, t1);
+                }
+            }
+        }
+        // ... then what they take from the LDS rows' right-hand side: column j of the workspace rows against x_NL .. x_{n-1}
+        if (lane >= NL && lane < n) F.yb[lane] = t0;
+        if (lane + 64 >= NL && lane + 64 < n) F.yb[lane + 64] = t1;
+        nl_wave_sync();
+        if (lane < NL) { const double s = gdot(F.Lg + lane, (size_t)F.ldg, F.yb + NL, n - NL); t0 -= s; }
+        if (lane + 64 < NL) { const double s = gdot(F.Lg + lane + 64, (size_t)F.ldg, F.yb + NL, n - NL); t1 -= s; }
+    }
     auto at0 = [&](int k) { return lane < k ? k * (k + 1) / 2 + lane : 0; };
     auto at1 = [&](int k) { return lane + 64 < k ? k * (k + 1) / 2 + lane + 64 : 0; };
-    double a0 = Lp[at0(n - 1)], a1 = Lp[at1(n - 1)], id = invd[n - 1];
-    for (int k = n - 1; k >= 0; --k) {
+    double a0 = Lp[at0(nl - 1)], a1 = Lp[at1(nl - 1)], id = invd[nl - 1];
+    for (int k = nl - 1; k >= 0; --k) {
         const int kn = max(k - 1, 0);
         const double a0n = Lp[at0(kn)], a1n = Lp[at1(kn)], idn = invd[kn];
         const double xk = (k < 64 ? read_lane(t0, k) : read_lane(t1, k - 64)) * id;
@@ -671,21 +718,33 @@ __device__ __forceinline__ void chol_backward(const double *Lp, const double *in
     }
 }
 // row n of the factor from y = L^-1 (column n of S) and S_nn; false: the row depends on the ones above
-__device__ __forceinline__ bool chol_append(double *Lp, double *invd, int n, double y0, double y1, double snn, double dmax, int lane)
+template <bool TWO>
+__device__ __forceinline__ bool chol_append(const Factor &F, int n, double y0, double y1, double snn, double dmax, int lane)
 {
-    const int on = n * (n + 1) / 2;
-    if (lane < n) Lp[on + lane] = y0;
-    if (lane + 64 < n) Lp[on + lane + 64] = y1;
     const double d2 = snn - wave_sum((lane < n ? y0 * y0 : 0.0) + (lane + 64 < n ? y1 * y1 : 0.0));
     const bool ok = d2 > 1e-13 * dmax;
     const double dd = sqrt(ok ? d2 : 1e-13 * dmax + 1e-300);
-    if (lane == 0) { Lp[on + n] = dd; invd[n] = 1.0 / dd; }
+    if (!TWO || n < F.NL) {
+        if (lane < n) F.Lp[n * (n + 1) / 2 + lane] = y0;
+        if (lane + 64 < n) F.Lp[n * (n + 1) / 2 + lane + 64] = y1;
+        if (lane == 0) F.Lp[n * (n + 1) / 2 + n] = dd;
+    } else {
+        double *row = F.Lg + (size_t)(n - F.NL) * F.ldg;
+        if (lane < n) row[lane] = y0;
+        if (lane + 64 < n) row[lane + 64] = y1;
+        if (lane == 0) row[n] = dd;
+    }
+    if (lane == 0) F.invd[n] = 1.0 / dd;
     nl_wave_sync();
     return ok;
 }
-// the factor of the leading n x n block of S (global memory, row stride ld), row by row
-__device__ __attribute__((noinline)) bool chol_factor(double *Lp, double *invd, const double *Sg, int ld, int n, int lane)
+// the factor of the leading n x n block of S (workspace, row stride ld), row by row.  Called with the LDS arrays as offsets
+// into the block's dynamic shared memory, so that the accesses stay LDS accesses across the call.
+template <bool TWO>
+__device__ __attribute__((noinline)) bool chol_factor(int lp_off, int invd_off, int yb_off, double *Lg, int NL, int ldg, const double *Sg, int ld, int n, int lane)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Factor F{smem + lp_off, smem + invd_off, smem + yb_off, Lg, NL, ldg};
     double dmax = 0.0;
     for (int r = lane; r < n; r += 64) dmax = fmax(dmax, Sg[r * ld + r]);
     dmax = wave_max(dmax);
@@ -693,13 +752,14 @@ __device__ __attribute__((noinline)) bool chol_factor(double *Lp, double *invd, 
     for (int i = 0; i < n; ++i) {
         double t0 = lane < i ? Sg[i * ld + lane] : 0.0, t1 = lane + 64 < i ? Sg[i * ld + lane + 64] : 0.0;
         const double sii = Sg[i * ld + i];
-        if (i) chol_forward(Lp, invd, i, t0, t1, lane);
-        ok &= chol_append(Lp, invd, i, t0, t1, sii, dmax, lane);
+        if (i) chol_forward<TWO>(F, i, t0, t1, lane);
+        ok &= chol_append<TWO>(F, i, t0, t1, sii, dmax, lane);
     }
     return ok;
 }
 
-template <class Mdl>
+// TWO: working sets may outgrow the LDS factor (M.kw > M.nl); otherwise that code is left out
+template <class Mdl, bool TWO = true>
 __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev &S)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU;
@@ -723,7 +783,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     double *wq = uq + KW;                                 // KW  row numbers (as doubles)
     double *sgq = wq + KW;                                // KW  orientation of the row in the working set (+1; -1 for an equality entered from below)
     double *invd = sgq + KW;                              // KW  reciprocal diagonal of the working set's factor
-    double *v0 = invd + KW;                               // 4 vectors of nr
+    double *ybuf = invd + KW;                             // KW  a vector of the substitutions (working sets beyond NL rows)
+    double *v0 = ybuf + KW;                               // 4 vectors of nr
     double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
     // the rest of the slice is the step (dXs, dUs), the transcription's scratch (Jm) and the condensing's (aug); none of
     // them lives across the sub-problem, whose factor Lp takes the whole tail: rows 0 .. NL-1 of the working set
@@ -1311,25 +1372,22 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             int nfac = 0, nfail = 0;
             int fac_n = 0;                                              // rows the factor in LDS stands for (-1: stale)
             double y0 = 0, y1 = 0;                                      // L^-1 t of the last solve: the factor's next row if the entering row joins
-            // tq <- S^-1 tq over the working set: the LDS factor (brought up to date if rows left) up to NL rows, beyond
-            // that an elimination in the workspace
+            // tq <- S^-1 tq over the working set, with its factor (brought up to date first if rows left)
+            const Factor Fac{Lp, invd, ybuf, Sbig, NL, SLD};
             auto solve_ws = [&]() -> bool {
-                if (nw <= NL) {
-                    bool ok = true;
-                    if (fac_n != nw) { ok = chol_factor(Lp, invd, Ssm, SLD, nw, lane); fac_n = ok ? nw : -1; ++nfac; nfail += !ok; }
-                    double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
-                    chol_forward(Lp, invd, nw, t0, t1, lane);
-                    y0 = t0; y1 = t1;
-                    chol_backward(Lp, invd, nw, t0, t1, lane);
-                    if (lane < nw) tq[lane] = t0;
-                    if (lane + 64 < nw) tq[lane + 64] = t1;
-                    nl_wave_sync();
-                    return ok;
+                bool ok = true;
+                if (fac_n != nw) {
+                    ok = chol_factor<TWO>((int)(Lp - smem), (int)(invd - smem), (int)(ybuf - smem), Sbig, NL, SLD, Ssm, SLD, nw, lane);
+                    fac_n = ok ? nw : -1; ++nfac; nfail += !ok;
                 }
-                fac_n = -1;
-                for (int e2 = lane; e2 < nw * nw; e2 += 64) Sbig[(e2 / nw) * SLD + e2 % nw] = Ssm[(e2 / nw) * SLD + e2 % nw];
+                double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
+                chol_forward<TWO>(Fac, nw, t0, t1, lane);
+                y0 = t0; y1 = t1;
+                chol_backward<TWO>(Fac, nw, t0, t1, lane);
+                if (lane < nw) tq[lane] = t0;
+                if (lane + 64 < nw) tq[lane + 64] = t1;
                 nl_wave_sync();
-                return spd_solve(Sbig, SLD, tq, nw, lane);
+                return ok;
             };
             auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
                 const int last = nw - 1;
@@ -1546,6 +1604,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     const double tcol = lane < nw ? tq[lane] : 0.0, tcol2 = lane + 64 < nw ? tq[lane + 64] : 0.0;   // keep N_W v: it becomes S[:, new]
                     ++qst[1];
                     const long long tf0 = __builtin_readcyclecounter();
+#ifdef MPCX_EXP_DOUBLE_SOLVE
+                    for (int rep = 0; rep < 4 && nw; ++rep) { solve_ws(); if (lane < nw) tq[lane] = tcol; if (lane + 64 < nw) tq[lane + 64] = tcol2; nl_wave_sync(); }
+#endif
                     if (nw) solve_ws();
                     qst[7] += __builtin_readcyclecounter() - tf0;
                     double zn = 0;
@@ -1589,7 +1650,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                         for (int q = lane; q < nq; q += 64) snn += np_[q] * vv[q];
                         snn = wave_sum(snn);
                         if (lane == 0) { Ssm[nw * SLD + nw] = snn; uq[nw] = up; wq[nw] = (double)pidx; sgq[nw] = sgn; }
-                        if (fac_n == nw && nw < NL) { chol_append(Lp, invd, nw, y0, y1, snn, snn, lane); fac_n = nw + 1; } else fac_n = -1;
+                        if (fac_n == nw) { chol_append<TWO>(Fac, nw, y0, y1, snn, snn, lane); fac_n = nw + 1; } else fac_n = -1;
                         ++nw; added = true;
                         if (pcn < 0) ++ndense_w;
                     } else {                                            // a multiplier hit zero: that row leaves, try again
@@ -1819,8 +1880,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 // sweeps and the finite differences), while the LDS slice of such a system already limits a CU to 3-6 wavefronts.  Large
 // systems therefore get the whole register file of a SIMD (512 VGPRs, one wavefront per SIMD) instead of spilling.
 template <class Mdl> constexpr int kSqpWavesPerSimd = Mdl::NX >= 12 ? 1 : 2;
-template <class Mdl>
-__global__ __launch_bounds__(256, kSqpWavesPerSimd<Mdl>) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl>(M, S); }
+template <class Mdl, bool TWO>
+__global__ __launch_bounds__(256, kSqpWavesPerSimd<Mdl>) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl, TWO>(M, S); }
 
 // ---- host side: workspace plan and launchers -----------------------------------------------------------------------
 #if !defined(__HIPCC_RTC__)
@@ -1840,7 +1901,7 @@ inline void nlmpc_plan(NlmpcDev &m)
     // the step, the transcription's and the condensing's scratch, and during the sub-problem the packed factor of the
     // working set's Schur complement -- as many rows (nl) as fit while the CU keeps its wavefronts: 39 KB where a SIMD runs
     // one (nx >= 12; four blocks of one share 160 KB), 16 KB where it runs two (two blocks of four)
-    const int fixed = (ph + 1) * (nx + nu) + ylds + 5 * KW + 4 * m.nr;
+    const int fixed = (ph + 1) * (nx + nu) + ylds + 6 * KW + 4 * m.nr;
     const int tail_min = imax(imax((ph + 1) * (nx + nu) + ph * nu + 2 * nx * nx, kNlLdsWorking * (kNlLdsWorking + 1) / 2),
                               (m.nineq + m.nue) * ((ph * nx + 63) / 64));           // (the structure words of the reduction live there too)
     int cap = nx >= 12 ? 4992 : 2048;
@@ -1894,12 +1955,16 @@ int launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream
     if (wpb < 1) return -2;
     const int blocks = (b->batch + wpb - 1) / wpb;
     const size_t lds = (size_t)wpb * m->lds_per_wave * sizeof(double);
+    const bool two = m->kw > m->nl;                           // the working set can outgrow the LDS factor
     if (getenv("MPCX_DEBUG_OCCUPANCY")) {                     // testing aid: resident blocks per CU as the runtime sees them
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl>, wpb * 64, lds);
-        fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d\n", blocks, wpb, lds, nb);
+        if (two) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl, true>, wpb * 64, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl, false>, wpb * 64, lds);
+        fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; factor rows in LDS %d of %d\n",
+                blocks, wpb, lds, nb, m->nl, m->kw);
     }
-    hipLaunchKernelGGL(nlmpc_sqp<Mdl>, dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
+    if (two) hipLaunchKernelGGL((nlmpc_sqp<Mdl, true>), dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
+    else hipLaunchKernelGGL((nlmpc_sqp<Mdl, false>), dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 #endif   // !__HIPCC_RTC__

@@ -147,7 +147,7 @@ std::string generate(const mpcx_nlmpc_source &s)
     t += "extern \"C\" __global__ __launch_bounds__(256) void mpcx_jit_evaluate(const mpcx::NlmpcDev M, const mpcx::NlmpcBatchDev B) "
          "{ mpcx::engine::evaluate_body<Model>(M, B); }\n";
     t += "extern \"C\" __global__ __launch_bounds__(256, mpcx::engine::kSqpWavesPerSimd<Model>) void mpcx_jit_sqp(const mpcx::NlmpcDev M, const mpcx::NlmpcSolveDev S) "
-         "{ mpcx::engine::sqp_body<Model>(M, S); }\n";
+         "{ mpcx::engine::sqp_body<Model, true>(M, S); }\n";
     return t;
 }
 
