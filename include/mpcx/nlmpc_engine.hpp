@@ -847,12 +847,22 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             for (int kb = lane; kb < M.nbnd; kb += 64) any |= M.bnd_idx[kb] < nxs;
             needs_phi = __ballot(any) != 0ull;
         }
+        // the sparse form of a row pays where the rows of the reduced problem are long, or where every row is sparse (nothing
+        // reads a state); next to short dense rows (one load per lane) it only adds dependent loads (measured: configs 3, 5 and the 6-oscillator case)
+        const bool sparse_rows = nq > 64 || !needs_phi;
         double nu_pen = 0.0, a_prev = 0.0;
         bool have_old = false;
         int resets = 0;
         int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
         long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
-        long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // sub-problem statistics (debug_workspace): steps, inner passes, rows at the end (sum, max), rows kept, rows shed at the warm start, cycles of the warm start, cycles of the factorisations
+#ifdef MPCX_NL_STATS
+        // sub-problem statistics (debug_workspace; a build with -DMPCX_NL_STATS, see tools/nlmpc_phases.py): steps, inner passes,
+        // rows at the end (sum, max), rows kept, rows shed at the warm start, cycles of the warm start, cycles of the factorisations
+        long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MPCX_STAT(x) x
+#else
+#define MPCX_STAT(x)
+#endif
         auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         double f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;       // the last accepted step, for nlopt's stopping rules
         bool stepped = false;
@@ -1112,6 +1122,74 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             return lam_max;
             };
+            // The sub-problem's rows in the sparse form (index, value lists of at most kNlSparse entries; spn < 0: not sparse, the
+            // row is column k of art).  A user row that reads no state is the row of the user Jacobian's input part (and the
+            // slack column) as it is: one lane scans one row -- the finite differences leave exact zeros -- and only a row with
+            // more entries is needed in art at all.  A bound on an input is one entry.
+            auto scan_user_rows = [&](const unsigned long long *fm, const int nchunk) {      // fm: structure words (null: no row reads a state)
+                for (int k0 = 0; k0 < m; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool live = k < m;
+                    bool xfree = sparse_rows;
+                    if (fm) for (int cb = 0; cb < nchunk; ++cb) xfree &= fm[(live ? k : 0) * nchunk + cb] == 0ull;
+                    const double *jr = jin + (size_t)(live ? k : 0) * nz;
+                    int cnt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                    if (xfree) {
+                        for (int q0 = 0; q0 < nq; q0 += 8) {
+                            double av[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const int q = min(q0 + u, nq - 1); av[u] = jr[q == nzu ? nz - 1 : nxs + q]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (q0 + u < nq && av[u] != 0.0) {
+                                    if (cnt == 0) { i0 = q0 + u; e0 = av[u]; } else if (cnt == 1) { i1 = q0 + u; e1 = av[u]; }
+                                    else if (cnt == 2) { i2 = q0 + u; e2 = av[u]; } else if (cnt == 3) { i3 = q0 + u; e3 = av[u]; }
+                                    ++cnt;
+                                }
+                            }
+                        }
+                    }
+                    const bool sp = xfree && cnt <= kNlSparse;
+                    if (live) {
+                        spn[k] = sp ? cnt : -1;
+                        spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
+                        spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
+                        if (!fm) {
+                            br[k] = gin[k];
+                            if (!sp) for (int q = 0; q < nr; ++q) art[(size_t)q * mld + k] = jr[q == nzu ? nz - 1 : nxs + q];
+                        }
+                    }
+                }
+            };
+            auto input_bounds = [&]() {
+                for (int kb = lane; kb < M.nbnd; kb += 64) {
+                    const int zi = M.bnd_idx[kb], k = m + kb;
+                    if (zi < nxs || !sparse_rows) { spn[k] = -1; continue; } // a bound on a state: a row of Phi (dense_bounds)
+                    const double sg = M.bnd_sign[kb];
+                    spn[k] = 1;
+                    spi[k * kNlSparse] = zi - nxs; spi[k * kNlSparse + 1] = 0; spi[k * kNlSparse + 2] = 0; spi[k * kNlSparse + 3] = 0;
+                    spv[k * kNlSparse] = sg; spv[k * kNlSparse + 1] = 0.0; spv[k * kNlSparse + 2] = 0.0; spv[k * kNlSparse + 3] = 0.0;
+                    br[k] = sg * (z[zi] - M.bnd_val[kb]);
+                }
+            };
+            auto dense_bounds = [&]() {                                  // the bounds kept as columns of art, 64 descriptors at a time
+                for (int kb0 = 0; kb0 < M.nbnd; kb0 += 64) {
+                    const int kbl = min(kb0 + lane, M.nbnd - 1);
+                    const int zl = M.bnd_idx[kbl];
+                    const double sgl = M.bnd_sign[kbl], vall = M.bnd_val[kbl];
+                    unsigned long long mk = __ballot(kb0 + lane < M.nbnd && (zl < nxs || !sparse_rows));
+                    while (mk) {
+                        const int l = (int)__builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        const int zi = __builtin_amdgcn_readlane(zl, l), kb = kb0 + l;
+                        const double sg = read_lane(sgl, l), val = read_lane(vall, l);
+                        for (int q = lane; q < nr; q += 64)
+                            art[(size_t)q * mld + m + kb] = zi < nxs ? (q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0) : (q == zi - nxs ? sg : 0.0);
+                        if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - val);
+                    }
+                }
+            };
             double lam_dyn = 0;                                         // this lane's share of the largest dynamics multiplier (sweep below)
             if (needs_phi) {
                 // reduced gradient, reduced inequality rows (transposed: art[q][k]) and their offsets
@@ -1193,17 +1271,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                 }
                 // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): a row of [Phi; I]
-                for (int kb = 0; kb < M.nbnd; ++kb) {
-                    const int zi = M.bnd_idx[kb];
-                    const double sg = M.bnd_sign[kb];
-                    for (int q = lane; q < nr; q += 64) {
-                        double v = 0.0;
-                        if (zi < nxs) v = q < nzu ? sg * phi[(size_t)zi * nzu + q] : 0.0;
-                        else v = (q == zi - nxs) ? sg : 0.0;
-                        art[(size_t)q * mld + m + kb] = v;
-                    }
-                    if (lane == 0) br[m + kb] = sg * (z[zi] + (zi < nxs ? r[zi] : 0.0) - M.bnd_val[kb]);
-                }
+                input_bounds();
+                dense_bounds();
                 for (int k = lane; k < m; k += 64) {
                     double s = gin[k];
                     for (int cb = 0; cb < nchunk; ++cb) {
@@ -1216,36 +1285,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     br[k] = s;
                 }
-                nl_wave_sync();
-                // Rows with at most kNlSparse entries (a bound on an input, a constraint on a single input, ...) are also kept as
-                // (index, value) lists: for those the sub-problem reads neither their column of art nor a full pass of B^-1.
-                // Found numerically (the finite differences leave exact zeros), lanes = rows, so the scan of art is coalesced.
-                for (int k0 = 0; k0 < mt; k0 += 64) {
-                    const int k = k0 + lane;
-                    const bool live = k < mt;
-                    int cnt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-                    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                    const double *ak = art + (live ? k : 0);
-                    for (int q0 = 0; q0 < nq; q0 += 8) {
-                        double av[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) av[u] = ak[(size_t)min(q0 + u, nq - 1) * mld];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (q0 + u < nq && av[u] != 0.0) {
-                                if (cnt == 0) { i0 = q0 + u; e0 = av[u]; } else if (cnt == 1) { i1 = q0 + u; e1 = av[u]; }
-                                else if (cnt == 2) { i2 = q0 + u; e2 = av[u]; } else if (cnt == 3) { i3 = q0 + u; e3 = av[u]; }
-                                ++cnt;
-                            }
-                        }
-                    }
-                    if (live) {
-                        const bool sp = cnt <= kNlSparse;
-                        spn[k] = sp ? cnt : -1;
-                        spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
-                        spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
-                    }
-                }
+                scan_user_rows(fmask, nchunk);
             } else {
                 // no row reads a state.  Reduced gradient gr = g_u + Ju' lam with Jx' lam = -g_x: one backward sweep.
                 for (int row = lane; row < nxs; row += 64) lamw[row] = g[row];
@@ -1265,44 +1305,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     gr[q] = s;
                 }
-                // The rows of the sub-problem are the rows of the user Jacobian's input part (and the slack column) as they are:
-                // one lane scans one row, and only a row with more than kNlSparse entries is copied into art at all.
-                for (int k0 = 0; k0 < m; k0 += 64) {
-                    const int k = k0 + lane;
-                    const bool live = k < m;
-                    const double *jr = jin + (size_t)(live ? k : 0) * nz;
-                    int cnt = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-                    double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                    for (int q0 = 0; q0 < nq; q0 += 8) {
-                        double av[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int q = min(q0 + u, nq - 1); av[u] = jr[q == nzu ? nz - 1 : nxs + q]; }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (q0 + u < nq && av[u] != 0.0) {
-                                if (cnt == 0) { i0 = q0 + u; e0 = av[u]; } else if (cnt == 1) { i1 = q0 + u; e1 = av[u]; }
-                                else if (cnt == 2) { i2 = q0 + u; e2 = av[u]; } else if (cnt == 3) { i3 = q0 + u; e3 = av[u]; }
-                                ++cnt;
-                            }
-                        }
-                    }
-                    const bool sp = cnt <= kNlSparse;
-                    if (live) {
-                        spn[k] = sp ? cnt : -1;
-                        spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
-                        spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
-                        br[k] = gin[k];
-                        if (!sp) for (int q = 0; q < nr; ++q) art[(size_t)q * mld + k] = jr[q == nzu ? nz - 1 : nxs + q];
-                    }
-                }
-                for (int kb = lane; kb < M.nbnd; kb += 64) {              // bounds on inputs: one entry each
-                    const int zi = M.bnd_idx[kb], k = m + kb;
-                    const double sg = M.bnd_sign[kb];
-                    spn[k] = 1;
-                    spi[k * kNlSparse] = zi - nxs; spi[k * kNlSparse + 1] = 0; spi[k * kNlSparse + 2] = 0; spi[k * kNlSparse + 3] = 0;
-                    spv[k * kNlSparse] = sg; spv[k * kNlSparse + 1] = 0.0; spv[k * kNlSparse + 2] = 0.0; spv[k * kNlSparse + 3] = 0.0;
-                    br[k] = sg * (z[zi] - M.bnd_val[kb]);
-                }
+                scan_user_rows(nullptr, 0);
+                input_bounds();
+                if (!sparse_rows) dense_bounds();
             }
             nl_wave_sync();
             lap(1);
@@ -1369,7 +1374,6 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 const double *v = spv + (size_t)k * kNlSparse; const int *ix = spi + (size_t)k * kNlSparse;
                 return fma(v[3], x[ix[3]], fma(v[2], x[ix[2]], fma(v[1], x[ix[1]], v[0] * x[ix[0]])));
             };
-            int nfac = 0, nfail = 0;
             int fac_n = 0;                                              // rows the factor in LDS stands for (-1: stale)
             double y0 = 0, y1 = 0;                                      // L^-1 t of the last solve: the factor's next row if the entering row joins
             // tq <- S^-1 tq over the working set, with its factor (brought up to date first if rows left)
@@ -1378,7 +1382,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 bool ok = true;
                 if (fac_n != nw) {
                     ok = chol_factor<TWO>((int)(Lp - smem), (int)(invd - smem), (int)(ybuf - smem), Sbig, NL, SLD, Ssm, SLD, nw, lane);
-                    fac_n = ok ? nw : -1; ++nfac; nfail += !ok;
+                    fac_n = ok ? nw : -1;
                 }
                 double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
                 chol_forward<TWO>(Fac, nw, t0, t1, lane);
@@ -1477,8 +1481,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             }
             // warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative --
             // the minimiser on that set with u >= 0 is a valid state of the dual method
-            const long long tw0 = __builtin_readcyclecounter();
-            qst[4] += nw_keep;
+            MPCX_STAT(const long long tw0 = __builtin_readcyclecounter();)
+            MPCX_STAT(qst[4] += nw_keep;)
             if (nw_keep > 0) {
                 nw = nw_keep;
                 for (int e2 = lane; e2 < nw * nw; e2 += 64) {
@@ -1516,7 +1520,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
                     if (neg < 0) break;
                     for (int t = nw - 1; t >= 0; --t) {
-                        if (sheds(t)) { const double tl = tq[nw - 1]; ++qst[5]; drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
+                        if (sheds(t)) { const double tl = tq[nw - 1]; MPCX_STAT(++qst[5];) drop_row(t); if (lane == 0) tq[t] = tl; nl_wave_sync(); }
                     }
                 }
                 if (nw > 0) {
@@ -1529,9 +1533,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 }
             }
             if (nw == 0) { fac_n = 0; ndense_w = 0; }
-            qst[6] += __builtin_readcyclecounter() - tw0;
+            MPCX_STAT(qst[6] += __builtin_readcyclecounter() - tw0;)
             for (int qit = 0; qit < 8 * (mt + nq) + 16; ++qit) {
-                ++qst[0];
+                MPCX_STAT(++qst[0];)
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < mt; k += 64) {
                     double s = br[k] + (spn[k] >= 0 ? sp_dot(k, xq) : gdot(art + k, mld, xq, nq));
@@ -1602,13 +1606,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     nl_wave_sync();
                     const double tcol = lane < nw ? tq[lane] : 0.0, tcol2 = lane + 64 < nw ? tq[lane + 64] : 0.0;   // keep N_W v: it becomes S[:, new]
-                    ++qst[1];
-                    const long long tf0 = __builtin_readcyclecounter();
-#ifdef MPCX_EXP_DOUBLE_SOLVE
-                    for (int rep = 0; rep < 4 && nw; ++rep) { solve_ws(); if (lane < nw) tq[lane] = tcol; if (lane + 64 < nw) tq[lane + 64] = tcol2; nl_wave_sync(); }
-#endif
+                    MPCX_STAT(++qst[1]; const long long tf0 = __builtin_readcyclecounter();)
                     if (nw) solve_ws();
-                    qst[7] += __builtin_readcyclecounter() - tf0;
+                    MPCX_STAT(qst[7] += __builtin_readcyclecounter() - tf0;)
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
                         const double s = vv[q] - gdot(qv + q, nr, tq, nw);
@@ -1666,8 +1666,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             for (int t = lane; t < nw; t += 64) mu[(int)wq[t]] = sgq[t] * uq[t];
             nw_keep = nw;
-            qst[2] += nw; qst[3] = nw > qst[3] ? nw : qst[3];
-            qst[4] += 1000000ll * nfac + 1000000000ll * nfail;
+            MPCX_STAT(qst[2] += nw; qst[3] = nw > qst[3] ? nw : qst[3];)
             for (int q = lane; q < nr; q += 64) p[q] = q < nq ? xq[q] : 0.0;
             nl_wave_sync();
 
@@ -1842,7 +1841,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             ++it;
         }
-        if (lane == 0) { for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k]; for (int k = 0; k < 8; ++k) scal[8 + k] = (double)qst[k]; }
+        if (lane == 0) { for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k]; MPCX_STAT(for (int k = 0; k < 8; ++k) scal[8 + k] = (double)qst[k];) }
 
         // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
         double gmax = -1e300;

@@ -24,5 +24,6 @@ tot = acc.sum()
 for n, v in zip(names, acc):
     print("%-18s %5.1f %%" % (n, 100 * v / tot))
 print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
-print("sub-problem, per SQP iteration: steps %.1f, inner passes %.1f, rows at the end %.1f (max %d over the solve), rows kept %.1f, shed at the warm start %.1f,"
-      " warm-start cycles %.0f, factorisation cycles %.0f" % (qst[0], qst[1], qst[2], int(qst[3] * it.mean()), qst[4], qst[5], qst[6], qst[7]))
+if qst.any():       # only a build with -DMPCX_NL_STATS (make -C libmpc_amd/csrc stats; MPCX_LIBRARY=libmpc_amd/libmpcx_stats.so) fills these
+    print("sub-problem, per SQP iteration: steps %.1f, inner passes %.1f, rows at the end %.1f (max %d over the solve), rows kept %.1f, shed at the warm start %.1f,"
+          " warm-start cycles %.0f, factorisation cycles %.0f" % (qst[0], qst[1], qst[2], int(qst[3] * it.mean()), qst[4], qst[5], qst[6], qst[7]))
