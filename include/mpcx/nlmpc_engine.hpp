@@ -940,7 +940,63 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // forward sweep, one column per lane: dx = r + Phi p with dx_0 = 0.  A_i = dc_i/dx_i (and E_i^-1) are the same for
             // every lane: they are staged in LDS, the next step's share already in flight while this step computes.
             // mode 0: every column (Phi and r); 1: r alone; 2: the state step r + Phi p itself (into d), p applied on the way
+            // One column alone (modes 1 and 2) is a chain of ph small matrix-vector products: four lanes share a row, so that a
+            // step is two rounds of (a few multiply-adds, a two-step butterfly, one LDS exchange) instead of one lane's 2 nx^2.
+            auto sweep_column = [&](const int mode) {
+                constexpr int CH = (NX + 3) / 4, CU = (NU + 3) / 4;
+                const int a = lane >> 2, part = lane & 3;
+                const bool rowlive = a < NX;
+                double *vs = aug, *ts = aug + NX;
+                double *out = mode == 2 ? d : r;
+                double an[CH], en[CH], bn[CU], cn = 0.0;
+                auto fetch = [&](int i) {
+                    const double *Jb = jeq + (size_t)i * NX * W + (size_t)(rowlive ? a : 0) * W;
+                    const double *Ei = einv + (size_t)i * NX * NX + (size_t)(rowlive ? a : 0) * NX;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int bb = min(part + 4 * u, NX - 1);
+                        an[u] = part + 4 * u < NX ? Jb[bb] : 0.0;
+                        en[u] = (CT && part + 4 * u < NX) ? Ei[bb] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < CU; ++u) bn[u] = (mode == 2 && part + 4 * u < NU) ? Jb[2 * NX + min(part + 4 * u, NU - 1)] : 0.0;
+                    cn = part == 0 ? c[i * NX + (rowlive ? a : 0)] : 0.0;
+                };
+                if (lane < NX) vs[lane] = 0.0;
+                fetch(0);
+                nl_wave_sync();
+                for (int i = 0; i < ph; ++i) {
+                    double ac[CH], ec[CH], s2 = cn;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) { ac[u] = an[u]; ec[u] = en[u]; }
+                    if (mode == 2) {
+                        const double *pb = p + min(i, ch - 1) * NU;
+#pragma unroll
+                        for (int u = 0; u < CU; ++u) s2 = fma(bn[u], pb[min(part + 4 * u, NU - 1)], s2);
+                    }
+                    if (i + 1 < ph) fetch(i + 1);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) s2 = fma(ac[u], vs[min(part + 4 * u, NX - 1)], s2);
+                    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+                    double va;
+                    if (CT) {
+                        if (rowlive && part == 0) ts[a] = s2;
+                        nl_wave_sync();
+                        double s3 = 0.0;
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) s3 = fma(ec[u], ts[min(part + 4 * u, NX - 1)], s3);
+                        s3 += __shfl_xor(s3, 1); s3 += __shfl_xor(s3, 2);
+                        va = -s3;
+                    } else {
+                        va = -s2;
+                    }
+                    nl_wave_sync();                                     // every lane has read v_i
+                    if (rowlive && part == 0) { vs[a] = va; out[i * NX + a] = va; }
+                    nl_wave_sync();
+                }
+            };
             auto sweep = [&](const int mode) {
+            if (NX >= 8 && NX <= 16 && mode != 0) { sweep_column(mode); return; }
             if constexpr (NX >= 8) {
             for (int q0 = mode == 0 ? 0 : (nzu & ~63); q0 <= nzu; q0 += 64) {
                     const int q = q0 + lane;
@@ -1702,13 +1758,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 
             // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
             for (int q = lane; q < nq; q += 64) {
-                double gl = gr[q];
-                for (int t = 0; t < nw_keep; ++t) {
-                    const int k = (int)wq[t], cn = spn[k];
-                    const double ml = sgq[t] * uq[t];
-                    if (cn < 0) gl += art[(size_t)q * mld + k] * ml;
-                    else for (int j = 0; j < cn; ++j) if (spi[k * kNlSparse + j] == q) gl += spv[k * kNlSparse + j] * ml;
-                }
+                // (the working set's normals, signs included, are still in qn: independent loads, coalesced over q)
+                const double gl = gr[q] + gdot(qn + q, nr, uq, nw_keep);
                 glold[q] = gl;
             }
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
