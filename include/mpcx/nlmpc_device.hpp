@@ -9,6 +9,7 @@ namespace mpcx {
 constexpr int kNlMaxWorking = 128;     // rows the QP sub-solver may hold active at once
 constexpr int kNlLdsWorking = 24;      // the LDS slice holds the factor of a working set of at least this many rows
 constexpr int kNlTrials = 8;           // step lengths the line search evaluates at a time
+constexpr int kSpDense = 0x7fff0000;   // marker in the LDS word of a row that is not in the sparse form
 constexpr int kNlSparse = 4;           // sub-problem rows with at most this many entries are also kept as (index, value) lists
 
 // offsets (in doubles) into one instance's slice of the SQP workspace

@@ -62,9 +62,10 @@ __device__ __forceinline__ double wave_max(double v)
 
 // sum_j a[j * stride] * x[j]: the loads of a batch are issued together and waited for once -- the compiler does not
 // pipeline loads across the iterations of a plain loop, and every iteration would pay the full memory latency
+// (U: loads in flight at a time; kernels that run one wavefront per SIMD have the registers for 32)
+template <int U = 8>
 __device__ __forceinline__ double gdot(const double *__restrict__ a, size_t stride, const double *x, int n)
 {
-    constexpr int U = 8;
     double s = 0;
     int j = 0;
     for (; j + U <= n; j += U) {
@@ -76,7 +77,18 @@ __device__ __forceinline__ double gdot(const double *__restrict__ a, size_t stri
 #pragma unroll
         for (int u = 0; u < U; ++u) s = fma(v[u], w[u], s);
     }
-    for (; j < n; ++j) s = fma(a[(size_t)j * stride], x[j], s);
+    if constexpr (U > 8) {
+        // the remainder in one more batch (clamped addresses, surplus products dropped): a short vector still has all its loads in flight
+        if (j < n) {
+            double v[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int jj = min(j + u, n - 1); v[u] = a[(size_t)jj * stride]; w[u] = x[jj]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (j + u < n) s = fma(v[u], w[u], s);
+        }
+    } else {
+        for (; j < n; ++j) s = fma(a[(size_t)j * stride], x[j], s);
+    }
     return s;
 }
 // the same with both operands strided in memory
@@ -512,8 +524,12 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 const int q = k - ph * NX, bl = q / NU, j = q - bl * NU;
                 const double du = dv * Ua(j);
                 const int i_first = bl, i_last = bl == ch - 1 ? ph - 1 : bl;       // the steps this block drives
+                // A block that drives several steps (the last one) adds their contributions up.  Where the model declares that the
+                // steps' row ranges do not overlap every entry has one contribution: plain stores, no zeroing and no read-modify-
+                // write chain through memory (each a full memory latency for the few lanes that own the last block).
+                constexpr bool disjoint = Mdl::INEQ_U_ROWS_DISJOINT;
                 if (jin_fill) for (int r = 0; r < nineq; ++r) J[(size_t)r * nz + k] = 0.0;
-                else
+                else if (!disjoint)
                     for (int i = i_first; i <= i_last; ++i) {      // the entries that get contributions below start from zero
                         int first, count;
                         Mdl::ineq_rows_of_u(i, first, count);
@@ -525,7 +541,8 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                     const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};
                     for (int t = 0; t < count; ++t) {
                         const int r = first + t;
-                        J[(size_t)r * nz + k] += sc.by_su((Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du), j);
+                        const double dj = sc.by_su((Mdl::ineq(r, X0, Up, e, ph, prm) - Mdl::ineq(r, X0, Um, e, ph, prm)) / (2 * du), j);
+                        if constexpr (disjoint) J[(size_t)r * nz + k] = 0.0 + dj; else J[(size_t)r * nz + k] += dj;
                     }
                 }
             } else {
@@ -763,6 +780,7 @@ template <class Mdl, bool TWO = true>
 __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev &S)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU;
+    constexpr int GU = Mdl::NX >= 12 ? 32 : 8;            // loads in flight in the long dot products (one wavefront per SIMD: 512 registers)
     constexpr bool MAYBE_CT = Mdl::CONTINUOUS;            // hook models: true, the run-time flag decides
     const bool CT = is_ct<Mdl>(M);
     const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
@@ -784,7 +802,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     double *sgq = wq + KW;                                // KW  orientation of the row in the working set (+1; -1 for an equality entered from below)
     double *invd = sgq + KW;                              // KW  reciprocal diagonal of the working set's factor
     double *ybuf = invd + KW;                             // KW  a vector of the substitutions (working sets beyond NL rows)
-    double *v0 = ybuf + KW;                               // 4 vectors of nr
+    double *s1v = ybuf + KW;                              // mt  first entry of every sub-problem row in the sparse form ...
+    int *s1m = reinterpret_cast<int *>(s1v + mt);         // mt  ... its index (low 16 bits) and the row's entry count (high bits; kSpDense: not sparse)
+    double *v0 = s1v + mt + ((mt + 1) >> 1);              // 4 vectors of nr
     double *v1 = v0 + nr, *v2 = v1 + nr, *v3 = v2 + nr;
     // the rest of the slice is the step (dXs, dUs), the transcription's scratch (Jm) and the condensing's (aug); none of
     // them lives across the sub-problem, whose factor Lp takes the whole tail: rows 0 .. NL-1 of the working set
@@ -802,7 +822,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                *art = w + M.ws.art, *br = w + M.ws.br, *hinv = w + M.ws.hinv, *mu = w + M.ws.mu, *glold = w + M.ws.glold,
                *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal,
                *lamw = w + M.ws.lamw, *hk = w + M.ws.hook, *spv = w + M.ws.sp;
-        int *spi = reinterpret_cast<int *>(spv + (size_t)mt * kNlSparse), *spn = spi + (size_t)mt * kNlSparse;   // sparse rows of the sub-problem
+        int *spi = reinterpret_cast<int *>(spv + (size_t)mt * kNlSparse);   // entries 1.. of the sub-problem's sparse rows (entry 0: LDS)
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
@@ -832,6 +852,10 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 
         // user constraints read few states: one bit per (row, state) entry of d g / d x that can hold anything, from the
         // structure the model declares (the finite differences leave exact zeros everywhere else)
+        // the sparse form of row k: entry count (-1: not sparse), and entry j -- the first from LDS, further ones from the workspace
+        auto sp_count = [&](int k) { const int mw = s1m[k]; return mw == kSpDense ? -1 : mw >> 16; };
+        auto sp_index = [&](int k, int j) { return j == 0 ? (s1m[k] & 0xffff) : spi[k * kNlSparse + j]; };
+        auto sp_value = [&](int k, int j) { return j == 0 ? s1v[k] : spv[k * kNlSparse + j]; };
         auto structure_word = [&](int e0, int nchunk) {
             const int k = e0 / nchunk, col = (e0 - k * nchunk) * 64 + lane;
             return __ballot(col < nxs && (k < mi ? Mdl::ineq_reads_x(k, col / NX + 1) : Mdl::eq_reads_x(k - mi, col / NX + 1)));
@@ -1208,7 +1232,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     const bool sp = xfree && cnt <= kNlSparse;
                     if (live) {
-                        spn[k] = sp ? cnt : -1;
+                        s1v[k] = sp ? e0 : 0.0; s1m[k] = sp ? (cnt << 16) | i0 : kSpDense;
                         spi[k * kNlSparse] = sp ? i0 : 0; spi[k * kNlSparse + 1] = sp ? i1 : 0; spi[k * kNlSparse + 2] = sp ? i2 : 0; spi[k * kNlSparse + 3] = sp ? i3 : 0;
                         spv[k * kNlSparse] = sp ? e0 : 0.0; spv[k * kNlSparse + 1] = sp ? e1 : 0.0; spv[k * kNlSparse + 2] = sp ? e2 : 0.0; spv[k * kNlSparse + 3] = sp ? e3 : 0.0;
                         if (!fm) {
@@ -1221,9 +1245,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             auto input_bounds = [&]() {
                 for (int kb = lane; kb < M.nbnd; kb += 64) {
                     const int zi = M.bnd_idx[kb], k = m + kb;
-                    if (zi < nxs || !sparse_rows) { spn[k] = -1; continue; } // a bound on a state: a row of Phi (dense_bounds)
+                    if (zi < nxs || !sparse_rows) { s1v[k] = 0.0; s1m[k] = kSpDense; continue; } // a bound on a state: a row of Phi (dense_bounds)
                     const double sg = M.bnd_sign[kb];
-                    spn[k] = 1;
+                    s1v[k] = sg; s1m[k] = (1 << 16) | (zi - nxs);
                     spi[k * kNlSparse] = zi - nxs; spi[k * kNlSparse + 1] = 0; spi[k * kNlSparse + 2] = 0; spi[k * kNlSparse + 3] = 0;
                     spv[k * kNlSparse] = sg; spv[k * kNlSparse + 1] = 0.0; spv[k * kNlSparse + 2] = 0.0; spv[k * kNlSparse + 3] = 0.0;
                     br[k] = sg * (z[zi] - M.bnd_val[kb]);
@@ -1373,10 +1397,10 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 for (int q = lane; q < nq; q += 64) {
                     double gl = gr[q];
                     for (int t = 0; t < nw_keep; ++t) {
-                        const int k = (int)wq[t], cn = spn[k];
+                        const int k = (int)wq[t], cn = sp_count(k);
                         const double ml = sgq[t] * uq[t];
                         if (cn < 0) gl += art[(size_t)q * mld + k] * ml;
-                        else for (int j = 0; j < cn; ++j) if (spi[k * kNlSparse + j] == q) gl += spv[k * kNlSparse + j] * ml;
+                        else for (int j = 0; j < cn; ++j) if (sp_index(k, j) == q) gl += sp_value(k, j) * ml;
                     }
                     const double y = gl - glold[q], Bs = -a_prev * glold[q];
                     v0[q] = y; v1[q] = Bs;
@@ -1393,7 +1417,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     const double rho = 1.0 / sy;
                     double yHy = 0;
                     for (int q = lane; q < nq; q += 64) {
-                        const double s = gdot(hinv + q, nr, v0, nq);
+                        const double s = gdot<GU>(hinv + q, nr, v0, nq);
                         v2[q] = s; yHy += s * v0[q];
                     }
                     yHy = wave_sum(yHy);
@@ -1427,8 +1451,13 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             int nw = 0, qp_fail = 0; bool qp_ok = true, qp_done = false;
             int ndense_w = 0;                                           // working rows that are not in the sparse form
             auto sp_dot = [&](int k, const double *x) {                 // (column k of art)' x for a row in the sparse form
-                const double *v = spv + (size_t)k * kNlSparse; const int *ix = spi + (size_t)k * kNlSparse;
-                return fma(v[3], x[ix[3]], fma(v[2], x[ix[2]], fma(v[1], x[ix[1]], v[0] * x[ix[0]])));
+                const int mw = s1m[k];
+                double acc = s1v[k] * x[mw & 0xffff];
+                if ((mw >> 16) > 1) {
+                    const double *v = spv + (size_t)k * kNlSparse; const int *ix = spi + (size_t)k * kNlSparse;
+                    acc = fma(v[3], x[ix[3]], fma(v[2], x[ix[2]], fma(v[1], x[ix[1]], acc)));
+                }
+                return acc;
             };
             int fac_n = 0;                                              // rows the factor in LDS stands for (-1: stale)
             double y0 = 0, y1 = 0;                                      // L^-1 t of the last solve: the factor's next row if the entering row joins
@@ -1451,7 +1480,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             };
             auto drop_row = [&](int kdrop) {                            // working-set slot kdrop <- the last slot
                 const int last = nw - 1;
-                if (spn[(int)wq[kdrop]] < 0) --ndense_w;
+                if (sp_count((int)wq[kdrop]) < 0) --ndense_w;
                 fac_n = -1;
                 if (kdrop != last) {
                     for (int q = lane; q < nq; q += 64) { qn[(size_t)kdrop * nr + q] = qn[(size_t)last * nr + q]; qv[(size_t)kdrop * nr + q] = qv[(size_t)last * nr + q]; }
@@ -1470,14 +1499,14 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // the warm start needs one per row.
             // A row in the sparse form needs no sweep: B^-1 n is a combination of a few columns of B^-1.
             for (int t = 0; t < nw_keep; ++t) {
-                const int k = (int)wq[t], cn = spn[k];
+                const int k = (int)wq[t], cn = sp_count(k);
                 if (cn < 0) continue;
                 const double sg = sgq[t];
                 for (int q = lane; q < nq; q += 64) {
                     double nvl = 0, hv = 0;
                     for (int j = 0; j < cn; ++j) {
-                        const int ix = spi[k * kNlSparse + j];
-                        const double v = sg * spv[k * kNlSparse + j];
+                        const int ix = sp_index(k, j);
+                        const double v = sg * sp_value(k, j);
                         if (ix == q) nvl += v;
                         hv = fma(hinv[(size_t)ix * nr + q], v, hv);
                     }
@@ -1488,7 +1517,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             for (bool first = true; first || cur < nw_keep; first = false) {
                 int slot[3] = {0, 0, 0}, nv = 0;
                 while (cur < nw_keep && nv < 3) {
-                    if (spn[(int)wq[cur]] < 0) { if (nv == 0) slot[0] = cur; else if (nv == 1) slot[1] = cur; else slot[2] = cur; ++nv; }
+                    if (sp_count((int)wq[cur]) < 0) { if (nv == 0) slot[0] = cur; else if (nv == 1) slot[1] = cur; else slot[2] = cur; ++nv; }
                     ++cur;
                 }
                 if (!first && nv == 0) break;
@@ -1502,7 +1531,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 nl_wave_sync();
                 if (nv == 0) {                                         // x = -B^-1 gr alone
                     for (int q = lane; q < nq; q += 64) {
-                        const double s = gdot(hinv + q, nr, gr, nq);
+                        const double s = gdot<GU>(hinv + q, nr, gr, nq);
                         xq[q] = -s;
                     }
                     nl_wave_sync();
@@ -1544,7 +1573,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 for (int e2 = lane; e2 < nw * nw; e2 += 64) {
                     const int a = e2 / nw, b2 = e2 - a * nw;
                     const int ka = (int)wq[a];
-                    const double s2 = spn[ka] >= 0 ? sgq[a] * sp_dot(ka, qv + (size_t)b2 * nr) : gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
+                    const double s2 = sp_count(ka) >= 0 ? sgq[a] * sp_dot(ka, qv + (size_t)b2 * nr) : gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
                     Ssm[a * SLD + b2] = s2;
                 }
                 nl_wave_sync();
@@ -1581,7 +1610,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 }
                 if (nw > 0) {
                     for (int q = lane; q < nq; q += 64) {
-                        const double s2 = xq[q] - gdot(qv + q, nr, tq, nw);
+                        const double s2 = xq[q] - gdot<GU>(qv + q, nr, tq, nw);
                         xq[q] = s2;
                     }
                     for (int r = lane; r < nw; r += 64) uq[r] = tq[r];
@@ -1594,7 +1623,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 MPCX_STAT(++qst[0];)
                 double vmax = -1e300; int pidx = 0x7fffffff;
                 for (int k = lane; k < mt; k += 64) {
-                    double s = br[k] + (spn[k] >= 0 ? sp_dot(k, xq) : gdot(art + k, mld, xq, nq));
+                    double s = br[k] + (sp_count(k) >= 0 ? sp_dot(k, xq) : gdot(art + k, mld, xq, nq));
                     if (k >= mi && k < m) s = fabs(s);                   // an equality is violated on either side
                     bool inw = mu[k] == -1.0 && !(k >= mi && k < m);     // set aside (see below)
                     for (int t = 0; t < nw; ++t) inw |= ((int)wq[t] == k);
@@ -1605,7 +1634,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                 if (nw >= KW) { qp_ok = false; qp_fail = -3; break; }           // working set full
                 // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
                 const bool p_is_eq = pidx >= mi && pidx < m;
-                const int pcn = spn[pidx];
+                const int pcn = sp_count(pidx);
                 double sgn = 1.0;
                 if (p_is_eq) {
                     double part = 0;
@@ -1618,8 +1647,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     for (int q = lane; q < nq; q += 64) {
                         double nvl = 0, hv = 0;
                         for (int j = 0; j < pcn; ++j) {
-                            const int ix = spi[pidx * kNlSparse + j];
-                            const double v = sgn * spv[pidx * kNlSparse + j];
+                            const int ix = sp_index(pidx, j);
+                            const double v = sgn * sp_value(pidx, j);
                             if (ix == q) nvl += v;
                             hv = fma(hinv[(size_t)ix * nr + q], v, hv);
                         }
@@ -1629,7 +1658,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     for (int q = lane; q < nq; q += 64) np_[q] = sgn * art[(size_t)q * mld + pidx];
                     nl_wave_sync();
                     for (int q = lane; q < nq; q += 64) {
-                        const double s = gdot(hinv + q, nr, np_, nq);
+                        const double s = gdot<GU>(hinv + q, nr, np_, nq);
                         vv[q] = s;
                     }
                 }
@@ -1667,7 +1696,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     MPCX_STAT(qst[7] += __builtin_readcyclecounter() - tf0;)
                     double zn = 0;
                     for (int q = lane; q < nq; q += 64) {
-                        const double s = vv[q] - gdot(qv + q, nr, tq, nw);
+                        const double s = vv[q] - gdot<GU>(qv + q, nr, tq, nw);
                         zd[q] = s; zn += s * np_[q];
                     }
                     zn = wave_sum(zn);
@@ -1759,7 +1788,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
             for (int q = lane; q < nq; q += 64) {
                 // (the working set's normals, signs included, are still in qn: independent loads, coalesced over q)
-                const double gl = gr[q] + gdot(qn + q, nr, uq, nw_keep);
+                const double gl = gr[q] + gdot<GU>(qn + q, nr, uq, nw_keep);
                 glold[q] = gl;
             }
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward sweep over the blocks;
@@ -1945,13 +1974,13 @@ inline void nlmpc_plan(NlmpcDev &m)
     m.nz = ph * nx + m.nzu + 1; m.neq = ph * nx;
     // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
     m.kw = imin(kNlMaxWorking, imax(kNlLdsWorking, imin(m.nineq + m.nue + m.nbnd, m.nr)));
-    const int KW = m.kw;
+    const int KW = m.kw, mtot_ = m.nineq + m.nue + m.nbnd;
     const int ylds = (m.vector_hooks && m.has_output) ? (ph + 1) * m.ny : 0;
     // LDS slice of a wavefront: trajectories, working-set vectors and four vectors of the sub-problem stay; the tail holds
     // the step, the transcription's and the condensing's scratch, and during the sub-problem the packed factor of the
     // working set's Schur complement -- as many rows (nl) as fit while the CU keeps its wavefronts: 39 KB where a SIMD runs
     // one (nx >= 12; four blocks of one share 160 KB), 16 KB where it runs two (two blocks of four)
-    const int fixed = (ph + 1) * (nx + nu) + ylds + 6 * KW + 4 * m.nr;
+    const int fixed = (ph + 1) * (nx + nu) + ylds + 6 * KW + 4 * m.nr + mtot_ + (mtot_ + 1) / 2;
     const int tail_min = imax(imax((ph + 1) * (nx + nu) + ph * nu + 2 * nx * nx, kNlLdsWorking * (kNlLdsWorking + 1) / 2),
                               (m.nineq + m.nue) * ((ph * nx + 63) / 64));           // (the structure words of the reduction live there too)
     int cap = nx >= 12 ? 4992 : 2048;

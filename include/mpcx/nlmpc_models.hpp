@@ -14,7 +14,7 @@
 //   ineq(k, X, U, e, ph, p)     component k of IConFunHandle's output vector, g_k <= 0
 //   neq_user(ph), eq(k, X, U, ph, p)
 //                               EConFunHandle: component k of the user equalities h_k = 0 (defaults: none, NoUserEq)
-//   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK
+//   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK, INEQ_U_ROWS_DISJOINT
 //                               structure of that vector, both ways round: which rows of X / U constraint k reads, and
 //                               which (contiguous) constraints read row i.  Everything else differentiates to an exact
 //                               zero (also in the reference's finite differences) and is skipped; the second form lets
@@ -66,6 +66,7 @@ struct NoUserEq {
     template <class XA, class UA>
     __device__ static double eq(int, const XA &, const UA &, int, const double *) { return 0.0; }
     __device__ static bool eq_reads_x(int, int) { return true; }       // dense unless the model says otherwise
+    static constexpr bool INEQ_U_ROWS_DISJOINT = false;                 // true: ineq_rows_of_u(i) and ineq_rows_of_u(i') share no row for i != i'
 };
 
 // ---- model zoo ----------------------------------------------------------------------------------
@@ -95,6 +96,7 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
     // structure of the inequality Jacobian: which rows of X / U constraint k reads (anything else differentiates to an exact 0)
     static constexpr bool INEQ_USES_SLACK = false;
+    static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     __device__ static bool ineq_reads_x(int, int) { return false; }
     __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
     __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
@@ -145,6 +147,7 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
         return p[4 + 3 * o] - sqrt(dx * dx + dy * dy);
     }
     static constexpr bool INEQ_USES_SLACK = false;
+    static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
     __device__ static bool ineq_reads_u(int, int) { return false; }
     __device__ static void ineq_rows_of_x(int i, int &first, int &count) { first = 2 * i; count = 2; }
@@ -182,6 +185,7 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }
     static constexpr bool INEQ_USES_SLACK = false;
+    static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     __device__ static bool ineq_reads_x(int, int) { return false; }
     __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
     __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
