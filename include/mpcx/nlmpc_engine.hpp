@@ -755,22 +755,52 @@ __device__ __forceinline__ bool chol_append(const Factor &F, int n, double y0, d
     nl_wave_sync();
     return ok;
 }
-// the factor of the leading n x n block of S (workspace, row stride ld), row by row.  Called with the LDS arrays as offsets
-// into the block's dynamic shared memory, so that the accesses stay LDS accesses across the call.
+// the factor of the leading n x n block of S (workspace, row stride ld).  The LDS rows by a right-looking elimination (the
+// updates of a column step are independent of each other: LDS throughput, not a chain of substitutions), the workspace
+// rows one at a time by substitution.  Called with the LDS arrays as offsets into the block's dynamic shared memory, so
+// that the accesses stay LDS accesses across the call.
 template <bool TWO>
 __device__ __attribute__((noinline)) bool chol_factor(int lp_off, int invd_off, int yb_off, double *Lg, int NL, int ldg, const double *Sg, int ld, int n, int lane)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Factor F{smem + lp_off, smem + invd_off, smem + yb_off, Lg, NL, ldg};
+    double *Lp = F.Lp;
+    const int nl = min(n, NL);
     double dmax = 0.0;
     for (int r = lane; r < n; r += 64) dmax = fmax(dmax, Sg[r * ld + r]);
     dmax = wave_max(dmax);
+    for (int e = lane; e < nl * (nl + 1) / 2; e += 64) {          // lower triangle of the LDS rows, packed
+        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        Lp[e] = Sg[r * ld + (e - r * (r + 1) / 2)];
+    }
+    nl_wave_sync();
     bool ok = true;
-    for (int i = 0; i < n; ++i) {
-        double t0 = lane < i ? Sg[i * ld + lane] : 0.0, t1 = lane + 64 < i ? Sg[i * ld + lane + 64] : 0.0;
-        const double sii = Sg[i * ld + i];
-        if (i) chol_forward<TWO>(F, i, t0, t1, lane);
-        ok &= chol_append<TWO>(F, i, t0, t1, sii, dmax, lane);
+    const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
+    for (int k = 0; k < nl; ++k) {
+        const double dkk = Lp[k * (k + 1) / 2 + k];
+        ok &= dkk > 1e-13 * dmax;
+        const double dd = sqrt(dkk > 1e-13 * dmax ? dkk : 1e-13 * dmax + 1e-300), id = 1.0 / dd;
+        double l0 = 0.0, l1 = 0.0;                                // this lane's rows' entries of column k
+        if (lane > k && lane < nl) { l0 = Lp[o0 + k] * id; Lp[o0 + k] = l0; }
+        if (lane + 64 > k && lane + 64 < nl) { l1 = Lp[o1 + k] * id; Lp[o1 + k] = l1; }
+        nl_wave_sync();
+        for (int j = k + 1; j < nl; ++j) {
+            const double ljk = Lp[j * (j + 1) / 2 + k];
+            if (lane >= j && lane < nl) Lp[o0 + j] = fma(-l0, ljk, Lp[o0 + j]);
+            if (lane + 64 >= j && lane + 64 < nl) Lp[o1 + j] = fma(-l1, ljk, Lp[o1 + j]);
+        }
+        if (lane == 0) { Lp[k * (k + 1) / 2 + k] = dd; F.invd[k] = id; }
+        nl_wave_sync();
+    }
+    if constexpr (TWO) {
+        for (int i = nl; i < n; ++i) {
+            double t0 = lane < i ? Sg[i * ld + lane] : 0.0, t1 = lane + 64 < i ? Sg[i * ld + lane + 64] : 0.0;
+            const double sii = Sg[i * ld + i];
+            chol_forward<TWO>(F, i, t0, t1, lane);
+            ok &= chol_append<TWO>(F, i, t0, t1, sii, dmax, lane);
+        }
     }
     return ok;
 }
@@ -781,6 +811,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU;
     constexpr int GU = Mdl::NX >= 12 ? 32 : 8;            // loads in flight in the long dot products (one wavefront per SIMD: 512 registers)
+    constexpr int WB = GU == 32 ? 8 : 2, SB = GU == 32 ? 4 : 1;   // rows / entries in flight in the warm start of the sub-problem
     constexpr bool MAYBE_CT = Mdl::CONTINUOUS;            // hook models: true, the run-time flag decides
     const bool CT = is_ct<Mdl>(M);
     const int KW = M.kw, SLD = KW + 1;                     // working-set capacity of this controller
@@ -1498,19 +1529,37 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             // working set at a time (their normals parked in LDS): every product with B^-1 costs a full pass of loads, and
             // the warm start needs one per row.
             // A row in the sparse form needs no sweep: B^-1 n is a combination of a few columns of B^-1.
-            for (int t = 0; t < nw_keep; ++t) {
-                const int k = (int)wq[t], cn = sp_count(k);
-                if (cn < 0) continue;
-                const double sg = sgq[t];
+            // (WB rows at a time: their columns of B^-1 are requested together)
+            for (int t0 = 0; t0 < nw_keep; t0 += WB) {
+                int kk[WB], cc[WB], i0[WB];
+                double v0s[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int tt = min(t0 + u, nw_keep - 1);
+                    kk[u] = (int)wq[tt];
+                    cc[u] = t0 + u < nw_keep ? sp_count(kk[u]) : -1;
+                    i0[u] = s1m[kk[u]] & 0xffff;
+                    v0s[u] = sgq[tt] * s1v[kk[u]];
+                }
                 for (int q = lane; q < nq; q += 64) {
-                    double nvl = 0, hv = 0;
-                    for (int j = 0; j < cn; ++j) {
-                        const int ix = sp_index(k, j);
-                        const double v = sg * sp_value(k, j);
-                        if (ix == q) nvl += v;
-                        hv = fma(hinv[(size_t)ix * nr + q], v, hv);
+                    double hv[WB], nvl[WB];
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) hv[u] = cc[u] >= 1 ? hinv[(size_t)i0[u] * nr + q] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) { hv[u] *= v0s[u]; nvl[u] = (cc[u] >= 1 && i0[u] == q) ? v0s[u] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) {
+                        if (cc[u] > 1) {
+                            const double sg = sgq[t0 + u];
+                            for (int j = 1; j < cc[u]; ++j) {
+                                const int ix = sp_index(kk[u], j);
+                                const double v = sg * sp_value(kk[u], j);
+                                if (ix == q) nvl[u] += v;
+                                hv[u] = fma(hinv[(size_t)ix * nr + q], v, hv[u]);
+                            }
+                        }
+                        if (cc[u] >= 0) { qn[(size_t)(t0 + u) * nr + q] = nvl[u]; qv[(size_t)(t0 + u) * nr + q] = hv[u]; }
                     }
-                    qn[(size_t)t * nr + q] = nvl; qv[(size_t)t * nr + q] = hv;
                 }
             }
             int cur = 0;
@@ -1570,11 +1619,20 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             MPCX_STAT(qst[4] += nw_keep;)
             if (nw_keep > 0) {
                 nw = nw_keep;
-                for (int e2 = lane; e2 < nw * nw; e2 += 64) {
-                    const int a = e2 / nw, b2 = e2 - a * nw;
-                    const int ka = (int)wq[a];
-                    const double s2 = sp_count(ka) >= 0 ? sgq[a] * sp_dot(ka, qv + (size_t)b2 * nr) : gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
-                    Ssm[a * SLD + b2] = s2;
+                for (int e0 = 0; e0 < nw * nw; e0 += 64 * SB) {         // SB entries per lane in flight
+                    double s4[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int e2 = min(e0 + 64 * u + lane, nw * nw - 1);
+                        const int a = e2 / nw, b2 = e2 - a * nw;
+                        const int ka = (int)wq[a];
+                        s4[u] = sp_count(ka) >= 0 ? sgq[a] * sp_dot(ka, qv + (size_t)b2 * nr) : gdot2(qn + (size_t)a * nr, 1, qv + (size_t)b2 * nr, 1, nq);
+                    }
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int e2 = e0 + 64 * u + lane;
+                        if (e2 < nw * nw) Ssm[(e2 / nw) * SLD + e2 % nw] = s4[u];
+                    }
                 }
                 nl_wave_sync();
                 while (nw > 0) {
@@ -1600,7 +1658,10 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     }
                     nl_wave_sync();
                     if (!solve_ws()) { nw = 0; break; }                              // dependent rows: start cold
-                    auto sheds = [&](int t) { const int k = (int)wq[t]; return tq[t] < 0.0 && !(k >= mi && k < m); };   // equalities stay
+                    // Every row with a negative multiplier leaves at once.  (Measured against shedding only the most negative ones
+                    // per round, config 5: fewer steps of the dual method afterwards, 11 instead of 14, but more rounds here and
+                    // rows leaving inside the dual method, each a re-factorisation: 12 % slower overall.)  Equalities stay.
+                    auto sheds = [&](int t) { const int k = (int)wq[t]; return tq[t] < 0.0 && !(k >= mi && k < m); };
                     int neg = -1;
                     for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
                     if (neg < 0) break;
