@@ -404,18 +404,25 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
         if (lane == 0 && cost) *cost = f0;
         if (grad) {
             double *g = grad;
-            for (int k = lane; k < ph * NX; k += 64) {
-                const int i = k / NX, j = k - i * NX;
-                const double dx = dv * Xa(j);
-                const Pert Xp{Xs, NX, i + 1, -1, j, dx};
-                g[k] = (Mdl::cost(Xp, U0, e, ph, prm) - f0) / dx;            // no chain rule for the state scaling (Objective.hpp:107-144)
+            // one loop over every perturbed copy of the point -- ph nx state entries, ph nu input entries, the slack both ways --
+            // so that the lanes share them evenly (each is a whole evaluation of the cost); one call site for all kinds
+            const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
+            const double de = fmax(dv, fabs(e)) * dv;
+            double fslack = 0.0;
+            for (int idx = lane; idx < nall; idx += 64) {
+                const bool isx = idx < nxv, isu = !isx && idx < nxv + nuv;
+                const int kk = isx ? idx : idx - nxv;
+                const int i = isx ? kk / NX : (isu ? kk / NU : 0), j = isx ? kk - i * NX : (isu ? kk - i * NU : 0);
+                const double dx = dv * Xa(j), du = dv * Ua(j);
+                const Pert Xp{Xs, NX, isx ? i + 1 : -1, -1, isx ? j : -1, isx ? dx : 0.0};       // no chain rule for the state scaling (Objective.hpp:107-144)
+                const Pert Up{Us, NU, isu ? i : -1, (isu && i == ph - 1) ? ph : -1, isu ? j : -1, isu ? du : 0.0};   // the last row moves with its copy
+                const double ee = idx == nall - 2 ? e + de : (idx == nall - 1 ? e - de : e);
+                const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
+                if (isx) g[kk] = (fp - f0) / dx;
+                else if (isu) Jm[kk] = (fp - f0) / du;
+                else fslack = fp;
             }
-            for (int k = lane; k < ph * NU; k += 64) {
-                const int i = k / NU, j = k - i * NU;
-                const double du = dv * Ua(j);
-                const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du};     // the last row moves with its copy
-                Jm[k] = (Mdl::cost(X0, Up, e, ph, prm) - f0) / du;
-            }
+            const double fplus = __shfl(fslack, (nall - 2) & 63), fminus = __shfl(fslack, (nall - 1) & 63);
             nl_wave_sync();
             for (int k = lane; k < ch * NU; k += 64) {
                 const int bl = k / NU, j = k - bl * NU;
@@ -423,10 +430,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
                 g[ph * NX + k] = sc.by_su(s, j);                            // Iz2u' * vec(Jmv)
             }
-            if (lane == 0) {
-                const double de = fmax(dv, fabs(e)) * dv;
-                g[nz - 1] = (Mdl::cost(X0, U0, e + de, ph, prm) - Mdl::cost(X0, U0, e - de, ph, prm)) / (2 * de);
-            }
+            if (lane == 0) g[nz - 1] = (fplus - fminus) / (2 * de);
             nl_wave_sync();
         }
     }
@@ -1766,10 +1770,15 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                     npn = wave_sum(npn);
                     // dual ratio test
                     double t1 = 1e300; int kdrop = -1;
-                    for (int t = 0; t < nw; ++t) {
-                        const double rr = tq[t];
-                        const int kt = (int)wq[t];
-                        if (rr > 1e-14 && !(kt >= mi && kt < m)) { const double tj = uq[t] / rr; if (tj < t1) { t1 = tj; kdrop = t; } }
+                    {
+                        double tneg = -1e300; int tidx = 0x7fffffff;      // the smallest ratio (lowest slot on ties), lanes = slots
+                        for (int t = lane; t < nw; t += 64) {
+                            const double rr = tq[t];
+                            const int kt = (int)wq[t];
+                            if (rr > 1e-14 && !(kt >= mi && kt < m)) { const double tj = uq[t] / rr; if (-tj > tneg) { tneg = -tj; tidx = t; } }
+                        }
+                        wave_argmax(tneg, tidx);
+                        if (tneg > -1e300) { t1 = -tneg; kdrop = tidx; }
                     }
                     const bool can_move = zn > 1e-13 * fmax(1.0, npn);
                     const double t2 = can_move ? sp / zn : 1e300;

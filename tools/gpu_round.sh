@@ -13,3 +13,6 @@ for w in vanderpol ugv osc6 osc8; do
   ( timeout 400 python bench.py --workload $w --cpu-seconds 0 ) > $O/${T}_bench_$w.json 2> $O/${T}_bench_$w.err; cut -c1-330 $O/${T}_bench_$w.json; tail -2 $O/${T}_bench_$w.err
 done
 timeout 400 tools/profile.sh $T lmpc20_b4096 --steps 60 --warmup 10
+timeout 500 tools/profile.sh $T ugv_b4096 --workload ugv --steps 3 --warmup 1
+timeout 500 tools/profile.sh $T osc8_b1024 --workload osc8 --steps 3 --warmup 1
+for w in osc8 ugv; do ( MPCX_LIBRARY=$PWD/libmpc_amd/libmpcx_stats.so timeout 300 python tools/nlmpc_phases.py $w 1024 ) > $O/${T}_phases_$w.txt 2>&1; grep -v amdgpu.ids $O/${T}_phases_$w.txt; done
