@@ -358,7 +358,7 @@ def test_reference_refresh_gives_the_results_of_a_fresh_controller():
         # equal up to round-off: the kept linear columns of the assemble maps were tabulated as differences around the OLD
         # references, those of the fresh controller around the new ones -- the same numbers to the last bit or two
         assert torch.equal(ra.status, rb.status)
-        np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-8, atol=1e-10)      # measured: 6e-12 absolute
         # the optimal cost is c0 + (a term of the solution): c0 carries ref' W ref, far larger than the cost, so the last bits of
         # the kept columns show up as ~1e-8 of the cost (measured 2e-8)
         np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=2e-7, atol=1e-9)
