@@ -369,21 +369,34 @@ def nl_make(name, B, first=0, device=0):
 
 
 def nl_flops(c, name, it, nact):
-    """algorithmic flops of the SQP solves of one batch: per iteration the transcription's function
-    evaluations, the condensing sweep, the reduction, the BFGS update and the dual active-set steps the final active set needs"""
+    """algorithmic flops of the SQP solves of one batch, for the path the kernel takes: per iteration
+    the transcription's function evaluations, the condensing, the reduction, the BFGS update, the dual active-set steps
+    the final active set needs, the state step and one line-search round.  Where no sub-problem row reads a state
+    (Van der Pol, the oscillator networks) the sensitivities Phi are never formed: condensing, reduction and the state
+    step are single sweeps over the dynamics blocks, and the sub-problem's rows are one-entry lists -- counted as such."""
     nx, nu, ph, ch, nz = c.nx, c.nu, c.ph, c.ch, c.nz
     nzu = ch * nu; nq = nzu + 1; nxs = ph * nx
     ct = name != "ugv"
+    matrix_free = name != "ugv"
     f_f = {"vanderpol": 8.0, "ugv": 16.0}.get(name, 6.0 * nu + 2.0 * nu * nu)        # one vector-field call
     f_cost = (ph + 1) * (2.0 * nx + 2.0 * nu)                                          # one cost call
     f_ineq = 4.0 if name == "ugv" else 1.0                                             # one constraint component
     ev = f_cost * (ph * (nx + nu) + 3) + f_f * ph * (1 + ct) * (1 + 2 * (nx + nu)) + f_ineq * c.nineq * 3
-    cond = ph * (nzu + 1) * 2.0 * nx * nx * (1 + ct) + (ph * 2.0 * nx ** 3 if ct else 0.0)
-    red = 2.0 * nxs * nzu + 2.0 * c.nineq * nzu
+    sweep = ph * (2.0 * nx * nx * (1 + ct) + 2.0 * nx * nu)                            # one column through the dynamics blocks
+    einv = ph * 2.0 * nx ** 3 if ct else 0.0
+    if matrix_free:
+        cond = sweep + einv
+        red = sweep                                                                    # backward sweep + Ju' lam
+        step = sweep
+        qp = 2.0 * nq * nq + nact * (2.0 * nq * nact + 2.0 * nact * nact)              # B^-1 g; per step: z = v - V rr, two substitutions
+    else:
+        cond = (nzu + 1) * sweep + einv
+        red = 2.0 * nxs * nzu + 2.0 * c.nineq * nzu
+        step = 2.0 * nxs * nzu
+        qp = 2.0 * nq * nq + nact * (2.0 * nq * nq + 4.0 * nq * nact)
     bfgs = 8.0 * nq * nq
-    qp = 2.0 * nq * nq + nact * (2.0 * nq * nq + 4.0 * nq * nact)
     ls = 8 * (f_cost + f_f * ph * (1 + ct) + f_ineq * c.nineq)
-    return float((it * (ev + cond + red + bfgs + ls) + it * qp).sum())
+    return float((it * (ev + cond + red + bfgs + step + ls) + it * qp).sum())
 
 
 def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, barrier):

@@ -1337,6 +1337,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     for (int s = 0; s < NZS; ++s) w[s] = polished ? wv[s] : x[s];
     const double qnan = __builtin_nan("");
     double cost;
+    bool cost_pending = false;
     if (infeasible) {
 #pragma unroll
         for (int s = 0; s < NZS; ++s) w[s] = qnan;
@@ -1355,6 +1356,17 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         for (int s = 0; s < NZS; ++s) j = fma(f[s], w[s], j);
         if (lane < na_last) j = fma(-lam[lane], wsb[lane], j);
         cost = 0.5 * wave_sum(j) + c0;
+    } else if (!ADMM && polished && !FUSED) {
+        // cost from its definition (M.cost_direct: the identity above loses digits on an ill-conditioned Hessian), but not here:
+        // H is nz x nz doubles per instance from L2 for a mat-vec, 320 KB at N = 50.  The solution goes to the workspace in
+        // t0's place and lmpc_cost_mfma does H W for sixteen instances per pass over H on the matrix pipe.
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldz) st2(ws + ldz + e, w[2 * c], w[2 * c + 1]);
+        }
+        cost = 0.0;
+        cost_pending = true;
     } else {
         // any other point (ADMM iterate, regularised Hessian): the definition
         double hw[NZS];
@@ -1372,7 +1384,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         if (e < nu) glw(Bt.cmd)[(size_t)b * nu + e] = w[s];
     }
     if (lane == 0) {
-        if (Bt.cost) glw(Bt.cost)[b] = cost;
+        if (Bt.cost && !cost_pending) glw(Bt.cost)[b] = cost;
         if (Bt.solver_status) glw(Bt.solver_status)[b] = solver_status;
         if (Bt.status) {
             // LOptimizer.hpp:386-415
@@ -1478,7 +1490,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
         }
     }
     wave_sync();
-    if (!ADMM && lane == 0) ws[ldz + ldy + 2 * ldg + 1] = 2.0;     // done: the fallback kernel skips it
+    if (!ADMM && lane == 0) ws[ldz + ldy + 2 * ldg + 1] = cost_pending ? 3.0 : 2.0;     // 2: done, the fallback kernel skips it; 3: lmpc_cost_mfma first
     stamp();   // 3: unpacked
     if (Bt.dbg_cycles && lane == 0)
 #ifdef MPCX_PROFILE_ROUNDS
@@ -1615,6 +1627,77 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
 }
 
 
+// cost = 0.5 w'Hw + f'w + c0 for the instances lmpc_solve marked "cost pending" (flag 3): H W on the f64 MFMA pipe, sixteen
+// instances per workgroup (same operand chaining as lmpc_assemble_mfma), one pass over H per sixteen instances
+__global__ __launch_bounds__(256) void lmpc_cost_mfma(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+    const int ldz = M.ldz, ldy = M.ldy, ldg = M.ldg, nz4 = M.nz16 >> 2, ntile = M.nz16 >> 4;
+    double *Bw = smem;                              // [nz4][64]
+    double *cs = Bw + (size_t)nz4 * 64;             // [4 wavefronts][16 instances]
+    const gdp H = GP(H);
+    for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
+        const int bj = b0 + j;
+        const bool live = bj < Bt.batch;
+        const int bc = live ? bj : Bt.batch - 1;
+        const gdp wsr = gl((const double *)wsbase) + (size_t)bc * M.wsld;
+        const bool pending = live && wsr[ldz + ldy + 2 * ldg + 1] == 3.0;
+        for (int kb = wave; kb < nz4; kb += 4) {
+            const int k = 4 * kb + kq;
+            Bw[kb * 64 + lane] = (pending && k < M.nz) ? wsr[ldz + k] : 0.0;
+        }
+        __syncthreads();
+        double part = 0.0;
+        for (int tl = wave; tl < ntile; tl += 4) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const int rowa = 16 * tl + j;
+            const gdp Ht = H + (rowa < ldz ? rowa : 0);
+            int kb = 0;
+            for (; kb + 4 <= nz4; kb += 4) {
+                double a[4], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = 4 * (kb + u) + kq;
+                    a[u] = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = Bw[(kb + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+            for (; kb < nz4; ++kb) {
+                const int col = 4 * kb + kq;
+                const double a = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bw[kb * 64 + lane], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tl + 4 * r + kq;
+                const double w = Bw[(4 * tl + r) * 64 + lane];
+                const double fr = (pending && row < M.nz) ? wsr[row] : 0.0;
+                part = fma(w, 0.5 * acc[r] + fr, part);
+            }
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (kq == 0) cs[wave * 16 + j] = part;      // one slot per wavefront, added up in a fixed order: the same bits every run
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int bb = b0 + threadIdx.x;
+            if (bb < Bt.batch) {
+                gdw wst = glw(wsbase) + (size_t)bb * M.wsld + ldz + ldy + 2 * ldg;
+                if (wst[1] == 3.0) {
+                    if (Bt.cost) glw(Bt.cost)[bb] = ((cs[threadIdx.x] + cs[16 + threadIdx.x]) + (cs[32 + threadIdx.x] + cs[48 + threadIdx.x])) + wst[0];
+                    wst[1] = 2.0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int CPZ, int CPG>
 int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which, int fast)
 {
@@ -1673,6 +1756,12 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
             hipLaunchKernelGGL(k5, dim3(wgs), dim3(512), ldsp, stream, m_dev, b, ws, b.pcounter);
         } else if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
         else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        if (m.cost_direct && m.polish && !fused) {       // the costs lmpc_solve left pending
+            const size_t ldsc = ((size_t)(m.nz16 / 4) * 64 + 64) * sizeof(double);
+            int blocksq = (b.batch + 15) / 16;
+            if (blocksq > 4096) blocksq = 4096;
+            hipLaunchKernelGGL(lmpc_cost_mfma, dim3(blocksq), dim3(256), ldsc, stream, m_dev, b, ws);
+        }
     }
     if (which & 4) {
         LmpcBatchDev b3 = b;

@@ -460,7 +460,8 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
     D.MF0 = h->up(o.MF[0], rc); D.MF1 = h->up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
-    D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384) ? 1 : 0;
+    // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
+    D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384 && !D.cost_direct) ? 1 : 0;
     D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
