@@ -1,0 +1,87 @@
+"""A mixed batch over a few different controllers.
+
+The engine's batch is B instances of ONE controller (one model, one set of weights and bounds: what a `mpc::LMPC<>` object
+is in the reference).  A fleet usually has a handful of vehicle variants, not B: `LMPCBank` holds K controllers, takes a
+batch whose instances carry a controller index, solves each group on its own HIP stream (the handles are independent: own
+workspace, own dispatch queues, so the groups overlap on the GPU) and returns the results in the caller's order.
+
+This is heterogeneity by grouping -- no new kernel, every instance is solved by exactly the code path and with exactly the
+results of its own controller.  Per-instance models (every instance its own A, B, C) need device-side condensing and are
+not built.  torch is used for what it is here for: device memory, index_select / index_copy and
+streams."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .lmpc import BatchResult
+
+
+def group_by_model(model, n_models: int):
+    """Stable grouping of instance indices by controller index.  Returns (order, offsets): `order[offsets[k]:offsets[k+1]]`
+    are the instances of controller k in their original relative order."""
+    model = np.asarray(model, dtype=np.int64).reshape(-1)
+    if model.size and (model.min() < 0 or model.max() >= n_models):
+        raise ValueError("controller index out of range")
+    order = np.argsort(model, kind="stable")
+    counts = np.bincount(model, minlength=n_models)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    return order, offsets
+
+
+class LMPCBank:
+    """K `libmpc_amd.LMPC` controllers of equal dimensions behind one `optimizeBatch(x0, lastU, model, ...)`."""
+
+    def __init__(self, controllers):
+        if not controllers:
+            raise ValueError("at least one controller")
+        c0 = controllers[0]
+        for c in controllers:
+            if (c.nx, c.nu, c.ny, c.ph, c.device) != (c0.nx, c0.nu, c0.ny, c0.ph, c0.device):
+                raise ValueError("the controllers of a bank share their dimensions and their device")
+        self.controllers = list(controllers)
+        self.nx, self.nu, self.ny, self.ph, self.device = c0.nx, c0.nu, c0.ny, c0.ph, c0.device
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in controllers]
+
+    def optimizeBatch(self, x0, lastU, model, yref=None, want_sequence=False) -> BatchResult:
+        """x0 [B, nx], lastU [B, nu], model [B] (controller index per instance), yref None | [B, ny] | [B, ph, ny]."""
+        dev = torch.device("cuda", self.device)
+        x0 = torch.as_tensor(x0, dtype=torch.float64, device=dev)
+        lastU = torch.as_tensor(lastU, dtype=torch.float64, device=dev)
+        if yref is not None:
+            yref = torch.as_tensor(yref, dtype=torch.float64, device=dev)
+        B = x0.shape[0]
+        order, offsets = group_by_model(model.cpu().numpy() if torch.is_tensor(model) else model, len(self.controllers))
+        if order.size != B:
+            raise ValueError("one controller index per instance")
+        order_t = torch.from_numpy(order).to(dev)
+        out = BatchResult(cmd=torch.empty((B, self.nu), dtype=torch.float64, device=dev),
+                          cost=torch.empty(B, dtype=torch.float64, device=dev),
+                          status=torch.empty(B, dtype=torch.int32, device=dev),
+                          solver_status=torch.empty(B, dtype=torch.int32, device=dev),
+                          is_feasible=torch.empty(B, dtype=torch.int32, device=dev),
+                          iterations=torch.empty(B, dtype=torch.int32, device=dev))
+        if want_sequence:
+            out.seq_state = torch.empty((B, self.ph + 1, self.nx), dtype=torch.float64, device=dev)
+            out.seq_output = torch.empty((B, self.ph + 1, self.ny), dtype=torch.float64, device=dev)
+            out.seq_input = torch.empty((B, self.ph + 1, self.nu), dtype=torch.float64, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        keep = []
+        for k, c in enumerate(self.controllers):
+            lo, hi = int(offsets[k]), int(offsets[k + 1])
+            if hi == lo:
+                continue
+            s = self._streams[k]
+            s.wait_stream(cur)                                   # the inputs were produced on the caller's stream
+            with torch.cuda.stream(s):
+                idx = order_t[lo:hi]
+                xk, uk = x0.index_select(0, idx), lastU.index_select(0, idx)
+                yk = None if yref is None else yref.index_select(0, idx)
+                r = c.optimizeBatch(xk, uk, yref=yk, want_sequence=want_sequence, stream=s)
+                for name in ("cmd", "cost", "status", "solver_status", "is_feasible", "iterations") + \
+                        (("seq_state", "seq_output", "seq_input") if want_sequence else ()):
+                    getattr(out, name).index_copy_(0, idx, getattr(r, name))
+                keep.append((r, xk, uk, yk, idx))
+            cur.wait_stream(s)                                   # the caller's stream sees the scattered results
+        out._inputs = keep
+        return out

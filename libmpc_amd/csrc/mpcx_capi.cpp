@@ -677,12 +677,26 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int which = 1; which <= 4; which *= 2) {
-        (void)hipEventRecord(e0, s);
-        for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which, fast);
-        (void)hipEventRecord(e1, s);
-        (void)hipEventSynchronize(e1);
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (which == 2 && h->dev.cost_direct) {
+            // with pending costs the solve leaves w in t0's place: every timed launch needs a freshly assembled workspace
+            for (int i = 0; i < repeats; i++) {
+                mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 1, fast);
+                (void)hipEventRecord(e0, s);
+                mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 2, fast);
+                (void)hipEventRecord(e1, s);
+                (void)hipEventSynchronize(e1);
+                float one = 0;
+                (void)hipEventElapsedTime(&one, e0, e1);
+                ms += one;
+            }
+        } else {
+            (void)hipEventRecord(e0, s);
+            for (int i = 0; i < repeats; i++) mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, which, fast);
+            (void)hipEventRecord(e1, s);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+        }
         ms2[which == 1 ? 0 : (which == 2 ? 1 : 2)] = ms / (float)repeats;
     }
     if (B.qcnt) (void)hipMemsetAsync(B.qcnt, 0, mpcx::kLmpcQueues * sizeof(int), s);     // full launches expect empty queues
