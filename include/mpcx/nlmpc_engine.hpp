@@ -44,6 +44,8 @@ namespace engine {
 
 using namespace models;
 
+typedef double __attribute__((address_space(1))) *gwp;      // a pointer known to point into HBM
+
 __device__ __forceinline__ void nl_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -384,6 +386,15 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                               double *jineq, bool jin_fill = true)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    if constexpr (!Mdl::VECTOR_HOOKS) {
+        // Inside the SQP kernels this function is a real call, and its pointer arguments arrive as generic pointers: every
+        // access to the trajectories would be a flat load (278 of them in the 8-oscillator instance, none to LDS as such).
+        // Re-deriving them from the block's dynamic shared memory tells the compiler where they point.  Not for hook models:
+        // their hooks read the trajectories through views that hold generic pointers, and LDS accesses of both kinds to the
+        // same data are not ordered with respect to each other (seen: an output trajectory written one way and read the other).
+        extern __shared__ __attribute__((aligned(16))) double lds_base[];
+        Xs = lds_base + (Xs - lds_base); Us = lds_base + (Us - lds_base); Jm = lds_base + (Jm - lds_base);
+    }
     const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
     const double dv = kDv;
     const double *prm = M.params;
@@ -403,7 +414,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
         const double f0 = Mdl::cost(X0, U0, e, ph, prm);
         if (lane == 0 && cost) *cost = f0;
         if (grad) {
-            double *g = grad;
+            gwp g = (gwp)grad;                               // (HBM: global stores, not flat ones that also tie up the LDS counter)
             // one loop over every perturbed copy of the point -- ph nx state entries, ph nu input entries, the slack both ways --
             // so that the lanes share them evenly (each is a whole evaluation of the cost); one call site for all kinds
             const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
@@ -447,7 +458,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
             for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
             if (c == 0) {
                 if (!ceq) continue;
-                double *cv = ceq + i * NX;
+                gwp cv = (gwp)ceq + i * NX;
                 call_f<Mdl>(fa, xk, uk, prm, i);
                 if (CT) {
                     call_f<Mdl>(fb, xk1, uk, prm, i);
@@ -458,7 +469,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 continue;
             }
             if (!jeq) continue;
-            double *J = jeq + (size_t)i * NX * W;          // [NX x W] row-major block of step i
+            gwp J = (gwp)jeq + (size_t)i * NX * W;          // [NX x W] row-major block of step i
             const int col = c - 1;
             auto cdiff = [&](const double *xx, const double *uu, int v, bool isu, double *out) {
                 double xp[NX], up[NU], f1[NX], f2[NX];
@@ -508,9 +519,9 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
     } else {
     // ---- Constraints::evaluateIneq + computeIneqJacobian (dense [nineq x nz], row-major)
     if (cineq)
-        for (int k = lane; k < nineq; k += 64) cineq[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
+        for (int k = lane; k < nineq; k += 64) ((gwp)cineq)[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
     if (jineq) {
-        double *J = jineq;
+        gwp J = (gwp)jineq;
         for (int k = lane; k < nz; k += 64) {
             if (k < ph * NX) {
                 const int i = k / NX, j = k - i * NX;
@@ -562,9 +573,9 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
     // Steps: the perturbed element's own magnitude for the states, row ph-1's for every input step, last input row paired.
     const int nue = M.nue;
     if (nue && cineq)
-        for (int k = lane; k < nue; k += 64) cineq[nineq + k] = Mdl::eq(k, X0, U0, ph, prm);
+        for (int k = lane; k < nue; k += 64) ((gwp)cineq)[nineq + k] = Mdl::eq(k, X0, U0, ph, prm);
     if (nue && jineq) {
-        double *J = jineq + (size_t)nineq * nz;
+        gwp J = (gwp)jineq + (size_t)nineq * nz;
         for (int k = lane; k < nz; k += 64) {
             if (k < ph * NX) {
                 const int i = k / NX, j = k - i * NX;
