@@ -86,9 +86,9 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
         // same arithmetic, term for term, as the reference example's lambda evaluated through mpcx/matrix.hpp
         double sx = 0, su = 0;
         for (int j = 0; j < NX; ++j)
-#pragma unroll 4
+#pragma unroll 8
             for (int i = 0; i <= ph; ++i) sx += X(i, j) * X(i, j);
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i <= ph; ++i) su += U(i, 0) * U(i, 0);
         return sx + su;
     }
@@ -131,7 +131,7 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
     {
         double s = 0;
         const double vx = p[0], vy = p[1];
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i <= ph; ++i) {
             const double a = X(i, 2) - vx, b = X(i, 3) - vy;
             s += 1e3 * (a * a + b * b);
@@ -175,10 +175,10 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     {
         double sx = 0, su = 0;                       // column-major order, as for VanDerPol above
         for (int j = 0; j < NX; ++j)
-#pragma unroll 2
+#pragma unroll 8
             for (int i = 0; i <= ph; ++i) sx += X(i, j) * X(i, j);
         for (int j = 0; j < NU; ++j)
-#pragma unroll 2
+#pragma unroll 8
             for (int i = 0; i <= ph; ++i) su += U(i, j) * U(i, j);
         return sx + su;
     }
