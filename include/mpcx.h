@@ -359,6 +359,11 @@ typedef struct mpcx_nlmpc_batch {
     double *multipliers;       /* extension, may be NULL: [B x (nineq + neq_user + nbnd)] multipliers of the last quadratic
                                   sub-problem -- user inequalities, user equalities, then the finite bounds in the order
                                   (index into z ascending; upper before lower); non-zero = in the active set        */
+    const double *params;      /* extension, may be NULL: [B x n_params] -- every instance its own parameters of the built-in
+                                  system (the constants the reference example's closures capture: each UGV its own obstacles
+                                  and preferred velocity, each oscillator network its own mu and coupling), in the order of
+                                  mpcx_nlmpc_create's `params`.  NULL: the controller's parameters for all.  Not for hook
+                                  models (their constants live in the closures).                                     */
 } mpcx_nlmpc_batch;
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream);
 /* The same for callers whose data lives in host memory (the reference's optimize(x0, lastU) is such a caller): stages,

@@ -62,6 +62,8 @@ struct NlmpcBatchDev {
     double *cineq, *jineq;      // [B x (nineq+nue)], [B x (nineq+nue) x nz] row-major: user inequalities, then user equalities
     double *hook_ws;            // vector-valued user hooks: [B x hook scratch] (handle-owned), null otherwise
     int hook_ld;
+    const double *params_b;     // optional [B x nparams]: every instance its own model parameters (built-in systems)
+    int nparams;
 };
 
 struct NlmpcSolveDev {
@@ -79,6 +81,8 @@ struct NlmpcSolveDev {
     double *seq_state, *seq_input;      // [B x (ph+1) x nx], [B x (ph+1) x nu]
     double *seq_output;                 // [B x (ph+1) x ny]
     double *mu_out;                     // [B x (nineq + nue + nbnd)] multipliers of the last sub-problem (0 = inactive)
+    const double *params_b;             // optional [B x nparams]: every instance its own model parameters (built-in systems)
+    int nparams;
 };
 
 // doubles of hook scratch per instance (NlmpcWsLayout::hook, NlmpcBatchDev::hook_ws): two column buffers [rows x 64], the

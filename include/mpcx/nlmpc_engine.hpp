@@ -383,7 +383,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
 template <class Mdl>
 __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, double *Jm, double *Ys,
                               double *hk, int lane, double *cost, double *grad, double *ceq, double *jeq, double *cineq,
-                              double *jineq, bool jin_fill = true)
+                              double *jineq, bool jin_fill = true, const double *prm_instance = nullptr)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     if constexpr (!Mdl::VECTOR_HOOKS) {
@@ -397,7 +397,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
     }
     const int ph = M.ph, ch = M.ch, nz = M.nz, nineq = M.nineq;
     const double dv = kDv;
-    const double *prm = M.params;
+    const double *prm = prm_instance ? prm_instance : M.params;     // the instance's own model parameters, if the batch brings them
     const Scale sc(M);
     const bool CT = is_ct<Mdl>(M);
     unwrap<Mdl>(M, z, x0, Xs, Us, lane);
@@ -619,7 +619,8 @@ __device__ __forceinline__ void evaluate_body(const NlmpcDev &M, const NlmpcBatc
         auto at = [&](double *p, size_t stride) { return p ? p + (size_t)b * stride : nullptr; };
         eval_instance<Mdl>(M, Bt.z + (size_t)b * nz, Bt.x0 + (size_t)b * NX, Xs, Us, Jm, Ys, at(Bt.hook_ws, Bt.hook_ld), lane,
                            at(Bt.cost, 1), at(Bt.grad, nz), at(Bt.ceq, M.neq), at(Bt.jeq, (size_t)ph * NX * (2 * NX + NU)),
-                           at(Bt.cineq, M.nineq + M.nue), at(Bt.jineq, (size_t)(M.nineq + M.nue) * nz));
+                           at(Bt.cineq, M.nineq + M.nue), at(Bt.jineq, (size_t)(M.nineq + M.nue) * nz), true,
+                           Bt.params_b ? Bt.params_b + (size_t)b * Bt.nparams : nullptr);
     }
 }
 template <class Mdl>
@@ -837,7 +838,6 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
     const int mt = m + M.nbnd;                           // sub-problem rows: user inequalities, then the finite bounds on z
     const int nq = S.hard ? nzu : nr;                     // variables of the sub-problem (slack only when soft)
     const int mld = (mt + 1) & ~1;
-    const double *prm = M.params;
     const Scale sc(M);
     double *Xs = smem + (size_t)wave * M.lds_per_wave;
     double *Us = Xs + (ph + 1) * NX;
@@ -870,6 +870,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                *lamw = w + M.ws.lamw, *hk = w + M.ws.hook, *spv = w + M.ws.sp;
         int *spi = reinterpret_cast<int *>(spv + (size_t)mt * kNlSparse);   // entries 1.. of the sub-problem's sparse rows (entry 0: LDS)
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
+        const double *prm = S.params_b ? S.params_b + (size_t)b * S.nparams : M.params;     // per-instance model parameters (built-in systems)
 
         // ---- initial guess (NLOptimizer.hpp:431-510): cold = (x0, u0) replicated; warm = previous solution shifted one step
         if (S.z_warm) {
@@ -924,16 +925,25 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         bool have_old = false;
         int resets = 0;
         int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
-        long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();   // per-phase cycle counts (debug_workspace)
 #ifdef MPCX_NL_STATS
-        // sub-problem statistics (debug_workspace; a build with -DMPCX_NL_STATS, see tools/nlmpc_phases.py): steps, inner passes,
-        // rows at the end (sum, max), rows kept, rows shed at the warm start, cycles of the warm start, cycles of the factorisations
+        // Statistics for tools/nlmpc_phases.py (debug_workspace), compiled in only with -DMPCX_NL_STATS (make stats) -- the
+        // counters are live across the whole iteration and cost the product kernels registers they do not have:
+        // per-phase cycle counts; sub-problem: steps, inner passes, rows at the end (sum, max), rows kept, rows shed at the
+        // warm start, cycles of the warm start, cycles of the factorisations
+        long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
         long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
 #define MPCX_STAT(x) x
 #else
+        // Phase boundaries keep a scheduling barrier in the product build.  Without one (an empty `lap`) the single-level
+        // instantiation for the 6-oscillator network reached the condensing phase with a corrupted EXEC mask (ROCm debug agent:
+        // lanes missing at the top level of the first iteration, then an access past the workspace); with the cycle counters,
+        // with a memory clobber or with this barrier the same source runs correctly.  Not understood further -- code generation
+        // around the two out-of-line calls is the suspect; tests/test_nlmpc_gpu.py::test_oscillator_network_solve_matches_oracle
+        // is the canary.
+        auto lap = [](int) { __builtin_amdgcn_sched_barrier(0); };
 #define MPCX_STAT(x)
 #endif
-        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
         double f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;       // the last accepted step, for nlopt's stopping rules
         bool stepped = false;
         const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
@@ -945,8 +955,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         for (;;) {
             if (!first_eval) lap(4);
             eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, Ys, hk, lane, scal, final_eval ? nullptr : g, c, final_eval ? nullptr : jeq, gin,
-                               final_eval ? nullptr : jin, first_eval);     // structural zeros are written once
-            if (!first_eval) lap(5); else tstamp = __builtin_readcyclecounter();
+                               final_eval ? nullptr : jin, first_eval, prm);     // structural zeros are written once
+            if (!first_eval) lap(5); else { MPCX_STAT(tstamp = __builtin_readcyclecounter();) }
             first_eval = false;
             if (final_eval) break;
             if (stepped && tol_on) {
@@ -2002,7 +2012,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             nl_wave_sync();
             ++it;
         }
-        if (lane == 0) { for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k]; MPCX_STAT(for (int k = 0; k < 8; ++k) scal[8 + k] = (double)qst[k];) }
+        MPCX_STAT(if (lane == 0) { for (int k = 0; k < 6; ++k) scal[2 + k] = (double)cyc[k]; for (int k = 0; k < 8; ++k) scal[8 + k] = (double)qst[k]; })
 
         // ---- results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user inequalities
         double gmax = -1e300;

@@ -80,7 +80,7 @@ class NlmpcBatch(C.Structure):
     _fields_ = [("batch", C.c_int), ("x0", C.c_void_p), ("u0", C.c_void_p), ("z_warm", C.c_void_p), ("cmd", C.c_void_p),
                 ("cost", C.c_void_p), ("status", C.c_void_p), ("solver_status", C.c_void_p), ("is_feasible", C.c_void_p),
                 ("iterations", C.c_void_p), ("z", C.c_void_p), ("seq_state", C.c_void_p), ("seq_input", C.c_void_p),
-                ("seq_output", C.c_void_p), ("warm_curvature", C.c_int), ("multipliers", C.c_void_p)]
+                ("seq_output", C.c_void_p), ("warm_curvature", C.c_int), ("multipliers", C.c_void_p), ("params", C.c_void_p)]
 
 
 class NlmpcDims(C.Structure):

@@ -28,6 +28,7 @@ struct mpcx_nlmpc {
     void *launch_ctx = nullptr;
     void *jit = nullptr;                 // run-time compiled module (nlmpc_jit.cpp), released with the handle
     double *params_d = nullptr;
+    int n_params = 0;                   // parameters of the built-in system (0: none, or a hook model)
     double *scale_d = nullptr;           // input scaling [nu] | state scaling [nx] (Mapping.hpp:71-86), ones by default
     std::vector<double> su, ss;
     double *hook_ws = nullptr;           // scratch of mpcx_nlmpc_evaluate_batch for vector-valued hooks
@@ -150,6 +151,7 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     d.model_id = model_id; d.nx = nx; d.nu = nu; d.ph = ph; d.ch = ch; d.nineq = nineq; d.nue = nue; d.ny = ny;
     d.Ts = Ts;
     d.params = h->params_d;
+    h->n_params = want;
     return finish_create(h, out);
 }
 
@@ -269,7 +271,7 @@ int mpcx_nlmpc_evaluate_batch(mpcx_nlmpc_t h, int batch, const double *z, const 
     if (batch == 0) return MPCX_OK;
     if (!z || !x0) return capi_fail(MPCX_E_INVALID, "z and x0 are required");
     if (hipSetDevice(h->device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed");
-    mpcx::NlmpcBatchDev b{batch, z, x0, cost, grad, ceq, jeq, cineq, jineq, nullptr, 0};
+    mpcx::NlmpcBatchDev b{batch, z, x0, cost, grad, ceq, jeq, cineq, jineq, nullptr, 0, nullptr, 0};
     if (h->dev.vector_hooks) {
         const int ld = mpcx::nlmpc_hook_scratch(h->dev);
         if ((size_t)batch > h->hook_cap) {
@@ -310,6 +312,10 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
     s.ftol_rel = h->prm.relative_ftol; s.ftol_abs = h->prm.absolute_ftol;        // NLOptimizer.hpp:135-138, <= 0: disabled
     s.xtol_rel = h->prm.relative_xtol; s.xtol_abs = h->prm.absolute_xtol;
     s.mu_out = b->multipliers;
+    if (b->params) {
+        if (h->n_params <= 0) return capi_fail(MPCX_E_INVALID, "this model has no parameters to give per instance");
+        s.params_b = b->params; s.nparams = h->n_params;
+    }
     s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch) ? 1 : 0;
     h->solved_batch = b->batch;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;

@@ -163,7 +163,7 @@ class NLMPC(NLMPCEvaluator):
                            "NLMPC.from_sources(...), or use a built-in model")
     setStateSpaceFunction = setObjectiveFunction = setIneqConFunction = setEqConFunction = setOutputFunction = _closures_are_fixed
 
-    def make_batch(self, x0, u0, z_warm=None, sequences=False, warm_curvature=False, multipliers=False):
+    def make_batch(self, x0, u0, z_warm=None, sequences=False, warm_curvature=False, multipliers=False, params=None):
         import torch
         dev = torch.device("cuda", self.device)
         x0 = x0.to(dev, torch.float64).contiguous(); u0 = u0.to(dev, torch.float64).contiguous()
@@ -181,12 +181,19 @@ class NLMPC(NLMPCEvaluator):
         b = _capi.NlmpcBatch(batch=B, x0=x0.data_ptr(), u0=u0.data_ptr(), z_warm=None if zw is None else zw.data_ptr(),
                              **{k: v.data_ptr() for k, v in out.items()})
         b.warm_curvature = int(bool(warm_curvature))
-        out["_keep"] = (x0, u0, zw)
+        pb = None
+        if params is not None:                   # [B, n_params]: every instance its own parameters of the built-in system
+            pb = torch.as_tensor(params).to(dev, torch.float64).contiguous()
+            assert pb.ndim == 2 and pb.shape[0] == B, "params: one row of model parameters per instance"
+            b.params = pb.data_ptr()
+        out["_keep"] = (x0, u0, zw, pb)
         return b, out
 
-    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None, warm_curvature=False, multipliers=False):
+    def optimizeBatch(self, x0, u0, z_warm=None, sequences=False, stream=None, warm_curvature=False, multipliers=False, params=None):
+        """`params` [B, n_params] (optional): per-instance parameters of the built-in system -- e.g. each UGV its own obstacles
+        (mpcx_nlmpc_batch.params); the row layout is that of the constructor's `params`."""
         import torch
-        b, out = self.make_batch(x0, u0, z_warm, sequences, warm_curvature, multipliers)
+        b, out = self.make_batch(x0, u0, z_warm, sequences, warm_curvature, multipliers, params)
         s = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream if stream is None else stream
         check(self._lib.mpcx_nlmpc_solve_batch(self._h, C.byref(b), s))
         return out

@@ -560,3 +560,46 @@ def test_control_gather_single_rank_through_the_c_abi():
     out2 = allgather_controls(a, gather=g)
     torch.cuda.synchronize()
     assert torch.equal(out2, a)
+
+
+def test_per_instance_model_parameters_give_each_instance_its_own_controller_s_result():
+    """mpcx_nlmpc_batch.params: every instance its own constants of the built-in system (each UGV its own obstacles and
+    preferred velocity).  An instance solved with its parameters in the batch is bit for bit the instance solved by a
+    controller created with those parameters."""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, UGV
+    rng = np.random.default_rng(12)
+    base = np.array([0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, 0.1])
+    sets = [base.copy() for _ in range(4)]
+    sets[1][2:5] = [1.5, 0.6, 0.4]                   # obstacle 0 elsewhere, larger
+    sets[2][:2] = [1.0, 0.0]                         # another preferred velocity
+    sets[3][5:8] = [0.5, 1.4, 0.2]                   # obstacle 1 elsewhere
+    B = 16
+    which = rng.integers(0, 4, size=B)
+    P = np.stack([sets[k] for k in which])
+    X0 = np.zeros((B, 4)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    U0 = np.zeros((B, 2))
+    c = NLMPC(UGV, 30, 30, 0.1)
+    c.setOptimizerParameters(NLParameters(maximum_iteration=150, hard_constraints=0))
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), params=torch.from_numpy(P))
+    torch.cuda.synchronize()
+    differs = 0
+    for k in range(4):
+        ck = NLMPC(UGV, 30, 30, 0.1, params=sets[k])
+        ck.setOptimizerParameters(NLParameters(maximum_iteration=150, hard_constraints=0))
+        idx = np.nonzero(which == k)[0]
+        if idx.size == 0:
+            continue
+        rk = ck.optimizeBatch(torch.from_numpy(X0[idx]), torch.from_numpy(U0[idx]))
+        torch.cuda.synchronize()
+        sel = torch.from_numpy(idx).cuda()
+        assert torch.equal(r["cmd"][sel], rk["cmd"]) and torch.equal(r["cost"][sel], rk["cost"])
+        assert torch.equal(r["solver_status"][sel], rk["solver_status"])
+        if k:
+            r0 = c.optimizeBatch(torch.from_numpy(X0[idx]), torch.from_numpy(U0[idx]))       # the controller's own parameters
+            torch.cuda.synchronize()
+            differs += int(not torch.equal(r0["cmd"], rk["cmd"]))
+    assert differs >= 2                              # the parameters matter
+    v = NLMPC(1, 10, 5, 0.1)                         # Van der Pol has no parameters: refused
+    with pytest.raises(Exception):
+        v.optimizeBatch(torch.zeros(2, 2, dtype=torch.float64), torch.zeros(2, 1, dtype=torch.float64), params=torch.zeros(2, 1, dtype=torch.float64))
