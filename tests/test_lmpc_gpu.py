@@ -275,6 +275,28 @@ def test_full_size_properties():
     assert err[pol].max() <= RTOL_CMD
 
 
+def test_full_size_properties_config4_shard():
+    """BASELINE config 4's per-GPU shard (N=50, B=32768): every instance solved and feasible, inputs inside their box,
+    bit-identical across launches (costs come from the batched MFMA kernel here), the first 32 instances against the oracle"""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    c = quadrotor_lmpc(50, device=0)
+    B = 32768
+    x0, u0, yref = quadrotor_batch(B)
+    a = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    b = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+    assert torch.equal(a.cmd, b.cmd) and torch.equal(a.cost, b.cost)
+    assert (a.status == 0).all() and (a.is_feasible == 1).all()
+    u = a.cmd.cpu().numpy()
+    assert u.min() >= 9.6 - 10.5916 - 1e-7 and u.max() <= 13 - 10.5916 + 1e-7
+    o = quadrotor_oracle(50).solve_batch_constref(x0[:32], u0[:32], yref[:32])
+    pol = o["polished"] == 1
+    err = np.abs(u[:32] - o["cmd"]).max(axis=1) / np.maximum(np.abs(o["cmd"]).max(axis=1), 1e-12)
+    assert pol.any() and err[pol].max() <= RTOL_CMD
+    cost = a.cost[:32].cpu().numpy()
+    assert (np.abs(cost - o["cost"])[pol] <= 1e-7 * np.maximum(1.0, np.abs(o["cost"][pol]))).all()
+
+
 def test_warm_start_carries_the_working_set():
     """f1: the previous tick's active set seeds the working set (LOptimizer.hpp:268-281 carries x, y): same results,
     an unchanged active set verifies in one round, a plant step needs fewer rounds than a cold start."""

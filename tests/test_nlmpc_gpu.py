@@ -83,7 +83,8 @@ def test_partial_outputs_and_empty_batch():
 # ---- the SQP solve (rows a21-a23) --------------------------------------------------------------------------------
 # Tolerance: both sides differentiate by finite differences (forward, step 1.5e-8) and stall at that noise floor; the
 # oracle (scipy SLSQP on the restated callbacks) itself stops with "positive directional derivative" there.  u* is
-# compared at 2e-5 relative, the optimal cost at 1e-8 relative.
+# compared at north_star's 1e-5 relative (of max(1, |u*|); measured 3e-7 ... 1e-6, printed by the tests), the optimal cost at
+# 1e-8 relative.
 def _solve_case(name, kw, X0, U0, hard, max_iter):
     import torch
     from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV, OSCILLATORS6
@@ -136,7 +137,7 @@ def test_ugv_solve_matches_oracle():
         o = m.solve(X0[b], U0[b], max_iter=100, hard=False)
         assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * abs(o["cost"]), (b, r["cost"][b], o["cost"])
         worst = max(worst, np.abs(r["cmd"][b] - o["cmd"]).max() / max(1.0, np.abs(o["cmd"]).max()))
-        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=1e-5, atol=1e-5)
     print("parity ugv (config 3): max |cmd - oracle| / max(1, |cmd|) = %.2e over %d instances" % (worst, B))
 
 
@@ -231,7 +232,7 @@ def test_state_and_input_bounds_match_oracle():
         assert (np.abs(r["seq_state"][b][1:, 0]) <= 0.8 + 1e-9).all()
         compared += 1
         assert abs(r["cost"][b] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
-        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=1e-5, atol=1e-5)
     assert compared >= B - 3
     # matrix form, one column per step; without the state bounds every start is feasible
     assert c.setInputBounds(np.full((1, 5), -0.2), np.full((1, 5), 0.2))
@@ -323,6 +324,7 @@ def test_user_equality_constraints_match_oracle():
         torch.cuda.synchronize()
         r = {k: v.cpu().numpy() for k, v in r.items() if k != "_keep"}
         compared = 0
+        worst = 0.0
         for b in range(B):
             o = m.solve(X0[b], U0[b], max_iter=500)
             if not o["success"]:
@@ -331,7 +333,9 @@ def test_user_equality_constraints_match_oracle():
             assert r["status"][b] == 0 and r["is_feasible"][b] == 1, (b, r["solver_status"][b])
             assert np.abs(r["seq_state"][b][10]).max() <= 1e-9
             assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
-            np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=5e-5, atol=5e-6)
+            worst = max(worst, np.abs(r["cmd"][b] - o["cmd"]).max() / max(1.0, np.abs(o["cmd"]).max()))
+            np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=1e-5, atol=1e-5)
+        print("parity user equalities: max |cmd - oracle| / max(1, |cmd|) = %.2e over %d instances" % (worst, compared))
         assert compared >= B - 1
 
 
@@ -347,6 +351,7 @@ def test_move_blocking_variants_solve_like_the_oracle(name, kw, hard):
     c, r = _solve_case(name, kw, X0, U0, hard, 200)
     m = ref.ugv(**kw) if name == "ugv" else ref.vanderpol(**kw)
     compared = 0
+    worst = 0.0
     for b in range(B):
         o = m.solve(X0[b], U0[b], max_iter=300, hard=hard)
         if not o["success"] and "Positive directional" not in o["message"]:
@@ -356,9 +361,11 @@ def test_move_blocking_variants_solve_like_the_oracle(name, kw, hard):
         compared += 1
         assert r["status"][b] != 3, (b, r["solver_status"][b])
         assert abs(r["cost"][b] - o["cost"]) <= 1e-7 * max(1.0, abs(o["cost"])), (b, r["cost"][b], o["cost"])
-        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=5e-5, atol=2e-5)
+        worst = max(worst, np.abs(r["cmd"][b] - o["cmd"]).max() / max(1.0, np.abs(o["cmd"]).max()))
+        np.testing.assert_allclose(r["cmd"][b], o["cmd"], rtol=1e-5, atol=1e-5)
         # the held last block: every step from ch-1 on applies the same input
         assert np.abs(r["seq_input"][b][kw["ch"] - 1:] - r["seq_input"][b][kw["ch"] - 1]).max() == 0.0
+    print("parity move blocking %s %s: max |cmd - oracle| / max(1, |cmd|) = %.2e over %d instances" % (name, kw, worst, compared))
     assert compared >= B - 1
 
 
