@@ -263,6 +263,20 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     lat_p50 = float(np.median(lat)) * 1e3
+    # the same single steps as one HIP graph each (mpcx_lmpc_graph_*: queue reset + three kernels behind one launch)
+    lat_graph = None
+    if world == 1:
+        side = torch.cuda.Stream(device=dev)
+        g = ctl.make_graph(batch, side)
+        lg = []
+        for _ in range(min(50, max(5, steps))):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctl.launch_graph(g, side)
+            side.synchronize()
+            lg.append(time.perf_counter() - t1)
+        ctl.destroy_graph(g)
+        lat_graph = float(np.median(lg)) * 1e3
 
     if rank != 0:
         return
@@ -340,6 +354,7 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
                                       % (world, world * B)) if gather else "single GPU",
                       "rccl_ranks": gather.world if gather else 0, "streams": ns},
            "p50_step_latency_ms": lat_p50,
+           "p50_step_latency_graph_ms": lat_graph,
            "pipelined": pipelined,
            "solved_fraction": float((status == 0).mean()),
            "roofline": roof, "cpu_baseline": cpu}

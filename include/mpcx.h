@@ -187,6 +187,17 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
  * back-to-back launches; returns the mean kernel time in milliseconds. */
 int mpcx_lmpc_time_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms_mean);
 
+/* One step as a HIP graph.  A control loop solves the same-sized batch from the same buffers every tick: the launches of
+ * one mpcx_lmpc_solve_batch (dispatch-queue reset, assemble, solve, fallback) are captured once for a batch descriptor and
+ * replayed with a single hipGraphLaunch.  The descriptor's pointers are baked into the graph; what they point to may change
+ * between launches (new x0, u0, references), the controller's set-up may not (create a new graph after a setter).
+ * `stream` of create: any non-default stream (used for one untimed warm-up solve and for the capture).  A handle still
+ * has one workspace: one launch of it in flight at a time, graph or not.                                          */
+typedef struct mpcx_lmpc_graph *mpcx_lmpc_graph_t;
+int mpcx_lmpc_graph_create(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, mpcx_lmpc_graph_t *out);
+int mpcx_lmpc_graph_launch(mpcx_lmpc_graph_t g, void *stream);
+int mpcx_lmpc_graph_destroy(mpcx_lmpc_graph_t g);
+
 /* Convenience for callers whose data lives in host memory (the reference's optimize(x0, lastU) is
  * such a caller): stages the inputs to HBM, runs mpcx_lmpc_solve_batch on the default stream, copies
  * the results back and synchronises.  References use the matrices given to the host setters.  Any

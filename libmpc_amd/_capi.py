@@ -61,6 +61,7 @@ EXPORTS = [
     "mpcx_lmpc_set_exogenous_inputs", "mpcx_lmpc_set_exogenous_inputs_slice",
     "mpcx_lmpc_set_optimizer_parameters", "mpcx_lmpc_set_strict_infeasibility", "mpcx_lmpc_setup", "mpcx_lmpc_solve_batch",
     "mpcx_lmpc_time_solve_batch", "mpcx_lmpc_solve_host", "mpcx_lmpc_get_info", "mpcx_version",
+    "mpcx_lmpc_graph_create", "mpcx_lmpc_graph_launch", "mpcx_lmpc_graph_destroy",
     "mpcx_nlmpc_create", "mpcx_nlmpc_destroy", "mpcx_nlmpc_get_dims", "mpcx_nlmpc_evaluate_batch",
     "mpcx_nlparams_default", "mpcx_nlmpc_set_optimizer_parameters", "mpcx_nlmpc_solve_batch", "mpcx_nlmpc_time_solve_batch", "mpcx_discretize_batch",
     "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice", "mpcx_nlmpc_solve_host",
@@ -121,6 +122,9 @@ def lib():
         _lib.mpcx_lmpc_set_scalar_constraint_index.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.mpcx_nlmpc_destroy.argtypes = [C.c_void_p]
+        _lib.mpcx_lmpc_graph_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mpcx_lmpc_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mpcx_lmpc_graph_destroy.argtypes = [C.c_void_p]
         _lib.mpcx_nlmpc_get_dims.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mpcx_nlmpc_evaluate_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib.mpcx_nlparams_default.restype = None

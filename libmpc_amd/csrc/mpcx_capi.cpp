@@ -546,6 +546,53 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     return MPCX_OK;
 }
 
+struct mpcx_lmpc_graph {
+    hipGraphExec_t exec = nullptr;
+    int device = 0;
+};
+
+int mpcx_lmpc_graph_create(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, mpcx_lmpc_graph_t *out)
+{
+    CHECK_H(h);
+    if (!b || !out) return fail(MPCX_E_INVALID, "null argument");
+    if (!stream) return fail(MPCX_E_INVALID, "a graph is captured on a non-default stream");
+    if (b->batch <= 0) return fail(MPCX_E_INVALID, "empty batch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // one plain solve first: it runs whatever set-up is pending, sizes the workspace and configures the kernels -- none of
+    // which can be part of a capture
+    int rc = mpcx_lmpc_solve_batch(h, b, stream);
+    if (rc != MPCX_OK) return rc;
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(MPCX_E_DEVICE, "the warm-up solve failed");
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return fail(MPCX_E_DEVICE, "hipStreamBeginCapture failed");
+    rc = mpcx_lmpc_solve_batch(h, b, stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc != MPCX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph) return fail(MPCX_E_DEVICE, "hipStreamEndCapture failed");
+    auto *g = new mpcx_lmpc_graph;
+    g->device = h->device;
+    const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { delete g; return fail(MPCX_E_DEVICE, "hipGraphInstantiate failed"); }
+    *out = g;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_graph_launch(mpcx_lmpc_graph_t g, void *stream)
+{
+    if (!g || !g->exec) return fail(MPCX_E_INVALID, "null graph");
+    if (hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(MPCX_E_DEVICE, "hipGraphLaunch failed");
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_graph_destroy(mpcx_lmpc_graph_t g)
+{
+    if (!g) return MPCX_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    delete g;
+    return MPCX_OK;
+}
+
 int mpcx_lmpc_solve_host(mpcx_lmpc_t h, int batch, const double *x0, const double *u0,
                          double *cmd, double *cost, int32_t *status, int32_t *solver_status, int32_t *is_feasible,
                          double *seq_state, double *seq_output, double *seq_input)

@@ -404,6 +404,20 @@ class LMPC:
                     t.record_stream(s)
         check(self._lib.mpcx_lmpc_solve_batch(self._h, C.byref(batch), C.c_void_p(s.cuda_stream)))
 
+    def make_graph(self, batch, stream):
+        """One step as a HIP graph (mpcx_lmpc_graph_create): the launches of `launch(batch)` captured once on `stream` (a
+        non-default torch stream) and replayed by `launch_graph`.  The descriptor's tensors stay where they are; write new
+        inputs into them in place."""
+        g = C.c_void_p()
+        check(self._lib.mpcx_lmpc_graph_create(self._h, C.byref(batch), C.c_void_p(stream.cuda_stream), C.byref(g)))
+        return g
+
+    def launch_graph(self, graph, stream):
+        check(self._lib.mpcx_lmpc_graph_launch(graph, C.c_void_p(stream.cuda_stream)))
+
+    def destroy_graph(self, graph):
+        check(self._lib.mpcx_lmpc_graph_destroy(graph))
+
     def time_launches(self, batch, repeats, stream=None):
         """Mean kernel time (ms) over `repeats` launches, HIP events on the launch stream."""
         torch, _ = self._torch()

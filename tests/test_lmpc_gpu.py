@@ -385,3 +385,30 @@ def test_reference_refresh_gives_the_results_of_a_fresh_controller():
         # the kept columns show up as ~1e-8 of the cost (measured 2e-8)
         np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=2e-7, atol=1e-9)
     assert not torch.equal(r0.cmd, ra.cmd)
+
+
+def test_a_step_replayed_as_a_hip_graph_gives_the_plain_launch_s_results():
+    """mpcx_lmpc_graph_*: the launches of one step captured once and replayed; new inputs written into the descriptor's
+    tensors in place are what the replay solves"""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    c = quadrotor_lmpc(20, device=0)
+    B = 512
+    x0, u0, yref = quadrotor_batch(2 * B)
+    batch, res, keep = c.make_batch(x0[:B], u0[:B], yref=yref[:B])
+    side = torch.cuda.Stream(device=0)
+    g = c.make_graph(batch, side)
+    c.launch_graph(g, side); side.synchronize()
+    plain = c.optimizeBatch(x0[:B], u0[:B], yref=yref[:B]); torch.cuda.synchronize()
+    assert torch.equal(res.cmd, plain.cmd) and torch.equal(res.cost, plain.cost) and torch.equal(res.status, plain.status)
+    # the next tick's data, in place
+    xk, uk, yk = [t for t in keep if t is not None][:3]
+    xk.copy_(torch.from_numpy(x0[B:]).to(xk.device)); uk.copy_(torch.from_numpy(u0[B:]).to(uk.device)); yk.copy_(torch.from_numpy(yref[B:]).to(yk.device))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        c.launch_graph(g, side)
+    side.synchronize()
+    plain2 = c.optimizeBatch(x0[B:], u0[B:], yref=yref[B:]); torch.cuda.synchronize()
+    assert torch.equal(res.cmd, plain2.cmd) and torch.equal(res.cost, plain2.cost)
+    assert not torch.equal(plain.cmd, plain2.cmd)
+    c.destroy_graph(g)
