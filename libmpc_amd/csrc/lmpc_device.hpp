@@ -36,6 +36,7 @@ struct LmpcDev {
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
     // per-wave LDS carve (in doubles)
     int stage_len, arena_len, lds_per_wave;
+    int fast_slice;                              // per-wave LDS slice of the lean solve kernels (doubles)
     int wsld;                                    // per-instance workspace record (doubles): f | t0 | gt0 | lg | ug | c0, flag
     // model, column-major
     const double *A, *B, *C, *Bd, *Dd;
@@ -78,6 +79,7 @@ struct LmpcBatchDev {
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
     int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1
+    int legacy;                                   // 1: the round-2 polish kernel (A/B measurements)
     int *pcounter;                                // work counter of the persistent fused kernel (null: one instance per launched wavefront)
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
@@ -90,5 +92,8 @@ int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not c
 int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream,
                 int which = 7, int fast_variant = -1);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
+int lmpc_fast_slice(const LmpcDev &m);          // needs wsld, kin, nx
+// implemented in lmpc_fast.hip: the lean polish kernel (b.fused: the fused / persistent forms) on `stream`
+int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream);
 
 }  // namespace mpcx

@@ -1,0 +1,832 @@
+// Lean polish kernels of the batched LMPC solve (see the comment at solve_fast); launched by lmpc_launch (lmpc_kernels.hip)
+// through lmpc_launch_fast.
+#include "lmpc_kernel_common.hpp"
+#include <cstdlib>
+
+namespace mpcx {
+
+namespace {
+
+// =====================================================================================
+// solve, lean form: the polish-only path of lmpc_solve, one instance per wavefront
+// =====================================================================================
+// Same algorithm and same outputs as solve_one<.., ADMM = false> (OSQP's polish promoted to the main iteration, a verified
+// point is the exact optimum), rebuilt around what the round-2 profile showed: the kernel is bound by the number of
+// instructions a wavefront issues per round and by the rounds of the slowest instances, not by arithmetic.
+//   * repair rule: wrong-signed rows leave AND violated rows enter in the same round (drop-then-add doubled the rounds of the
+//     hard instances); the first working set holds the rows violated at the unconstrained optimum by at least 0.3 x the
+//     largest violation, later rounds add from 0.2 x.  tools/activeset_sim.py, config 2, 32768 instances: mean 5.1 -> 3.5
+//     rounds, maximum 12 -> 8.
+//   * the Schur system is solved by Gauss-Jordan elimination with the right-hand side as an extra column, lane i owning row i:
+//     no forward / backward substitution, no transposition through LDS, no predication -- 3 instructions per eliminated entry
+//     (two v_readlane, one fma) instead of 5 plus two substitutions.  On the Schur complements of config 2 / config 4 its error
+//     is that of the Cholesky factorisation (6e-15 relative).
+//   * the rows of Y the update w = t0 - Y[:, A] lambda needs are requested together with the Schur entries, before the
+//     elimination: one trip to L2 per round instead of three; the multipliers reach the update by v_readlane, not through LDS;
+//     the working-set indices are wave-uniform and live in SGPRs (scalar row addresses).
+//   * wave-wide maxima by DPP row operations and four v_readlane pairs (the ds_bpermute butterfly of __shfl_xor is a chain of
+//     six LDS round trips);
+//   * what a round only reads -- t0, G t0, the linear term and the bounds -- stays in LDS: the wave's slice has the layout of the
+//     workspace record (f | t0 | gt0 | lg | ug | c0, flag) followed by a small arena, the box bounds are shared by the
+//     workgroup.  The one-chunk variant fits 128 VGPRs and 3.3 KB of LDS per wavefront: four wavefronts per SIMD, i.e. at the
+//     benchmark batch every instance is resident at once (the dispatch order no longer matters).
+// Working sets of more than kFastCap rows are left to the fallback kernel (none in 32768 instances of config 2, none in 8192 of
+// config 4).
+#ifndef MPCX_FAST_PF
+#define MPCX_FAST_PF 4
+#endif
+constexpr int kFastCap = 16;
+#ifndef MPCX_FAST_SAFE_AFTER
+#define MPCX_FAST_SAFE_AFTER 12       // rounds of the block repair rule before the single-exchange rule takes over
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// maximum over the wavefront of non-NaN values, the same in every lane
+__device__ __forceinline__ double wave_max_dpp(double v)
+{
+    v = fmax(v, dpp_mov_d<0xB1>(v));     // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_mov_d<0x4E>(v));     // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_mov_d<0x141>(v));    // row_half_mirror
+    v = fmax(v, dpp_mov_d<0x140>(v));    // row_mirror: every row of 16 lanes is uniform now
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
+
+// One solve of the working-set system and the update of the primal point, working set of at most CAP (<= 16) rows.
+// In: wsidx / wsb in LDS (unified indices and bound values of the na working rows), t0s = [t0 (128 CPZ) | G t0] in LDS.
+// Out: lam[0..na) in LDS, wv / gw = w and G w in registers, lmax = largest |multiplier|; returns the position of a linearly
+// dependent row, or -1.
+// profiling aid (tools/phase_cycles.py): cycles per phase of a round, compiled in with -DMPCX_PROFILE_ROUNDS only
+#ifdef MPCX_PROFILE_ROUNDS
+#define MPCX_LAP(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); pacc[k] += now_ - plast; plast = now_; } while (0)
+#define MPCX_LAP_WAIT(k) do { __builtin_amdgcn_s_waitcnt(0); MPCX_LAP(k); } while (0)
+#define MPCX_PROF_ARGS , long long (&pacc)[6], long long &plast
+#define MPCX_PROF_PASS , pacc, plast
+#else
+#define MPCX_LAP(k) do {} while (0)
+#define MPCX_LAP_WAIT(k) do {} while (0)
+#define MPCX_PROF_ARGS
+#define MPCX_PROF_PASS
+#endif
+
+template <int CAP, int CPZ, int CPG>
+__device__ __forceinline__ int ws_solve_reg(const gdp gY, const int ldy, const int ldz, const int na, const int lane,
+                                            const int *wsidx, const double *wsb, const double *t0s, double *lam,
+                                            const int (&offz)[CPZ], const int (&offg)[CPG],
+                                            double (&wv)[2 * CPZ], double (&gw)[2 * CPG], double &lmax MPCX_PROF_ARGS)
+{
+    constexpr int PF = CAP < MPCX_FAST_PF ? CAP : MPCX_FAST_PF;          // rows of Y requested ahead of the elimination
+    const bool real = lane < na;
+    const int li = real ? lane : 0;
+    const int qi = wsidx[li];
+    int qc[CAP];                                    // wave-uniform: SGPRs
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) qc[c] = __builtin_amdgcn_readfirstlane(wsidx[c < na ? c : 0]);
+    double Sr[CAP];
+    const int rowoff = qi * ldy;
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) Sr[c] = (gY + qc[c])[rowoff];
+    d2 pz[PF][CPZ], pg[PF][CPG];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const gdp row = gY + (size_t)qc[u] * ldy;
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) pz[u][c] = ld2(row + offz[c]);
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) pg[u][c] = ld2(row + offg[c]);
+    }
+    double y = real ? t0s[qi < ldz ? qi : qi - ldz + 128 * CPZ] - wsb[li] : 0.0;       // [t0 | G t0] by unified index (padded arrays)
+    MPCX_LAP_WAIT(1);                              // 1: working set to registers + every load of the round answered
+    // rows and columns past na: the identity (the elimination below is straight-line code over all CAP steps)
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) Sr[c] = (real && c < na) ? Sr[c] : (lane == c ? 1.0 : 0.0);
+    double pthr = 0.0, mydinv = 1.0;               // this lane's pivot threshold (relative to its original diagonal)
+#pragma unroll
+    for (int c = 0; c < CAP; ++c) if (lane == c) pthr = 1e-11 * Sr[c];
+    unsigned long long dep = 0ull;
+    // Gauss-Jordan on [S | y], lane i = row i; a failed pivot test is recorded and looked at once, after the loop
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) {
+        dep |= __ballot(lane == k && !(Sr[k] > pthr));
+        const double rinv = pivot_rcp(readlane_d(Sr[k], k));
+        double pj[CAP];
+#pragma unroll
+        for (int j = k + 1; j < CAP; ++j) pj[j] = readlane_d(Sr[j], k);
+        const double py = readlane_d(y, k);
+        if (lane == k) mydinv = rinv;
+        else {
+            const double m = Sr[k] * rinv;
+#pragma unroll
+            for (int j = k + 1; j < CAP; ++j) Sr[j] = fma(-m, pj[j], Sr[j]);
+            y = fma(-m, py, y);
+        }
+    }
+    MPCX_LAP(2);                                   // 2: elimination
+    if (dep != 0ull) return (int)__builtin_ctzll(dep);
+    y *= mydinv;                                   // lanes >= na: 0
+    if (real) lam[lane] = y;
+    // w = t0 - Y[:, A] lambda
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {
+        const double2 v = *reinterpret_cast<const double2 *>(t0s + 128 * c + 2 * lane);
+        wv[2 * c] = v.x; wv[2 * c + 1] = v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const double2 v = *reinterpret_cast<const double2 *>(t0s + 128 * CPZ + 128 * c + 2 * lane);
+        gw[2 * c] = v.x; gw[2 * c + 1] = v.y;
+    }
+    double lm = 0.0;
+#pragma unroll
+    for (int a = 0; a < PF; ++a) {
+        const double la = readlane_d(y, a);        // rows past na: copies of row 0 with multiplier 0
+        lm = fmax(lm, fabs(la));
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) { wv[2 * c] = fma(-la, pz[a][c].x, wv[2 * c]); wv[2 * c + 1] = fma(-la, pz[a][c].y, wv[2 * c + 1]); }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) { gw[2 * c] = fma(-la, pg[a][c].x, gw[2 * c]); gw[2 * c + 1] = fma(-la, pg[a][c].y, gw[2 * c + 1]); }
+    }
+    if constexpr (CAP > PF) {
+        constexpr int RB = CAP - PF < 4 ? CAP - PF : 4;
+#pragma unroll
+        for (int a0 = PF; a0 < CAP; a0 += RB) {
+            if (a0 < na) {
+                d2 mz[RB][CPZ], mgv[RB][CPG];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const gdp row = gY + (size_t)qc[a0 + u < CAP ? a0 + u : 0] * ldy;
+#pragma unroll
+                    for (int c = 0; c < CPZ; ++c) mz[u][c] = ld2(row + offz[c]);
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) mgv[u][c] = ld2(row + offg[c]);
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (a0 + u < CAP) {
+                        const double la = readlane_d(y, a0 + u < CAP ? a0 + u : 0);
+                        lm = fmax(lm, fabs(la));
+#pragma unroll
+                        for (int c = 0; c < CPZ; ++c) { wv[2 * c] = fma(-la, mz[u][c].x, wv[2 * c]); wv[2 * c + 1] = fma(-la, mz[u][c].y, wv[2 * c + 1]); }
+#pragma unroll
+                        for (int c = 0; c < CPG; ++c) { gw[2 * c] = fma(-la, mgv[u][c].x, gw[2 * c]); gw[2 * c + 1] = fma(-la, mgv[u][c].y, gw[2 * c + 1]); }
+                    }
+                }
+            }
+        }
+    }
+    lmax = lm;
+    return -1;
+}
+
+// this wavefront's LDS slice (doubles), ZP = 128 CPZ, GPD = 128 CPG -- every array padded to whole lane pairs so that no lane needs a
+// range predicate: t0 pads 0, bounds pad -inf / +inf (a padded row is never violated, never active):
+//   t0 [ZP] | gt0 [GPD] | lg [GPD] | ug [GPD] | f, later w [ZP] | c0, flag | lam [kFastCap + 2] | wsb [kFastCap + 2] | wsidx (ints) | scratch
+// lwuw: the workgroup's copy of the box bounds [lw (ZP) | uw (ZP)], padded the same way
+template <int CPZ, int CPG> constexpr int fast_slice_fixed() { return 2 * 128 * CPZ + 3 * 128 * CPG + 2 + 2 * (kFastCap + 2) + (kFastCap + 2) / 2 + 1; }
+
+template <int CPZ, int CPG, bool FUSED = false>
+__device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
+                           double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr)
+{
+    constexpr int NZS = 2 * CPZ, NGS = 2 * CPG, ZP = 128 * CPZ, GPD = 128 * CPG;
+    const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
+    const int nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
+    const gdp gY = GP(Y);
+    double *t0s = slice, *gt0s = t0s + ZP, *lgs = gt0s + GPD, *ugs = lgs + GPD, *fs = ugs + GPD, *tail = fs + ZP;
+    double *lam = tail + 2, *wsb = lam + (kFastCap + 2);
+    int *wsidx = reinterpret_cast<int *>(wsb + (kFastCap + 2));
+    double *scratch = wsb + (kFastCap + 2) + (kFastCap + 2) / 2 + 1;
+    const double *lws = lwuw, *uws = lwuw + ZP;
+    const double INF = __builtin_huge_val();
+
+    long long tstamp[4];
+#ifdef MPCX_PROFILE_ROUNDS
+    long long pacc[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
+#endif
+    int tsi = 0;
+    auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 4) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
+    stamp();
+
+    // offsets of this lane's element pairs into the rows of Y (clamped: lanes past the end re-read pair 0, their results are never used)
+    int offz[CPZ], offg[CPG];
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) { const int e = 128 * c + 2 * lane; offz[c] = e < ldz ? e : 0; }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) { const int r = 128 * c + 2 * lane; offg[c] = ldz + (r < ldg ? r : 0); }
+
+    // ---- the assembled problem: the workspace record the assemble kernel left, copied into the slice, or computed in place
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {                  // pads first (the record overwrites what exists)
+        const int e = 128 * c + 2 * lane;
+        if (e >= ldz) { *reinterpret_cast<double2 *>(t0s + e) = make_double2(0.0, 0.0); *reinterpret_cast<double2 *>(fs + e) = make_double2(0.0, 0.0); }
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const int r = 128 * c + 2 * lane;
+        if (r >= ldg) {
+            *reinterpret_cast<double2 *>(gt0s + r) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(lgs + r) = make_double2(-INF, -INF);
+            *reinterpret_cast<double2 *>(ugs + r) = make_double2(INF, INF);
+        }
+    }
+    if (lane == 0) { lam[kFastCap] = 0.0; lam[kFastCap + 1] = 0.0; }      // where the rows outside the working set look their multiplier up
+    if constexpr (FUSED) {
+        RecPtrs rp{fs, t0s, gt0s, lgs, ugs, tail};
+        fused_record(M, Bt, b, lane, scratch, rp, mf_lds);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldz) {
+                const d2 vf = ld2(ws + e), vt = ld2(ws + ldz + e);
+                *reinterpret_cast<double2 *>(fs + e) = make_double2(vf.x, vf.y);
+                *reinterpret_cast<double2 *>(t0s + e) = make_double2(vt.x, vt.y);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const int r = 128 * c + 2 * lane;
+            if (r < ldg) {
+                const d2 vt = ld2(ws + 2 * ldz + r), vl = ld2(ws + ldz + ldy + r), vu = ld2(ws + ldz + ldy + ldg + r);
+                *reinterpret_cast<double2 *>(gt0s + r) = make_double2(vt.x, vt.y);
+                *reinterpret_cast<double2 *>(lgs + r) = make_double2(vl.x, vl.y);
+                *reinterpret_cast<double2 *>(ugs + r) = make_double2(vu.x, vu.y);
+            }
+        }
+        if (lane == 0) { const d2 t = ld2(ws + ldz + ldy + 2 * ldg); *reinterpret_cast<double2 *>(tail) = make_double2(t.x, t.y); }
+        wave_sync();
+    }
+    const double c0 = tail[0];
+    const double flag0 = tail[1];
+    // a violated step-0 / input-independent row: see solve_one
+    const bool fixed_violation = flag0 == 1.0;
+    const bool infeasible = fixed_violation && M.strict_infeasible;
+
+    // working-set state of this lane's rows: 0 free, -1 / +1 at the lower / upper bound, 2 equality row (always in, never shed)
+    int actb[NZS], actg[NGS];
+    const double ptol = 1e-8;
+    auto viol = [&](double v, double lo, double hi) {
+        return fmax(fmax(lo - ptol * fmax(1.0, fabs(lo)) - v, v - hi - ptol * fmax(1.0, fabs(hi))), 0.0);
+    };
+    {
+        // first working set: equalities, and the rows the unconstrained optimum violates by >= MPCX_INIT_THETA x the largest violation
+        double vb[NZS], vg[NGS], vinit = 0.0;
+        bool lowb[NZS], lowg[NGS];
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            const double2 l = *reinterpret_cast<const double2 *>(lws + e), u = *reinterpret_cast<const double2 *>(uws + e);
+            const double2 t = *reinterpret_cast<const double2 *>(t0s + e);
+            vb[2 * c] = viol(t.x, l.x, u.x); vb[2 * c + 1] = viol(t.y, l.y, u.y);
+            lowb[2 * c] = t.x < l.x; lowb[2 * c + 1] = t.y < l.y;
+            actb[2 * c] = l.x == u.x ? 2 : 0; actb[2 * c + 1] = l.y == u.y ? 2 : 0;
+            vinit = fmax(vinit, fmax(vb[2 * c], vb[2 * c + 1]));
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const int r = 128 * c + 2 * lane;
+            const double2 l = *reinterpret_cast<const double2 *>(lgs + r), u = *reinterpret_cast<const double2 *>(ugs + r);
+            const double2 t = *reinterpret_cast<const double2 *>(gt0s + r);
+            const d2 l0 = ld2(GP(lg0) + (offg[c] - ldz)), u0 = ld2(GP(ug0) + (offg[c] - ldz));
+            const bool ok = r < ldg;
+            vg[2 * c] = viol(t.x, l.x, u.x); vg[2 * c + 1] = viol(t.y, l.y, u.y);
+            lowg[2 * c] = t.x < l.x; lowg[2 * c + 1] = t.y < l.y;
+            actg[2 * c] = (ok && l0.x == u0.x) ? 2 : 0; actg[2 * c + 1] = (ok && l0.y == u0.y) ? 2 : 0;
+            vinit = fmax(vinit, fmax(vg[2 * c], vg[2 * c + 1]));
+        }
+        const double thr0 = MPCX_INIT_THETA * wave_max_dpp(vinit);
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) actb[s] = (actb[s] == 0 && vb[s] > 0.0 && vb[s] >= thr0) ? (lowb[s] ? -1 : 1) : actb[s];
+#pragma unroll
+        for (int s = 0; s < NGS; ++s) actg[s] = (actg[s] == 0 && vg[s] > 0.0 && vg[s] >= thr0) ? (lowg[s] ? -1 : 1) : actg[s];
+    }
+    stamp();   // 1: loaded
+
+    if (Bt.warm_lower) {
+        // warm start: the first working set is the previous solve's active set (see solve_one)
+        const unsigned MPCX_GAS *wl = gl(Bt.warm_lower) + (size_t)b * M.active_words;
+        const unsigned MPCX_GAS *wu = gl(Bt.warm_upper) + (size_t)b * M.active_words;
+        const int na = M.nx + M.nu, n1 = M.ph + 1;
+        const int b_box = M.neq_ref, b_out = b_box + n1 * na, b_du = b_out + n1 * M.ny, b_sc = b_du + M.ph * M.nu;
+        auto look = [&](int rr) {
+            if (!Bt.warm_shift) return rr;
+            if (rr < b_out) return rr + na < b_out ? rr + na : rr;
+            if (rr < b_du) return rr + M.ny < b_du ? rr + M.ny : rr;
+            if (rr < b_sc) return rr;
+            return rr + 1 < M.m_ref ? rr + 1 : rr;
+        };
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) {
+            const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+            if (e >= nz || actb[s] == 2) continue;
+            const double lo = lws[e], hi = uws[e];
+            int side = 0;
+            for (int p = GP(boxrow_ptr)[e]; p < GP(boxrow_ptr)[e + 1]; ++p) {
+                const int rr = look(GP(boxrow_ref)[p]);
+                if (((wl[rr >> 5] >> (rr & 31)) & 1u) && GP(boxrow_lo)[p] == lo) side = -1;
+                if (((wu[rr >> 5] >> (rr & 31)) & 1u) && GP(boxrow_hi)[p] == hi) side = 1;
+            }
+            actb[s] = side;
+        }
+#pragma unroll
+        for (int s = 0; s < NGS; ++s) {
+            const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+            if (r >= mg || actg[s] == 2) continue;
+            const int rr = look(GP(g_refrow)[r]);
+            actg[s] = ((wl[rr >> 5] >> (rr & 31)) & 1u) ? -1 : (((wu[rr >> 5] >> (rr & 31)) & 1u) ? 1 : 0);
+        }
+    }
+
+    double wv[NZS], gw[NGS];
+    int posb[NZS], posg[NGS];                        // position in the working set (kFastCap: not in it)
+    double dtol_last = 0;
+    int na_last = 0, rounds_total = 0;
+    bool solved = false;
+
+    if (!infeasible && M.polish) {
+        const int rounds = M.polish_rounds0;
+        for (int rd = 0; rd < rounds; ++rd) {
+            ++rounds_total;
+#ifdef MPCX_PROFILE_ROUNDS
+            plast = (long long)__builtin_readcyclecounter();
+#endif
+            // ---- the working set, in row order, to LDS: unified index and bound value per row.  Straight-line code: a row that
+            // is not in the set writes to the spare slot kFastCap (so does a row past the capacity, which ends the solve below).
+            int na = 0;
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lws + e), u = *reinterpret_cast<const double2 *>(uws + e);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int s = 2 * c + h;
+                    const bool act = actb[s] != 0;
+                    const unsigned long long mk = __ballot(act);
+                    int pos = na + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    pos = (act && pos < kFastCap) ? pos : kFastCap;
+                    posb[s] = pos;
+                    wsidx[pos] = e + h;
+                    wsb[pos] = actb[s] < 0 ? (h ? l.y : l.x) : (h ? u.y : u.x);
+                    na += __popcll(mk);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const int r = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lgs + r), u = *reinterpret_cast<const double2 *>(ugs + r);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int s = 2 * c + h;
+                    const bool act = actg[s] != 0;
+                    const unsigned long long mk = __ballot(act);
+                    int pos = na + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    pos = (act && pos < kFastCap) ? pos : kFastCap;
+                    posg[s] = pos;
+                    wsidx[pos] = ldz + r + h;
+                    wsb[pos] = actg[s] < 0 ? (h ? l.y : l.x) : (h ? u.y : u.x);
+                    na += __popcll(mk);
+                }
+            }
+            if (na > kFastCap) break;                // left to the fallback kernel
+            na_last = na;
+            wave_sync();
+            MPCX_LAP_WAIT(0);                        // 0: working set built and in LDS
+            int dep_at = -1;
+            double lmax = 0.0;
+            if (na == 0) {
+#pragma unroll
+                for (int c = 0; c < CPZ; ++c) { const double2 v = *reinterpret_cast<const double2 *>(t0s + 128 * c + 2 * lane); wv[2 * c] = v.x; wv[2 * c + 1] = v.y; }
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) { const double2 v = *reinterpret_cast<const double2 *>(gt0s + 128 * c + 2 * lane); gw[2 * c] = v.x; gw[2 * c + 1] = v.y; }
+            } else if (na <= 4) dep_at = ws_solve_reg<4, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else if (na <= 6) dep_at = ws_solve_reg<6, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else if (na <= 8) dep_at = ws_solve_reg<8, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else if (na <= 12) dep_at = ws_solve_reg<12, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else dep_at = ws_solve_reg<kFastCap, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            if (dep_at >= 0) {
+                // linearly dependent working set: drop the offending row and try again
+                const int q = wsidx[dep_at];
+#pragma unroll
+                for (int s = 0; s < NZS; ++s)
+                    if (128 * (s >> 1) + 2 * lane + (s & 1) == q) actb[s] = 0;
+#pragma unroll
+                for (int s = 0; s < NGS; ++s)
+                    if (ldz + 128 * (s >> 1) + 2 * lane + (s & 1) == q) actg[s] = 0;
+                wave_sync();
+                continue;
+            }
+            wave_sync();                             // lam is in LDS
+            MPCX_LAP_WAIT(3);                        // 3: w = t0 - Y[:, A] lambda, multipliers in LDS
+            const double dtol = 1e-9 * lmax + 1e-300;
+            dtol_last = dtol;
+            // ---- how wrong is each working row's multiplier (> dtol: wrong sign), how violated each free row: straight-line code,
+            // every slot looks a multiplier up (0 in the spare slot) and measures a violation, selects decide which one counts
+            double badb[NZS], badg[NGS], vb[NZS], vg[NGS], vm = 0.0, bm = 0.0, chk = 0.0;
+            bool lowb[NZS], lowg[NGS];
+            double lmb[NZS], lmg[NGS];
+#pragma unroll
+            for (int s = 0; s < NZS; ++s) lmb[s] = lam[posb[s]];
+#pragma unroll
+            for (int s = 0; s < NGS; ++s) lmg[s] = lam[posg[s]];
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lws + e), u = *reinterpret_cast<const double2 *>(uws + e);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int s = 2 * c + h;
+                    const double lo = h ? l.y : l.x, hi = h ? u.y : u.x;
+                    chk += wv[s];
+                    lowb[s] = wv[s] < lo;
+                    const double v = viol(wv[s], lo, hi);
+                    vb[s] = actb[s] == 0 ? v : 0.0;
+                    badb[s] = actb[s] == -1 ? lmb[s] : (actb[s] == 1 ? -lmb[s] : 0.0);
+                    vm = fmax(vm, vb[s]); bm = fmax(bm, badb[s]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const int r = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lgs + r), u = *reinterpret_cast<const double2 *>(ugs + r);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int s = 2 * c + h;
+                    const double lo = h ? l.y : l.x, hi = h ? u.y : u.x;
+                    chk += gw[s];
+                    lowg[s] = gw[s] < lo;
+                    const double v = viol(gw[s], lo, hi);
+                    vg[s] = actg[s] == 0 ? v : 0.0;
+                    badg[s] = actg[s] == -1 ? lmg[s] : (actg[s] == 1 ? -lmg[s] : 0.0);
+                    vm = fmax(vm, vg[s]); bm = fmax(bm, badg[s]);
+                }
+            }
+            if (wave_any(!(chk - chk == 0.0))) break;       // a NaN or an infinity in the point: left to the fallback kernel
+            MPCX_LAP(4);                             // 4: multipliers and violations
+            const bool any_bad = wave_any(bm > dtol), any_viol = wave_any(vm > 0.0);
+            if (!any_bad && !any_viol) { solved = true; break; }
+            if (rd < MPCX_FAST_SAFE_AFTER) {
+                // every wrong-signed row leaves, and the rows violated by at least MPCX_FAST_ADD_THETA x the largest violation enter
+                const double thr = any_viol ? MPCX_FAST_ADD_THETA * wave_max_dpp(vm) : INF;
+#pragma unroll
+                for (int s = 0; s < NZS; ++s) actb[s] = badb[s] > dtol ? 0 : ((vb[s] > 0.0 && vb[s] >= thr) ? (lowb[s] ? -1 : 1) : actb[s]);
+#pragma unroll
+                for (int s = 0; s < NGS; ++s) actg[s] = badg[s] > dtol ? 0 : ((vg[s] > 0.0 && vg[s] >= thr) ? (lowg[s] ? -1 : 1) : actg[s]);
+            } else {
+                // an instance that is still here (none in 40 000 of the benchmark workloads: the rule above may cycle in principle) goes
+                // on with one exchange per round: the most wrong multiplier leaves, else the most violated row enters
+                const double mx = wave_max_dpp(any_bad ? bm : vm);
+                int slot = -1;
+#pragma unroll
+                for (int s = 0; s < NZS; ++s) if (slot < 0 && (any_bad ? badb[s] : vb[s]) == mx) slot = s;
+#pragma unroll
+                for (int s = 0; s < NGS; ++s) if (slot < 0 && (any_bad ? badg[s] : vg[s]) == mx) slot = NZS + s;
+                const unsigned long long mk = __ballot(slot >= 0);
+                if (slot >= 0 && lane == (int)__builtin_ctzll(mk)) {
+#pragma unroll
+                    for (int s = 0; s < NZS; ++s) if (slot == s) actb[s] = any_bad ? 0 : (lowb[s] ? -1 : 1);
+#pragma unroll
+                    for (int s = 0; s < NGS; ++s) if (slot == NZS + s) actg[s] = any_bad ? 0 : (lowg[s] ? -1 : 1);
+                }
+            }
+            wave_sync();
+            MPCX_LAP(5);                             // 5: repair
+        }
+    }
+    stamp();   // 2: solved
+
+    if (!infeasible && !solved) {
+        // left for the fallback kernel (flag stays 0 / 1), which reads the workspace record
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                if (e < ldz) {
+                    const double2 vf = *reinterpret_cast<const double2 *>(fs + e), vt = *reinterpret_cast<const double2 *>(t0s + e);
+                    st2(ws + e, vf.x, vf.y); st2(ws + ldz + e, vt.x, vt.y);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const int r = 128 * c + 2 * lane;
+                if (r < ldg) {
+                    const double2 vt = *reinterpret_cast<const double2 *>(gt0s + r), vl = *reinterpret_cast<const double2 *>(lgs + r),
+                                  vu = *reinterpret_cast<const double2 *>(ugs + r);
+                    st2(ws + ldz + ldz + r, vt.x, vt.y);
+                    st2(ws + ldz + ldy + r, vl.x, vl.y);
+                    st2(ws + ldz + ldy + ldg + r, vu.x, vu.y);
+                }
+            }
+            if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, flag0);
+        }
+        return;
+    }
+    const int solver_status = infeasible ? -3 : (fixed_violation ? -2 : 1);
+
+    // ---- unpack (LOptimizer.hpp:305-347)
+    double w[NZS], f[NZS];
+    const double qnan = __builtin_nan("");
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {
+        const double2 vf = *reinterpret_cast<const double2 *>(fs + 128 * c + 2 * lane);
+        f[2 * c] = vf.x; f[2 * c + 1] = vf.y;
+    }
+#pragma unroll
+    for (int s = 0; s < NZS; ++s) w[s] = infeasible ? qnan : ((128 * (s >> 1) + 2 * lane + (s & 1) < nz) ? wv[s] : 0.0);
+    double *stage = fs;                              // the solution replaces the linear term
+    double cost;
+    bool cost_pending = false;
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) *reinterpret_cast<double2 *>(stage + 128 * c + 2 * lane) = make_double2(w[2 * c], w[2 * c + 1]);
+    wave_sync();
+    if (infeasible) {
+        cost = 1e30;
+    } else if (!M.cost_direct) {
+        // cost from the multipliers: (f'w - lambda'b_A)/2 + c0 (see solve_one)
+        double j = 0;
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) j = fma(f[s], w[s], j);
+        if (lane < na_last) j = fma(-lam[lane], wsb[lane], j);
+        cost = 0.5 * wave_sum(j) + c0;
+    } else if (!FUSED) {
+        // cost from its definition by lmpc_cost_mfma: the solution goes to the workspace in t0's place
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldz) st2(ws + ldz + e, w[2 * c], w[2 * c + 1]);
+        }
+        cost = 0.0;
+        cost_pending = true;
+    } else {
+        double hw[NZS];
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) hw[s] = 0;
+        matvec_acc<CPZ>(GP(H), ldz, ldz, nz, stage, hw, lane);
+        double j = 0;
+#pragma unroll
+        for (int s = 0; s < NZS; ++s) j += w[s] * (0.5 * hw[s] + f[s]);
+        cost = wave_sum(j) + c0;
+    }
+#pragma unroll
+    for (int s = 0; s < NZS; ++s) {
+        const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+        if (e < nu) glw(Bt.cmd)[(size_t)b * nu + e] = w[s];
+    }
+    if (lane == 0) {
+        if (Bt.cost && !cost_pending) glw(Bt.cost)[b] = cost;
+        if (Bt.solver_status) glw(Bt.solver_status)[b] = solver_status;
+        if (Bt.status) glw(Bt.status)[b] = solver_status == 1 ? 0 : (solver_status == -2 ? 1 : 2);     // LOptimizer.hpp:386-415
+        if (Bt.is_feasible) glw(Bt.is_feasible)[b] = solver_status == -3 ? 0 : 1;
+        if (Bt.iterations) glw(Bt.iterations)[b] = 0;
+        if (Bt.polish_rounds) glw(Bt.polish_rounds)[b] = rounds_total;
+        if (Bt.active_count) glw(Bt.active_count)[b] = infeasible ? 0 : na_last;
+    }
+
+    if (Bt.active_lower && Bt.active_upper) {
+        // bits assembled in LDS (in t0's place: no longer needed), written out as whole words
+        wave_sync();
+        unsigned *bl = reinterpret_cast<unsigned *>(t0s);
+        unsigned *bu = bl + M.active_words;
+        for (int wd = lane; wd < 2 * M.active_words; wd += 64) bl[wd] = 0u;
+        wave_sync();
+        if (!infeasible) {
+#pragma unroll
+            for (int s = 0; s < NZS; ++s) {
+                const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
+                if (e >= nz || actb[s] == 0) continue;
+                const double l = lam[posb[s]];
+                if (!(fabs(l) > dtol_last)) continue;
+                const int side = l < 0 ? -1 : 1;
+                const double lo = lws[e], hi = uws[e];
+                for (int p = GP(boxrow_ptr)[e]; p < GP(boxrow_ptr)[e + 1]; ++p) {
+                    const int rr = GP(boxrow_ref)[p];
+                    if (side < 0 && GP(boxrow_lo)[p] == lo) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
+                    if (side > 0 && GP(boxrow_hi)[p] == hi) atomicOr(&bu[rr >> 5], 1u << (rr & 31));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NGS; ++s) {
+                const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+                if (r >= mg || actg[s] == 0) continue;
+                const double l = lam[posg[s]];
+                if (!(fabs(l) > dtol_last)) continue;
+                const int rr = GP(g_refrow)[r];
+                if (l < 0) atomicOr(&bl[rr >> 5], 1u << (rr & 31));
+                else atomicOr(&bu[rr >> 5], 1u << (rr & 31));
+            }
+        }
+        wave_sync();
+        for (int wd = lane; wd < M.active_words; wd += 64) {
+            glw(Bt.active_lower)[(size_t)b * M.active_words + wd] = bl[wd];
+            glw(Bt.active_upper)[(size_t)b * M.active_words + wd] = bu[wd];
+        }
+        wave_sync();
+    }
+
+    if (Bt.seq_state || Bt.seq_input || Bt.seq_output) {
+        // OptSequence (LOptimizer.hpp:305-338): roll the model forward with the optimal inputs
+        wave_sync();
+        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas);
+        const gip gblk = GP(blk);
+        auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
+        double *xs0 = scratch, *xs1 = scratch + nx;      // ping-pong state
+        if (lane < nx) xs0[lane] = infeasible ? qnan : gl(Bt.x0)[(size_t)b * nx + lane];
+        wave_sync();
+        for (int i = 0; i <= ph; ++i) {
+            const double *xc = (i & 1) ? xs1 : xs0;
+            double *xn = (i & 1) ? xs0 : xs1;
+            const int k = i > 0 ? i - 1 : 0;
+            if (Bt.seq_state && lane < nx) glw(Bt.seq_state)[((size_t)b * (ph + 1) + i) * nx + lane] = xc[lane];
+            if (Bt.seq_input && lane < nu) {
+                const int ii = (i + 1 <= ph) ? i + 1 : ph;
+                glw(Bt.seq_input)[((size_t)b * (ph + 1) + i) * nu + lane] = stage[gblk[ii] * nu + lane];
+            }
+            if (Bt.seq_output && lane < ny) {
+                double yv = 0;
+                for (int c = 0; c < nx; ++c) yv = fma(gC[lane + c * ny], xc[c], yv);
+                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) yv = fma(gDd[lane + dd * ny], dm(k, dd), yv);
+                glw(Bt.seq_output)[((size_t)b * (ph + 1) + i) * ny + lane] = yv;
+            }
+            if (i < ph && lane < nx) {
+                double s = 0;
+                for (int c = 0; c < nx; ++c) s = fma(gA[lane + c * nx], xc[c], s);
+                for (int c = 0; c < nu; ++c) s = fma(gB[lane + c * nx], stage[gblk[i + 1] * nu + c], s);
+                if (M.has_dist) for (int dd = 0; dd < ndu; ++dd) s = fma(gBd[lane + dd * nx], dm(i, dd), s);
+                xn[lane] = s;
+            }
+            wave_sync();
+        }
+    }
+    wave_sync();
+    if (lane == 0) ws[ldz + ldy + 2 * ldg + 1] = cost_pending ? 3.0 : 2.0;     // 2: done, the fallback kernel skips it; 3: lmpc_cost_mfma first
+    stamp();   // 3: unpacked
+    if (Bt.dbg_cycles && lane == 0)
+#ifdef MPCX_PROFILE_ROUNDS
+        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < 2 ? tstamp[k + 1] - tstamp[k] : pacc[k >= 2 ? k - 2 : 0];      // load, solve, six phases
+#else
+        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = (k < 4 && k < tsi) ? tstamp[k & 3] : 0;
+#endif
+}
+
+// waves per SIMD the lean kernels are compiled for: the one-chunk variant fits 128 VGPRs
+#ifndef MPCX_FAST_WAVES1
+#define MPCX_FAST_WAVES1 4
+#endif
+template <int CPZ> constexpr int fast_waves() { return CPZ == 1 ? MPCX_FAST_WAVES1 : 2; }
+
+// LDS of the lean kernels: [lw | uw] of the workgroup (padded to whole lane pairs), then one slice per wavefront (M.fast_slice doubles)
+template <int CPZ>
+__device__ __forceinline__ void fast_load_box(const LmpcDev &M, double *lwuw)
+{
+    constexpr int ZP = 128 * CPZ;
+    const double INF = __builtin_huge_val();
+    for (int e = 2 * (int)threadIdx.x; e < ZP; e += 2 * (int)blockDim.x) {
+        const bool ok = e < M.ldz;
+        const d2 vl = ld2(GP(lw) + (ok ? e : 0)), vu = ld2(GP(uw) + (ok ? e : 0));
+        *reinterpret_cast<double2 *>(lwuw + e) = ok ? make_double2(vl.x, vl.y) : make_double2(-INF, -INF);
+        *reinterpret_cast<double2 *>(lwuw + ZP + e) = ok ? make_double2(vu.x, vu.y) : make_double2(INF, INF);
+    }
+    __syncthreads();
+}
+
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    fast_load_box<CPZ>(M, smem);
+    double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
+    const int wpb = blockDim.x >> 6;
+    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
+        const int b = queued_instance(Bt, i, lane);
+        solve_fast<CPZ, CPG, false>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
+    }
+}
+
+// The same with the record computed in place (no assemble kernel, no workspace traffic): instances in batch order
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_solve_fused(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    fast_load_box<CPZ>(M, smem);
+    double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+        solve_fast<CPZ, CPG, true>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
+}
+
+// The fused form as a persistent kernel: one workgroup of kPersistWaves wavefronts per CU loads the composed map into LDS once
+// (87.5 KB at N = 20; with twelve 5.6 KB slices 157 of the 160 KB of a CU), then every wavefront pulls instances from a device
+// counter until the batch is exhausted -- the record of an instance costs one pass over LDS instead of a round trip through
+// HBM, nobody waits for a neighbour, and an early finisher simply takes the next instance.
+constexpr int kPersistWaves = 12;
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kPersistWaves * 64) void lmpc_solve_persistent(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase,
+                                                                             int *counter)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nmf = M.rowsF * M.kin;                  // even
+    {
+        const gdp src = gl(Bt.fused == 2 ? M.MF1 : M.MF0);
+        for (int k = 2 * (int)threadIdx.x; k < nmf; k += 2 * (int)blockDim.x) {
+            const d2 v = ld2(src + k);
+            *reinterpret_cast<double2 *>(smem + k) = make_double2(v.x, v.y);
+        }
+    }
+    double *lwuw = smem + nmf;
+    fast_load_box<CPZ>(M, lwuw);
+    double *rec = lwuw + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
+    // The first instance of a wavefront is its own number; the rest of the batch is handed out by eight counters (one per
+    // residue of the workgroup number, i.e. per XCD under the usual placement), each over every eighth instance: a single
+    // device-scope counter serves about 88 pulls per microsecond, which thousands of wavefronts starting together would queue on.
+    const int nwaves = gridDim.x * kPersistWaves, shard = blockIdx.x & 7;
+    int b = blockIdx.x * kPersistWaves + wave;
+    while (b < Bt.batch) {
+        solve_fast<CPZ, CPG, true>(M, Bt, b, lane, rec, lwuw, glw(wsbase) + (size_t)b * M.wsld, smem);
+        int n = 0;
+        if (lane == 0) n = atomicAdd(counter + shard, 1);
+        n = __builtin_amdgcn_readfirstlane(n);
+        b = nwaves + shard + 8 * n;
+    }
+}
+
+template <int CPZ, int CPG>
+int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
+{
+    size_t ldsf = ((size_t)2 * 128 * CPZ + (size_t)kWavesPerBlock * m.fast_slice) * sizeof(double);
+    if (const char *pad = getenv("MPCX_DBG_LDS_PAD")) ldsf += (size_t)atoi(pad);
+    if (ldsf > 160 * 1024) return -2;
+    auto k2 = lmpc_solve<CPZ, CPG>;
+    // the fused forms serve the one-chunk variant only (fused_record: up to 384 rows of the composed map)
+    auto k4 = lmpc_solve_fused<1, 1>;
+    auto k5 = lmpc_solve_persistent<1, 1>;
+    static std::atomic<size_t> configured[64];
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    devid &= 63;
+    if (ldsf > configured[devid].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf) != hipSuccess)
+            return -3;
+        size_t prev = configured[devid].load(std::memory_order_relaxed);
+        while (prev < ldsf && !configured[devid].compare_exchange_weak(prev, ldsf, std::memory_order_release)) {}
+    }
+    int blocks = (b.batch + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int cap = 256 * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
+    // persistent form: the composed map, the box bounds and kPersistWaves slices must fit one CU's LDS, and the batch must be worth
+    // the prologue of every workgroup (the composed map: 87 KB at N = 20)
+    const size_t ldsp = ((size_t)m.rowsF * m.kin + 2 * (size_t)128 + kPersistWaves * (size_t)m.fast_slice) * sizeof(double);
+    if (fused && b.pcounter && ldsp <= 160 * 1024 && b.batch >= 1024) {
+        static std::atomic<int> pconf[64];
+        if (!pconf[devid].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+            pconf[devid].store(1, std::memory_order_release);
+        }
+        (void)hipMemsetAsync(b.pcounter, 0, 8 * sizeof(int), stream);
+        int wgs = (b.batch + kPersistWaves - 1) / kPersistWaves;
+        if (wgs > 256) wgs = 256;
+        hipLaunchKernelGGL(k5, dim3(wgs), dim3(kPersistWaves * 64), ldsp, stream, m_dev, b, ws, b.pcounter);
+    } else if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), ldsf, stream, m_dev, b, ws);
+    else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), ldsf, stream, m_dev, b, ws);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+int lmpc_fast_slice(const LmpcDev &m)
+{
+    const int cp = lmpc_kernel_variant(m.ldz, m.ldg);
+    if (cp < 1) return 0;
+    const int fixed = cp == 1 ? fast_slice_fixed<1, 1>() : (cp == 2 ? fast_slice_fixed<2, 2>() : fast_slice_fixed<4, 4>());
+    const int scratch = m.kin > 2 * m.nx ? m.kin : 2 * m.nx;    // vin of the fused record / ping-pong state of the sequence roll-out
+    return (fixed + scratch + 1) / 2 * 2;
+}
+
+int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (lmpc_kernel_variant(m.ldz, m.ldg)) {
+    case 1: return launch_fast_variant<1, 1>(m, m_dev, b, ws, s);
+#ifndef MPCX_FAST_ONLY_CP1
+    case 2: return launch_fast_variant<2, 2>(m, m_dev, b, ws, s);
+    case 4: return launch_fast_variant<4, 4>(m, m_dev, b, ws, s);
+#endif
+    default: return -2;
+    }
+}
+
+}  // namespace mpcx

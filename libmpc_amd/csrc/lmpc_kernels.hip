@@ -21,163 +21,11 @@
 // through the wave's LDS slice; the shared matrices stream from L2 with 16-byte loads that
 // are coalesced across the wavefront and never predicated (out-of-range lanes re-read
 // element 0), so the compiler keeps many of them in flight.
-#include <hip/hip_runtime.h>
-
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <type_traits>
-
-#include "lmpc_device.hpp"
+#include "lmpc_kernel_common.hpp"
 
 namespace mpcx {
 
 namespace {
-
-#ifndef MPCX_WAVES_PER_BLOCK
-#define MPCX_WAVES_PER_BLOCK 2
-#endif
-constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
-constexpr int kFallbackChunk = 64;      // instances one wavefront of the fallback kernel screens (one flag per lane)
-constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
-constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
-// a working set with all signs right grows by the rows violated by at least this fraction of the largest violation: adding
-// every violated row at once over-constrains, the surplus rows are shed one round later and the slowest instances ping-pong
-// (max rounds 18-22 over six batches of 4096 with 0, 12-14 with 0.3; 0.1 and 0.5 are worse than either)
-#ifndef MPCX_ADD_THETA
-#define MPCX_ADD_THETA 0.3
-#endif
-#ifndef MPCX_SOLVE_WAVES
-#define MPCX_SOLVE_WAVES 2
-#endif
-
-// Pointers that come out of the model struct are generic pointers to the compiler, which
-// would emit flat_load (tied to both vmcnt and lgkmcnt, serialising against LDS traffic).
-// Everything they point to lives in HBM: say so.
-#define MPCX_GAS __attribute__((address_space(1)))
-typedef const double MPCX_GAS *gdp;
-typedef const int MPCX_GAS *gip;
-typedef double MPCX_GAS *gdw;
-template <typename T> __device__ __forceinline__ const T MPCX_GAS *gl(const T *p) { return (const T MPCX_GAS *)p; }
-template <typename T> __device__ __forceinline__ T MPCX_GAS *glw(T *p) { return (T MPCX_GAS *)p; }
-typedef double d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ d2 ld2(gdp p) { return *reinterpret_cast<const d2 MPCX_GAS *>(p); }
-__device__ __forceinline__ void st2(gdw p, double a, double b)
-{
-    d2 v; v.x = a; v.y = b;
-    *reinterpret_cast<d2 MPCX_GAS *>(p) = v;
-}
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-// broadcast lane l's value (l wave-uniform): two v_readlane_b32, no LDS round trip
-__device__ __forceinline__ double readlane_d(double v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-constexpr int kRegCap = 16;      // working sets up to this size are factored in registers
-// 1/d for a positive, well-scaled pivot: hardware estimate + two Newton steps (full precision, a third of the latency of the
-// IEEE division sequence, which sits on the dependent chain of every elimination step)
-__device__ __forceinline__ double pivot_rcp(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
-
-// acc += M[:, 0..ncols) * xs.  M column-major, leading dimension ld, R (even) valid rows.
-template <int CP>
-__device__ __forceinline__ void matvec_acc(gdp M, int ld, int R, int ncols, const double *xs,
-                                           double (&acc)[2 * CP], int lane)
-{
-    int off[CP];
-    double t[2 * CP];
-#pragma unroll
-    for (int c = 0; c < CP; ++c) {
-        const int e = 128 * c + 2 * lane;
-        off[c] = e < R ? e : 0;
-        t[2 * c] = 0; t[2 * c + 1] = 0;
-    }
-    // explicit software pipelining: issue a batch of column fetches, then consume them
-    constexpr int U = CP == 1 ? 8 : (CP == 2 ? 4 : 2);
-    int j = 0;
-    for (; j + U <= ncols; j += U) {
-        d2 m[U][CP];
-        double xj[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            gdp col = M + (size_t)(j + u) * ld;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) m[u][c] = ld2(col + off[c]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) xj[u] = xs[j + u];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int c = 0; c < CP; ++c) {
-                t[2 * c] = fma(m[u][c].x, xj[u], t[2 * c]);
-                t[2 * c + 1] = fma(m[u][c].y, xj[u], t[2 * c + 1]);
-            }
-        }
-    }
-    for (; j < ncols; ++j) {
-        const double xj = xs[j];
-        gdp col = M + (size_t)j * ld;
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-            const d2 m = ld2(col + off[c]);
-            t[2 * c] = fma(m.x, xj, t[2 * c]);
-            t[2 * c + 1] = fma(m.y, xj, t[2 * c + 1]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CP; ++c)
-        if (128 * c + 2 * lane < R) { acc[2 * c] += t[2 * c]; acc[2 * c + 1] += t[2 * c + 1]; }
-}
-
-template <int CP>
-__device__ __forceinline__ void stage_store(double *xs, const double (&v)[2 * CP], int n, int lane)
-{
-#pragma unroll
-    for (int c = 0; c < CP; ++c) {
-        const int e = 128 * c + 2 * lane;
-        if (e < n) *reinterpret_cast<double2 *>(xs + e) = make_double2(v[2 * c], v[2 * c + 1]);
-    }
-}
-
-__device__ __forceinline__ double ref_at(gdp p, long bs, long ks, int b, int k, int a)
-{
-    return p[(size_t)b * bs + (size_t)k * ks + a];
-}
-
-__device__ __forceinline__ bool violates(double v, double lo, double hi, double ea, double er)
-{
-    // same slack OSQP's primal tolerance would grant a fixed row
-    return (v < lo - (ea + er * fabs(lo))) || (v > hi + (ea + er * fabs(hi)));
-}
-
-#define GP(field) gl(M.field)
 
 // =====================================================================================
 // assemble, generic form: one instance per wavefront
@@ -396,7 +244,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(con
 // B-operand layout of k-step 4*tile + r, so results chain into the next product without any
 // cross-lane movement: each lane parks its own registers in LDS and reads them back by k index.
 // The four wavefronts of a workgroup split the row tiles and share the operands through LDS.
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt,
                                                            double *wsbase, const int variant)
@@ -555,97 +402,6 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
 }
 
 // =====================================================================================
-// the record of one instance without the workspace: ProblemBuilder::get as ONE mat-vec
-// =====================================================================================
-// Everything the solve needs of an instance -- f, t0 = -Hinv f, G t0, the row offsets, the feasibility rows and the cost
-// constant -- is MF * vin with vin = [x0 | lastU | yref | 1] (lmpc_model.cpp: compose_fused_maps).  The wavefront computes it
-// into its own LDS slice, in the layout of the workspace record (f | t0 | gt0 | lg | ug | c0, flag), and solve_one reads it
-// from there: no assemble kernel, no 2.7 KB per instance written to HBM and read back.  MF streams from L2 (87 KB at N = 20).
-constexpr int kCpFused = 3;            // rows of MF per lane pair: up to 384
-__device__ __noinline__ void fused_record(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane, double *stage, double *rec,
-                                          const double *mf_lds)
-{
-    const int nx = M.nx, nu = M.nu, ny = M.ny, kin = M.kin;
-    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, rowsF = M.rowsF;
-    const int variant = Bt.fused - 1;
-    // vin: the same k -> (x0 | lastU | yref | 1) map as lmpc_assemble_mfma
-    if (lane < kin) {
-        const int k = lane;
-        double v = 0.0;
-        if (k < M.nxp) { if (k < nx) v = gl(Bt.x0)[(size_t)b * nx + k]; }
-        else if (k < M.nxp + M.nup) { const int c = k - M.nxp; if (c < nu) v = gl(Bt.u0)[(size_t)b * nu + c]; }
-        else if (k < M.ione) { const int c = k - M.nxp - M.nup; if (variant && c < ny) v = gl(Bt.yref)[(size_t)b * Bt.yref_bs + c]; }
-        else if (k == M.ione) v = 1.0;
-        stage[k] = v;
-    }
-    wave_sync();
-    double acc[2 * kCpFused];
-#pragma unroll
-    for (int s = 0; s < 2 * kCpFused; ++s) acc[s] = 0.0;
-    if (mf_lds) {
-        // the composed map sits in this workgroup's LDS (lmpc_solve_persistent loaded it once): sixteen-byte reads, lanes on
-        // consecutive rows (no bank conflicts), four columns in flight
-        int off[kCpFused];
-#pragma unroll
-        for (int c = 0; c < kCpFused; ++c) { const int e = 128 * c + 2 * lane; off[c] = e < rowsF ? e : 0; }
-        for (int j = 0; j < kin; j += 4) {
-            double2 m[4][kCpFused];
-            double xj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double *col = mf_lds + (size_t)(j + u) * rowsF;
-#pragma unroll
-                for (int c = 0; c < kCpFused; ++c) m[u][c] = *reinterpret_cast<const double2 *>(col + off[c]);
-                xj[u] = stage[j + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int c = 0; c < kCpFused; ++c) {
-                    acc[2 * c] = fma(m[u][c].x, xj[u], acc[2 * c]);
-                    acc[2 * c + 1] = fma(m[u][c].y, xj[u], acc[2 * c + 1]);
-                }
-            }
-        }
-    } else {
-        // from L2, two columns per batch: the stream is bandwidth-bound there -- every wavefront of the launch reads the same
-        // 87 KB -- and deeper batches only made the burst worse (146 us against 122 us for the launch at the benchmark batch)
-        matvec_acc<kCpFused>(gl(variant ? M.MF1 : M.MF0), rowsF, rowsF, kin, stage, acc, lane);
-    }
-    const int r_goff = ldy, r_f = r_goff + ldg, r_s = r_f + ldz, r_q = r_s + M.nsp;
-    double c0p = 0.0;
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < kCpFused; ++c) {
-        const int e = 128 * c + 2 * lane;          // block boundaries are even: a pair never straddles two blocks
-        if (e >= rowsF) continue;
-        const double a0 = acc[2 * c], a1 = acc[2 * c + 1];
-        if (e < r_goff) {                          // t0 | gt0
-            *reinterpret_cast<double2 *>(rec + ldz + e) = make_double2(a0, a1);
-        } else if (e < r_f) {                      // row offsets -> bounds of this instance
-            const int r = e - r_goff;
-            const d2 l0 = ld2(GP(lg0) + r), u0 = ld2(GP(ug0) + r);
-            *reinterpret_cast<double2 *>(rec + ldz + ldy + r) = make_double2(l0.x - a0, l0.y - a1);
-            *reinterpret_cast<double2 *>(rec + ldz + ldy + ldg + r) = make_double2(u0.x - a0, u0.y - a1);
-        } else if (e < r_s) {                      // linear term
-            *reinterpret_cast<double2 *>(rec + (e - r_f)) = make_double2(a0, a1);
-        } else if (e < r_q) {                      // rows that do not see the inputs: pure feasibility conditions on (x0, lastU)
-            const int r = e - r_s;
-            if (r < M.ns) bad |= violates(a0, GP(slo)[r], GP(shi)[r], M.eps_abs, M.eps_rel);
-            if (r + 1 < M.ns) bad |= violates(a1, GP(slo)[r + 1], GP(shi)[r + 1], M.eps_abs, M.eps_rel);
-        } else {                                   // cost constant: vin' Qc vin / 2
-            const int k = e - r_q;
-            c0p = fma(0.5 * stage[k], a0, c0p);
-            c0p = fma(0.5 * stage[k + 1], a1, c0p);
-        }
-    }
-    c0p = wave_sum(c0p);
-    const bool anybad = wave_any(bad);
-    if (lane == 0) *reinterpret_cast<double2 *>(rec + ldz + ldy + 2 * ldg) = make_double2(c0p, anybad ? 1.0 : 0.0);
-    wave_sync();
-}
-
-// =====================================================================================
 // solve: one instance per wavefront
 // =====================================================================================
 template <int CPZ, int CPG, bool ADMM, bool FUSED = false>
@@ -674,7 +430,10 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 
     // ---- load the assembled problem: from the workspace record the assemble kernel left, or from the one this wavefront just
     // computed into its LDS slice (same layout)
-    if constexpr (FUSED) fused_record(M, Bt, b, lane, stage, arena, mf_lds);
+    if constexpr (FUSED) {
+        RecPtrs rp{arena, arena + ldz, arena + 2 * ldz, arena + ldz + ldy, arena + ldz + ldy + ldg, arena + ldz + ldy + 2 * ldg};
+        fused_record(M, Bt, b, lane, stage, rp, mf_lds);
+    }
     auto rec2 = [&](int at) -> d2 {
         if constexpr (FUSED) { const double2 v = *reinterpret_cast<const double2 *>(arena + at); d2 r; r.x = v.x; r.y = v.y; return r; }
         else return ld2(ws + at);
@@ -1500,30 +1259,10 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 #endif
 }
 
-// i-th instance in dispatch order: hardest class first, its ways in turn (identity when no queues were built).
-// kQueueWays == 64: lane l reads the counter of way l, a wave scan finds the way that holds position i.
-__device__ __forceinline__ int queued_instance(const LmpcBatchDev &Bt, int i, int lane)
-{
-    if (!Bt.qcnt) return i;
-    int rem = i;
-    for (int c = kQueueKeys - 1; c >= 0; --c) {
-        const int n = min(Bt.qcnt[c * kQueueWays + lane], Bt.qcap);
-        int incl = n;
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const int tot = __shfl(incl, 63);
-        if (rem < tot) {
-            const unsigned long long hit = __ballot(incl > rem);
-            const int L = (int)__builtin_ctzll(hit);
-            const int pos = rem - (__shfl(incl, L) - __shfl(n, L));
-            return Bt.qlist[(size_t)(c * kQueueWays + L) * Bt.qcap + pos];
-        }
-        rem -= tot;
-    }
-    return i;        // not reached when every instance was queued
-}
 
+// the round-2 polish kernel, kept for A/B measurements (mpcx_lmpc_debug_use_legacy)
 template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve_legacy(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
@@ -1535,58 +1274,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_so
     for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
         const int b = queued_instance(Bt, i, lane);
         solve_one<CPZ, CPG, false>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
-    }
-}
-
-// The same with the record computed in place (no assemble kernel, no workspace traffic): instances in batch order
-template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve_fused(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *stage = smem + (size_t)wave * M.lds_per_wave;
-    double *nt0 = stage + M.stage_len;
-    double *arena = nt0 + M.ldy;
-    const int wpb = blockDim.x >> 6;
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
-}
-
-// The fused form as a persistent kernel: one workgroup of eight wavefronts per CU loads the composed map into LDS once
-// (87.5 KB at N = 20; together with the eight per-wave slices that is 157 of the 160 KB of a CU), then every wavefront pulls
-// instances from a device counter until the batch is exhausted -- the record of an instance costs one pass over LDS instead of
-// a round trip through HBM, nobody waits for a neighbour, and an early finisher simply takes the next instance.
-template <int CPZ, int CPG>
-__global__ __launch_bounds__(512, MPCX_SOLVE_WAVES) void lmpc_solve_persistent(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase,
-                                                                                int *counter)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nmf = M.rowsF * M.kin;                  // even
-    {
-        const gdp src = gl(Bt.fused == 2 ? M.MF1 : M.MF0);
-        for (int k = 2 * (int)threadIdx.x; k < nmf; k += 2 * (int)blockDim.x) {
-            const d2 v = ld2(src + k);
-            *reinterpret_cast<double2 *>(smem + k) = make_double2(v.x, v.y);
-        }
-    }
-    __syncthreads();
-    double *stage = smem + nmf + (size_t)wave * M.lds_per_wave;
-    double *nt0 = stage + M.stage_len;
-    double *arena = nt0 + M.ldy;
-    // The first instance of a wavefront is its own number; the rest of the batch is handed out by eight counters (one per
-    // residue of the workgroup number, i.e. per XCD under the usual placement), each over every eighth instance: a single
-    // device-scope counter serves about 88 pulls per microsecond, which 2048 wavefronts starting together would queue on.
-    const int nwaves = gridDim.x * 8, shard = blockIdx.x & 7;
-    int b = blockIdx.x * 8 + wave;
-    while (b < Bt.batch) {
-        solve_one<CPZ, CPG, false, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld, smem);
-        int n = 0;
-        if (lane == 0) n = atomicAdd(counter + shard, 1);
-        n = __builtin_amdgcn_readfirstlane(n);
-        b = nwaves + shard + 8 * n;
     }
 }
 
@@ -1704,10 +1391,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
     if (lds > 160 * 1024) return -2;
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
-    auto k2 = lmpc_solve<CPZ, CPG>;
+    auto k2l = lmpc_solve_legacy<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
-    auto k4 = lmpc_solve_fused<CPZ, CPG>;
-    auto k5 = lmpc_solve_persistent<CPZ, CPG>;
     // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
     // two handles on different GPUs cannot skip or tear the update)
     static std::atomic<size_t> configured[64];
@@ -1716,9 +1401,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     devid &= 63;
     if (lds > configured[devid].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k2l), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         size_t prev = configured[devid].load(std::memory_order_relaxed);
         while (prev < lds && !configured[devid].compare_exchange_weak(prev, lds, std::memory_order_release)) {}
@@ -1741,21 +1425,13 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         }
     }
     if (which & 2) {
-        // persistent form: the composed map and eight per-wave slices must fit one CU's LDS, and the batch must be worth the
-        // 87 KB prologue of every workgroup
-        const size_t ldsp = ((size_t)m.rowsF * m.kin + 8 * (size_t)m.lds_per_wave) * sizeof(double);
-        if (fused && b.pcounter && ldsp <= 160 * 1024 && b.batch >= 1024) {
-            static std::atomic<int> pconf[64];
-            if (!pconf[devid].load(std::memory_order_acquire)) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
-                pconf[devid].store(1, std::memory_order_release);
-            }
-            (void)hipMemsetAsync(b.pcounter, 0, 8 * sizeof(int), stream);
-            int wgs = (b.batch + 7) / 8;
-            if (wgs > 256) wgs = 256;
-            hipLaunchKernelGGL(k5, dim3(wgs), dim3(512), ldsp, stream, m_dev, b, ws, b.pcounter);
-        } else if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
-        else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        if (b.legacy && !fused) hipLaunchKernelGGL(k2l, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+        else {
+            LmpcBatchDev bf = b;
+            if (!fused) bf.fused = 0;
+            const int rf = lmpc_launch_fast(m, m_dev, bf, ws, stream);      // lean kernels (lmpc_fast.hip)
+            if (rf != 0) return rf;
+        }
         if (m.cost_direct && m.polish && !fused) {       // the costs lmpc_solve left pending
             const size_t ldsc = ((size_t)(m.nz16 / 4) * 64 + 64) * sizeof(double);
             int blocksq = (b.batch + 15) / 16;

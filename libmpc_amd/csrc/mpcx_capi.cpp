@@ -44,6 +44,7 @@ struct mpcx_lmpc {
     bool force_generic = false;
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
+    bool use_legacy = false;            // A/B: the round-2 polish kernel instead of the lean one (mpcx_lmpc_debug_use_legacy)
     bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
     // Fused forms (lmpc_solve_fused / lmpc_solve_persistent): the instance's record is computed inside the solve kernel instead of
     // being handed over through the HBM workspace (3 MB instead of 25 MB of traffic per 4096 instances), but the hardest-first
@@ -457,6 +458,7 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     D.blk = h->up(o.blk, rc);
     D.kin = o.kin; D.nxp = o.nxp; D.nup = o.nup; D.nyp = o.nyp; D.ione = o.ione;
     D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
+    D.fast_slice = mpcx::lmpc_fast_slice(D);
     D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
     D.MF0 = h->up(o.MF[0], rc); D.MF1 = h->up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
@@ -503,6 +505,7 @@ static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDe
     B.warm_lower = b->warm_active_lower; B.warm_upper = b->warm_active_upper; B.warm_shift = b->warm_shift;
     if ((B.warm_lower == nullptr) != (B.warm_upper == nullptr)) return fail(MPCX_E_INVALID, "warm_active_lower and warm_active_upper go together");
     B.dbg_cycles = h->dbg_cycles;
+    B.legacy = h->use_legacy ? 1 : 0;
     return MPCX_OK;
 }
 
@@ -539,7 +542,9 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
     if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
-    else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
+    // hardest-first dispatch only pays while a launch is several waves of dispatches deep: the round-2 kernel at two wavefronts per
+    // SIMD.  The lean kernel keeps a batch of 4096 resident at once.
+    else if (fast >= 0 && h->use_queues && h->use_legacy) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
@@ -719,7 +724,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
     if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
-    else if (fast >= 0 && h->use_queues) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
+    else if (fast >= 0 && h->use_queues && h->use_legacy) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -765,6 +770,14 @@ int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);
     h->use_queues = on != 0;
+    return MPCX_OK;
+}
+
+/* A/B knob: 1 = the round-2 polish kernel (drop-then-add repair rule, LDL' + substitutions) instead of the lean one */
+int mpcx_lmpc_debug_use_legacy(mpcx_lmpc_t h, int on)
+{
+    CHECK_H(h);
+    h->use_legacy = on != 0;
     return MPCX_OK;
 }
 
@@ -823,6 +836,11 @@ int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap)
         tmp = {(double)o.nz, (double)o.mg, (double)o.ldz, (double)o.ldg, (double)o.ldy, (double)o.nf,
                (double)o.n_ref, (double)o.m_ref, (double)o.neq_ref, (double)o.fixed_rows.size(),
                (double)h->dev.lds_per_wave, (double)(o.h_regularised ? 1 : 0)};
+        v = &tmp;
+    } else if (n == "MA0") v = &o.MA[0]; else if (n == "MA1") v = &o.MA[1];
+    else if (n == "dims_maps") {
+        tmp = {(double)o.kin, (double)o.nxp, (double)o.nup, (double)o.nyp, (double)o.ione, (double)o.nz16, (double)o.mg16,
+               (double)o.ns, (double)o.ns16, (double)o.kq16, (double)o.rowsA, (double)o.ldy16};
         v = &tmp;
     } else if (n == "g_refrow") { tmp.assign(o.g_refrow.begin(), o.g_refrow.end()); v = &tmp; }
     else if (n == "g_step") { tmp.assign(o.g_step.begin(), o.g_step.end()); v = &tmp; }

@@ -1,6 +1,6 @@
-"""A/B on the GPU box: the two-kernel LMPC path (assemble -> workspace -> solve) against the fused forms (record computed inside
-the solve kernel; persistent with the composed map in LDS at large batches).  Prints ms per step, per-kernel times and the largest
-difference of the results."""
+"""A/B on the GPU box: the round-2 polish kernel against the lean one, each as two kernels (assemble -> workspace -> solve) and,
+for the lean one, in the fused forms (record computed inside the solve kernel; persistent with the composed map in LDS).
+Prints ms per step, per-kernel times and the largest difference of the results to the first variant."""
 import ctypes as C
 import sys
 import time
@@ -11,10 +11,12 @@ import torch
 from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ph = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 x0, u0, yref = quadrotor_batch(B)
 ref = None
-for fused in (0, 1, 0, 1):
-    c = quadrotor_lmpc(20, device=0)
+for name, legacy, fused in (("legacy", 1, 0), ("lean", 0, 0), ("lean-fused", 0, 1), ("legacy", 1, 0), ("lean", 0, 0), ("lean-fused", 0, 1)):
+    c = quadrotor_lmpc(ph, device=0)
+    c._lib.mpcx_lmpc_debug_use_legacy(c._h, legacy)
     c.debug_use_fused(bool(fused))
     b, r, keep = c.make_batch(x0, u0, yref=yref)
     s = torch.cuda.current_stream(0)
@@ -31,6 +33,7 @@ for fused in (0, 1, 0, 1):
     if ref is None:
         ref = out
     dcmd = np.abs(out[0] - ref[0]).max(); dcost = np.abs(out[1] - ref[1]).max() / np.abs(ref[1]).max()
-    print("fused", fused, "batch", B, "ms/step %.4f" % dt, "kernels", [round(v, 4) for v in ms3], "rounds mean %.2f max %d" %
-          (r.polish_rounds.float().mean().item(), r.polish_rounds.max().item()), "solved", (r.status == 0).float().mean().item(),
-          "max|dcmd| %.2e rel dcost %.2e status equal %s" % (dcmd, dcost, np.array_equal(out[2], ref[2])))
+    print("%-11s batch %d N %d ms/step %.4f" % (name, B, ph, dt), "kernels", [round(v, 4) for v in ms3], "rounds mean %.2f max %d" %
+          (r.polish_rounds.float().mean().item(), r.polish_rounds.max().item()), "admm iters max %d" % r.iterations.max().item(),
+          "solved", (r.status == 0).float().mean().item(),
+          "max|dcmd| %.2e rel dcost %.2e status equal %s" % (dcmd, dcost, np.array_equal(out[2], ref[2])), flush=True)

@@ -33,6 +33,14 @@ ms2 = (C.c_float * 3)()
 c._lib.mpcx_lmpc_debug_time_kernels(c._h, C.byref(batch), C.c_void_p(torch.cuda.current_stream().cuda_stream), 20, ms2)
 print("assemble ms %.4f  polish-solve ms %.4f  admm-fallback ms %.4f" % (ms2[0], ms2[1], ms2[2]))
 rd = res.polish_rounds.cpu().numpy()
+na = res.active_count.cpu().numpy()
+A = np.stack([np.ones_like(rd, dtype=float), rd.astype(float)], axis=1)
+coef, *_ = np.linalg.lstsq(A, d[:, 1].astype(float), rcond=None)
+print("solve cycles ~ %.0f + %.0f x rounds (least squares over instances); rounds mean %.2f max %d" % (coef[0], coef[1], rd.mean(), rd.max()))
+for lo, hi in ((0, 4), (5, 6), (7, 8), (9, 12), (13, 16)):
+    sel = (na >= lo) & (na <= hi) & (rd >= 2)
+    if sel.sum() > 4:
+        print("   final |A| in [%d, %d]: %5d instances, cycles per round (median) %.0f" % (lo, hi, sel.sum(), np.median(d[sel, 1] / rd[sel])))
 start = t[:, 0] - t[:, 0].min(); end = t[:, 3] - t[:, 0].min()
 order = np.argsort(end)[::-1][:8]
 print("last finishers: (instance, rounds, start, end, own cycles)")
