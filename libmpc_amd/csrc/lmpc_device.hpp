@@ -15,12 +15,6 @@
 
 namespace mpcx {
 
-#ifndef MPCX_QUEUE_KEYS
-#define MPCX_QUEUE_KEYS 4               // difficulty classes of the dispatch order ...
-#define MPCX_QUEUE_SHIFT 2              // ... class = min(rows violated at the unconstrained optimum >> shift, classes - 1)
-#endif
-constexpr int kLmpcQueueWays = 64;      // sub-queues per class (spreads the device-scope atomics)
-constexpr int kLmpcQueues = MPCX_QUEUE_KEYS * kLmpcQueueWays;
 constexpr int kMaxActive = 28;          // working-set capacity of the in-kernel polish
 constexpr int kSld = kMaxActive + 1;    // LDS row stride of the Schur complement
 
@@ -57,7 +51,7 @@ struct LmpcDev {
     int kin, nxp, nup, nyp, ione, nz16, mg16, ns, ns16, kq16, rowsA, ldy16;
     const double *MA0, *MA1, *Ym, *slo, *shi;
     // composed maps of the fused solve kernel: rows [t0; gt0 (ldy) | goff (ldg) | f (ldz) | feasibility rows (nsp) | Qc vin (kin)]
-    int rowsF, nsp, fused_ok;
+    int rowsF, nsp, fused_ok, group_ok;
     const double *MF0, *MF1;
 };
 
@@ -77,9 +71,7 @@ struct LmpcBatchDev {
     const uint32_t *warm_lower, *warm_upper;      // optional previous active sets (reference row numbering)
     int warm_shift;
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
-    int *qcnt, *qlist; int qcap, qreset;                  // difficulty queues built by lmpc_assemble_mfma (null: identity order)
-    int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1
-    int legacy;                                   // 1: the round-2 polish kernel (A/B measurements)
+    int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1; 3 / 4: lmpc_solve_group with MA0 / MA1
     int *pcounter;                                // work counter of the persistent fused kernel (null: one instance per launched wavefront)
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };

@@ -36,6 +36,9 @@ namespace {
 #define MPCX_FAST_PF 4
 #endif
 constexpr int kFastCap = 16;
+#ifndef MPCX_FAST_ADD_THETA_LATE
+#define MPCX_FAST_ADD_THETA_LATE 0.02       // ... and from the fourth round on (the instances still open then are the ones that set the launch time)
+#endif
 #ifndef MPCX_FAST_SAFE_AFTER
 #define MPCX_FAST_SAFE_AFTER 12       // rounds of the block repair rule before the single-exchange rule takes over
 #endif
@@ -184,13 +187,39 @@ __device__ __forceinline__ int ws_solve_reg(const gdp gY, const int ldy, const i
     return -1;
 }
 
+// the pads of a slice (written once per wavefront: nothing ever overwrites them except the solution w, whose pads are 0 too)
+template <int CPZ, int CPG>
+__device__ __forceinline__ void fast_init_pads(double *slice, const int ldz, const int ldg, const int lane)
+{
+    constexpr int ZP = 128 * CPZ, GPD = 128 * CPG;
+    const double INF = __builtin_huge_val();
+    double *t0s = slice, *gt0s = t0s + ZP, *lgs = gt0s + GPD, *ugs = lgs + GPD, *fs = ugs + GPD, *lam = fs + ZP + 2;
+#pragma unroll
+    for (int c = 0; c < CPZ; ++c) {
+        const int e = 128 * c + 2 * lane;
+        if (e >= ldz) { *reinterpret_cast<double2 *>(t0s + e) = make_double2(0.0, 0.0); *reinterpret_cast<double2 *>(fs + e) = make_double2(0.0, 0.0); }
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const int r = 128 * c + 2 * lane;
+        if (r >= ldg) {
+            *reinterpret_cast<double2 *>(gt0s + r) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(lgs + r) = make_double2(-INF, -INF);
+            *reinterpret_cast<double2 *>(ugs + r) = make_double2(INF, INF);
+        }
+    }
+    if (lane == 0) { lam[kFastCap] = 0.0; lam[kFastCap + 1] = 0.0; }      // where the rows outside the working set look their multiplier up
+}
+
 // this wavefront's LDS slice (doubles), ZP = 128 CPZ, GPD = 128 CPG -- every array padded to whole lane pairs so that no lane needs a
 // range predicate: t0 pads 0, bounds pad -inf / +inf (a padded row is never violated, never active):
 //   t0 [ZP] | gt0 [GPD] | lg [GPD] | ug [GPD] | f, later w [ZP] | c0, flag | lam [kFastCap + 2] | wsb [kFastCap + 2] | wsidx (ints) | scratch
 // lwuw: the workgroup's copy of the box bounds [lw (ZP) | uw (ZP)], padded the same way
 template <int CPZ, int CPG> constexpr int fast_slice_fixed() { return 2 * 128 * CPZ + 3 * 128 * CPG + 2 + 2 * (kFastCap + 2) + (kFastCap + 2) / 2 + 1; }
 
-template <int CPZ, int CPG, bool FUSED = false>
+// SRC: where the instance's record comes from -- 0 the workspace (two-kernel path), 1 computed here by fused_record (one mat-vec
+// with the composed maps), 2 already in the slice (lmpc_solve_group: the workgroup's MFMA assemble phase put it there)
+template <int CPZ, int CPG, int SRC = 0>
 __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
                            double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr)
 {
@@ -220,23 +249,12 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
 #pragma unroll
     for (int c = 0; c < CPG; ++c) { const int r = 128 * c + 2 * lane; offg[c] = ldz + (r < ldg ? r : 0); }
 
+    constexpr bool FUSED = SRC != 0;                 // the workspace holds no record of this instance
     // ---- the assembled problem: the workspace record the assemble kernel left, copied into the slice, or computed in place
-#pragma unroll
-    for (int c = 0; c < CPZ; ++c) {                  // pads first (the record overwrites what exists)
-        const int e = 128 * c + 2 * lane;
-        if (e >= ldz) { *reinterpret_cast<double2 *>(t0s + e) = make_double2(0.0, 0.0); *reinterpret_cast<double2 *>(fs + e) = make_double2(0.0, 0.0); }
-    }
-#pragma unroll
-    for (int c = 0; c < CPG; ++c) {
-        const int r = 128 * c + 2 * lane;
-        if (r >= ldg) {
-            *reinterpret_cast<double2 *>(gt0s + r) = make_double2(0.0, 0.0);
-            *reinterpret_cast<double2 *>(lgs + r) = make_double2(-INF, -INF);
-            *reinterpret_cast<double2 *>(ugs + r) = make_double2(INF, INF);
-        }
-    }
-    if (lane == 0) { lam[kFastCap] = 0.0; lam[kFastCap + 1] = 0.0; }      // where the rows outside the working set look their multiplier up
-    if constexpr (FUSED) {
+    if constexpr (SRC != 2) fast_init_pads<CPZ, CPG>(slice, ldz, ldg, lane);
+    if constexpr (SRC == 2) {
+        // nothing to do: the record is in place
+    } else if constexpr (SRC == 1) {
         RecPtrs rp{fs, t0s, gt0s, lgs, ugs, tail};
         fused_record(M, Bt, b, lane, scratch, rp, mf_lds);
     } else {
@@ -356,6 +374,11 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
 #ifdef MPCX_PROFILE_ROUNDS
             plast = (long long)__builtin_readcyclecounter();
 #endif
+            // A launch lasts as long as its slowest instance, and the slow ones are those that need many rounds: from the fourth
+            // round on a wavefront asks the instruction arbiter for precedence over its three neighbours on the SIMD.
+            if (rd == 3) __builtin_amdgcn_s_setprio(1);
+            else if (rd == 5) __builtin_amdgcn_s_setprio(2);
+            else if (rd == 7) __builtin_amdgcn_s_setprio(3);
             // ---- the working set, in row order, to LDS: unified index and bound value per row.  Straight-line code: a row that
             // is not in the set writes to the spare slot kFastCap (so does a row past the capacity, which ends the solve below).
             int na = 0;
@@ -472,7 +495,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
             if (!any_bad && !any_viol) { solved = true; break; }
             if (rd < MPCX_FAST_SAFE_AFTER) {
                 // every wrong-signed row leaves, and the rows violated by at least MPCX_FAST_ADD_THETA x the largest violation enter
-                const double thr = any_viol ? MPCX_FAST_ADD_THETA * wave_max_dpp(vm) : INF;
+                const double thr = any_viol ? (rd < 3 ? MPCX_FAST_ADD_THETA : MPCX_FAST_ADD_THETA_LATE) * wave_max_dpp(vm) : INF;
 #pragma unroll
                 for (int s = 0; s < NZS; ++s) actb[s] = badb[s] > dtol ? 0 : ((vb[s] > 0.0 && vb[s] >= thr) ? (lowb[s] ? -1 : 1) : actb[s]);
 #pragma unroll
@@ -498,6 +521,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
             MPCX_LAP(5);                             // 5: repair
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     stamp();   // 2: solved
 
     if (!infeasible && !solved) {
@@ -705,8 +729,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
     const int wpb = blockDim.x >> 6;
     for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
-        const int b = queued_instance(Bt, i, lane);
-        solve_fast<CPZ, CPG, false>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
+        solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
     }
 }
 
@@ -721,7 +744,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
     const int wpb = blockDim.x >> 6;
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_fast<CPZ, CPG, true>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
+        solve_fast<CPZ, CPG, 1>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
 }
 
 // The fused form as a persistent kernel: one workgroup of kPersistWaves wavefronts per CU loads the composed map into LDS once
@@ -753,11 +776,153 @@ __global__ __launch_bounds__(kPersistWaves * 64) void lmpc_solve_persistent(cons
     const int nwaves = gridDim.x * kPersistWaves, shard = blockIdx.x & 7;
     int b = blockIdx.x * kPersistWaves + wave;
     while (b < Bt.batch) {
-        solve_fast<CPZ, CPG, true>(M, Bt, b, lane, rec, lwuw, glw(wsbase) + (size_t)b * M.wsld, smem);
+        solve_fast<CPZ, CPG, 1>(M, Bt, b, lane, rec, lwuw, glw(wsbase) + (size_t)b * M.wsld, smem);
         int n = 0;
         if (lane == 0) n = atomicAdd(counter + shard, 1);
         n = __builtin_amdgcn_readfirstlane(n);
         b = nwaves + shard + 8 * n;
+    }
+}
+
+// =====================================================================================
+// assemble + solve in one workgroup: sixteen instances per workgroup of sixteen wavefronts
+// =====================================================================================
+// Phase 1 is lmpc_assemble_mfma (lmpc_kernels.hip) on sixteen wavefronts instead of four: ProblemBuilder::get for sixteen instances
+// as two small GEMMs on v_mfma_f64_16x16x4_f64 (instances = the N dimension), every row tile written straight into the LDS slice
+// of its instance.  Phase 2: wavefront w solves instance w from its slice (solve_fast, SRC = 2).  No workspace record, no second
+// launch: the only HBM traffic of a solve is its inputs and outputs.  One workgroup per CU; at the benchmark batch the launch is
+// one workgroup deep.  A workgroup moves on when its slowest instance is done, so long batches use the two-kernel path instead.
+constexpr int kGroupWaves = 16;
+constexpr int kGroupKU = 20;              // MFMA k-steps whose A operands are in flight together (the whole of N = 20's second product)
+__global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase, const int variant)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nx = M.nx, nu = M.nu, ny = M.ny;
+    const int kin4 = M.kin >> 2, nz4 = M.nz16 >> 2;
+    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
+    constexpr int ZP = 128, GPD = 128;
+    double *lwuw = smem;
+    double *slices = lwuw + 2 * ZP;
+    double *Bv = slices + (size_t)kGroupWaves * M.fast_slice;      // [kin4][64]   vin as MFMA B operands
+    double *Bf = Bv + (size_t)kin4 * 64;                           // [nz4][64]    f as MFMA B operands
+    double *c0s = Bf + (size_t)nz4 * 64;                           // [16 wavefronts][16 instances]
+    unsigned *bad = reinterpret_cast<unsigned *>(c0s + kGroupWaves * 16);   // [16]
+    fast_load_box<1>(M, lwuw);
+    double *mine = slices + (size_t)wave * M.fast_slice;
+    const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
+    const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
+    // the slice of instance j (this lane's MFMA column)
+    double *sj = slices + (size_t)j * M.fast_slice;
+    double *t0j = sj, *gt0j = sj + ZP, *lgj = gt0j + GPD, *ugj = lgj + GPD, *fj = ugj + GPD;
+
+    for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
+        const int bj = b0 + j;
+        const int bc = bj < Bt.batch ? bj : Bt.batch - 1;
+        const long long ta0 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
+        fast_init_pads<1, 1>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
+        // vin operands: k-step kb holds rows 4kb + kq of instance j
+        for (int kb = wave; kb < kin4; kb += kGroupWaves) {
+            const int k = 4 * kb + kq;
+            double v = 0.0;
+            if (k < M.nxp) { if (k < nx) v = gl(Bt.x0)[(size_t)bc * nx + k]; }
+            else if (k < M.nxp + M.nup) { const int c = k - M.nxp; if (c < nu) v = gl(Bt.u0)[(size_t)bc * nu + c]; }
+            else if (k < M.ione) { const int c = k - M.nxp - M.nup; if (variant && c < ny) v = gl(Bt.yref)[(size_t)bc * Bt.yref_bs + c]; }
+            else if (k == M.ione) v = 1.0;
+            Bv[kb * 64 + lane] = v;
+        }
+        if (threadIdx.x < 16) bad[threadIdx.x] = 0u;
+        __syncthreads();
+
+        double c0p = 0.0;
+        bool badl = false;
+        for (int t = wave; t < ntile1; t += kGroupWaves) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const gdp Mt = MA + 16 * t + j;
+            // every A operand of the tile requested at once: nothing else is resident on this CU to hide a chain of L2 round trips
+            for (int kb = 0; kb < kin4; kb += kGroupKU) {
+                double a[kGroupKU], bq[kGroupKU];
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) a[u] = Mt[(size_t)(4 * (kb + u < kin4 ? kb + u : kb) + kq) * M.rowsA];
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) bq[u] = kb + u < kin4 ? Bv[(kb + u < kin4 ? kb + u : kb) * 64 + lane] : 0.0;
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+            if (t < tg) {
+                // linear term: operand of the second product, and the instance's f
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Bf[(4 * t + r) * 64 + lane] = acc[r];
+                    const int row = 16 * t + 4 * r + kq;
+                    if (row < ldz) fj[row] = acc[r];
+                }
+            } else if (t < ts) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (t - tg) + 4 * r + kq;
+                    if (row < ldg) { lgj[row] = GP(lg0)[row] - acc[r]; ugj[row] = GP(ug0)[row] - acc[r]; }
+                }
+            } else if (t < tq) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (t - ts) + 4 * r + kq;
+                    if (row < M.ns) badl |= violates(acc[r], GP(slo)[row], GP(shi)[row], M.eps_abs, M.eps_rel);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kb2 = 4 * (t - tq) + r;
+                    if (kb2 < kin4) c0p = fma(0.5 * Bv[kb2 * 64 + lane], acc[r], c0p);
+                }
+            }
+        }
+        if (badl) atomicOr(&bad[j], 1u);
+        // this wavefront's share of the cost constant of instance j (no atomics: the sum must not depend on arrival order)
+        c0p += __shfl_xor(c0p, 16, 64);
+        c0p += __shfl_xor(c0p, 32, 64);
+        if (kq == 0) c0s[wave * 16 + j] = c0p;
+        __syncthreads();
+        const long long ta1 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
+
+        const int ntile2 = M.ldy16 >> 4;
+        for (int t = wave; t < ntile2; t += kGroupWaves) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const gdp Yt = Ym + 16 * t + j;
+            for (int kb = 0; kb < nz4; kb += kGroupKU) {
+                double a[kGroupKU], bq[kGroupKU];
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) a[u] = Yt[(size_t)(4 * (kb + u < nz4 ? kb + u : kb) + kq) * M.ldy16];
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) bq[u] = kb + u < nz4 ? Bf[(kb + u < nz4 ? kb + u : kb) * 64 + lane] : 0.0;
+#pragma unroll
+                for (int u = 0; u < kGroupKU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * r + kq;
+                if (row < ldz) t0j[row] = acc[r];
+                else if (row < ldy) gt0j[row - ldz] = acc[r];
+            }
+        }
+        if (threadIdx.x < 16) {
+            double *tl = slices + (size_t)threadIdx.x * M.fast_slice + 2 * ZP + 3 * GPD;
+            double c0 = 0.0;
+            for (int w = 0; w < kGroupWaves; ++w) c0 += c0s[w * 16 + threadIdx.x];
+            tl[0] = c0;
+            tl[1] = bad[threadIdx.x] ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const int b = b0 + wave;
+        const long long ta2 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
+        if (b < Bt.batch) {
+            solve_fast<1, 1, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld);
+            // profiling aid: when the workgroup started this batch, when the first product was done, when the records were complete
+            if (Bt.dbg_cycles && lane == 0) { Bt.dbg_cycles[(size_t)b * 8 + 4] = ta0; Bt.dbg_cycles[(size_t)b * 8 + 5] = ta1; Bt.dbg_cycles[(size_t)b * 8 + 6] = ta2; }
+        }
+        __syncthreads();
     }
 }
 
@@ -787,6 +952,20 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
+    if (fused && b.fused >= 3) {
+        // assemble + solve in one workgroup of sixteen wavefronts (one per CU)
+        const size_t ldsg = ((size_t)2 * 128 + (size_t)kGroupWaves * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + kGroupWaves * 16 + 16) * sizeof(double);
+        if (ldsg > 160 * 1024) return -2;
+        static std::atomic<int> gconf[64];
+        if (!gconf[devid].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+            gconf[devid].store(1, std::memory_order_release);
+        }
+        int wgs = (b.batch + 15) / 16;
+        if (wgs > 256) wgs = 256;
+        hipLaunchKernelGGL(lmpc_solve_group, dim3(wgs), dim3(kGroupWaves * 64), ldsg, stream, m_dev, b, ws, b.fused - 3);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     // persistent form: the composed map, the box bounds and kPersistWaves slices must fit one CU's LDS, and the batch must be worth
     // the prologue of every workgroup (the composed map: 87 KB at N = 20)
     const size_t ldsp = ((size_t)m.rowsF * m.kin + 2 * (size_t)128 + kPersistWaves * (size_t)m.fast_slice) * sizeof(double);
@@ -813,7 +992,9 @@ int lmpc_fast_slice(const LmpcDev &m)
     if (cp < 1) return 0;
     const int fixed = cp == 1 ? fast_slice_fixed<1, 1>() : (cp == 2 ? fast_slice_fixed<2, 2>() : fast_slice_fixed<4, 4>());
     const int scratch = m.kin > 2 * m.nx ? m.kin : 2 * m.nx;    // vin of the fused record / ping-pong state of the sequence roll-out
-    return (fixed + scratch + 1) / 2 * 2;
+    int n = (fixed + scratch + 1) / 2 * 2;
+    while (n % 16 != 2) n += 2;                                 // slices 2 doubles apart modulo the 32 LDS banks x 4 bytes
+    return n;
 }
 
 int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)

@@ -19,8 +19,6 @@ namespace {
 #endif
 constexpr int kWavesPerBlock = MPCX_WAVES_PER_BLOCK;
 constexpr int kFallbackChunk = 64;      // instances one wavefront of the fallback kernel screens (one flag per lane)
-constexpr int kQueues = mpcx::kLmpcQueues;        // difficulty classes x kQueueWays sub-queues (to spread the atomics)
-constexpr int kQueueWays = mpcx::kLmpcQueueWays, kQueueKeys = kQueues / kQueueWays;
 // a working set with all signs right grows by the rows violated by at least this fraction of the largest violation: adding
 // every violated row at once over-constrains, the surplus rows are shed one round later and the slowest instances ping-pong
 // (max rounds 18-22 over six batches of 4096 with 0, 12-14 with 0.3; 0.1 and 0.5 are worse than either)
@@ -264,28 +262,6 @@ __device__ MPCX_FUSED_RECORD_INLINE void fused_record(const LmpcDev &M, const Lm
     const bool anybad = wave_any(bad);
     if (lane == 0) *reinterpret_cast<double2 *>(rp.tail) = make_double2(c0p, anybad ? 1.0 : 0.0);
     wave_sync();
-}
-
-// i-th instance in dispatch order: hardest class first, its ways in turn (identity when no queues were built).
-// kQueueWays == 64: lane l reads the counter of way l, a wave scan finds the way that holds position i.
-__device__ __forceinline__ int queued_instance(const LmpcBatchDev &Bt, int i, int lane)
-{
-    if (!Bt.qcnt) return i;
-    int rem = i;
-    for (int c = kQueueKeys - 1; c >= 0; --c) {
-        const int n = min(Bt.qcnt[c * kQueueWays + lane], Bt.qcap);
-        int incl = n;
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const int tot = __shfl(incl, 63);
-        if (rem < tot) {
-            const unsigned long long hit = __ballot(incl > rem);
-            const int L = (int)__builtin_ctzll(hit);
-            const int pos = rem - (__shfl(incl, L) - __shfl(n, L));
-            return Bt.qlist[(size_t)(c * kQueueWays + L) * Bt.qcap + pos];
-        }
-        rem -= tot;
-    }
-    return i;        // not reached when every instance was queued
 }
 
 }  // namespace

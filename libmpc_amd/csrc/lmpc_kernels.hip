@@ -254,13 +254,11 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
     const int j = lane & 15, kq = lane >> 4;
     const int nx = M.nx, nu = M.nu, ny = M.ny;
     const int kin4 = M.kin >> 2, nz4 = M.nz16 >> 2;
-    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy, nz = M.nz, mg = M.mg;
+    const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
     double *Bv = smem;                               // [kin4][64]   vin as MFMA B operands
     double *Bf = Bv + (size_t)kin4 * 64;             // [nz4][64]    f as MFMA B operands
     double *c0s = Bf + (size_t)nz4 * 64;             // [4][16]: one slot per wavefront and instance, added up in wave order
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + 64);   // [16]
-    unsigned *nviol = bad + 16;                                // [16] rows violated at the unconstrained optimum
-    double *offs = c0s + 64 + 32;                              // [ldg][16] row offsets (only when the queue is built)
     const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
 
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             else if (k == M.ione) v = 1.0;
             Bv[kb * 64 + lane] = v;
         }
-        if (threadIdx.x < 16) { bad[threadIdx.x] = 0u; nviol[threadIdx.x] = 0u; }
+        if (threadIdx.x < 16) bad[threadIdx.x] = 0u;
         __syncthreads();
 
         gdw wsj = glw(wsbase) + (size_t)bc * M.wsld;
@@ -315,7 +313,6 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
                         wsj[ldz + ldy + row] = GP(lg0)[row] - acc[r];
                         wsj[ldz + ldy + ldg + row] = GP(ug0)[row] - acc[r];
                     }
-                    if (Bt.qcnt && row < ldg) offs[row * 16 + j] = acc[r];
                 }
             } else if (t < tq) {
 #pragma unroll
@@ -351,19 +348,11 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             }
             for (; kb < nz4; ++kb)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
-            unsigned nv = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
                 if (live && row < ldy) wsj[ldz + row] = acc[r];
-                if (Bt.qcnt) {              // same test as the first working set of lmpc_solve
-                    double lo = -__builtin_inf(), hi = __builtin_inf();
-                    if (row < nz) { lo = GP(lw)[row]; hi = GP(uw)[row]; }
-                    else if (row >= ldz && row - ldz < mg) { const double o = offs[(row - ldz) * 16 + j]; lo = GP(lg0)[row - ldz] - o; hi = GP(ug0)[row - ldz] - o; }
-                    nv += (acc[r] < lo - 1e-8 * fmax(1.0, fabs(lo))) || (acc[r] > hi + 1e-8 * fmax(1.0, fabs(hi)));
-                }
             }
-            if (Bt.qcnt && nv) atomicAdd(&nviol[j], nv);
         }
         // this wavefront's share of the cost constant of instance j (no atomics: the sum must not depend on arrival order)
         c0p += __shfl_xor(c0p, 16, 64);
@@ -374,28 +363,6 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
             gdw wst = glw(wsbase) + (size_t)(b0 + threadIdx.x) * M.wsld + ldz + ldy + 2 * ldg;
             wst[0] = ((c0s[threadIdx.x] + c0s[16 + threadIdx.x]) + c0s[32 + threadIdx.x]) + c0s[48 + threadIdx.x];
             wst[1] = bad[threadIdx.x] ? 1.0 : 0.0;
-        }
-        if (Bt.qcnt) {
-            // difficulty queues: the rounds an instance needs grow with its working set, and a launch lasts as long as its
-            // slowest wavefront -- instances with many violated rows are dispatched first.  kQueueKeys classes x kQueueWays
-            // ways (the way is the workgroup's, which spreads the device-scope atomics: one per class and workgroup).
-            int *cls = reinterpret_cast<int *>(nviol + 16), *cbase = cls + 16;
-            const int way = blockIdx.x & (kQueueWays - 1);
-            if (threadIdx.x < 16) cls[threadIdx.x] = b0 + (int)threadIdx.x < Bt.batch ? min((int)nviol[threadIdx.x] >> MPCX_QUEUE_SHIFT, kQueueKeys - 1) : -1;
-            __syncthreads();
-            if (threadIdx.x < kQueueKeys) {
-                int n = 0;
-                for (int u = 0; u < 16; ++u) n += cls[u] == (int)threadIdx.x;
-                cbase[threadIdx.x] = n ? atomicAdd(&Bt.qcnt[threadIdx.x * kQueueWays + way], n) : 0;
-            }
-            __syncthreads();
-            if (threadIdx.x < 16 && cls[threadIdx.x] >= 0) {
-                const int c = cls[threadIdx.x];
-                int rank = 0;
-                for (int u = 0; u < (int)threadIdx.x; ++u) rank += cls[u] == c;
-                const int pos = cbase[c] + rank;
-                if (pos < Bt.qcap) Bt.qlist[(size_t)(c * kQueueWays + way) * Bt.qcap + pos] = b0 + threadIdx.x;
-            }
         }
         __syncthreads();
     }
@@ -1260,23 +1227,6 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
 }
 
 
-// the round-2 polish kernel, kept for A/B measurements (mpcx_lmpc_debug_use_legacy)
-template <int CPZ, int CPG>
-__global__ __launch_bounds__(kWavesPerBlock * 64, MPCX_SOLVE_WAVES) void lmpc_solve_legacy(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *stage = smem + (size_t)wave * M.lds_per_wave;
-    double *nt0 = stage + M.stage_len;
-    double *arena = nt0 + M.ldy;
-    const int wpb = blockDim.x >> 6;
-    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
-        const int b = queued_instance(Bt, i, lane);
-        solve_one<CPZ, CPG, false>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
-    }
-}
-
 // Fallback for the instances the polish-only kernel left unsolved (a handful in a thousand, or
 // everything when polish is switched off): ADMM iterations, then polish again.
 template <int CPZ, int CPG>
@@ -1308,9 +1258,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
         for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
             solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
     }
-    // last kernel of a launch: leave the dispatch queues empty for the next one
-    if (Bt.qcnt && Bt.qreset && blockIdx.x == 0)
-        for (int q = threadIdx.x; q < kQueues; q += blockDim.x) Bt.qcnt[q] = 0;
 }
 
 
@@ -1391,7 +1338,6 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
     if (lds > 160 * 1024) return -2;
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
-    auto k2l = lmpc_solve_legacy<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
     // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
     // two handles on different GPUs cannot skip or tear the update)
@@ -1401,7 +1347,6 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     devid &= 63;
     if (lds > configured[devid].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k2l), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         size_t prev = configured[devid].load(std::memory_order_relaxed);
@@ -1413,10 +1358,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     if (blocks < 1) blocks = 1;
     const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
     if ((which & 1) && !fused) {
-        // the counters are cleared by the last kernel of a full launch; partial launches (profiling) clear them here
-        if (b.qcnt && which != 7) (void)hipMemsetAsync(b.qcnt, 0, kQueues * sizeof(int), stream);
         if (fast >= 0) {
-            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 64 + 32 + (b.qcnt ? (size_t)m.ldg * 16 : 0)) * sizeof(double);
+            const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 64 + 32) * sizeof(double);
             int blocks1 = (b.batch + 15) / 16;
             if (blocks1 > 4096) blocks1 = 4096;
             hipLaunchKernelGGL(lmpc_assemble_mfma, dim3(blocks1), dim3(256), lds1, stream, m_dev, b, ws, fast);
@@ -1425,8 +1368,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
         }
     }
     if (which & 2) {
-        if (b.legacy && !fused) hipLaunchKernelGGL(k2l, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
-        else {
+        {
             LmpcBatchDev bf = b;
             if (!fused) bf.fused = 0;
             const int rf = lmpc_launch_fast(m, m_dev, bf, ws, stream);      // lean kernels (lmpc_fast.hip)

@@ -44,21 +44,20 @@ struct mpcx_lmpc {
     bool force_generic = false;
     bool strict_infeasible = false;
     int dbg_rounds0 = 30, dbg_check_every = 10;      // experiment knobs (mpcx_lmpc_debug_set_rounds)
-    bool use_legacy = false;            // A/B: the round-2 polish kernel instead of the lean one (mpcx_lmpc_debug_use_legacy)
-    bool use_queues = true;             // hardest-first dispatch order for lmpc_solve (MFMA assemble path)
     // Fused forms (lmpc_solve_fused / lmpc_solve_persistent): the instance's record is computed inside the solve kernel instead of
     // being handed over through the HBM workspace (3 MB instead of 25 MB of traffic per 4096 instances), but the hardest-first
     // dispatch order of the two-kernel path is lost -- worth 22 us of its 70 us at 4096 instances, nothing at large batches.
     // Measured (quadrotor N = 20, ms per step, two kernels / fused): 4096: 0.097 / 0.125; 16384: 0.309 / 0.300; 65536: 1.10 / 1.00.
     // -1 = automatic (fused from 16384 instances on), 0 = never, 1 = wherever the dimensions allow (mpcx_lmpc_debug_use_fused)
     int use_fused = -1;
+    int group_max = 4096;               // automatic mode: batches up to this size take lmpc_solve_group (assemble + solve in one workgroup)
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
     double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
     size_t stage_cap = 0;               // instances
     int warm_batch = 0;                 // batch size whose active sets are in stage_act (0: none)
     int n_full_setups = 0, n_ref_refreshes = 0;      // how often each kind of set-up ran (mpcx_lmpc_debug_setup_counts)
     double *ws = nullptr;               // per-instance workspace between assemble and solve
-    int *queues = nullptr;              // dispatch queues: kLmpcQueues counters, then kLmpcQueues lists of ws_cap instances
+    int *pcounter = nullptr;            // work counters of the persistent fused kernel (eight ints of its own)
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
 
@@ -67,8 +66,8 @@ struct mpcx_lmpc {
         for (void *p : allocs) (void)hipFree(p);
         allocs.clear();
         if (ws) (void)hipFree(ws);
-        if (queues) (void)hipFree(queues);
-        ws = nullptr; queues = nullptr; ws_cap = 0;
+        if (pcounter) (void)hipFree(pcounter);
+        ws = nullptr; pcounter = nullptr; ws_cap = 0;
         warm_batch = 0;                 // row numbering may have changed with the model
     }
     void release_staging()
@@ -464,6 +463,8 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
     // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
     D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384 && !D.cost_direct) ? 1 : 0;
+    // assemble + solve in one workgroup (lmpc_solve_group): the one-chunk variant, cost from the multipliers
+    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct) ? 1 : 0;
     D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
@@ -505,7 +506,6 @@ static int make_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, mpcx::LmpcBatchDe
     B.warm_lower = b->warm_active_lower; B.warm_upper = b->warm_active_upper; B.warm_shift = b->warm_shift;
     if ((B.warm_lower == nullptr) != (B.warm_upper == nullptr)) return fail(MPCX_E_INVALID, "warm_active_lower and warm_active_upper go together");
     B.dbg_cycles = h->dbg_cycles;
-    B.legacy = h->use_legacy ? 1 : 0;
     return MPCX_OK;
 }
 
@@ -524,14 +524,13 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     if ((size_t)b->batch > h->ws_cap) {
         // grows only when a larger batch than ever before arrives (not capturable in a graph)
         if (h->ws) (void)hipFree(h->ws);
-        if (h->queues) (void)hipFree(h->queues);
-        h->ws = nullptr; h->queues = nullptr; h->ws_cap = 0;
-        const size_t qcap = (size_t)b->batch / mpcx::kLmpcQueueWays + 16;       // a way only receives its own workgroups' instances
-        const size_t qn = (size_t)mpcx::kLmpcQueues * (qcap + 1);
-        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&h->queues), qn * sizeof(int)) != hipSuccess)
+        h->ws = nullptr; h->ws_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess)
             return fail(MPCX_E_DEVICE, "workspace allocation failed");
-        (void)hipMemset(h->queues, 0, mpcx::kLmpcQueues * sizeof(int));
+        if (!h->pcounter) {
+            if (hipMalloc(reinterpret_cast<void **>(&h->pcounter), 8 * sizeof(int)) != hipSuccess) return fail(MPCX_E_DEVICE, "workspace allocation failed");
+            (void)hipMemset(h->pcounter, 0, 8 * sizeof(int));
+        }
         h->ws_cap = (size_t)b->batch;
     }
     // the MFMA assemble kernel serves shared or per-instance-constant output references with
@@ -541,10 +540,8 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
-    // hardest-first dispatch only pays while a launch is several waves of dispatches deep: the round-2 kernel at two wavefronts per
-    // SIMD.  The lean kernel keeps a batch of 4096 resident at once.
-    else if (fast >= 0 && h->use_queues && h->use_legacy) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); B.qreset = 1; }
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) B.fused = fast + 3;
+    else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
     if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
@@ -723,8 +720,8 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && (h->use_fused > 0 || b->batch >= 16384)) { B.fused = fast + 1; B.pcounter = h->queues; }
-    else if (fast >= 0 && h->use_queues && h->use_legacy) { B.qcnt = h->queues; B.qlist = h->queues + mpcx::kLmpcQueues; B.qcap = (int)(h->ws_cap / mpcx::kLmpcQueueWays + 16); }
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) B.fused = fast + 3;
+    else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -751,7 +748,6 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         }
         ms2[which == 1 ? 0 : (which == 2 ? 1 : 2)] = ms / (float)repeats;
     }
-    if (B.qcnt) (void)hipMemsetAsync(B.qcnt, 0, mpcx::kLmpcQueues * sizeof(int), s);     // full launches expect empty queues
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MPCX_OK;
 }
@@ -765,28 +761,12 @@ int mpcx_lmpc_debug_setup_counts(mpcx_lmpc_t h, int *full, int *refs)
     return MPCX_OK;
 }
 
-/* testing aid: 0 = dispatch lmpc_solve in instance order instead of hardest-first */
-int mpcx_lmpc_debug_use_queues(mpcx_lmpc_t h, int on)
-{
-    CHECK_H(h);
-    h->use_queues = on != 0;
-    return MPCX_OK;
-}
-
-/* A/B knob: 1 = the round-2 polish kernel (drop-then-add repair rule, LDL' + substitutions) instead of the lean one */
-int mpcx_lmpc_debug_use_legacy(mpcx_lmpc_t h, int on)
-{
-    CHECK_H(h);
-    h->use_legacy = on != 0;
-    return MPCX_OK;
-}
-
 /* experiment / testing knob: 1 = wherever the dimensions allow, compute each instance's record inside the solve kernel instead of
  * handing it over through the HBM workspace; 0 = never; -1 = automatic (the default: from 16384 instances on) */
 int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int on)
 {
     CHECK_H(h);
-    h->use_fused = on < 0 ? -1 : (on != 0);
+    h->use_fused = on < 0 ? -1 : (on > 2 ? 2 : on);      // 2: lmpc_solve_group (assemble + solve in one workgroup of sixteen wavefronts)
     h->dirty = true;
     return MPCX_OK;
 }

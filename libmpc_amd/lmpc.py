@@ -295,10 +295,11 @@ class LMPC:
         check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))
 
     def debug_use_fused(self, on=True):
-        """experiment knob: True = fused solve kernel wherever the dimensions allow, False = never, None = automatic (default)"""
-        check(self._lib.mpcx_lmpc_debug_use_fused(self._h, -1 if on is None else int(bool(on))))
+        """experiment / testing knob: False / 0 = assemble and solve as two kernels, True / 1 = the record computed inside the solve
+        kernel by one mat-vec (persistent form from 1024 instances on), 2 = assemble + solve in one workgroup of sixteen
+        wavefronts (lmpc_solve_group), -1 = automatic (the default: the workgroup form up to 8192 instances, two kernels beyond)"""
+        check(self._lib.mpcx_lmpc_debug_use_fused(self._h, -1 if on is None else int(on)))
 
-    # -- the hot path ------------------------------------------------------------------
     def _torch(self):
         import torch
         if self.device < 0 or not torch.cuda.is_available():

@@ -196,3 +196,51 @@ def bits_to_rows(words, m):
 def rel_err(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def oracle_batch_parallel(ph, x0, u0, yref, want_active=False, workers=None, **kw):
+    """solve_batch_constref of the C oracle over a thread pool (ctypes releases the GIL during the call; one oracle handle per
+    thread): the whole benchmark batch in seconds instead of a sample of it"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    B = len(x0)
+    workers = workers or max(1, min(16, (os.cpu_count() or 1)))
+    bounds = np.linspace(0, B, workers + 1).astype(int)
+    def job(k):
+        lo, hi = bounds[k], bounds[k + 1]
+        if hi <= lo:
+            return None
+        return quadrotor_oracle(ph, **kw).solve_batch_constref(x0[lo:hi], u0[lo:hi], yref[lo:hi], want_active=want_active)
+    with ThreadPoolExecutor(workers) as ex:
+        parts = [r for r in ex.map(job, range(workers)) if r is not None]
+    out = {}
+    for k in parts[0]:
+        if parts[0][k] is None or np.isscalar(parts[0][k]):
+            out[k] = parts[0][k]
+        else:
+            out[k] = np.concatenate([p_[k] for p_ in parts])
+    return out
+
+
+def assert_matches_oracle(r, ref, o_neq, o_ncon, rtol_cmd=1e-5, rtol_cost=1e-7, check_active=True):
+    """GPU batch result against oracle results: cmd, cost on the instances the oracle polished, active sets bit for bit there,
+    loose on the others (the reference returns an eps = 1e-4 ADMM iterate there, the GPU the exact optimum); returns the number
+    of unpolished instances"""
+    cmd = r.cmd.cpu().numpy(); cost = r.cost.cpu().numpy(); st = r.status.cpu().numpy()
+    pol = ref["polished"] == 1
+    assert np.array_equal(st[ref["status"] == 0], np.zeros((ref["status"] == 0).sum(), dtype=st.dtype))
+    scale = np.maximum(np.abs(ref["cmd"]).max(axis=1), 1e-12)
+    err = np.abs(cmd - ref["cmd"]).max(axis=1) / scale
+    assert err[pol].max() <= rtol_cmd, (err[pol].max(), int(np.argmax(err * pol)))
+    if (~pol).any():
+        assert err[~pol].max() <= 5e-2
+    cerr = np.abs(cost - ref["cost"]) / np.maximum(1.0, np.abs(ref["cost"]))
+    assert cerr[pol].max() <= rtol_cost, cerr[pol].max()
+    if check_active:
+        wl = np.ascontiguousarray(r.active_lower.cpu().numpy()).astype(np.uint32); wu = np.ascontiguousarray(r.active_upper.cpu().numpy()).astype(np.uint32)
+        bl = np.unpackbits(wl.view(np.uint8).reshape(len(wl), -1), axis=1, bitorder="little")[:, :o_ncon]
+        bu = np.unpackbits(wu.view(np.uint8).reshape(len(wu), -1), axis=1, bitorder="little")[:, :o_ncon]
+        rl = (ref["active_lower"] != 0).astype(np.uint8); ru = (ref["active_upper"] != 0).astype(np.uint8)
+        same = (bl[:, o_neq:] == rl[:, o_neq:]).all(axis=1) & (bu[:, o_neq:] == ru[:, o_neq:]).all(axis=1)
+        assert same[pol].all(), int(np.argmin(same | ~pol))
+    return int((~pol).sum())

@@ -134,3 +134,41 @@ def study2(ph, B):
         namax = max(max(x[1]) if x[1] else 0 for x in rr)
         print("add %.2f init %.2f drop %.2f: mean %.2f p90 %d max %d cycles %d maxna %d hist %s" % (
             ta, t0, df, r[ok].mean(), np.percentile(r[ok], 90), r[ok].max(), (~ok).sum(), namax, np.bincount(r[ok])[:16]))
+
+
+def run3(Y, t, lo, hi, sched, theta0=0.3, maxr=40):
+    """simultaneous drop + add, add threshold by round: sched(rd) -> theta"""
+    ptol = 1e-8
+    tol_lo = lo - ptol * np.maximum(1, np.abs(lo)); tol_hi = hi + ptol * np.maximum(1, np.abs(hi))
+    v0 = np.maximum(np.maximum(tol_lo - t, t - tol_hi), 0.0)
+    act = np.where((v0 > 0) & (v0 >= theta0 * v0.max()), np.where(t < lo, -1, 1), 0)
+    seen = set()
+    for rd in range(1, maxr + 1):
+        key = act.tobytes()
+        if key in seen:
+            return -rd
+        seen.add(key)
+        w, lam, A = solve_ws(Y, t, lo, hi, act)
+        dtol = 1e-9 * (np.abs(lam).max() if len(lam) else 0) + 1e-300
+        bad = np.where(act[A] < 0, lam, -lam) if len(A) else np.zeros(0)
+        wrong = bad > dtol
+        viol = np.maximum(np.maximum(tol_lo - w, w - tol_hi), 0.0)
+        viol[A] = 0
+        if not wrong.any() and viol.max() <= 0:
+            return rd
+        act[A[wrong]] = 0
+        add = (viol > 0) & (viol >= sched(rd) * viol.max())
+        act[add] = np.where(w[add] < lo[add], -1, 1)
+    return -maxr
+
+
+def study3(ph, B):
+    Y, T, LO, HI = setup(ph, B)
+    scheds = {"0.2 flat": lambda r: 0.2, "0.2 then 0.05 from round 3": lambda r: 0.2 if r < 3 else 0.05, "0.2 then 0.1 from 3": lambda r: 0.2 if r < 3 else 0.1,
+              "0.3,0.2,0.1,0.05..": lambda r: max(0.05, 0.4 - 0.1 * r), "0.1 flat": lambda r: 0.1, "0.2 then 0.02 from 4": lambda r: 0.2 if r < 4 else 0.02,
+              "0.2 then 0 from 4": lambda r: 0.2 if r < 4 else 0.0}
+    for name, f in scheds.items():
+        for t0 in (0.3, 0.15):
+            r = np.array([run3(Y, T[i], LO[i], HI[i], f, t0) for i in range(B)])
+            ok = r > 0
+            print("%-28s init %.2f: mean %.3f p99 %d max %d cycles %d hist %s" % (name, t0, r[ok].mean(), np.percentile(r[ok], 99), r[ok].max(), (~ok).sum(), np.bincount(r[ok])[1:12]))

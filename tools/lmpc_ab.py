@@ -1,5 +1,6 @@
-"""A/B on the GPU box: the round-2 polish kernel against the lean one, each as two kernels (assemble -> workspace -> solve) and,
-for the lean one, in the fused forms (record computed inside the solve kernel; persistent with the composed map in LDS).
+"""A/B on the GPU box: the LMPC solve as two kernels (assemble -> workspace -> solve), with the record computed inside the solve kernel
+by one mat-vec (persistent with the composed map in LDS from 1024 instances on), and as one workgroup per sixteen instances
+(MFMA assemble into LDS, then one wavefront per instance).
 Prints ms per step, per-kernel times and the largest difference of the results to the first variant."""
 import ctypes as C
 import sys
@@ -14,10 +15,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ph = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 x0, u0, yref = quadrotor_batch(B)
 ref = None
-for name, legacy, fused in (("legacy", 1, 0), ("lean", 0, 0), ("lean-fused", 0, 1), ("legacy", 1, 0), ("lean", 0, 0), ("lean-fused", 0, 1)):
+for name, fused in (("two-kernel", 0), ("fused-matvec", 1), ("group", 2), ("two-kernel", 0), ("group", 2)):
     c = quadrotor_lmpc(ph, device=0)
-    c._lib.mpcx_lmpc_debug_use_legacy(c._h, legacy)
-    c.debug_use_fused(bool(fused))
+    c.debug_use_fused(fused)
     b, r, keep = c.make_batch(x0, u0, yref=yref)
     s = torch.cuda.current_stream(0)
     for _ in range(30):
