@@ -51,15 +51,32 @@ __device__ __forceinline__ void nl_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// Wave-wide reductions, the result in every lane.  Within a row of sixteen lanes by DPP operations (VALU, no LDS round trip --
+// the __shfl_xor butterfly compiles to six dependent ds_bpermute, about 700 cycles a reduction), across the four rows by
+// v_readlane.  The order of the additions is fixed: the same bits on every run.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
+{
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double lane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// 0xB1: quad_perm [1,0,3,2]; 0x4E: quad_perm [2,3,0,1]; 0x141: row_half_mirror; 0x140: row_mirror
 __device__ __forceinline__ double wave_sum(double v)
 {
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    // the argument is often a product: without this the compiler contracts it into the first addition for one operand (fma(a, b,
+    // moved copy of round(a b))) wherever inlining lets it see the product -- the same source then rounds differently from one
+    // instantiation to the next
+    asm volatile("" : "+v"(v));
+    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-    for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    v = fmax(v, dpp_d<0xB1>(v)); v = fmax(v, dpp_d<0x4E>(v)); v = fmax(v, dpp_d<0x141>(v)); v = fmax(v, dpp_d<0x140>(v));
+    return fmax(fmax(lane_d(v, 0), lane_d(v, 16)), fmax(lane_d(v, 32), lane_d(v, 48)));
 }
 
 // sum_j a[j * stride] * x[j]: the loads of a batch are issued together and waited for once -- the compiler does not
@@ -112,11 +129,16 @@ __device__ __forceinline__ double gdot2(const double *__restrict__ a, size_t sa,
 // largest value and the lowest lane-supplied index holding it
 __device__ __forceinline__ void wave_argmax(double &v, int &idx)
 {
-    for (int o = 32; o; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    auto take = [&](double ov, int oi) { if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } };
+    take(dpp_d<0xB1>(v), dpp_i<0xB1>(idx));
+    take(dpp_d<0x4E>(v), dpp_i<0x4E>(idx));
+    take(dpp_d<0x141>(v), dpp_i<0x141>(idx));
+    take(dpp_d<0x140>(v), dpp_i<0x140>(idx));
+    const double v0 = lane_d(v, 0), v1 = lane_d(v, 16), v2 = lane_d(v, 32), v3 = lane_d(v, 48);
+    const int i0 = __builtin_amdgcn_readlane(idx, 0), i1 = __builtin_amdgcn_readlane(idx, 16), i2 = __builtin_amdgcn_readlane(idx, 32),
+              i3 = __builtin_amdgcn_readlane(idx, 48);
+    v = v0; idx = i0;
+    take(v1, i1); take(v2, i2); take(v3, i3);
 }
 
 constexpr double kDv = 1.4901161193847656e-08;          // sqrt(DBL_EPSILON), Objective.hpp:283
