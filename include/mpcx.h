@@ -245,6 +245,7 @@ typedef struct mpcx_nlmpc_dims {
     int neq_user;/* user equalities (NLMPC::setEqConFunction)                                         */
     int ny;      /* outputs (NLMPC::setOutputFunction; zeros in the sequence when the model has none)  */
     int nbnd;    /* finite state / input bounds: rows nineq + neq_user .. of the sub-problem (multipliers) */
+    int n_params;/* model parameters of a built-in system = columns of mpcx_nlmpc_batch.params (0: hooks)  */
 } mpcx_nlmpc_dims;
 /* NLMPC::setDiscretizationSamplingTime / setStateSpaceFunction / setObjectiveFunction /
  * setIneqConFunction (NLMPC.hpp:108-214) for a built-in model; `params` (n doubles, may be NULL
@@ -413,6 +414,35 @@ int mpcx_comm_world(mpcx_comm_t c);
  * Enqueued on `stream` -- pass the stream of the preceding mpcx_*_solve_batch so that the collective starts when the
  * solve retires, with no host synchronisation in between.  u_all may not alias u_local.                              */
 int mpcx_allgather_u(mpcx_comm_t c, const double *u_local, int rows_per_rank, int nu, double *u_all, void *stream);
+
+/* ---- profiling and testing aids ------------------------------------------------------------------------------------
+ * Not part of the reference-facing surface, but part of the exported ABI: bench.py's roofline block, tools/ and tests/ call
+ * them, so they are declared (and kept) here.  "debug" in a name = may change between versions.                        */
+/* mean time (ms) of [0] the assemble kernel, [1] the solve kernel, [2] the ADMM fallback kernel of one batch, each timed alone
+ * with HIP events on `stream` over `repeats` launches (one-kernel forms: [0] = 0, [1] = the whole step's kernel)          */
+int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms3);
+/* condensed arrays of the host set-up by name ("H", "Kinv", "Gr", "Gc", "Y", "lw", "uw", "rho_b", "lg0", "ug0", "rho_g", "dims",
+ * "dims_maps", "MA0", "MA1", "g_refrow", "g_step", "g_kind", "g_comp"); out = NULL returns the length                       */
+int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap);
+/* how many full set-ups (condensing + device rebuild) and how many reference-only refreshes have run on this handle */
+int mpcx_lmpc_debug_setup_counts(mpcx_lmpc_t h, int *full, int *refs);
+/* solve path: 0 = assemble and solve as two kernels; 1 = the record computed inside the solve kernel by one mat-vec (persistent
+ * form from 1024 instances on); 2 = assemble + solve in one workgroup of sixteen wavefronts; -1 = automatic (the default)   */
+int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int mode);
+/* 1 = always the generic (roll-out) assemble kernel, whatever the reference layout */
+int mpcx_lmpc_debug_force_generic(mpcx_lmpc_t h, int on);
+/* rounds the polish-only kernel may spend before an instance goes to the ADMM kernel (default 30), and the ADMM iterations
+ * between two polish attempts there (default 10); rounds0 = 1 sends nearly every instance through the ADMM path            */
+int mpcx_lmpc_debug_set_rounds(mpcx_lmpc_t h, int rounds0, int check_every);
+/* device buffer [B x 8] of int64 receiving per-instance cycle stamps of the solve kernel (NULL: off) */
+int mpcx_lmpc_debug_set_cycle_buffer(mpcx_lmpc_t h, void *dev_ptr);
+/* the SQP kernel's own convergence test: step length relative to max(1, |z|) and largest constraint defect */
+int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_con);
+/* one instance's slice of the SQP workspace copied to the host, with the offsets of its arrays (NlmpcWsLayout) */
+int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, int *layout, int nlayout);
+/* user hooks given as source: the translation unit the run-time compiler is fed / a compile-only check (0 = it builds) */
+int mpcx_nlmpc_debug_generated_source(const mpcx_nlmpc_source *src, char *out, int cap);
+int mpcx_nlmpc_debug_compile_source(const mpcx_nlmpc_source *src);
 
 const char *mpcx_version(void);
 

@@ -93,6 +93,14 @@ inline int nlmpc_hook_scratch(const NlmpcDev &m)
     return 2 * 64 * rows + kNlTrials * rows + kNlTrials * (m.ph + 1) * m.ny + 2;
 }
 
+// wavefronts per workgroup of the two NLMPC kernels: a power of two, so that the blocks of a CU (160 KB of LDS) leave no slice
+// unused; 0 = the slice exceeds the 64 KB a workgroup may ask for.  One definition for the compiled and the run-time compiled path.
+inline int nlmpc_waves_per_block(const NlmpcDev &m)
+{
+    const unsigned long bytes = (unsigned long)m.lds_per_wave * sizeof(double);
+    return bytes <= 16 * 1024 ? 4 : bytes <= 32 * 1024 ? 2 : bytes <= 64 * 1024 ? 1 : 0;
+}
+
 // ---- host-side plumbing ---------------------------------------------------------------------------------------
 // How the library launches the two kernels of a controller.  Zoo models: thunks inside libmpcx.so.  User hooks compiled
 // in the user's translation unit (mpcx/nlmpc_hooks.hpp): thunks instantiated there and registered through

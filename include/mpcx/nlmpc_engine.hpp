@@ -947,6 +947,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         bool have_old = false;
         int resets = 0;
         int nw_keep = 0;                                    // rows active at the end of the previous sub-problem (in wq)
+        // Run-time guard for the failure described below: every phase boundary checks that the whole wavefront arrived (the wave-level
+        // reductions and the hooks behind pointers rely on it); an instance that ever lost lanes is reported as FAILURE, never as a result.
+        bool exec_full = true;
 #ifdef MPCX_NL_STATS
         // Statistics for tools/nlmpc_phases.py (debug_workspace), compiled in only with -DMPCX_NL_STATS (make stats) -- the
         // counters are live across the whole iteration and cost the product kernels registers they do not have:
@@ -954,7 +957,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         // warm start, cycles of the warm start, cycles of the factorisations
         long long cyc[6] = {0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
         long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; };
+        auto lap = [&](int ph_) { const long long now = __builtin_readcyclecounter(); cyc[ph_] += now - tstamp; tstamp = now; exec_full &= __builtin_amdgcn_read_exec() == ~0ull; };
 #define MPCX_STAT(x) x
 #else
         // Phase boundaries keep a scheduling barrier in the product build.  Without one (an empty `lap`) the single-level
@@ -963,7 +966,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         // with a memory clobber or with this barrier the same source runs correctly.  Not understood further -- code generation
         // around the two out-of-line calls is the suspect; tests/test_nlmpc_gpu.py::test_oscillator_network_solve_matches_oracle
         // is the canary.
-        auto lap = [](int) { __builtin_amdgcn_sched_barrier(0); };
+        auto lap = [&](int) { __builtin_amdgcn_sched_barrier(0); exec_full &= __builtin_amdgcn_read_exec() == ~0ull; };
 #define MPCX_STAT(x)
 #endif
         double f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;       // the last accepted step, for nlopt's stopping rules
@@ -2042,6 +2045,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         for (int k = lane; k < m; k += 64) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
         gmax = wave_max(gmax); hmax = wave_max(hmax);
         unwrap<Mdl>(M, z, x0, Xs, Us, lane);
+        if (!exec_full) code = -1;
         const bool failed = code < 0;
         if (S.cmd) for (int j = lane; j < NU; j += 64) S.cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
         if (S.z_out) for (int k = lane; k < nz; k += 64) S.z_out[(size_t)b * nz + k] = z[k];
@@ -2117,13 +2121,6 @@ inline void nlmpc_plan(NlmpcDev &m)
     w.hook = take(m.vector_hooks ? nlmpc_hook_scratch(m) : 0);
     w.sp = take(mtot * kNlSparse + (mtot * kNlSparse + mtot + 1) / 2);
     w.total = o;
-}
-
-inline int nlmpc_waves_per_block(const NlmpcDev &m)
-{
-    // a power of two, so that the blocks of a CU (160 KB of LDS) leave no slice unused
-    const size_t bytes = m.lds_per_wave * sizeof(double);
-    return bytes <= 16 * 1024 ? 4 : bytes <= 32 * 1024 ? 2 : bytes <= 64 * 1024 ? 1 : 0;
 }
 
 template <class Mdl>

@@ -67,6 +67,10 @@ EXPORTS = [
     "mpcx_nlmpc_set_state_bounds_slice", "mpcx_nlmpc_set_input_bounds_slice", "mpcx_nlmpc_solve_host",
     "mpcx_nlmpc_create_custom", "mpcx_nlmpc_create_from_source", "mpcx_nlmpc_set_input_scale", "mpcx_nlmpc_set_state_scale",
     "mpcx_comm_get_unique_id", "mpcx_comm_create", "mpcx_comm_destroy", "mpcx_comm_rank", "mpcx_comm_world", "mpcx_allgather_u",
+    # profiling and testing aids (declared in include/mpcx.h under that heading)
+    "mpcx_lmpc_debug_time_kernels", "mpcx_lmpc_debug_get", "mpcx_lmpc_debug_setup_counts", "mpcx_lmpc_debug_use_fused",
+    "mpcx_lmpc_debug_force_generic", "mpcx_lmpc_debug_set_rounds", "mpcx_lmpc_debug_set_cycle_buffer",
+    "mpcx_nlmpc_debug_set_tolerances", "mpcx_nlmpc_debug_get_ws", "mpcx_nlmpc_debug_generated_source", "mpcx_nlmpc_debug_compile_source",
 ]
 
 
@@ -85,7 +89,7 @@ class NlmpcBatch(C.Structure):
 
 
 class NlmpcDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w", "neq_user", "ny", "nbnd")]
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "ph", "ch", "nz", "neq", "nineq", "jeq_w", "neq_user", "ny", "nbnd", "n_params")]
 
 
 class NlmpcSource(C.Structure):

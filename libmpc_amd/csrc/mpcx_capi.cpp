@@ -389,6 +389,9 @@ static int refresh_references(mpcx_lmpc_t h)
     ++h->n_ref_refreshes;
     if (h->host_only) return MPCX_OK;
     if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    // the arrays are overwritten in place: launches of this handle still in flight on a non-blocking stream (they read them) are not
+    // ordered against a copy on the null stream -- wait for the device first (a reference change is a host-side event, not the hot path)
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MPCX_E_DEVICE, "hipDeviceSynchronize failed");
     const mpcx::LmpcDev &D = h->dev;
     const bool ok = h->reup(D.yref_s, c.yRef.a) && h->reup(D.uref_s, c.uRef.a) && h->reup(D.duref_s, c.duRef.a) &&
                     h->reup(D.dmeas_s, c.dMeas.a) && h->reup(D.MA0, h->cond.MA[0]) && h->reup(D.MA1, h->cond.MA[1]) &&
@@ -551,6 +554,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
 struct mpcx_lmpc_graph {
     hipGraphExec_t exec = nullptr;
     int device = 0;
+    mpcx_lmpc_t owner = nullptr;        // the controller whose step was captured
 };
 
 int mpcx_lmpc_graph_create(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, mpcx_lmpc_graph_t *out)
@@ -573,6 +577,7 @@ int mpcx_lmpc_graph_create(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream
     if (ec != hipSuccess || !graph) return fail(MPCX_E_DEVICE, "hipStreamEndCapture failed");
     auto *g = new mpcx_lmpc_graph;
     g->device = h->device;
+    g->owner = h;
     const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { delete g; return fail(MPCX_E_DEVICE, "hipGraphInstantiate failed"); }
@@ -583,6 +588,11 @@ int mpcx_lmpc_graph_create(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream
 int mpcx_lmpc_graph_launch(mpcx_lmpc_graph_t g, void *stream)
 {
     if (!g || !g->exec) return fail(MPCX_E_INVALID, "null graph");
+    // a setter since the capture needs a set-up pass the captured launches do not contain (mpcx_lmpc_solve_batch runs it; a
+    // reference-only change is picked up by one plain solve, anything else needs a new graph)
+    if (g->owner && (g->owner->dirty || g->owner->refs_dirty))
+        return fail(MPCX_E_STATE, "the controller changed since the graph was captured: call mpcx_lmpc_solve_batch once (references) or capture again");
+    if (hipSetDevice(g->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
     if (hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(MPCX_E_DEVICE, "hipGraphLaunch failed");
     return MPCX_OK;
 }

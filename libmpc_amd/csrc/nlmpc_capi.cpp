@@ -155,10 +155,12 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     return finish_create(h, out);
 }
 
-// shared by mpcx_nlmpc_create_custom and the run-time compiled path (nlmpc_jit.cpp)
-int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, void *jit, mpcx_nlmpc_t *out)
+// shared by mpcx_nlmpc_create_custom and the run-time compiled path (nlmpc_jit.cpp); internal: not exported
+__attribute__((visibility("hidden"))) int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, void *jit, mpcx_nlmpc_t *out)
 {
-    using mpcx::capi_fail;
+    // `jit` (the run-time compiled module, may be null) belongs to the handle from here on: every way out that creates no handle
+    // releases it
+    auto capi_fail = [&](int code, const char *msg) { if (jit) mpcx::nlmpc_jit_release(jit); return mpcx::capi_fail(code, msg); };
     if (!c || !out) return capi_fail(MPCX_E_INVALID, "null argument");
     if (c->nx < 1 || c->nu < 1 || c->ny < 0 || c->nineq < 0 || c->neq_user < 0) return capi_fail(MPCX_E_INVALID, "bad dimensions");
     if (c->ph < 1 || c->ch < 1 || c->ch > c->ph) return capi_fail(MPCX_E_INVALID, "need 1 <= ch <= ph");
@@ -171,8 +173,8 @@ int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, 
     const size_t nb = c->hooks_bytes > 0 ? (size_t)c->hooks_bytes : sizeof(double);
     if (hipMalloc(reinterpret_cast<void **>(&h->params_d), nb) != hipSuccess ||
         (c->hooks_bytes > 0 && hipMemcpy(h->params_d, c->hooks, nb, hipMemcpyHostToDevice) != hipSuccess)) {
-        mpcx_nlmpc_destroy(h);
-        return capi_fail(MPCX_E_DEVICE, "could not upload the hook closures");
+        mpcx_nlmpc_destroy(h);                       // releases the module too
+        return mpcx::capi_fail(MPCX_E_DEVICE, "could not upload the hook closures");
     }
     h->launch_eval = reinterpret_cast<mpcx::nlmpc_launch_eval_fn>(c->launch_evaluate);
     h->launch_solve = reinterpret_cast<mpcx::nlmpc_launch_solve_fn>(c->launch_solve);
@@ -209,7 +211,7 @@ int mpcx_nlmpc_get_dims(mpcx_nlmpc_t h, mpcx_nlmpc_dims *d)
     const mpcx::NlmpcDev &m = h->dev;
     int nb = 0;                                   // finite bounds = rows of the sub-problem after the user constraints
     for (int k = 0; k < m.nz - 1; ++k) nb += (h->ub[k] < 1e30) + (h->lb[k] > -1e30);
-    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue, m.ny, nb};
+    *d = mpcx_nlmpc_dims{m.nx, m.nu, m.ph, m.ch, m.nz, m.neq, m.nineq, 2 * m.nx + m.nu, m.nue, m.ny, nb, h->n_params};
     return MPCX_OK;
 }
 

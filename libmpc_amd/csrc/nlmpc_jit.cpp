@@ -22,7 +22,7 @@ namespace mpcx {
 int capi_fail(int code, const std::string &msg);
 void nlmpc_plan_host(NlmpcDev &m);
 }
-extern "C" int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, void *jit, mpcx_nlmpc_t *out);
+extern "C" __attribute__((visibility("hidden"))) int mpcx_nlmpc_create_hooked(const mpcx_nlmpc_custom *c, double Ts, int device, void *jit, mpcx_nlmpc_t *out);
 
 namespace {
 
@@ -76,11 +76,7 @@ struct JitModule {
     int device = 0;
 };
 
-int waves_per_block(const mpcx::NlmpcDev &m)
-{
-    int wpb = (int)((64 * 1024) / (m.lds_per_wave * sizeof(double)));
-    return wpb > 4 ? 4 : wpb;
-}
+int waves_per_block(const mpcx::NlmpcDev &m) { return mpcx::nlmpc_waves_per_block(m); }      // the engine's own plan
 
 int jit_launch_eval(void *ctx, const void *devp, const void *batchp, void *stream)
 {
@@ -176,7 +172,7 @@ int mpcx_nlmpc_debug_generated_source(const mpcx_nlmpc_source *src, char *out, i
 
 /* Compiles the hooks for gfx950; code_out (may be NULL) receives the code object.  No GPU is needed for this step, which is
  * what the CPU-only tests exercise; mpcx_nlmpc_create_from_source loads the result.  Returns the code size or an error.  */
-int mpcx_nlmpc_compile_source(const mpcx_nlmpc_source *src, std::vector<char> *code_out)
+__attribute__((visibility("hidden"))) int mpcx_nlmpc_compile_source(const mpcx_nlmpc_source *src, std::vector<char> *code_out)      // internal (C++ signature)
 {
     using mpcx::capi_fail;
     if (!src || !src->state_fn || !src->objective_fn) return capi_fail(MPCX_E_INVALID, "state_fn and objective_fn are required");
@@ -214,6 +210,12 @@ int mpcx_nlmpc_create_from_source(const mpcx_nlmpc_source *src, double Ts, int d
     using mpcx::capi_fail;
     if (!out) return capi_fail(MPCX_E_INVALID, "null output handle");
     if (hipSetDevice(device) != hipSuccess) return capi_fail(MPCX_E_DEVICE, "hipSetDevice failed: no usable HIP device");
+    {
+        // the engine is written for gfx950 and the hooks are compiled for it: say so instead of failing inside hipModuleLoadData
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            return capi_fail(MPCX_E_UNSUPPORTED, std::string("run-time compiled hooks target gfx950, this device is ") + prop.gcnArchName);
+    }
     std::vector<char> code;
     const int n = mpcx_nlmpc_compile_source(src, &code);
     if (n < 0) return n;

@@ -48,7 +48,9 @@ class ControlGather:
             self._check(self._lib.mpcx_comm_get_unique_id(ident))
         if self.world > 1:
             box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0, group=group)      # rendezvous only: 128 bytes through the store
+            # rendezvous only: 128 bytes through the store; the source is the group's rank 0 as a GLOBAL rank (sub-groups)
+            src = dist.get_global_rank(group, 0) if (group is not None and dist.is_initialized()) else 0
+            dist.broadcast_object_list(box, src=src, group=group)
             ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
         self._h = C.c_void_p()
         self._check(self._lib.mpcx_comm_create(self.device, self.rank, self.world, ident, C.byref(self._h)))

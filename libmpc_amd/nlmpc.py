@@ -72,6 +72,7 @@ class NLMPCEvaluator:
         check(self._lib.mpcx_nlmpc_get_dims(self._h, C.byref(d)))
         self.nx, self.nu, self.ph, self.ch, self.nz, self.neq, self.nineq, self.jeq_w, self.neq_user, self.ny = (
             d.nx, d.nu, d.ph, d.ch, d.nz, d.neq, d.nineq, d.jeq_w, d.neq_user, d.ny)
+        self.n_params = d.n_params
 
     @property
     def nbnd(self):
@@ -184,7 +185,8 @@ class NLMPC(NLMPCEvaluator):
         pb = None
         if params is not None:                   # [B, n_params]: every instance its own parameters of the built-in system
             pb = torch.as_tensor(params).to(dev, torch.float64).contiguous()
-            assert pb.ndim == 2 and pb.shape[0] == B, "params: one row of model parameters per instance"
+            if pb.ndim != 2 or pb.shape[0] != B or pb.shape[1] != self.n_params:
+                raise ValueError("params: [batch, %d] -- one row of this system's model parameters per instance, got %s" % (self.n_params, tuple(pb.shape)))
             b.params = pb.data_ptr()
         out["_keep"] = (x0, u0, zw, pb)
         return b, out

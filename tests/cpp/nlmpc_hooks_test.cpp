@@ -138,8 +138,11 @@ static int solve()
     for (int b = 0; b < 3; ++b) {
         std::printf("instance %d  zoo %.17g  setters %.17g  setHooks %.17g  sources %.17g\n", b, rz.cmd[b], re.cmd[b], rf.cmd[b], rj.cmd[b]);
         CHECK(re.status[b] == 0 && rf.status[b] == 0 && rj.status[b] == 0);
-        // the three routes run the same source through the same engine: bit for bit the same answer
-        CHECK(re.cmd[b] == rf.cmd[b] && re.cmd[b] == rj.cmd[b] && re.cost[b] == rf.cost[b] && re.cost[b] == rj.cost[b]);
+        // the three routes run the same source through the same engine: the same answer up to the last bits (the routes are
+        // separate instantiations -- calls through pointers, everything inlined, run-time compiled -- and the compiler contracts a
+        // product into a following addition in one and not in the other: a few ulp)
+        auto close = [](double a, double c) { return std::fabs(a - c) <= 1e-13 * std::fmax(1.0, std::fabs(a)); };
+        CHECK(close(re.cmd[b], rf.cmd[b]) && close(re.cmd[b], rj.cmd[b]) && close(re.cost[b], rf.cost[b]) && close(re.cost[b], rj.cost[b]));
         // the built-in model spells the same functions by hand: the compiler may contract its products differently, and one
         // ulp in the cost is 1e-8 in a forward-difference gradient -- the optimum agrees to that noise, not to the bit
         const double tol = 2e-6 * std::fmax(1.0, std::fabs(rz.cmd[b]));

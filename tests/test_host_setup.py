@@ -24,6 +24,22 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.mpcx_version().startswith(b"mpcx")
 
 
+def test_cabi_declares_every_exported_symbol():
+    """the other direction: whatever the library exports under the mpcx_ prefix is declared in include/mpcx.h -- the measured and
+    tested ABI is the documented one"""
+    import shutil
+    import subprocess
+    from libmpc_amd import _capi
+    nm = shutil.which("nm")
+    if not nm:
+        pytest.skip("binutils not installed")
+    out = subprocess.run([nm, "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("mpcx_")}
+    hdr = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+    declared = set(re.findall(r"\b(mpcx_[a-z0-9_]+)\s*\(", hdr))
+    assert exported - declared == set(), sorted(exported - declared)
+
+
 def test_unsupported_calls_raise_like_the_reference():
     """LMPC.hpp:68-100: discrete-time only, no scaling"""
     from libmpc_amd import LMPC
