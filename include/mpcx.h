@@ -415,6 +415,20 @@ int mpcx_comm_world(mpcx_comm_t c);
  * solve retires, with no host synchronisation in between.  u_all may not alias u_local.                              */
 int mpcx_allgather_u(mpcx_comm_t c, const double *u_local, int rows_per_rank, int nu, double *u_all, void *stream);
 
+/* ---- heterogeneous batches (every instance its own model) ------------------------------------------
+ * In the reference every controller object owns its model, weights and bounds (LMPC.hpp:751; ProblemBuilder.hpp:184-211,
+ * 642-825).  A bank is K configured controllers (host-only handles are enough) with the same dimensions and the same pattern
+ * of finite bounds, solved together: instance b of a batch uses controller model_index[b] (device array; NULL: controller b,
+ * batch = K).  "Shared" references mean each controller's own setReferences / setExogenousInputs values.  The bank copies what
+ * it needs: the controllers may be destroyed or changed afterwards (changes do not reach the bank).                          */
+typedef struct mpcx_lmpc_hetero *mpcx_lmpc_hetero_t;
+int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int device, mpcx_lmpc_hetero_t *out);
+int mpcx_lmpc_hetero_destroy(mpcx_lmpc_hetero_t f);
+int mpcx_lmpc_hetero_get_info(mpcx_lmpc_hetero_t f, int *count, int *active_words, int *m_ref, double *bytes_per_model);
+int mpcx_lmpc_hetero_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream);
+int mpcx_lmpc_hetero_time_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream,
+                                      int repeats, float *ms_mean);
+
 /* ---- profiling and testing aids ------------------------------------------------------------------------------------
  * Not part of the reference-facing surface, but part of the exported ABI: bench.py's roofline block, tools/ and tests/ call
  * them, so they are declared (and kept) here.  "debug" in a name = may change between versions.                        */

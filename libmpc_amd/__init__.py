@@ -8,8 +8,8 @@ There is no CPU fallback: a missing libmpcx.so or GPU raises.
 from .lmpc import (LMPC, HorizonSlice, LParameters, Result, OptSequence, BatchResult, ResultStatus, SolutionStats, inf)
 from .nlmpc import NLMPC, NLMPCEvaluator, NLParameters
 from ._capi import MpcxError
-from .bank import LMPCBank, group_by_model
+from .bank import LMPCBank, LMPCHetero, group_by_model
 
 __all__ = ["LMPC", "NLMPC", "NLMPCEvaluator", "HorizonSlice", "LParameters", "NLParameters", "Result", "OptSequence",
-           "BatchResult", "ResultStatus", "MpcxError", "SolutionStats", "inf", "LMPCBank", "group_by_model"]
+           "BatchResult", "ResultStatus", "MpcxError", "SolutionStats", "inf", "LMPCBank", "LMPCHetero", "group_by_model"]
 __version__ = "0.1.0"

@@ -6,15 +6,20 @@ batch whose instances carry a controller index, solves each group on its own HIP
 workspace, own dispatch queues, so the groups overlap on the GPU) and returns the results in the caller's order.
 
 This is heterogeneity by grouping -- no new kernel, every instance is solved by exactly the code path and with exactly the
-results of its own controller.  Per-instance models (every instance its own A, B, C) need device-side condensing and are
-not built.  torch is used for what it is here for: device memory, index_select / index_copy and
+results of its own controller.  `LMPCHetero` is the other end: K controllers (K up to the batch size: every instance its own
+A, B, C, weights, bounds) behind ONE set of kernels, each instance reading its own model's factors from HBM
+(mpcx_lmpc_hetero_*, include/mpcx.h).  torch is used for what it is here for: device memory, index_select / index_copy and
 streams."""
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-from .lmpc import BatchResult
+import ctypes as C
+
+from . import _capi
+from ._capi import check
+from .lmpc import LMPC, BatchResult
 
 
 def group_by_model(model, n_models: int):
@@ -85,3 +90,65 @@ class LMPCBank:
             cur.wait_stream(s)                                   # the caller's stream sees the scattered results
         out._inputs = keep
         return out
+
+
+class LMPCHetero:
+    """K configured `libmpc_amd.LMPC` controllers (host-only handles, `device=-1`, are enough) of equal dimensions and equal
+    pattern of finite bounds, solved together by one set of kernels: instance b uses controller `model[b]` (default: b).
+    In the reference each of them is its own `mpc::LMPC<>` object (LMPC.hpp:751)."""
+
+    def __init__(self, controllers, device=0):
+        if not controllers:
+            raise ValueError("at least one controller")
+        c0 = controllers[0]
+        self.nx, self.nu, self.ny, self.ndu, self.ph = c0.nx, c0.nu, c0.ny, c0.ndu, c0.ph
+        self.device = int(device)
+        self._lib = _capi.lib()
+        arr = (C.c_void_p * len(controllers))(*[c._h for c in controllers])
+        self._h = C.c_void_p()
+        check(self._lib.mpcx_lmpc_hetero_create(arr, len(controllers), self.device, C.byref(self._h)))
+        n, aw, mref, bpm = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(self._lib.mpcx_lmpc_hetero_get_info(self._h, C.byref(n), C.byref(aw), C.byref(mref), C.byref(bpm)))
+        self.count, self.active_words, self.m_ref, self.bytes_per_model = n.value, aw.value, mref.value, bpm.value
+        self._template = c0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.mpcx_lmpc_hetero_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        return {"active_words": self.active_words, "m_ref": self.m_ref}
+
+    # the descriptor is the single-controller one: borrow its builder (it only needs the dimensions and info())
+    _torch, _dev, _ref = LMPC._torch, LMPC._dev, LMPC._ref
+
+    def make_batch(self, x0, u0, model=None, **kw):
+        b, res, keep = LMPC.make_batch(self, x0, u0, **kw)
+        mi = None
+        if model is not None:
+            mi = torch.as_tensor(model).to(device=torch.device("cuda", self.device), dtype=torch.int32).contiguous()
+            if mi.numel() != b.batch or (mi.numel() and (int(mi.min()) < 0 or int(mi.max()) >= self.count)):
+                raise ValueError("model: one controller index in [0, %d) per instance" % self.count)
+        return b, res, keep + (mi,), mi
+
+    def launch(self, b, mi=None, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(self._lib.mpcx_lmpc_hetero_solve_batch(self._h, C.byref(b), None if mi is None else C.c_void_p(mi.data_ptr()), C.c_void_p(s.cuda_stream)))
+
+    def time_launches(self, b, mi, repeats, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ms = C.c_float()
+        check(self._lib.mpcx_lmpc_hetero_time_solve_batch(self._h, C.byref(b), None if mi is None else C.c_void_p(mi.data_ptr()),
+                                                          C.c_void_p(s.cuda_stream), int(repeats), C.byref(ms)))
+        return ms.value
+
+    def optimizeBatch(self, x0, lastU, model=None, yref=None, uref=None, duref=None, dmeas=None, want_active=False, want_sequence=False,
+                      stream=None) -> BatchResult:
+        """x0 [B, nx], lastU [B, nu]; model [B] controller index per instance (None: instance b = controller b); references None
+        (each controller's own) | [B, n] | [B, ph, n]"""
+        b, res, keep, mi = self.make_batch(x0, lastU, model, yref=yref, uref=uref, duref=duref, dmeas=dmeas, want_active=want_active,
+                                           want_sequence=want_sequence)
+        self.launch(b, mi, stream)
+        res._inputs = keep
+        return res

@@ -73,8 +73,14 @@ struct LmpcBatchDev {
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1; 3 / 4: lmpc_solve_group with MA0 / MA1
     int *pcounter;                                // work counter of the persistent fused kernel (null: one instance per launched wavefront)
+    // heterogeneous batch (mpcx_lmpc_hetero_*): the kernels' model pointer is an array of n_models structs of identical dimensions and
+    // constraint structure, instance b uses entry model_index[b] (null: entry b); 0 models = the one shared controller
+    int n_models;
+    const int32_t *model_index;
     long long *dbg_cycles;       // optional [B x 8] per-phase cycle counts (profiling aid)
 };
+// which entry of the model array instance b uses
+__host__ __device__ inline int lmpc_model_of(const LmpcBatchDev &Bt, int b) { return Bt.n_models <= 0 ? 0 : (Bt.model_index ? Bt.model_index[b] : b); }
 
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered

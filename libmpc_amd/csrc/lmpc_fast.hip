@@ -578,7 +578,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
         for (int s = 0; s < NZS; ++s) j = fma(f[s], w[s], j);
         if (lane < na_last) j = fma(-lam[lane], wsb[lane], j);
         cost = 0.5 * wave_sum(j) + c0;
-    } else if (!FUSED) {
+    } else if (!FUSED && Bt.n_models <= 0) {
         // cost from its definition by lmpc_cost_mfma: the solution goes to the workspace in t0's place
 #pragma unroll
         for (int c = 0; c < CPZ; ++c) {
@@ -656,7 +656,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
     if (Bt.seq_state || Bt.seq_input || Bt.seq_output) {
         // OptSequence (LOptimizer.hpp:305-338): roll the model forward with the optimal inputs
         wave_sync();
-        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas);
+        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas ? Bt.dmeas : M.dmeas_s);
         const gip gblk = GP(blk);
         auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
         double *xs0 = scratch, *xs1 = scratch + nx;      // ping-pong state
@@ -725,11 +725,31 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    fast_load_box<CPZ>(M, smem);
-    double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
+    constexpr int ZP = 128 * CPZ;
     const int wpb = blockDim.x >> 6;
-    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
-        solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
+    double *rec = smem + 2 * ZP + (size_t)wave * M.fast_slice;
+    if (Bt.n_models <= 0) {
+        fast_load_box<CPZ>(M, smem);
+        for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb)
+            solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
+    } else {
+        // heterogeneous batch: every instance its own model, so every wavefront keeps its own copy of the box bounds (after the slices)
+        double *box = smem + 2 * ZP + (size_t)wpb * M.fast_slice + (size_t)wave * 2 * ZP;
+        const double INF = __builtin_huge_val();
+        for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
+            const LmpcDev &Mi = Mp[lmpc_model_of(Bt, i)];
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                const bool ok = e < Mi.ldz;
+                const d2 vl = ld2(gl(Mi.lw) + (ok ? e : 0)), vu = ld2(gl(Mi.uw) + (ok ? e : 0));
+                *reinterpret_cast<double2 *>(box + e) = ok ? make_double2(vl.x, vl.y) : make_double2(-INF, -INF);
+                *reinterpret_cast<double2 *>(box + ZP + e) = ok ? make_double2(vu.x, vu.y) : make_double2(INF, INF);
+            }
+            wave_sync();
+            solve_fast<CPZ, CPG, 0>(Mi, Bt, i, lane, rec, box, glw(wsbase) + (size_t)i * M.wsld);
+            wave_sync();
+        }
     }
 }
 
@@ -929,7 +949,7 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
 template <int CPZ, int CPG>
 int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
 {
-    size_t ldsf = ((size_t)2 * 128 * CPZ + (size_t)kWavesPerBlock * m.fast_slice) * sizeof(double);
+    size_t ldsf = ((size_t)2 * 128 * CPZ + (size_t)kWavesPerBlock * m.fast_slice + (b.n_models > 0 ? (size_t)kWavesPerBlock * 2 * 128 * CPZ : 0)) * sizeof(double);
     if (const char *pad = getenv("MPCX_DBG_LDS_PAD")) ldsf += (size_t)atoi(pad);
     if (ldsf > 160 * 1024) return -2;
     auto k2 = lmpc_solve<CPZ, CPG>;

@@ -40,7 +40,9 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     const bool has_dist = M.has_dist != 0;
     const double ea = M.eps_abs, er = M.eps_rel;
     const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd);
-    const gdp gdm = gl(Bt.dmeas), gyr = gl(Bt.yref), gur = gl(Bt.uref), gdr = gl(Bt.duref);
+    // a null reference pointer (heterogeneous batches, "shared" mode): this model's own reference arrays
+    const gdp gdm = gl(Bt.dmeas ? Bt.dmeas : M.dmeas_s), gyr = gl(Bt.yref ? Bt.yref : M.yref_s), gur = gl(Bt.uref ? Bt.uref : M.uref_s),
+              gdr = gl(Bt.duref ? Bt.duref : M.duref_s);
 
     double *xb = arena;                       // free response, (ph+1) x nx
     double *ey = xb + (ph + 1) * nx;          // weighted output error, (ph+1) x ny
@@ -222,13 +224,13 @@ template <int CPZ, int CPG>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
+    const LmpcDev &M0 = *Mp;                       // dimensions and the LDS plan are the same for every model of a heterogeneous batch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *stage = smem + (size_t)wave * M.lds_per_wave;
-    double *arena = stage + M.stage_len + M.ldy;
+    double *stage = smem + (size_t)wave * M0.lds_per_wave;
+    double *arena = stage + M0.stage_len + M0.ldy;
     const int wpb = blockDim.x >> 6;
     for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        assemble_one<CPZ, CPG>(M, Bt, b, lane, stage, arena, glw(wsbase) + (size_t)b * M.wsld);
+        assemble_one<CPZ, CPG>(Mp[lmpc_model_of(Bt, b)], Bt, b, lane, stage, arena, glw(wsbase) + (size_t)b * M0.wsld);
 }
 
 
@@ -1184,7 +1186,7 @@ __device__ void solve_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b,
     if (Bt.seq_state || Bt.seq_input || Bt.seq_output) {
         // OptSequence (LOptimizer.hpp:305-338): roll the model forward with the optimal inputs
         wave_sync();
-        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas);
+        const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd), gdm = gl(Bt.dmeas ? Bt.dmeas : M.dmeas_s);
         const gip gblk = GP(blk);
         auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
         double *xs0 = arena, *xs1 = arena + nx;      // ping-pong state
@@ -1251,12 +1253,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
             while (todo) {
                 const int b = c0 + (int)__builtin_ctzll(todo);
                 todo &= todo - 1;
-                solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+                solve_one<CPZ, CPG, true>(Mp[lmpc_model_of(Bt, b)], Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
             }
         }
     } else {
         for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-            solve_one<CPZ, CPG, true>(M, Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
+            solve_one<CPZ, CPG, true>(Mp[lmpc_model_of(Bt, b)], Bt, b, lane, stage, nt0, arena, glw(wsbase) + (size_t)b * M.wsld);
     }
 }
 
@@ -1374,7 +1376,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
             const int rf = lmpc_launch_fast(m, m_dev, bf, ws, stream);      // lean kernels (lmpc_fast.hip)
             if (rf != 0) return rf;
         }
-        if (m.cost_direct && m.polish && !fused) {       // the costs lmpc_solve left pending
+        if (m.cost_direct && m.polish && !fused && b.n_models <= 0) {       // the costs lmpc_solve left pending
             const size_t ldsc = ((size_t)(m.nz16 / 4) * 64 + 64) * sizeof(double);
             int blocksq = (b.batch + 15) / 16;
             if (blocksq > 4096) blocksq = 4096;

@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mpcx.h"
@@ -94,6 +97,120 @@ struct mpcx_lmpc {
         return static_cast<const T *>(p);
     }
 };
+
+// The device view of one condensed controller: scalars ...
+static void fill_dev_scalars(const mpcx_lmpc *h, const mpcx::LmpcController &c, const mpcx::Condensed &o, mpcx::LmpcDev &D)
+{
+    D = mpcx::LmpcDev{};
+    D.nx = c.d.nx; D.nu = c.d.nu; D.ndu = c.d.ndu; D.ny = c.d.ny; D.ph = c.d.ph; D.ch = c.d.ch;
+    D.nf = o.nf; D.nz = o.nz; D.mg = o.mg; D.ldz = o.ldz; D.ldg = o.ldg; D.ldy = o.ldy;
+    D.m_ref = o.m_ref; D.neq_ref = o.neq_ref; D.active_words = o.active_words;
+    D.has_dist = o.has_dist ? 1 : 0;
+    D.n_fixed = (int)o.fixed_rows.size();
+    D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
+    D.strict_infeasible = h->strict_infeasible ? 1 : 0;
+    D.cost_direct = (o.h_regularised || o.inverse_residual > 1e-9) ? 1 : 0;
+    D.check_every = h->dbg_check_every; D.polish_rounds0 = h->dbg_rounds0; D.polish_rounds = 10;
+    D.alpha = c.prm.alpha; D.sigma = 1e-6;
+    D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
+    D.lds_per_wave = mpcx::lmpc_lds_per_wave(D, &D.stage_len, &D.arena_len);
+    D.wsld = D.ldz + D.ldy + 2 * D.ldg + 2;
+    D.s0lo = c.sMin[0]; D.s0hi = c.sMax[0];
+}
+
+// ... and arrays, through an uploader (one hipMalloc per array for a single controller, offsets into one slab for a bank of them)
+template <class Uploader>
+static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, const mpcx::Condensed &o, mpcx::LmpcDev &D, Uploader &U, int &rc)
+{
+    D.A = U.up(c.A.a, rc); D.B = U.up(c.B.a, rc); D.C = U.up(c.C.a, rc);
+    D.Bd = U.up(c.Bd.a, rc); D.Dd = U.up(c.Dd.a, rc);
+    D.Wy = U.up(c.wOutput.a, rc); D.Wu = U.up(c.wU.a, rc); D.Wdu = U.up(c.wDeltaU.a, rc);
+    D.yref_s = U.up(c.yRef.a, rc); D.uref_s = U.up(c.uRef.a, rc);
+    D.duref_s = U.up(c.duRef.a, rc); D.dmeas_s = U.up(c.dMeas.a, rc);
+    {
+        std::vector<double> lo0x(c.d.nx), hi0x(c.d.nx), lo0u(c.d.nu), hi0u(c.d.nu), lo0y(c.d.ny), hi0y(c.d.ny);
+        for (int j = 0; j < c.d.nx; j++) { lo0x[j] = c.minX(j, 0); hi0x[j] = c.maxX(j, 0); }
+        for (int j = 0; j < c.d.nu; j++) { lo0u[j] = c.minU(j, 0); hi0u[j] = c.maxU(j, 0); }
+        for (int j = 0; j < c.d.ny; j++) { lo0y[j] = c.minY(j, 0); hi0y[j] = c.maxY(j, 0); }
+        D.lo0x = U.up(lo0x, rc); D.hi0x = U.up(hi0x, rc); D.lo0u = U.up(lo0u, rc); D.hi0u = U.up(hi0u, rc);
+        D.lo0y = U.up(lo0y, rc); D.hi0y = U.up(hi0y, rc);
+        D.sX = U.up(c.sX, rc); D.sU = U.up(c.sU, rc);
+    }
+    D.H = U.up(o.H, rc); D.Kinv = U.up(o.Kinv, rc); D.Gr = U.up(o.Gr, rc); D.Gc = U.up(o.Gc, rc); D.Y = U.up(o.Y, rc);
+    D.lw = U.up(o.lw, rc); D.uw = U.up(o.uw, rc); D.rho_b = U.up(o.rho_b, rc);
+    D.lg0 = U.up(o.lg0, rc); D.ug0 = U.up(o.ug0, rc); D.rho_g = U.up(o.rho_g, rc);
+    D.g_kind = U.up(o.g_kind, rc); D.g_step = U.up(o.g_step, rc); D.g_comp = U.up(o.g_comp, rc); D.g_refrow = U.up(o.g_refrow, rc);
+    {
+        std::vector<int> fk, fs, fc; std::vector<double> fl, fh;
+        for (auto &r : o.fixed_rows) { fk.push_back(r.kind); fs.push_back(r.step); fc.push_back(r.comp); fl.push_back(r.lo); fh.push_back(r.hi); }
+        D.f_kind = U.up(fk, rc); D.f_step = U.up(fs, rc); D.f_comp = U.up(fc, rc); D.f_lo = U.up(fl, rc); D.f_hi = U.up(fh, rc);
+    }
+    D.boxrow_ptr = U.up(o.boxrow_ptr, rc); D.boxrow_ref = U.up(o.boxrow_ref, rc);
+    D.boxrow_lo = U.up(o.boxrow_lo, rc); D.boxrow_hi = U.up(o.boxrow_hi, rc);
+    D.blk = U.up(o.blk, rc);
+    D.kin = o.kin; D.nxp = o.nxp; D.nup = o.nup; D.nyp = o.nyp; D.ione = o.ione;
+    D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
+    D.fast_slice = mpcx::lmpc_fast_slice(D);
+    D.MA0 = U.up(o.MA[0], rc); D.MA1 = U.up(o.MA[1], rc); D.Ym = U.up(o.Ym, rc);
+    D.MF0 = U.up(o.MF[0], rc); D.MF1 = U.up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
+    // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
+    // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
+    D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384 && !D.cost_direct) ? 1 : 0;
+    // assemble + solve in one workgroup (lmpc_solve_group): the one-chunk variant, cost from the multipliers
+    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct) ? 1 : 0;
+    D.slo = U.up(o.slo, rc); D.shi = U.up(o.shi, rc);
+}
+
+// ---- heterogeneous batches: a bank of controllers solved together -------------------------------------------------------------
+// In the reference every controller object owns its model (LMPC.hpp:751; ProblemBuilder.hpp:184-211 rebuilds the QP from it,
+// :642-825).  A bank is K such objects -- same dimensions, same pattern of finite bounds, otherwise free: own A, B, C, weights,
+// bounds, references, parameters -- condensed on the host cores in parallel and kept in one slab of HBM as K device structs; the
+// kernels pick the struct of each instance (lmpc_model_of).  Per-model factors cannot be shared through L2: the assemble kernel
+// reads its model's -Hinv and G Hinv once per instance, the solve the rows of Y in the working set -- this path is HBM-bound.
+struct SlabUploader {
+    std::vector<char> host;                      // staging image of the slab
+    template <typename T>
+    const T *up(const std::vector<T> &v, int &)
+    {
+        const size_t at = (host.size() + 15) / 16 * 16;
+        host.resize(at + (v.size() ? v.size() : 1) * sizeof(T), 0);
+        if (v.size()) std::memcpy(host.data() + at, v.data(), v.size() * sizeof(T));
+        return reinterpret_cast<const T *>(at + 1);          // offset + 1 (so that offset 0 is not a null pointer); rebased below
+    }
+};
+
+struct mpcx_lmpc_hetero {
+    int device = 0, count = 0;
+    mpcx_dims d{};
+    mpcx::LmpcDev dev0{};                        // model 0 with device pointers (dimensions, LDS plan)
+    mpcx::LmpcDev *models_d = nullptr;           // [count] device structs
+    char *slab = nullptr;
+    double *ws = nullptr; size_t ws_cap = 0;
+    int active_words = 0, m_ref = 0;
+    ~mpcx_lmpc_hetero()
+    {
+        if (models_d) (void)hipFree(models_d);
+        if (slab) (void)hipFree(slab);
+        if (ws) (void)hipFree(ws);
+    }
+};
+
+static void rebase_dev(mpcx::LmpcDev &D, const char *base)
+{
+    // every pointer member was filled with (offset + 1) by SlabUploader: turn it into base + offset
+    auto fix = [&](auto &p) {
+        using P = std::remove_reference_t<decltype(p)>;
+        p = p ? reinterpret_cast<P>(base + (reinterpret_cast<size_t>(p) - 1)) : nullptr;
+    };
+    fix(D.A); fix(D.B); fix(D.C); fix(D.Bd); fix(D.Dd); fix(D.Wy); fix(D.Wu); fix(D.Wdu);
+    fix(D.yref_s); fix(D.uref_s); fix(D.duref_s); fix(D.dmeas_s);
+    fix(D.lo0x); fix(D.hi0x); fix(D.lo0u); fix(D.hi0u); fix(D.lo0y); fix(D.hi0y); fix(D.sX); fix(D.sU);
+    fix(D.H); fix(D.Kinv); fix(D.Gr); fix(D.Gc); fix(D.Y); fix(D.lw); fix(D.uw); fix(D.rho_b); fix(D.lg0); fix(D.ug0); fix(D.rho_g);
+    fix(D.g_kind); fix(D.g_step); fix(D.g_comp); fix(D.g_refrow);
+    fix(D.f_kind); fix(D.f_step); fix(D.f_comp); fix(D.f_lo); fix(D.f_hi);
+    fix(D.boxrow_ptr); fix(D.boxrow_ref); fix(D.boxrow_lo); fix(D.boxrow_hi); fix(D.blk);
+    fix(D.MA0); fix(D.MA1); fix(D.Ym); fix(D.slo); fix(D.shi); fix(D.MF0); fix(D.MF1);
+}
 
 extern "C" {
 
@@ -412,63 +529,13 @@ int mpcx_lmpc_setup(mpcx_lmpc_t h)
     if (mpcx::lmpc_kernel_variant(o.ldz, o.ldg) < 0)
         return fail(MPCX_E_UNSUPPORTED, "condensed problem larger than 512 variables / rows");
     mpcx::LmpcDev &D = h->dev;
-    D = mpcx::LmpcDev{};
-    D.nx = c.d.nx; D.nu = c.d.nu; D.ndu = c.d.ndu; D.ny = c.d.ny; D.ph = c.d.ph; D.ch = c.d.ch;
-    D.nf = o.nf; D.nz = o.nz; D.mg = o.mg; D.ldz = o.ldz; D.ldg = o.ldg; D.ldy = o.ldy;
-    D.m_ref = o.m_ref; D.neq_ref = o.neq_ref; D.active_words = o.active_words;
-    D.has_dist = o.has_dist ? 1 : 0;
-    D.n_fixed = (int)o.fixed_rows.size();
-    D.max_iter = c.prm.maximum_iteration; D.polish = c.prm.polish ? 1 : 0;
-    D.strict_infeasible = h->strict_infeasible ? 1 : 0;
-    D.cost_direct = (o.h_regularised || o.inverse_residual > 1e-9) ? 1 : 0;
-    D.check_every = h->dbg_check_every; D.polish_rounds0 = h->dbg_rounds0; D.polish_rounds = 10;
-    D.alpha = c.prm.alpha; D.sigma = 1e-6;
-    D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
-    D.lds_per_wave = mpcx::lmpc_lds_per_wave(D, &D.stage_len, &D.arena_len);
-    D.wsld = D.ldz + D.ldy + 2 * D.ldg + 2;
-    D.s0lo = c.sMin[0]; D.s0hi = c.sMax[0];
+    fill_dev_scalars(h, c, o, D);
     if (h->host_only) { h->dirty = false; return MPCX_OK; }
 
     if (hipSetDevice(h->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
     h->release();
     int rc = MPCX_OK;
-    D.A = h->up(c.A.a, rc); D.B = h->up(c.B.a, rc); D.C = h->up(c.C.a, rc);
-    D.Bd = h->up(c.Bd.a, rc); D.Dd = h->up(c.Dd.a, rc);
-    D.Wy = h->up(c.wOutput.a, rc); D.Wu = h->up(c.wU.a, rc); D.Wdu = h->up(c.wDeltaU.a, rc);
-    D.yref_s = h->up(c.yRef.a, rc); D.uref_s = h->up(c.uRef.a, rc);
-    D.duref_s = h->up(c.duRef.a, rc); D.dmeas_s = h->up(c.dMeas.a, rc);
-    {
-        std::vector<double> lo0x(c.d.nx), hi0x(c.d.nx), lo0u(c.d.nu), hi0u(c.d.nu), lo0y(c.d.ny), hi0y(c.d.ny);
-        for (int j = 0; j < c.d.nx; j++) { lo0x[j] = c.minX(j, 0); hi0x[j] = c.maxX(j, 0); }
-        for (int j = 0; j < c.d.nu; j++) { lo0u[j] = c.minU(j, 0); hi0u[j] = c.maxU(j, 0); }
-        for (int j = 0; j < c.d.ny; j++) { lo0y[j] = c.minY(j, 0); hi0y[j] = c.maxY(j, 0); }
-        D.lo0x = h->up(lo0x, rc); D.hi0x = h->up(hi0x, rc); D.lo0u = h->up(lo0u, rc); D.hi0u = h->up(hi0u, rc);
-        D.lo0y = h->up(lo0y, rc); D.hi0y = h->up(hi0y, rc);
-        D.sX = h->up(c.sX, rc); D.sU = h->up(c.sU, rc);
-    }
-    D.H = h->up(o.H, rc); D.Kinv = h->up(o.Kinv, rc); D.Gr = h->up(o.Gr, rc); D.Gc = h->up(o.Gc, rc); D.Y = h->up(o.Y, rc);
-    D.lw = h->up(o.lw, rc); D.uw = h->up(o.uw, rc); D.rho_b = h->up(o.rho_b, rc);
-    D.lg0 = h->up(o.lg0, rc); D.ug0 = h->up(o.ug0, rc); D.rho_g = h->up(o.rho_g, rc);
-    D.g_kind = h->up(o.g_kind, rc); D.g_step = h->up(o.g_step, rc); D.g_comp = h->up(o.g_comp, rc); D.g_refrow = h->up(o.g_refrow, rc);
-    {
-        std::vector<int> fk, fs, fc; std::vector<double> fl, fh;
-        for (auto &r : o.fixed_rows) { fk.push_back(r.kind); fs.push_back(r.step); fc.push_back(r.comp); fl.push_back(r.lo); fh.push_back(r.hi); }
-        D.f_kind = h->up(fk, rc); D.f_step = h->up(fs, rc); D.f_comp = h->up(fc, rc); D.f_lo = h->up(fl, rc); D.f_hi = h->up(fh, rc);
-    }
-    D.boxrow_ptr = h->up(o.boxrow_ptr, rc); D.boxrow_ref = h->up(o.boxrow_ref, rc);
-    D.boxrow_lo = h->up(o.boxrow_lo, rc); D.boxrow_hi = h->up(o.boxrow_hi, rc);
-    D.blk = h->up(o.blk, rc);
-    D.kin = o.kin; D.nxp = o.nxp; D.nup = o.nup; D.nyp = o.nyp; D.ione = o.ione;
-    D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
-    D.fast_slice = mpcx::lmpc_fast_slice(D);
-    D.MA0 = h->up(o.MA[0], rc); D.MA1 = h->up(o.MA[1], rc); D.Ym = h->up(o.Ym, rc);
-    D.MF0 = h->up(o.MF[0], rc); D.MF1 = h->up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
-    // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
-    // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
-    D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384 && !D.cost_direct) ? 1 : 0;
-    // assemble + solve in one workgroup (lmpc_solve_group): the one-chunk variant, cost from the multipliers
-    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct) ? 1 : 0;
-    D.slo = h->up(o.slo, rc); D.shi = h->up(o.shi, rc);
+    fill_dev_arrays(h, c, o, D, *h, rc);
     if (rc != MPCX_OK) return fail(rc, "device upload failed");
     {
         void *p = nullptr;
@@ -712,6 +779,154 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info)
                                   2.0 * nz * (nz + mg) + 2.0 * nz * nz;
     info->bytes_per_solve = 8.0 * (d.nx + d.nu) + 8.0 * d.nu + 8.0 + 16.0;
     return MPCX_OK;
+}
+
+/* ---- heterogeneous batches -------------------------------------------------------------------------------------------------- */
+int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int device, mpcx_lmpc_hetero_t *out)
+{
+    if (!controllers || !out || count < 1) return fail(MPCX_E_INVALID, "need at least one controller");
+    for (int k = 0; k < count; ++k) if (!controllers[k]) return fail(MPCX_E_INVALID, "null controller in the bank");
+    int ndev = 0;
+    if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev)
+        return fail(MPCX_E_DEVICE, "no such HIP device (the solve path has no CPU fallback)");
+    // condense every controller on the host cores (what mpcx_lmpc_setup does for one), in parallel
+    std::vector<mpcx::Condensed> cond((size_t)count);
+    std::vector<std::string> errs((size_t)count);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if (nt > 32) nt = 32;
+        if ((int)nt > count) nt = (unsigned)count;
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&]() {
+                for (int k = next.fetch_add(1); k < count; k = next.fetch_add(1)) errs[(size_t)k] = controllers[k]->ctl.condense(cond[(size_t)k]);
+            });
+        for (auto &th : pool) th.join();
+    }
+    for (int k = 0; k < count; ++k)
+        if (!errs[(size_t)k].empty()) return fail(MPCX_E_NUMERIC, "controller " + std::to_string(k) + ": " + errs[(size_t)k]);
+    // one structure for all: dimensions, constraint rows (which bounds are finite), move blocking
+    const auto &c0 = controllers[0]->ctl;
+    const auto &o0 = cond[0];
+    if (mpcx::lmpc_kernel_variant(o0.ldz, o0.ldg) < 0) return fail(MPCX_E_UNSUPPORTED, "condensed problem larger than 512 variables / rows");
+    for (int k = 1; k < count; ++k) {
+        const auto &ck = controllers[k]->ctl;
+        const auto &ok = cond[(size_t)k];
+        const bool same = ck.d.nx == c0.d.nx && ck.d.nu == c0.d.nu && ck.d.ny == c0.d.ny && ck.d.ndu == c0.d.ndu && ck.d.ph == c0.d.ph && ck.d.ch == c0.d.ch &&
+                          ok.nz == o0.nz && ok.mg == o0.mg && ok.g_refrow == o0.g_refrow && ok.boxrow_ptr == o0.boxrow_ptr && ok.boxrow_ref == o0.boxrow_ref &&
+                          ok.fixed_rows.size() == o0.fixed_rows.size() && ok.blk == o0.blk;
+        if (!same) return fail(MPCX_E_INVALID, "controller " + std::to_string(k) + " differs from controller 0 in dimensions or in which bounds are finite");
+    }
+    std::unique_ptr<mpcx_lmpc_hetero> f(new mpcx_lmpc_hetero);
+    f->device = device; f->count = count; f->d = c0.d; f->active_words = o0.active_words; f->m_ref = o0.m_ref;
+    if (hipSetDevice(device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    SlabUploader U;
+    std::vector<mpcx::LmpcDev> devs((size_t)count);
+    int rc = MPCX_OK;
+    for (int k = 0; k < count; ++k) {
+        auto &o = cond[(size_t)k];
+        // the stacked maps of the MFMA assemble kernel serve sixteen instances of ONE model: not used here, not uploaded
+        o.MA[0].clear(); o.MA[1].clear(); o.MF[0].clear(); o.MF[1].clear(); o.Ym.clear();
+        fill_dev_scalars(controllers[k], controllers[k]->ctl, o, devs[(size_t)k]);
+        fill_dev_arrays(controllers[k], controllers[k]->ctl, o, devs[(size_t)k], U, rc);
+        devs[(size_t)k].fused_ok = 0; devs[(size_t)k].group_ok = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&f->slab), U.host.size()) != hipSuccess ||
+        hipMemcpy(f->slab, U.host.data(), U.host.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MPCX_E_DEVICE, "could not upload the bank (" + std::to_string(U.host.size() >> 20) + " MiB)");
+    for (auto &D : devs) rebase_dev(D, f->slab);
+    if (hipMalloc(reinterpret_cast<void **>(&f->models_d), sizeof(mpcx::LmpcDev) * (size_t)count) != hipSuccess ||
+        hipMemcpy(f->models_d, devs.data(), sizeof(mpcx::LmpcDev) * (size_t)count, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MPCX_E_DEVICE, "could not upload the bank's model table");
+    f->dev0 = devs[0];
+    *out = f.release();
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_hetero_destroy(mpcx_lmpc_hetero_t f)
+{
+    if (!f) return MPCX_OK;
+    (void)hipSetDevice(f->device);
+    delete f;
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_hetero_get_info(mpcx_lmpc_hetero_t f, int *count, int *active_words, int *m_ref, double *bytes_per_model)
+{
+    if (!f) return fail(MPCX_E_INVALID, "null bank");
+    if (count) *count = f->count;
+    if (active_words) *active_words = f->active_words;
+    if (m_ref) *m_ref = f->m_ref;
+    if (bytes_per_model) {
+        const auto &D = f->dev0;
+        // what a solve reads of its own model: -Hinv and G Hinv once (assemble), the model and weight arrays, the bounds
+        *bytes_per_model = 8.0 * ((double)D.nz * D.ldy + (double)D.nx * D.nx + (double)D.nx * D.nu + (double)D.ny * D.nx +
+                                  (double)(D.ph + 1) * (D.ny + D.nu) + (double)D.ph * D.nu + 2.0 * D.ldz + 2.0 * D.ldg);
+    }
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_hetero_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream)
+{
+    if (!f || !b) return fail(MPCX_E_INVALID, "null argument");
+    if (hipSetDevice(f->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    if (b->batch == 0) return MPCX_OK;
+    if (b->batch < 0 || !b->x0 || !b->u0 || !b->cmd) return fail(MPCX_E_INVALID, "x0, u0 and cmd are required");
+    if (!model_index && b->batch != f->count) return fail(MPCX_E_INVALID, "without a model index the batch must be the bank: instance b uses controller b");
+    const auto &d = f->d;
+    mpcx::LmpcBatchDev B{};
+    B.batch = b->batch; B.x0 = b->x0; B.u0 = b->u0;
+    // references: per instance or per step from the caller; "shared" = each controller's own (its setReferences), read through the model
+    auto refsel = [&](const double *p, int mode, int n, const double *&op, long &bs, long &ks) -> bool {
+        if (mode == MPCX_REF_SHARED) { op = nullptr; bs = 0; ks = n; return true; }
+        if (!p) return false;
+        if (mode == MPCX_REF_PER_INSTANCE) { op = p; bs = n; ks = 0; return true; }
+        if (mode == MPCX_REF_PER_STEP) { op = p; bs = (long)d.ph * n; ks = n; return true; }
+        return false;
+    };
+    if (!refsel(b->yref, b->yref_mode, d.ny, B.yref, B.yref_bs, B.yref_ks) || !refsel(b->uref, b->uref_mode, d.nu, B.uref, B.uref_bs, B.uref_ks) ||
+        !refsel(b->duref, b->duref_mode, d.nu, B.duref, B.duref_bs, B.duref_ks) || !refsel(b->dmeas, b->dmeas_mode, d.ndu, B.dmeas, B.dmeas_bs, B.dmeas_ks))
+        return fail(MPCX_E_INVALID, "reference array missing for a non-shared mode, or unknown mode");
+    B.cmd = b->cmd; B.cost = b->cost; B.status = b->status; B.solver_status = b->solver_status;
+    B.is_feasible = b->is_feasible; B.iterations = b->iterations;
+    B.active_lower = b->active_lower; B.active_upper = b->active_upper;
+    B.seq_state = b->seq_state; B.seq_output = b->seq_output; B.seq_input = b->seq_input;
+    B.polish_rounds = b->polish_rounds; B.active_count = b->active_count;
+    B.warm_lower = b->warm_active_lower; B.warm_upper = b->warm_active_upper; B.warm_shift = b->warm_shift;
+    if ((B.warm_lower == nullptr) != (B.warm_upper == nullptr)) return fail(MPCX_E_INVALID, "warm_active_lower and warm_active_upper go together");
+    B.n_models = f->count; B.model_index = model_index;
+    if ((size_t)b->batch > f->ws_cap) {
+        if (f->ws) (void)hipFree(f->ws);
+        f->ws = nullptr; f->ws_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&f->ws), (size_t)b->batch * f->dev0.wsld * sizeof(double)) != hipSuccess)
+            return fail(MPCX_E_DEVICE, "workspace allocation failed");
+        f->ws_cap = (size_t)b->batch;
+    }
+    const int lr = mpcx::lmpc_launch(f->dev0, f->models_d, B, f->ws, stream, 7, -1);      // roll-out assemble, lean solve, ADMM fallback
+    if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
+    if (lr != 0) return fail(MPCX_E_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    return MPCX_OK;
+}
+
+int mpcx_lmpc_hetero_time_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream, int repeats, float *ms_mean)
+{
+    if (!f || !b || !ms_mean || repeats < 1) return fail(MPCX_E_INVALID, "bad argument");
+    int rc = mpcx_lmpc_hetero_solve_batch(f, b, model_index, stream);
+    if (rc != MPCX_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MPCX_E_DEVICE, "hipEventCreate failed");
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < repeats && rc == MPCX_OK; i++) rc = mpcx_lmpc_hetero_solve_batch(f, b, model_index, stream);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_mean = ms / (float)repeats;
+    return rc;
 }
 
 /* profiling aid: mean time (ms) of the assemble and of the solve kernel, each timed alone with

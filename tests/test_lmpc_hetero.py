@@ -1,0 +1,105 @@
+"""GPU parity tests of heterogeneous LMPC batches (mpcx_lmpc_hetero_*): every instance its own controller -- own A, B, C,
+weights, bounds, references -- against the CPU oracle's front-end, one oracle controller per instance, exactly as the
+reference would hold one mpc::LMPC<> object per problem (LMPC.hpp:751)."""
+import numpy as np
+import pytest
+
+from helpers import OracleFrontEnd, bits_to_rows, configure_quadrotor, configure_random, quadrotor_oracle, random_lmpc_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_family(K, seed0=100):
+    """K full-feature controllers (disturbances, per-step weights, slices of bounds, scalar constraint, move blocking) with the
+    same dimensions and the same pattern of finite bounds, everything else different"""
+    specs = [random_lmpc_spec(seed0 + k) for k in range(K)]
+    return specs
+
+
+def test_every_instance_its_own_random_controller_matches_the_oracle():
+    import torch
+    from libmpc_amd import LMPC, LMPCHetero, LParameters
+    K = 48
+    specs = _random_family(K)
+    ctrls, oracles = [], []
+    for sp in specs:
+        c = configure_random(LMPC(*sp["dims"], device=-1), sp)
+        c.setOptimizerParameters(LParameters(maximum_iteration=2000))
+        ctrls.append(c)
+        o = configure_random(OracleFrontEnd(*sp["dims"]), sp)
+        o.setOptimizerParameters(maximum_iteration=2000)
+        oracles.append(o)
+    het = LMPCHetero(ctrls, device=0)
+    assert het.count == K
+    rng = np.random.default_rng(7)
+    nx, nu = specs[0]["dims"][0], specs[0]["dims"][1]
+    x0 = rng.uniform(-1, 1, size=(K, nx)); x0[:, 0] *= 0.5
+    u0 = rng.uniform(-0.5, 0.5, size=(K, nu))
+    r = het.optimizeBatch(x0, u0, want_active=True, want_sequence=True); torch.cuda.synchronize()
+    cmd = r.cmd.cpu().numpy(); cost = r.cost.cpu().numpy(); st = r.status.cpu().numpy()
+    checked = 0
+    for k in range(K):
+        ref = oracles[k].optimize(x0[k], u0[k])
+        if ref["polished"] != 1:
+            continue
+        checked += 1
+        assert st[k] == 0
+        assert np.abs(cmd[k] - ref["cmd"]).max() <= 1e-5 * max(np.abs(ref["cmd"]).max(), 1e-12), (k, cmd[k], ref["cmd"])
+        assert abs(cost[k] - ref["cost"]) <= 1e-6 * max(1.0, abs(ref["cost"]))
+        assert np.allclose(r.seq_state[k].cpu().numpy(), ref["state"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(r.seq_input[k].cpu().numpy(), ref["input"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(r.seq_output[k].cpu().numpy(), ref["output"], rtol=1e-5, atol=1e-7)
+    assert checked >= K * 3 // 4, checked
+    # a bank is K controllers: every instance equals what its controller returns on its own through the shared-model path (whose
+    # active sets tests/test_lmpc_gpu.py pins to the oracle's, move blocking included) -- commands, costs and active sets
+    for k in range(K):
+        c = configure_random(LMPC(*specs[k]["dims"], device=0), specs[k])
+        c.setOptimizerParameters(LParameters(maximum_iteration=2000))
+        one = c.optimizeBatch(x0[k:k + 1], u0[k:k + 1], want_active=True); torch.cuda.synchronize()
+        np.testing.assert_allclose(one.cmd.cpu().numpy()[0], cmd[k], rtol=1e-9, atol=1e-11)
+        assert int(one.status[0]) == st[k]
+        assert torch.equal(one.active_lower[0], r.active_lower[k]) and torch.equal(one.active_upper[0], r.active_upper[k]), k
+
+
+def test_quadrotor_variants_with_a_model_index():
+    """a fleet: 64 quadrotor variants (scaled dynamics, own weights and input limits), 512 instances drawing their controller from
+    an index; every instance against the C oracle of its own controller"""
+    import torch
+    from libmpc_amd import LMPC, LMPCHetero
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_variant
+    K, B, ph = 64, 512, 10
+    ctrls = [quadrotor_variant(k, ph, device=-1) for k in range(K)]
+    het = LMPCHetero(ctrls, device=0)
+    x0, u0, yref = quadrotor_batch(B)
+    model = (np.arange(B) * 7) % K
+    r = het.optimizeBatch(x0, u0, model=model, yref=yref, want_active=True); torch.cuda.synchronize()
+    cmd = r.cmd.cpu().numpy(); st = r.status.cpu().numpy()
+    assert (st == 0).all()
+    lo = bits_to_rows(r.active_lower.cpu().numpy(), het.m_ref); up = bits_to_rows(r.active_upper.cpu().numpy(), het.m_ref)
+    worst = 0.0
+    for k in range(K):
+        idx = np.nonzero(model == k)[0]
+        f = OracleFrontEnd(12, 4, 4, 12, ph, ph)
+        quadrotor_variant(k, ph, into=f)
+        from oracle.lmpc_oracle import default_params
+        f.o.params = default_params(maximum_iteration=250)
+        ref = f.o.solve_batch_constref(x0[idx], u0[idx], yref[idx], want_active=True)
+        pol = ref["polished"] == 1
+        err = np.abs(cmd[idx] - ref["cmd"]).max(axis=1) / np.maximum(np.abs(ref["cmd"]).max(axis=1), 1e-12)
+        assert err[pol].max() <= 1e-5
+        worst = max(worst, err[pol].max())
+        for t, b in enumerate(idx):
+            if pol[t]:
+                rl = np.nonzero(ref["active_lower"][t][f.o.neq:])[0] + f.o.neq; ru = np.nonzero(ref["active_upper"][t][f.o.neq:])[0] + f.o.neq
+                assert np.array_equal(lo[b], rl) and np.array_equal(up[b], ru)
+    print("fleet of %d variants, %d instances: worst relative error of u* %.2e" % (K, B, worst))
+
+
+def test_structure_mismatch_is_refused():
+    from libmpc_amd import LMPC, LMPCHetero, MpcxError
+    from libmpc_amd.workloads import quadrotor_variant
+    a = quadrotor_variant(0, 10, device=-1)
+    b = quadrotor_variant(1, 10, device=-1)
+    b.setStateBounds([-1.0] * 12, [1.0] * 12, (0, 10))          # more finite bounds than controller 0: another row structure
+    with pytest.raises(MpcxError):
+        LMPCHetero([a, b], device=0)
