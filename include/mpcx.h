@@ -423,6 +423,10 @@ int mpcx_allgather_u(mpcx_comm_t c, const double *u_local, int rows_per_rank, in
  * it needs: the controllers may be destroyed or changed afterwards (changes do not reach the bank).                          */
 typedef struct mpcx_lmpc_hetero *mpcx_lmpc_hetero_t;
 int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int device, mpcx_lmpc_hetero_t *out);
+/* condense_on_host = 1: every controller's prediction matrices, Hessian, factors and dual Hessian on the host cores (what a single
+ * controller's set-up does); 0: on the device, one workgroup per controller, the products on the f64 matrix pipe (falls back to the
+ * host when the condensed problem exceeds 96 variables / the kernel's LDS plan)                                                 */
+int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int device, int condense_on_host, mpcx_lmpc_hetero_t *out);
 int mpcx_lmpc_hetero_destroy(mpcx_lmpc_hetero_t f);
 int mpcx_lmpc_hetero_get_info(mpcx_lmpc_hetero_t f, int *count, int *active_words, int *m_ref, double *bytes_per_model);
 int mpcx_lmpc_hetero_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream);
@@ -457,6 +461,9 @@ int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, 
 /* user hooks given as source: the translation unit the run-time compiler is fed / a compile-only check (0 = it builds) */
 int mpcx_nlmpc_debug_generated_source(const mpcx_nlmpc_source *src, char *out, int cap);
 int mpcx_nlmpc_debug_compile_source(const mpcx_nlmpc_source *src);
+/* one O(n^3) array ("H", "Kinv", "Gr", "Gc", "Y", "rho_b", "rho_g"; "flags" = [cost_direct, condensed on the device]) of controller k
+ * of a bank, copied to the host; out = NULL returns the length */
+int mpcx_lmpc_hetero_debug_get(mpcx_lmpc_hetero_t f, int k, const char *name, double *out, int cap);
 
 const char *mpcx_version(void);
 

@@ -68,7 +68,7 @@ EXPORTS = [
     "mpcx_nlmpc_create_custom", "mpcx_nlmpc_create_from_source", "mpcx_nlmpc_set_input_scale", "mpcx_nlmpc_set_state_scale",
     "mpcx_comm_get_unique_id", "mpcx_comm_create", "mpcx_comm_destroy", "mpcx_comm_rank", "mpcx_comm_world", "mpcx_allgather_u",
     "mpcx_lmpc_hetero_create", "mpcx_lmpc_hetero_destroy", "mpcx_lmpc_hetero_get_info", "mpcx_lmpc_hetero_solve_batch",
-    "mpcx_lmpc_hetero_time_solve_batch",
+    "mpcx_lmpc_hetero_time_solve_batch", "mpcx_lmpc_hetero_create_ex", "mpcx_lmpc_hetero_debug_get",
     # profiling and testing aids (declared in include/mpcx.h under that heading)
     "mpcx_lmpc_debug_time_kernels", "mpcx_lmpc_debug_get", "mpcx_lmpc_debug_setup_counts", "mpcx_lmpc_debug_use_fused",
     "mpcx_lmpc_debug_force_generic", "mpcx_lmpc_debug_set_rounds", "mpcx_lmpc_debug_set_cycle_buffer",

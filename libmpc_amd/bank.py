@@ -97,7 +97,9 @@ class LMPCHetero:
     pattern of finite bounds, solved together by one set of kernels: instance b uses controller `model[b]` (default: b).
     In the reference each of them is its own `mpc::LMPC<>` object (LMPC.hpp:751)."""
 
-    def __init__(self, controllers, device=0):
+    def __init__(self, controllers, device=0, condense_on_host=False):
+        """condense_on_host: every controller's prediction matrices, Hessian and factors on the host cores instead of by the
+        device kernel (lmpc_hetero.hip; the default wherever the dimensions fit it)"""
         if not controllers:
             raise ValueError("at least one controller")
         c0 = controllers[0]
@@ -106,7 +108,7 @@ class LMPCHetero:
         self._lib = _capi.lib()
         arr = (C.c_void_p * len(controllers))(*[c._h for c in controllers])
         self._h = C.c_void_p()
-        check(self._lib.mpcx_lmpc_hetero_create(arr, len(controllers), self.device, C.byref(self._h)))
+        check(self._lib.mpcx_lmpc_hetero_create_ex(arr, len(controllers), self.device, int(bool(condense_on_host)), C.byref(self._h)))
         n, aw, mref, bpm = C.c_int(), C.c_int(), C.c_int(), C.c_double()
         check(self._lib.mpcx_lmpc_hetero_get_info(self._h, C.byref(n), C.byref(aw), C.byref(mref), C.byref(bpm)))
         self.count, self.active_words, self.m_ref, self.bytes_per_model = n.value, aw.value, mref.value, bpm.value
@@ -119,6 +121,14 @@ class LMPCHetero:
 
     def info(self):
         return {"active_words": self.active_words, "m_ref": self.m_ref}
+
+    def debug_get(self, k, name):
+        """testing aid: an O(n^3) array of controller k as the bank holds it on the device"""
+        f = self._lib.mpcx_lmpc_hetero_debug_get
+        n = check(f(self._h, int(k), name.encode(), None, 0))
+        out = np.zeros(n)
+        check(f(self._h, int(k), name.encode(), out.ctypes.data_as(C.c_void_p), n))
+        return out
 
     # the descriptor is the single-controller one: borrow its builder (it only needs the dimensions and info())
     _torch, _dev, _ref = LMPC._torch, LMPC._dev, LMPC._ref

@@ -28,6 +28,7 @@ struct LmpcDev {
     int cost_direct;                             // 1: cost from its definition (regularised Hessian), 0: from the multipliers
     int strict_infeasible;                       // 1: report INFEASIBLE / NaN; 0: behave as the reference does
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
+    int adaptive_rho; double rho_user;            // LParameters::adaptive_rho / rho (the ADMM step sizes of the set-up)
     // per-wave LDS carve (in doubles)
     int stage_len, arena_len, lds_per_wave;
     int fast_slice;                              // per-wave LDS slice of the lean solve kernels (doubles)
@@ -93,5 +94,9 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 int lmpc_fast_slice(const LmpcDev &m);          // needs wsld, kin, nx
 // implemented in lmpc_fast.hip: the lean polish kernel (b.fused: the fused / persistent forms) on `stream`
 int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream);
+// implemented in lmpc_hetero.hip: the O(n^3) arrays of `count` model structs (device array) computed in place, one workgroup each;
+// -2: the dimensions do not fit the kernel's LDS plan (the bank then condenses on the host)
+size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out);
+int lmpc_condense_launch(LmpcDev *models_d, const LmpcDev &m0, int count, void *stream);
 
 }  // namespace mpcx

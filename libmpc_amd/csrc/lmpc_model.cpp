@@ -168,8 +168,11 @@ void LmpcController::set_scalar_idx(int idx, double smin, double smax, const dou
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-std::string LmpcController::condense(Condensed &o) const
+std::string LmpcController::condense(Condensed &o, const Condensed *like) const
 {
+    // like != nullptr: structure only (mpcx_lmpc_hetero_*: the O(n^3) arrays are computed on the device, lmpc_hetero.hip) -- the rows
+    // are classified as in `like` (a controller of the same bank, condensed in full), the matrices are allocated and left zero
+    const bool light = like != nullptr;
     const int nx = d.nx, nu = d.nu, ny = d.ny, ndu = d.ndu, ph = d.ph, ch = d.ch;
     if (!have_model) return "state-space model not set";
     o = Condensed();
@@ -194,8 +197,8 @@ std::string LmpcController::condense(Condensed &o) const
     for (double v : Dd.a) if (v != 0.0) o.has_dist = true;
 
     // prediction: Sx_i = sum_{j<=i} A^{i-j} B E_j   (nx x nz), i = 1..ph  -- the "A^h, B-stack"
-    std::vector<Mat> Sx(ph + 1, Mat(nx, nz));
-    {
+    std::vector<Mat> Sx(light ? 0 : ph + 1, Mat(nx, nz));
+    if (!light) {
         // recursion Sx_i = A Sx_{i-1} + B E_i
         for (int i = 1; i <= ph; i++) {
             if (i > 1) Sx[i] = matmul(A, Sx[i - 1]);
@@ -207,7 +210,7 @@ std::string LmpcController::condense(Condensed &o) const
 
     // Hessian
     Mat H(nz, nz);
-    for (int i = 1; i <= ph; i++) {
+    for (int i = 1; i <= ph && !light; i++) {
         Mat CS = matmul(C, Sx[i]);                       // ny x nz
         for (int q = 0; q < nz; q++)
             for (int p = 0; p <= q; p++) {
@@ -247,7 +250,7 @@ std::string LmpcController::condense(Condensed &o) const
             double lo = minX(j, i), hi = maxX(j, i);
             if (!finite_any(lo, hi)) continue;
             std::vector<double> g(nz);
-            for (int q = 0; q < nz; q++) g[q] = Sx[i](j, q);
+            for (int q = 0; q < nz && !light; q++) g[q] = Sx[i](j, q);
             rows.push_back({G_STATE, i, j, o.neq_ref + i * na + j, lo, hi});
             grow.push_back(std::move(g));
         }
@@ -263,7 +266,7 @@ std::string LmpcController::condense(Condensed &o) const
             double lo = minY(j, i), hi = maxY(j, i);
             if (!finite_any(lo, hi)) continue;
             std::vector<double> g(nz, 0.0);
-            for (int q = 0; q < nz; q++) {
+            for (int q = 0; q < nz && !light; q++) {
                 double s = 0;
                 for (int a = 0; a < nx; a++) s += C(j, a) * Sx[i](a, q);
                 g[q] = s;
@@ -273,7 +276,7 @@ std::string LmpcController::condense(Condensed &o) const
         }
         if (finite_any(sMin[i], sMax[i])) {
             std::vector<double> g(nz, 0.0);
-            for (int q = 0; q < nz; q++) {
+            for (int q = 0; q < nz && !light; q++) {
                 double s = 0;
                 for (int a = 0; a < nx; a++) s += sX[a] * Sx[i](a, q);
                 g[q] = s;
@@ -289,6 +292,11 @@ std::string LmpcController::condense(Condensed &o) const
         for (size_t r = 0; r < rows.size(); r++) {
             double nrm = 0;
             for (double v : grow[r]) nrm = std::max(nrm, std::fabs(v));
+            if (light) {
+                nrm = 1.0;
+                for (const auto &fr : like->fixed_rows)
+                    if (fr.kind == rows[r].kind && fr.step == rows[r].step && fr.comp == rows[r].comp) nrm = 0.0;
+            }
             if (nrm < 1e-14) o.fixed_rows.push_back(rows[r]);
             else { keep.push_back(rows[r]); gk.push_back(std::move(grow[r])); }
         }
@@ -300,8 +308,24 @@ std::string LmpcController::condense(Condensed &o) const
     o.ldg = ldg;
     o.ldy = ldz + ldg;
 
+    if (light) {
+        // everything the device fills: allocated, zero (padding stays zero)
+        const int ldy = o.ldy;
+        o.H.assign((size_t)ldz * ldz, 0.0); o.Kinv.assign((size_t)ldz * ldz, 0.0);
+        o.Gr.assign((size_t)ldg * ldz, 0.0); o.Gc.assign((size_t)ldz * ldg, 0.0);
+        o.Y.assign((size_t)ldy * ldy, 0.0);
+        o.lw = lw; o.uw = uw;
+        o.rho_b.assign(ldz, 0.0);
+        o.lg0.assign(ldg, -kInf); o.ug0.assign(ldg, kInf); o.rho_g.assign(ldg, 1.0);
+        o.g_kind.assign(ldg, 0); o.g_step.assign(ldg, 0); o.g_comp.assign(ldg, 0); o.g_refrow.assign(ldg, -1);
+        for (int r = 0; r < mg; r++) {
+            o.lg0[r] = rows[r].lo; o.ug0[r] = rows[r].hi;
+            o.g_kind[r] = rows[r].kind; o.g_step[r] = rows[r].step; o.g_comp[r] = rows[r].comp; o.g_refrow[r] = rows[r].refrow;
+        }
+    }
     // regularise a singular Hessian (zero weights): no unique optimum then anyway
     double maxd = 0;
+    if (!light) {
     for (int q = 0; q < nz; q++) maxd = std::max(maxd, std::fabs(H(q, q)));
     Mat L = H;
     double piv = cholesky_lower(L);
@@ -403,6 +427,7 @@ std::string LmpcController::condense(Condensed &o) const
             o.Gc[(size_t)q * ldg + r] = G(r, q);
         }
 
+    }   // !light
     // var -> reference rows (CSR)
     o.boxrow_ptr.assign(ldz + 1, 0);
     for (auto &b : boxrefs) o.boxrow_ptr[b.var + 1]++;
@@ -418,7 +443,7 @@ std::string LmpcController::condense(Condensed &o) const
         }
     }
     (void)ndu;
-    build_fast_maps(o);
+    if (!light) build_fast_maps(o);
     return std::string();
 }
 

@@ -120,7 +120,8 @@ struct LmpcController {
     void set_scalar_idx(int idx, double smin, double smax, const double *X, const double *U);
 
     // returns empty string on success, message otherwise
-    std::string condense(Condensed &out) const;
+    // like != nullptr: the structure and the O(n) arrays only, rows classified as in `like` (see lmpc_model.cpp)
+    std::string condense(Condensed &out, const Condensed *like = nullptr) const;
     // host evaluation of what the generic assemble kernel computes for one instance
     void assemble_host(const Condensed &o, const double *x0, const double *u0, const Mat &yR, const Mat &uR,
                        const Mat &dR, const Mat &dM, AsmOut &out) const;

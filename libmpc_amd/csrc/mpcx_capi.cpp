@@ -112,6 +112,7 @@ static void fill_dev_scalars(const mpcx_lmpc *h, const mpcx::LmpcController &c, 
     D.cost_direct = (o.h_regularised || o.inverse_residual > 1e-9) ? 1 : 0;
     D.check_every = h->dbg_check_every; D.polish_rounds0 = h->dbg_rounds0; D.polish_rounds = 10;
     D.alpha = c.prm.alpha; D.sigma = 1e-6;
+    D.adaptive_rho = c.prm.adaptive_rho ? 1 : 0; D.rho_user = c.prm.rho;
     D.eps_abs = c.prm.eps_abs; D.eps_rel = c.prm.eps_rel; D.eps_prim_inf = c.prm.eps_prim_inf;
     D.lds_per_wave = mpcx::lmpc_lds_per_wave(D, &D.stage_len, &D.arena_len);
     D.wsld = D.ldz + D.ldy + 2 * D.ldg + 2;
@@ -187,6 +188,7 @@ struct mpcx_lmpc_hetero {
     char *slab = nullptr;
     double *ws = nullptr; size_t ws_cap = 0;
     int active_words = 0, m_ref = 0;
+    bool condensed_on_device = false;
     ~mpcx_lmpc_hetero()
     {
         if (models_d) (void)hipFree(models_d);
@@ -784,14 +786,30 @@ int mpcx_lmpc_get_info(mpcx_lmpc_t h, mpcx_lmpc_info *info)
 /* ---- heterogeneous batches -------------------------------------------------------------------------------------------------- */
 int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int device, mpcx_lmpc_hetero_t *out)
 {
+    return mpcx_lmpc_hetero_create_ex(controllers, count, device, 0, out);
+}
+
+int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int device, int condense_on_host, mpcx_lmpc_hetero_t *out)
+{
     if (!controllers || !out || count < 1) return fail(MPCX_E_INVALID, "need at least one controller");
     for (int k = 0; k < count; ++k) if (!controllers[k]) return fail(MPCX_E_INVALID, "null controller in the bank");
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev)
         return fail(MPCX_E_DEVICE, "no such HIP device (the solve path has no CPU fallback)");
-    // condense every controller on the host cores (what mpcx_lmpc_setup does for one), in parallel
+    // Controller 0 is condensed in full on the host: it fixes the structure (dimensions, constraint rows) and says whether the
+    // dimensions fit the device kernel.  The others: in full too (condense_on_host, or dimensions beyond the kernel's LDS plan), or
+    // their structure and O(n) arrays only -- the O(n^3) arrays of all K are then computed by lmpc_condense_models.
     std::vector<mpcx::Condensed> cond((size_t)count);
     std::vector<std::string> errs((size_t)count);
+    errs[0] = controllers[0]->ctl.condense(cond[0]);
+    if (!errs[0].empty()) return fail(MPCX_E_NUMERIC, "controller 0: " + errs[0]);
+    bool on_device = !condense_on_host;
+    {
+        mpcx::LmpcDev probe{};
+        probe.nz = cond[0].nz; probe.mg = cond[0].mg; probe.nx = controllers[0]->ctl.d.nx; probe.ny = controllers[0]->ctl.d.ny;
+        if (mpcx::lmpc_condense_lds(probe, nullptr, nullptr) > 160 * 1024 - 64) on_device = false;
+    }
+    const mpcx::Condensed *like = on_device ? &cond[0] : nullptr;
     {
         unsigned nt = std::thread::hardware_concurrency();
         if (nt < 1) nt = 1;
@@ -801,7 +819,7 @@ int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int devic
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < nt; ++t)
             pool.emplace_back([&]() {
-                for (int k = next.fetch_add(1); k < count; k = next.fetch_add(1)) errs[(size_t)k] = controllers[k]->ctl.condense(cond[(size_t)k]);
+                for (int k = next.fetch_add(1) + 1; k < count; k = next.fetch_add(1) + 1) errs[(size_t)k] = controllers[k]->ctl.condense(cond[(size_t)k], like);
             });
         for (auto &th : pool) th.join();
     }
@@ -841,6 +859,13 @@ int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int devic
         hipMemcpy(f->models_d, devs.data(), sizeof(mpcx::LmpcDev) * (size_t)count, hipMemcpyHostToDevice) != hipSuccess)
         return fail(MPCX_E_DEVICE, "could not upload the bank's model table");
     f->dev0 = devs[0];
+    if (on_device) {
+        const int lr = mpcx::lmpc_condense_launch(f->models_d, f->dev0, count, nullptr);
+        if (lr != 0) return fail(MPCX_E_DEVICE, "the device condensing kernel could not be launched (" + std::to_string(lr) + ")");
+        const hipError_t es = hipDeviceSynchronize();
+        if (es != hipSuccess) return fail(MPCX_E_DEVICE, std::string("the device condensing kernel failed: ") + hipGetErrorString(es));
+    }
+    f->condensed_on_device = on_device;
     *out = f.release();
     return MPCX_OK;
 }
@@ -851,6 +876,27 @@ int mpcx_lmpc_hetero_destroy(mpcx_lmpc_hetero_t f)
     (void)hipSetDevice(f->device);
     delete f;
     return MPCX_OK;
+}
+
+/* testing aid: one O(n^3) array ("H", "Kinv", "Gr", "Gc", "Y", "rho_b", "rho_g") of model k copied to the host; returns its length */
+int mpcx_lmpc_hetero_debug_get(mpcx_lmpc_hetero_t f, int k, const char *name, double *out, int cap)
+{
+    if (!f || k < 0 || k >= f->count || !name) return fail(MPCX_E_INVALID, "bad argument");
+    if (hipSetDevice(f->device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
+    mpcx::LmpcDev D;
+    if (hipMemcpy(&D, f->models_d + k, sizeof(D), hipMemcpyDeviceToHost) != hipSuccess) return fail(MPCX_E_DEVICE, "hipMemcpy failed");
+    const std::string n(name);
+    const double *src = nullptr; size_t len = 0;
+    if (n == "H") { src = D.H; len = (size_t)D.ldz * D.ldz; } else if (n == "Kinv") { src = D.Kinv; len = (size_t)D.ldz * D.ldz; }
+    else if (n == "Gr") { src = D.Gr; len = (size_t)D.ldg * D.ldz; } else if (n == "Gc") { src = D.Gc; len = (size_t)D.ldz * D.ldg; }
+    else if (n == "Y") { src = D.Y; len = (size_t)D.ldy * D.ldy; } else if (n == "rho_b") { src = D.rho_b; len = (size_t)D.ldz; }
+    else if (n == "rho_g") { src = D.rho_g; len = (size_t)D.ldg; }
+    else if (n == "flags") { if (out && cap >= 2) { out[0] = D.cost_direct; out[1] = f->condensed_on_device ? 1.0 : 0.0; } return 2; }
+    else return fail(MPCX_E_INVALID, "unknown array name");
+    if (!out) return (int)len;
+    if ((size_t)cap < len) return fail(MPCX_E_INVALID, "buffer too small");
+    if (hipMemcpy(out, src, len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(MPCX_E_DEVICE, "hipMemcpy failed");
+    return (int)len;
 }
 
 int mpcx_lmpc_hetero_get_info(mpcx_lmpc_hetero_t f, int *count, int *active_words, int *m_ref, double *bytes_per_model)

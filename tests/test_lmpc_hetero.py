@@ -103,3 +103,41 @@ def test_structure_mismatch_is_refused():
     b.setStateBounds([-1.0] * 12, [1.0] * 12, (0, 10))          # more finite bounds than controller 0: another row structure
     with pytest.raises(MpcxError):
         LMPCHetero([a, b], device=0)
+
+
+@pytest.mark.parametrize("family", ["quadrotor", "random"])
+def test_device_condensing_matches_the_host_set_up(family):
+    """the bank's O(n^3) arrays -- Hessian, constraint rows, dual Hessian, ADMM matrix -- computed by lmpc_condense_models (MFMA)
+    against LmpcController::condense on the host, array by array, and the solves of the two banks against each other"""
+    import torch
+    from libmpc_amd import LMPC, LMPCHetero, LParameters
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_variant
+    if family == "quadrotor":
+        K = 24
+        ctrls = [quadrotor_variant(k, 20, device=-1) for k in range(K)]
+        x0, u0, yref = quadrotor_batch(K)
+    else:
+        K = 24
+        ctrls = []
+        for sp in _random_family(K):
+            c = configure_random(LMPC(*sp["dims"], device=-1), sp)
+            c.setOptimizerParameters(LParameters(maximum_iteration=2000))
+            ctrls.append(c)
+        rng = np.random.default_rng(3)
+        x0 = rng.uniform(-1, 1, size=(K, ctrls[0].nx)); x0[:, 0] *= 0.5
+        u0 = rng.uniform(-0.5, 0.5, size=(K, ctrls[0].nu)); yref = None
+    host = LMPCHetero(ctrls, device=0, condense_on_host=True)
+    dev = LMPCHetero(ctrls, device=0)
+    assert host.debug_get(0, "flags")[1] == 0.0 and dev.debug_get(0, "flags")[1] == 1.0
+    for k in (0, 1, K // 2, K - 1):
+        for name, tol in (("H", 1e-12), ("Gr", 1e-12), ("Gc", 1e-12), ("Y", 1e-9), ("rho_b", 1e-9), ("rho_g", 1e-9), ("Kinv", 1e-8)):
+            a, b = host.debug_get(k, name), dev.debug_get(k, name)
+            scale = max(np.abs(a).max(), 1e-300)
+            assert np.abs(a - b).max() <= tol * scale, (k, name, np.abs(a - b).max() / scale)
+        assert host.debug_get(k, "flags")[0] == dev.debug_get(k, "flags")[0]
+    ra = host.optimizeBatch(x0, u0, yref=yref, want_active=True); rb = dev.optimizeBatch(x0, u0, yref=yref, want_active=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ra.status, rb.status)
+    np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=1e-8, atol=1e-8)
+    assert torch.equal(ra.active_lower, rb.active_lower) and torch.equal(ra.active_upper, rb.active_upper)
