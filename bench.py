@@ -92,6 +92,35 @@ def _nl_cpu_worker(job):
     return done, time.perf_counter() - t0
 
 
+def _sq_counters(kernel, tag):
+    """unit-busy fractions of one kernel from the committed hardware-counter summary of this command (tools/profile_sq.sh):
+    VALU / MFMA / LDS / scalar busy cycles over the cycles its wavefronts were resident (all SQ counters count 4-cycle steps
+    per wavefront), L2 hit rate.  Same staleness rule as the traffic figure."""
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_%s.json" % tag)))
+    if not cand:
+        return None
+    pm = json.load(open(cand[-1]))
+    if pm.get("kernel_source_hash") != kernel_source_hash():
+        return {"source": os.path.basename(cand[-1]), "note": "counter summary is stale: kernel sources changed since it was measured"}
+    g = lambda c: pm.get(c, {}).get(kernel, {}).get("mean")
+    wc = g("SQ_WAVE_CYCLES")
+    if not wc:
+        return {"source": os.path.basename(cand[-1]), "note": "kernel %s not in the counter summary" % kernel}
+    frac = lambda c: (g(c) / wc) if g(c) is not None else None
+    hit, miss = g("TCC_HIT"), g("TCC_MISS")
+    return {"source": os.path.basename(cand[-1]), "valu_busy_per_wave": frac("SQ_ACTIVE_INST_VALU"), "mfma_busy_per_wave": frac("SQ_VALU_MFMA_BUSY_CYCLES"),
+            "lds_busy_per_wave": frac("SQ_ACTIVE_INST_LDS"), "scalar_busy_per_wave": frac("SQ_ACTIVE_INST_SCA"),
+            "waiting_per_wave": frac("SQ_WAIT_INST_ANY"), "waves": g("SQ_WAVES"),
+            "instructions_per_wave": {k: (g("SQ_INSTS_" + k) / g("SQ_WAVES")) if g("SQ_INSTS_" + k) is not None and g("SQ_WAVES") else None
+                                      for k in ("VALU", "SALU", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")},
+            "f64_fma_per_wave": (g("SQ_INSTS_VALU_FMA_F64") / g("SQ_WAVES")) if g("SQ_INSTS_VALU_FMA_F64") is not None and g("SQ_WAVES") else None,
+            "mfma_f64_ops": g("SQ_INSTS_VALU_MFMA_MOPS_F64"), "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
+            "l2_hit_rate": (hit / (hit + miss)) if hit is not None and miss is not None and hit + miss > 0 else None,
+            "note": "busy = cycles the unit executed this kernel's instructions / cycles its wavefronts were resident (per wavefront; "
+                    "with w wavefronts per SIMD the SIMD's utilisation is about w x that)"}
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -122,7 +151,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config number (1..5)")
-    ap.add_argument("--workload", default=None, choices=["lmpc", "lmpc50", "ugv", "osc8", "osc6", "vanderpol"],
+    ap.add_argument("--workload", default=None, choices=["lmpc", "lmpc50", "lmpc-hetero", "ugv", "osc8", "osc6", "vanderpol"],
                     help="lmpc = quadrotor LMPC N=20 (config 2, the default); lmpc50 = N=50 (config 4); the others are NLMPC")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=None, help="LMPC prediction horizon (overrides the workload's)")
@@ -137,10 +166,10 @@ def main():
     workload, batch = CONFIGS[args.config] if args.config else ("lmpc", 4096)
     if args.workload:
         workload = args.workload
-        batch = {"lmpc": 4096, "lmpc50": 32768, "ugv": 4096, "osc8": 1024, "osc6": 1024, "vanderpol": 4096}[workload]
+        batch = {"lmpc": 4096, "lmpc50": 32768, "lmpc-hetero": 4096, "ugv": 4096, "osc8": 1024, "osc6": 1024, "vanderpol": 4096}[workload]
     if args.batch:
         batch = args.batch
-    nl = workload not in ("lmpc", "lmpc50")
+    nl = workload not in ("lmpc", "lmpc50", "lmpc-hetero")
     steps = args.steps if args.steps is not None else (200 if not nl else {"vanderpol": 50, "ugv": 5, "osc6": 5, "osc8": 3}[workload])
     warmup = args.warmup if args.warmup is not None else (20 if not nl else 1)
 
@@ -184,6 +213,8 @@ def main():
     B = batch
     if nl:
         run_nlmpc(args, workload, B, steps, warmup, world, rank, local, dev, gather, barrier)
+    elif workload == "lmpc-hetero":
+        run_lmpc_hetero(args, args.horizon if args.horizon else 20, B, steps, warmup, world, rank, local, dev, gather, barrier)
     else:
         ph = args.horizon if args.horizon else (50 if workload == "lmpc50" else 20)
         run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrier)
@@ -297,7 +328,10 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
     fl_assemble = B * (2.0 * (nz + mg + nin + nin) * nin + 2.0 * (nz + mg) * nz)
     fl_polish = float((rounds * (na ** 3 / 3.0 + 2.0 * na ** 2 + 2.0 * na * (nz + mg) + 8.0 * (nz + mg))).sum() + B * 4.0 * nz)
     fl_admm = float(iters.sum() * info["flops_per_admm_iter"])
-    kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve": (ms3[1], fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
+    if ms3[0] < 1e-3:      # one-kernel form (lmpc_solve_group: MFMA assemble into LDS + one wavefront per instance): both parts' flops
+        kern = {"lmpc_solve_group": (ms3[1], fl_assemble + fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
+    else:
+        kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve": (ms3[1], fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
     dom = max(kern, key=lambda k: kern[k][0])
     kern_ms, flops = kern[dom]
     bytes_alg = float(B) * (8.0 * (12 + 4 + 12) + 8.0 * 4 + 8.0 + 16.0)   # x0,u0,yref in; cmd,cost,4 ints out
@@ -314,7 +348,8 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
             "mean_admm_iters": float(iters.mean()),
             "hbm_achieved_GBs": bytes_alg / (all_ms * 1e-3) / 1e9,
             "hbm_frac": bytes_alg / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "algorithmic_bytes_per_launch": bytes_alg, "kernel_source_hash": kernel_source_hash()}
+            "algorithmic_bytes_per_launch": bytes_alg, "kernel_source_hash": kernel_source_hash(),
+            "counters": _sq_counters(dom, "lmpc%d_b%d" % (ph, B))}
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
         # (i) one thread, every instance in turn -> per-solve latency and single-core rate; (ii) all host
@@ -358,6 +393,71 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
            "pipelined": pipelined,
            "solved_fraction": float((status == 0).mean()),
            "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
+
+
+def run_lmpc_hetero(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrier):
+    """every instance its own controller (own dynamics, weights, limits: quadrotor_variant(k)) -- SURVEY.md 8(d)'s "fully
+    heterogeneous" case.  One step = one batched solve of B instances against B models; the bank's set-up (device condensing) is
+    timed apart: in the reference it is part of every solve, here it is paid when a model changes."""
+    import ctypes as C
+    from libmpc_amd import LMPCHetero
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_variant
+    t0 = time.perf_counter()
+    ctrls = [quadrotor_variant(rank * B + k, ph, device=-1) for k in range(B)]
+    t_cfg = time.perf_counter() - t0
+    het = LMPCHetero(ctrls, device=local)
+    flags = het.debug_get(0, "flags")
+    x0, u0, yref = quadrotor_batch(B, first=rank * B)
+    b, res, keep, mi = het.make_batch(x0, u0, yref=yref)
+    stream = torch.cuda.current_stream(local)
+    all_k = torch.empty((world * B, 4), dtype=torch.float64, device=dev) if gather else None
+
+    def step():
+        het.launch(b, mi, stream)
+        if gather:
+            return gather.allgather(res.cmd, out=all_k, stream=stream.cuda_stream)
+        return res.cmd
+
+    dt = timed(step, steps, warmup, barrier, world, dev)
+    if rank != 0:
+        return
+    ms = het.time_launches(b, mi, max(10, min(steps, 100)), stream)
+    torch.cuda.synchronize()
+    status = res.status.cpu().numpy()
+    rounds = res.polish_rounds.cpu().numpy().astype(np.float64)
+    nx, nu, ny = 12, 4, 12
+    # SURVEY.md 8(d): compulsory bytes of a fully heterogeneous solve -- model, per-step weights, bounds and references in, u* out
+    bytes_in = 8.0 * (nx * nx + nx * nu + ny * nx) + 8.0 * (ny + 2 * nu) * ph + 8.0 * 2 * (nx + ny + nu) * ph + 8.0 * (ny + 2 * nu) * ph + 8.0 * (nx + nu)
+    bytes_alg = float(B) * (bytes_in + 8.0 * nu + 8.0)
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
+    gbs_read = float(B) * het.bytes_per_model / (ms * 1e-3) / 1e9
+    traffic, traffic_src, traffic_note = _traffic("lmpc_assemble_generic", "lmpchetero%d_b%d" % (ph, B))
+    roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+            "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
+            "kernel": "lmpc_assemble_generic + lmpc_solve (every instance reads its own model's factors)", "all_kernels_ms": ms,
+            "algorithmic_bytes_per_solve": bytes_in + 8.0 * nu + 8.0, "algorithmic_bytes_per_launch": bytes_alg,
+            "factor_bytes_read_per_solve": het.bytes_per_model, "factor_read_GBs": gbs_read, "factor_read_frac": gbs_read / PEAK_HBM_GBS,
+            "mean_polish_rounds": float(rounds.mean()),
+            "note": "algorithmic = what the reference's ProblemBuilder consumes per solve (SURVEY 8d: 18 176 B at N = 20); this path reads the "
+                    "controller's precomputed factors instead (-Hinv, G Hinv: factor_bytes_read_per_solve) and pays the condensing once per "
+                    "model change (set_up below)",
+            "kernel_source_hash": kernel_source_hash(), "counters": _sq_counters("lmpc_assemble_generic", "lmpchetero%d_b%d" % (ph, B))}
+    setup = {"controllers": B, "condensed_on_device": bool(flags[1]), "condense_kernel_ms": float(flags[2]), "create_ms": float(flags[3]),
+             "python_configure_s": t_cfg, "flops_per_controller": float(flags[4]),
+             "mfma_achieved_TFLOPs": (B * flags[4] / (flags[2] * 1e-3) / 1e12) if flags[2] > 0 else None,
+             "mfma_frac": (B * flags[4] / (flags[2] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if flags[2] > 0 else None,
+             "note": "lmpc_condense_models: one workgroup per controller, prediction matrices / Hessian / dual Hessian / ADMM matrix on "
+                     "v_mfma_f64_16x16x4_f64, Cholesky and triangular inverses in LDS; flops = the host set-up's count"}
+    total = world * B * steps
+    out = {"metric": "MPC solves/sec (whole node), quadrotor LMPC N=%d, every instance its own controller, batch=%d" % (ph, B),
+           "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "quadrotor LMPC nx=12 nu=4 ny=12 ph=ch=%d, %d controllers (quadrotor_variant: own dynamics, weights, limits), one "
+                                  "instance each per GPU, SplitMix64 x0/u0/yref" % (ph, B),
+                      "parallelism": ("batch-sharded x%d" % world) if gather else "single GPU", "rccl_ranks": gather.world if gather else 0},
+           "solved_fraction": float((status == 0).mean()), "roofline": roof, "set_up": setup, "cpu_baseline": None}
     print(json.dumps(out))
 
 

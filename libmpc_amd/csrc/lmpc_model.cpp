@@ -311,9 +311,8 @@ std::string LmpcController::condense(Condensed &o, const Condensed *like) const
     if (light) {
         // everything the device fills: allocated, zero (padding stays zero)
         const int ldy = o.ldy;
-        o.H.assign((size_t)ldz * ldz, 0.0); o.Kinv.assign((size_t)ldz * ldz, 0.0);
-        o.Gr.assign((size_t)ldg * ldz, 0.0); o.Gc.assign((size_t)ldz * ldg, 0.0);
-        o.Y.assign((size_t)ldy * ldy, 0.0);
+        // (sizes only: the bank reserves them in its device-only region, nothing is staged on the host)
+        o.big_n[0] = o.big_n[1] = (size_t)ldz * ldz; o.big_n[2] = (size_t)ldg * ldz; o.big_n[3] = (size_t)ldz * ldg; o.big_n[4] = (size_t)ldy * ldy;
         o.lw = lw; o.uw = uw;
         o.rho_b.assign(ldz, 0.0);
         o.lg0.assign(ldg, -kInf); o.ug0.assign(ldg, kInf); o.rho_g.assign(ldg, 1.0);

@@ -59,6 +59,7 @@ struct Condensed {
     bool has_dist = false, h_regularised = false;
     double inverse_residual = 0;                 // || H Hinv - I ||_max of the computed inverse
     std::vector<double> H, Kinv, Gr, Gc, Y;      // padded, see lmpc_device.hpp
+    size_t big_n[5] = {0, 0, 0, 0, 0};           // structure-only condensing: the lengths H, Kinv, Gr, Gc, Y would have (they stay empty)
     std::vector<double> lw, uw, rho_b;           // [ldz]
     std::vector<double> lg0, ug0, rho_g;         // [ldg]
     std::vector<int> g_kind, g_step, g_comp, g_refrow;      // [ldg]

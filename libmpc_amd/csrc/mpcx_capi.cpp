@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -86,6 +87,9 @@ struct mpcx_lmpc {
     {
         return v.empty() || hipMemcpy(const_cast<T *>(dst), v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
     }
+    // the O(n^3) arrays (H, Kinv, Gr, Gc, Y): for a single controller they are uploaded like everything else
+    template <typename T> const T *up_big(const std::vector<T> &v, int &rc) { return up(v, rc); }
+    const double *reserve_big(size_t) { return nullptr; }         // (banks only)
     template <typename T>
     const T *up(const std::vector<T> &v, int &rc)
     {
@@ -137,7 +141,11 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
         D.lo0y = U.up(lo0y, rc); D.hi0y = U.up(hi0y, rc);
         D.sX = U.up(c.sX, rc); D.sU = U.up(c.sU, rc);
     }
-    D.H = U.up(o.H, rc); D.Kinv = U.up(o.Kinv, rc); D.Gr = U.up(o.Gr, rc); D.Gc = U.up(o.Gc, rc); D.Y = U.up(o.Y, rc);
+    if (o.big_n[0]) {          // structure-only condensing: room for what the device kernel computes
+        D.H = U.reserve_big(o.big_n[0]); D.Kinv = U.reserve_big(o.big_n[1]); D.Gr = U.reserve_big(o.big_n[2]); D.Gc = U.reserve_big(o.big_n[3]); D.Y = U.reserve_big(o.big_n[4]);
+    } else {
+        D.H = U.up_big(o.H, rc); D.Kinv = U.up_big(o.Kinv, rc); D.Gr = U.up_big(o.Gr, rc); D.Gc = U.up_big(o.Gc, rc); D.Y = U.up_big(o.Y, rc);
+    }
     D.lw = U.up(o.lw, rc); D.uw = U.up(o.uw, rc); D.rho_b = U.up(o.rho_b, rc);
     D.lg0 = U.up(o.lg0, rc); D.ug0 = U.up(o.ug0, rc); D.rho_g = U.up(o.rho_g, rc);
     D.g_kind = U.up(o.g_kind, rc); D.g_step = U.up(o.g_step, rc); D.g_comp = U.up(o.g_comp, rc); D.g_refrow = U.up(o.g_refrow, rc);
@@ -169,7 +177,10 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
 // kernels pick the struct of each instance (lmpc_model_of).  Per-model factors cannot be shared through L2: the assemble kernel
 // reads its model's -Hinv and G Hinv once per instance, the solve the rows of Y in the working set -- this path is HBM-bound.
 struct SlabUploader {
-    std::vector<char> host;                      // staging image of the slab
+    static constexpr size_t kDevRegion = (size_t)1 << 44; // offsets from here on: the device-only region
+    std::vector<char> host;                      // staging image of the uploaded region
+    size_t dev_bytes = 0;                        // device-only region: arrays the condensing kernel fills (zeroed on the device, never staged)
+    bool big_on_device = false;
     template <typename T>
     const T *up(const std::vector<T> &v, int &)
     {
@@ -178,6 +189,18 @@ struct SlabUploader {
         if (v.size()) std::memcpy(host.data() + at, v.data(), v.size() * sizeof(T));
         return reinterpret_cast<const T *>(at + 1);          // offset + 1 (so that offset 0 is not a null pointer); rebased below
     }
+    const double *reserve_big(size_t n)
+    {
+        const size_t at = (dev_bytes + 15) / 16 * 16;
+        dev_bytes = at + (n ? n : 1) * sizeof(double);
+        return reinterpret_cast<const double *>(kDevRegion + at + 1);
+    }
+    template <typename T>
+    const T *up_big(const std::vector<T> &v, int &rc)
+    {
+        if (!big_on_device) return up(v, rc);
+        return reinterpret_cast<const T *>(reserve_big(v.size()));
+    }
 };
 
 struct mpcx_lmpc_hetero {
@@ -185,24 +208,29 @@ struct mpcx_lmpc_hetero {
     mpcx_dims d{};
     mpcx::LmpcDev dev0{};                        // model 0 with device pointers (dimensions, LDS plan)
     mpcx::LmpcDev *models_d = nullptr;           // [count] device structs
-    char *slab = nullptr;
+    char *slab = nullptr, *slab_dev = nullptr;     // uploaded arrays / arrays the condensing kernel fills
     double *ws = nullptr; size_t ws_cap = 0;
     int active_words = 0, m_ref = 0;
     bool condensed_on_device = false;
+    float setup_kernel_ms = 0, setup_total_ms = 0;   // the condensing kernel alone / the whole mpcx_lmpc_hetero_create
+    double setup_flops = 0;                          // per controller (the host set-up's count)
     ~mpcx_lmpc_hetero()
     {
         if (models_d) (void)hipFree(models_d);
         if (slab) (void)hipFree(slab);
+        if (slab_dev) (void)hipFree(slab_dev);
         if (ws) (void)hipFree(ws);
     }
 };
 
-static void rebase_dev(mpcx::LmpcDev &D, const char *base)
+static void rebase_dev(mpcx::LmpcDev &D, const char *base, const char *base_dev)
 {
-    // every pointer member was filled with (offset + 1) by SlabUploader: turn it into base + offset
+    // every pointer member was filled with (offset + 1) by SlabUploader: turn it into base + offset (of its region)
     auto fix = [&](auto &p) {
         using P = std::remove_reference_t<decltype(p)>;
-        p = p ? reinterpret_cast<P>(base + (reinterpret_cast<size_t>(p) - 1)) : nullptr;
+        if (!p) return;
+        const size_t off = reinterpret_cast<size_t>(p) - 1;
+        p = off >= SlabUploader::kDevRegion ? reinterpret_cast<P>(base_dev + (off - SlabUploader::kDevRegion)) : reinterpret_cast<P>(base + off);
     };
     fix(D.A); fix(D.B); fix(D.C); fix(D.Bd); fix(D.Dd); fix(D.Wy); fix(D.Wu); fix(D.Wdu);
     fix(D.yref_s); fix(D.uref_s); fix(D.duref_s); fix(D.dmeas_s);
@@ -792,6 +820,7 @@ int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int devic
 int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int device, int condense_on_host, mpcx_lmpc_hetero_t *out)
 {
     if (!controllers || !out || count < 1) return fail(MPCX_E_INVALID, "need at least one controller");
+    const auto t_begin = std::chrono::steady_clock::now();
     for (int k = 0; k < count; ++k) if (!controllers[k]) return fail(MPCX_E_INVALID, "null controller in the bank");
     int ndev = 0;
     if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev)
@@ -841,6 +870,7 @@ int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int de
     f->device = device; f->count = count; f->d = c0.d; f->active_words = o0.active_words; f->m_ref = o0.m_ref;
     if (hipSetDevice(device) != hipSuccess) return fail(MPCX_E_DEVICE, "hipSetDevice failed");
     SlabUploader U;
+    U.big_on_device = on_device;
     std::vector<mpcx::LmpcDev> devs((size_t)count);
     int rc = MPCX_OK;
     for (int k = 0; k < count; ++k) {
@@ -854,18 +884,31 @@ int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int de
     if (hipMalloc(reinterpret_cast<void **>(&f->slab), U.host.size()) != hipSuccess ||
         hipMemcpy(f->slab, U.host.data(), U.host.size(), hipMemcpyHostToDevice) != hipSuccess)
         return fail(MPCX_E_DEVICE, "could not upload the bank (" + std::to_string(U.host.size() >> 20) + " MiB)");
-    for (auto &D : devs) rebase_dev(D, f->slab);
+    if (U.dev_bytes) {
+        if (hipMalloc(reinterpret_cast<void **>(&f->slab_dev), U.dev_bytes) != hipSuccess || hipMemset(f->slab_dev, 0, U.dev_bytes) != hipSuccess)
+            return fail(MPCX_E_DEVICE, "could not allocate the bank's factors (" + std::to_string(U.dev_bytes >> 20) + " MiB)");
+    }
+    for (auto &D : devs) rebase_dev(D, f->slab, f->slab_dev);
     if (hipMalloc(reinterpret_cast<void **>(&f->models_d), sizeof(mpcx::LmpcDev) * (size_t)count) != hipSuccess ||
         hipMemcpy(f->models_d, devs.data(), sizeof(mpcx::LmpcDev) * (size_t)count, hipMemcpyHostToDevice) != hipSuccess)
         return fail(MPCX_E_DEVICE, "could not upload the bank's model table");
     f->dev0 = devs[0];
+    f->setup_flops = cond[0].flops_setup;
     if (on_device) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, nullptr);
         const int lr = mpcx::lmpc_condense_launch(f->models_d, f->dev0, count, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&f->setup_kernel_ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (lr != 0) return fail(MPCX_E_DEVICE, "the device condensing kernel could not be launched (" + std::to_string(lr) + ")");
         const hipError_t es = hipDeviceSynchronize();
         if (es != hipSuccess) return fail(MPCX_E_DEVICE, std::string("the device condensing kernel failed: ") + hipGetErrorString(es));
     }
     f->condensed_on_device = on_device;
+    f->setup_total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = f.release();
     return MPCX_OK;
 }
@@ -891,7 +934,10 @@ int mpcx_lmpc_hetero_debug_get(mpcx_lmpc_hetero_t f, int k, const char *name, do
     else if (n == "Gr") { src = D.Gr; len = (size_t)D.ldg * D.ldz; } else if (n == "Gc") { src = D.Gc; len = (size_t)D.ldz * D.ldg; }
     else if (n == "Y") { src = D.Y; len = (size_t)D.ldy * D.ldy; } else if (n == "rho_b") { src = D.rho_b; len = (size_t)D.ldz; }
     else if (n == "rho_g") { src = D.rho_g; len = (size_t)D.ldg; }
-    else if (n == "flags") { if (out && cap >= 2) { out[0] = D.cost_direct; out[1] = f->condensed_on_device ? 1.0 : 0.0; } return 2; }
+    else if (n == "flags") {       // cost_direct, condensed on the device, condensing kernel ms, whole create ms, set-up flops per controller
+        if (out && cap >= 5) { out[0] = D.cost_direct; out[1] = f->condensed_on_device ? 1.0 : 0.0; out[2] = f->setup_kernel_ms; out[3] = f->setup_total_ms; out[4] = f->setup_flops; }
+        return 5;
+    }
     else return fail(MPCX_E_INVALID, "unknown array name");
     if (!out) return (int)len;
     if ((size_t)cap < len) return fail(MPCX_E_INVALID, "buffer too small");
