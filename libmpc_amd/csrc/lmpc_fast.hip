@@ -32,6 +32,9 @@ namespace {
 //     benchmark batch every instance is resident at once (the dispatch order no longer matters).
 // Working sets of more than kFastCap rows are left to the fallback kernel (none in 32768 instances of config 2, none in 8192 of
 // config 4).
+#ifndef MPCX_FAST_RB
+#define MPCX_FAST_RB 4
+#endif
 #ifndef MPCX_FAST_PF
 #define MPCX_FAST_PF 4
 #endif
@@ -156,7 +159,7 @@ __device__ __forceinline__ int ws_solve_reg(const gdp gY, const int ldy, const i
         for (int c = 0; c < CPG; ++c) { gw[2 * c] = fma(-la, pg[a][c].x, gw[2 * c]); gw[2 * c + 1] = fma(-la, pg[a][c].y, gw[2 * c + 1]); }
     }
     if constexpr (CAP > PF) {
-        constexpr int RB = CAP - PF < 4 ? CAP - PF : 4;
+        constexpr int RB = CAP - PF < MPCX_FAST_RB ? CAP - PF : MPCX_FAST_RB;      // rows of Y per later batch (the elimination's registers are free by now)
 #pragma unroll
         for (int a0 = PF; a0 < CAP; a0 += RB) {
             if (a0 < na) {
@@ -430,7 +433,9 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
             } else if (na <= 4) dep_at = ws_solve_reg<4, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
             else if (na <= 6) dep_at = ws_solve_reg<6, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
             else if (na <= 8) dep_at = ws_solve_reg<8, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else if (na <= 10) dep_at = ws_solve_reg<10, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
             else if (na <= 12) dep_at = ws_solve_reg<12, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
+            else if (na <= 14) dep_at = ws_solve_reg<14, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
             else dep_at = ws_solve_reg<kFastCap, CPZ, CPG>(gY, ldy, ldz, na, lane, wsidx, wsb, t0s, lam, offz, offg, wv, gw, lmax MPCX_PROF_PASS);
             if (dep_at >= 0) {
                 // linearly dependent working set: drop the offending row and try again
@@ -728,28 +733,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     constexpr int ZP = 128 * CPZ;
     const int wpb = blockDim.x >> 6;
     double *rec = smem + 2 * ZP + (size_t)wave * M.fast_slice;
-    if (Bt.n_models <= 0) {
-        fast_load_box<CPZ>(M, smem);
-        for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb)
-            solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
-    } else {
-        // heterogeneous batch: every instance its own model, so every wavefront keeps its own copy of the box bounds (after the slices)
-        double *box = smem + 2 * ZP + (size_t)wpb * M.fast_slice + (size_t)wave * 2 * ZP;
-        const double INF = __builtin_huge_val();
-        for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
-            const LmpcDev &Mi = Mp[lmpc_model_of(Bt, i)];
+    fast_load_box<CPZ>(M, smem);
+    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb)
+        solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
+}
+
+// The same for a heterogeneous batch (mpcx_lmpc_hetero_*): every instance its own model struct, so every wavefront keeps its own
+// copy of the box bounds (after the slices).  A kernel of its own: the shared-model kernel above keeps its register allocation.
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_solve_hetero(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LmpcDev &M = *Mp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int ZP = 128 * CPZ;
+    const int wpb = blockDim.x >> 6;
+    double *rec = smem + 2 * ZP + (size_t)wave * M.fast_slice;
+    double *box = smem + 2 * ZP + (size_t)wpb * M.fast_slice + (size_t)wave * 2 * ZP;
+    const double INF = __builtin_huge_val();
+    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
+        const LmpcDev &Mi = Mp[lmpc_model_of(Bt, i)];
 #pragma unroll
-            for (int c = 0; c < CPZ; ++c) {
-                const int e = 128 * c + 2 * lane;
-                const bool ok = e < Mi.ldz;
-                const d2 vl = ld2(gl(Mi.lw) + (ok ? e : 0)), vu = ld2(gl(Mi.uw) + (ok ? e : 0));
-                *reinterpret_cast<double2 *>(box + e) = ok ? make_double2(vl.x, vl.y) : make_double2(-INF, -INF);
-                *reinterpret_cast<double2 *>(box + ZP + e) = ok ? make_double2(vu.x, vu.y) : make_double2(INF, INF);
-            }
-            wave_sync();
-            solve_fast<CPZ, CPG, 0>(Mi, Bt, i, lane, rec, box, glw(wsbase) + (size_t)i * M.wsld);
-            wave_sync();
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            const bool ok = e < Mi.ldz;
+            const d2 vl = ld2(gl(Mi.lw) + (ok ? e : 0)), vu = ld2(gl(Mi.uw) + (ok ? e : 0));
+            *reinterpret_cast<double2 *>(box + e) = ok ? make_double2(vl.x, vl.y) : make_double2(-INF, -INF);
+            *reinterpret_cast<double2 *>(box + ZP + e) = ok ? make_double2(vu.x, vu.y) : make_double2(INF, INF);
         }
+        wave_sync();
+        solve_fast<CPZ, CPG, 0>(Mi, Bt, i, lane, rec, box, glw(wsbase) + (size_t)i * M.wsld);
+        wave_sync();
     }
 }
 
@@ -953,6 +967,7 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
     if (const char *pad = getenv("MPCX_DBG_LDS_PAD")) ldsf += (size_t)atoi(pad);
     if (ldsf > 160 * 1024) return -2;
     auto k2 = lmpc_solve<CPZ, CPG>;
+    auto k2h = lmpc_solve_hetero<CPZ, CPG>;
     // the fused forms serve the one-chunk variant only (fused_record: up to 384 rows of the composed map)
     auto k4 = lmpc_solve_fused<1, 1>;
     auto k5 = lmpc_solve_persistent<1, 1>;
@@ -962,6 +977,7 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
     devid &= 63;
     if (ldsf > configured[devid].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k2h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf) != hipSuccess)
             return -3;
         size_t prev = configured[devid].load(std::memory_order_relaxed);
@@ -1000,6 +1016,7 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
         if (wgs > 256) wgs = 256;
         hipLaunchKernelGGL(k5, dim3(wgs), dim3(kPersistWaves * 64), ldsp, stream, m_dev, b, ws, b.pcounter);
     } else if (fused) hipLaunchKernelGGL(k4, dim3(blocks), dim3(kWavesPerBlock * 64), ldsf, stream, m_dev, b, ws);
+    else if (b.n_models > 0) hipLaunchKernelGGL(k2h, dim3(blocks), dim3(kWavesPerBlock * 64), ldsf, stream, m_dev, b, ws);
     else hipLaunchKernelGGL(k2, dim3(blocks), dim3(kWavesPerBlock * 64), ldsf, stream, m_dev, b, ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

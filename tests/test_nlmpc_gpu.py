@@ -610,3 +610,24 @@ def test_per_instance_model_parameters_give_each_instance_its_own_controller_s_r
     v = NLMPC(1, 10, 5, 0.1)                         # Van der Pol has no parameters: refused
     with pytest.raises(Exception):
         v.optimizeBatch(torch.zeros(2, 2, dtype=torch.float64), torch.zeros(2, 1, dtype=torch.float64), params=torch.zeros(2, 1, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("name,kw,hard,iters", [("vanderpol", dict(ph=10, ch=5, Ts=0.1), True, 200), ("ugv", dict(ph=12, ch=4), False, 150)])
+def test_shards_equal_rows_of_the_unsharded_solve(name, kw, hard, iters):
+    """multi-GPU readiness on one device: a batch solved as four shards (what four ranks would do) gives, bit for bit, the rows of
+    the unsharded solve -- commands, costs, statuses, decision vectors"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV
+    m = NLMPC(dict(vanderpol=VANDERPOL, ugv=UGV)[name], kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+    m.setOptimizerParameters(NLParameters(maximum_iteration=iters, hard_constraints=int(hard)))
+    rng = np.random.default_rng(11)
+    Bs, R = 96, 4
+    X0 = rng.uniform(-0.5, 0.5, size=(Bs * R, m.nx)); U0 = np.zeros((Bs * R, m.nu))
+    if name == "ugv":
+        X0[:, 2:] = 0.0
+    whole = m.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0)); torch.cuda.synchronize()
+    for rk in range(R):
+        sl = slice(rk * Bs, (rk + 1) * Bs)
+        part = m.optimizeBatch(torch.from_numpy(X0[sl]), torch.from_numpy(U0[sl])); torch.cuda.synchronize()
+        for key in ("cmd", "cost", "status", "z"):
+            assert torch.equal(part[key], whole[key][sl]), (rk, key)

@@ -149,3 +149,35 @@ def test_terminal_constraint_solve_property():
     m = vanderpol_terminal(ph=10, ch=10)
     o = m.solve([0.1, 0.1], [0.0], max_iter=500)
     assert o["success"] and np.abs(o["X"][10]).max() < 1e-8 and (o["U"][:, 0] <= 0.5 + 1e-9).all()
+
+
+@pytest.mark.parametrize("name", ["vanderpol", "ugv", "osc6", "osc8"])
+def test_compiled_callbacks_equal_the_numpy_restatement(name):
+    """oracle/nlmpc_callbacks.c (bench.py's compiled NLMPC CPU baseline) against oracle/nlmpc_numpy.py (pinned above by the
+    reference's component known answers): cost and constraint values to round-off, the central-difference Jacobians to their
+    noise, the forward-difference gradient to its (one ulp of the cost over a 1.5e-8 step)"""
+    from oracle import nlmpc_c
+    from oracle import nlmpc_numpy as N
+    a = dict(vanderpol=lambda: N.vanderpol(10, 5, 0.1), ugv=lambda: N.ugv(30, 30), osc6=lambda: N.oscillators(6, 20, 10),
+             osc8=lambda: N.oscillators(8, 30, 15))[name]()
+    b = nlmpc_c.make(name)
+    assert (a.nz, a.ineq) == (b.nz, b.nineq)
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        x0 = rng.uniform(-0.5, 0.5, size=a.nx); a.x0 = x0; b.x0 = x0
+        z = 0.7 * rng.normal(size=a.nz)
+        fa, ga = a.objective(z); fb, gb = b.objective(z)
+        assert abs(fa - fb) <= 1e-13 * abs(fa)
+        assert np.abs(ga - gb).max() <= 2e-5 * max(1.0, np.abs(ga).max())
+        ca, Ja = a.state_eq(z); cb, Jb = b.state_eq(z)
+        assert np.abs(ca - cb).max() <= 1e-13 and np.abs(Ja - Jb).max() <= 1e-7
+        ia, Ia = a.user_ineq(z); ib, Ib = b.user_ineq(z)
+        assert np.abs(ia - ib).max() <= 1e-13 and np.abs(Ia - Ib).max() <= 1e-7
+
+
+def test_compiled_baseline_solves_like_the_numpy_oracle():
+    from oracle import nlmpc_c
+    from oracle import nlmpc_numpy as N
+    a, b = N.vanderpol(10, 5, 0.1), nlmpc_c.make("vanderpol")
+    ra = a.solve([0.0, 1.0], [0.0], max_iter=200); rb = b.solve([0.0, 1.0], [0.0], max_iter=200)
+    assert rb["success"] and abs(ra["cmd"][0] - rb["cmd"][0]) <= 1e-6 and abs(ra["cost"] - rb["cost"]) <= 1e-8 * abs(ra["cost"])
