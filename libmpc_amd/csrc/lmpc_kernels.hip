@@ -39,7 +39,6 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     const int nz = M.nz, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
     const bool has_dist = M.has_dist != 0;
     const double ea = M.eps_abs, er = M.eps_rel;
-    const gdp gA = GP(A), gB = GP(B), gC = GP(C), gBd = GP(Bd), gDd = GP(Dd);
     // a null reference pointer (heterogeneous batches, "shared" mode): this model's own reference arrays
     const gdp gdm = gl(Bt.dmeas ? Bt.dmeas : M.dmeas_s), gyr = gl(Bt.yref ? Bt.yref : M.yref_s), gur = gl(Bt.uref ? Bt.uref : M.uref_s),
               gdr = gl(Bt.duref ? Bt.duref : M.duref_s);
@@ -48,6 +47,19 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     double *ey = xb + (ph + 1) * nx;          // weighted output error, (ph+1) x ny
     double *pv = ey + (ph + 1) * ny;          // adjoint ping-pong, 2 x nx
     double *u0s = pv + 2 * nx;                // lastU
+    // The model matrices in the wave's LDS slice: the roll-out and the adjoint pass are chains of ph dependent steps that read them in
+    // every step -- from L2 that is a memory latency per step, and in a heterogeneous batch (every instance its own model) from HBM
+    double *gA = u0s + ((nu + 1) & ~1), *gB = gA + nx * nx, *gC = gB + nx * nu, *gBd = gC + ny * nx, *gDd = gBd + nx * ndu;
+    {
+        const gdp mA = GP(A), mB = GP(B), mC = GP(C), mBd = GP(Bd), mDd = GP(Dd);
+        for (int e = lane; e < nx * nx; e += 64) gA[e] = mA[e];
+        for (int e = lane; e < nx * nu; e += 64) gB[e] = mB[e];
+        for (int e = lane; e < ny * nx; e += 64) gC[e] = mC[e];
+        if (has_dist) {
+            for (int e = lane; e < nx * ndu; e += 64) gBd[e] = mBd[e];
+            for (int e = lane; e < ny * ndu; e += 64) gDd[e] = mDd[e];
+        }
+    }
     if (lane < nx) xb[lane] = gl(Bt.x0)[(size_t)b * nx + lane];
     if (lane < nu) u0s[lane] = gl(Bt.u0)[(size_t)b * nu + lane];
     wave_sync();
@@ -1412,7 +1424,8 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len)
 {
     int st = m.ldz > m.ldg ? m.ldz : m.ldg;
     st = (st + 1) / 2 * 2;
-    int a1 = (m.ph + 1) * (m.nx + m.ny) + 2 * m.nx + m.nu + 8;
+    int a1 = (m.ph + 1) * (m.nx + m.ny) + 2 * m.nx + m.nu + 8 +
+             m.nx * m.nx + m.nx * m.nu + m.ny * m.nx + m.nx * m.ndu + m.ny * m.ndu;      // + the model matrices (assemble_one)
     int a2 = kMaxActive * kSld + 3 * kMaxActive + kMaxActive;      // S, lam, wsb, dg0, wsidx (ints)
     int ar = a1 > a2 ? a1 : a2;
     ar = (ar + 1) / 2 * 2;
