@@ -73,6 +73,7 @@ struct LmpcBatchDev {
     int warm_shift;
     int chunked;                                  // fallback kernel: one wavefront screens a chunk of instances
     int fused;                                    // 0: record from the workspace; 1 / 2: lmpc_solve_fused with MF0 / MF1; 3 / 4: lmpc_solve_group with MA0 / MA1
+    int32_t *done;                                // lmpc_solve_group: [B] 2 = solved there, 0 = left to the fallback kernel (null: the flag in the workspace record)
     int *pcounter;                                // work counter of the persistent fused kernel (null: one instance per launched wavefront)
     // heterogeneous batch (mpcx_lmpc_hetero_*): the kernels' model pointer is an array of n_models structs of identical dimensions and
     // constraint structure, instance b uses entry model_index[b] (null: entry b); 0 models = the one shared controller

@@ -32,6 +32,9 @@ namespace {
 //     benchmark batch every instance is resident at once (the dispatch order no longer matters).
 // Working sets of more than kFastCap rows are left to the fallback kernel (none in 32768 instances of config 2, none in 8192 of
 // config 4).
+#ifndef MPCX_FAST_PF_MAXCAP
+#define MPCX_FAST_PF_MAXCAP 12
+#endif
 #ifndef MPCX_FAST_RB
 #define MPCX_FAST_RB 4
 #endif
@@ -87,7 +90,9 @@ __device__ __forceinline__ int ws_solve_reg(const gdp gY, const int ldy, const i
                                             const int (&offz)[CPZ], const int (&offg)[CPG],
                                             double (&wv)[2 * CPZ], double (&gw)[2 * CPG], double &lmax MPCX_PROF_ARGS)
 {
-    constexpr int PF = CAP < MPCX_FAST_PF ? CAP : MPCX_FAST_PF;          // rows of Y requested ahead of the elimination
+    // rows of Y requested ahead of the elimination (none for the largest working sets: their elimination needs the registers, and a
+    // spilled register is HBM traffic -- scratch is memory)
+    constexpr int PF = CAP > MPCX_FAST_PF_MAXCAP ? 0 : (CAP < MPCX_FAST_PF ? CAP : MPCX_FAST_PF);
     const bool real = lane < na;
     const int li = real ? lane : 0;
     const int qi = wsidx[li];
@@ -98,7 +103,7 @@ __device__ __forceinline__ int ws_solve_reg(const gdp gY, const int ldy, const i
     const int rowoff = qi * ldy;
 #pragma unroll
     for (int c = 0; c < CAP; ++c) Sr[c] = (gY + qc[c])[rowoff];
-    d2 pz[PF][CPZ], pg[PF][CPG];
+    d2 pz[PF > 0 ? PF : 1][CPZ], pg[PF > 0 ? PF : 1][CPG];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const gdp row = gY + (size_t)qc[u] * ldy;
@@ -224,8 +229,10 @@ template <int CPZ, int CPG> constexpr int fast_slice_fixed() { return 2 * 128 * 
 // with the composed maps), 2 already in the slice (lmpc_solve_group: the workgroup's MFMA assemble phase put it there)
 template <int CPZ, int CPG, int SRC = 0>
 __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
-                           double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr)
+                           double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr, double *outs = nullptr)
 {
+    // outs (lmpc_solve_group): the instance's scalar results and its command go to this LDS record [cost, status, solver status,
+    // feasible, iterations, rounds, active rows, done | cmd (nu)] instead of to HBM; the workgroup writes sixteen of them coalesced
     constexpr int NZS = 2 * CPZ, NGS = 2 * CPG, ZP = 128 * CPZ, GPD = 128 * CPG;
     const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
     const int nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
@@ -237,13 +244,12 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
     const double *lws = lwuw, *uws = lwuw + ZP;
     const double INF = __builtin_huge_val();
 
-    long long tstamp[4];
+    long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;          // profiling aid: start, loaded, solved, unpacked (Bt.dbg_cycles)
 #ifdef MPCX_PROFILE_ROUNDS
     long long pacc[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
 #endif
-    int tsi = 0;
-    auto stamp = [&]() { if (Bt.dbg_cycles && tsi < 4) tstamp[tsi++] = (long long)__builtin_readcyclecounter(); };
-    stamp();
+    auto stamp = [&](long long &t) { if (Bt.dbg_cycles) t = (long long)__builtin_readcyclecounter(); };
+    stamp(ts0);
 
     // offsets of this lane's element pairs into the rows of Y (clamped: lanes past the end re-read pair 0, their results are never used)
     int offz[CPZ], offg[CPG];
@@ -327,7 +333,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
 #pragma unroll
         for (int s = 0; s < NGS; ++s) actg[s] = (actg[s] == 0 && vg[s] > 0.0 && vg[s] >= thr0) ? (lowg[s] ? -1 : 1) : actg[s];
     }
-    stamp();   // 1: loaded
+    stamp(ts1);   // 1: loaded
 
     if (Bt.warm_lower) {
         // warm start: the first working set is the previous solve's active set (see solve_one)
@@ -527,7 +533,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    stamp();   // 2: solved
+    stamp(ts2);   // 2: solved
 
     if (!infeasible && !solved) {
         // left for the fallback kernel (flag stays 0 / 1), which reads the workspace record
@@ -553,6 +559,7 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
             }
             if (lane == 0) st2(ws + ldz + ldy + 2 * ldg, c0, flag0);
         }
+        if (outs && lane == 0) outs[7] = 0.0;
         return;
     }
     const int solver_status = infeasible ? -3 : (fixed_violation ? -2 : 1);
@@ -605,9 +612,14 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
 #pragma unroll
     for (int s = 0; s < NZS; ++s) {
         const int e = 128 * (s >> 1) + 2 * lane + (s & 1);
-        if (e < nu) glw(Bt.cmd)[(size_t)b * nu + e] = w[s];
+        if (e < nu) { if (outs) outs[8 + e] = w[s]; else glw(Bt.cmd)[(size_t)b * nu + e] = w[s]; }
     }
-    if (lane == 0) {
+    if (outs) {
+        if (lane == 0) {
+            outs[0] = cost; outs[1] = solver_status == 1 ? 0 : (solver_status == -2 ? 1 : 2); outs[2] = solver_status;
+            outs[3] = solver_status == -3 ? 0 : 1; outs[4] = 0; outs[5] = rounds_total; outs[6] = infeasible ? 0 : na_last; outs[7] = 2.0;
+        }
+    } else if (lane == 0) {
         if (Bt.cost && !cost_pending) glw(Bt.cost)[b] = cost;
         if (Bt.solver_status) glw(Bt.solver_status)[b] = solver_status;
         if (Bt.status) glw(Bt.status)[b] = solver_status == 1 ? 0 : (solver_status == -2 ? 1 : 2);     // LOptimizer.hpp:386-415
@@ -693,14 +705,18 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
         }
     }
     wave_sync();
-    if (lane == 0) ws[ldz + ldy + 2 * ldg + 1] = cost_pending ? 3.0 : 2.0;     // 2: done, the fallback kernel skips it; 3: lmpc_cost_mfma first
-    stamp();   // 3: unpacked
+    if (lane == 0 && !outs) ws[ldz + ldy + 2 * ldg + 1] = cost_pending ? 3.0 : 2.0;     // 2: done, the fallback kernel skips it; 3: lmpc_cost_mfma first
+    stamp(ts3);   // 3: unpacked
     if (Bt.dbg_cycles && lane == 0)
+    {
+        long long *o = Bt.dbg_cycles + (size_t)b * 8;
 #ifdef MPCX_PROFILE_ROUNDS
-        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = k < 2 ? tstamp[k + 1] - tstamp[k] : pacc[k >= 2 ? k - 2 : 0];      // load, solve, six phases
+        o[0] = ts1 - ts0; o[1] = ts2 - ts1;                    // load, solve, six phases
+        for (int k = 0; k < 6; ++k) o[2 + k] = pacc[k];
 #else
-        for (int k = 0; k < 8; ++k) Bt.dbg_cycles[(size_t)b * 8 + k] = (k < 4 && k < tsi) ? tstamp[k & 3] : 0;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;        // (slots 4..6: lmpc_solve_group's own stamps)
 #endif
+    }
 }
 
 // waves per SIMD the lean kernels are compiled for: the one-chunk variant fits 128 VGPRs
@@ -734,8 +750,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     const int wpb = blockDim.x >> 6;
     double *rec = smem + 2 * ZP + (size_t)wave * M.fast_slice;
     fast_load_box<CPZ>(M, smem);
-    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb)
-        solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
+    // one instance per wavefront, no loop over instances: the grid covers the batch (a loop makes the compiler hoist the per-lane
+    // addresses of every input and output array out of it and keep them alive -- in scratch, i.e. in HBM -- across the whole solve)
+    const int i = blockIdx.x * wpb + wave;
+    if (i < Bt.batch) solve_fast<CPZ, CPG, 0>(M, Bt, i, lane, rec, smem, glw(wsbase) + (size_t)i * M.wsld);
 }
 
 // The same for a heterogeneous batch (mpcx_lmpc_hetero_*): every instance its own model struct, so every wavefront keeps its own
@@ -751,7 +769,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     double *rec = smem + 2 * ZP + (size_t)wave * M.fast_slice;
     double *box = smem + 2 * ZP + (size_t)wpb * M.fast_slice + (size_t)wave * 2 * ZP;
     const double INF = __builtin_huge_val();
-    for (int i = blockIdx.x * wpb + wave; i < Bt.batch; i += gridDim.x * wpb) {
+    const int i = blockIdx.x * wpb + wave;
+    if (i < Bt.batch) {
         const LmpcDev &Mi = Mp[lmpc_model_of(Bt, i)];
 #pragma unroll
         for (int c = 0; c < CPZ; ++c) {
@@ -777,8 +796,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, fast_waves<CPZ>()) void lmpc_s
     fast_load_box<CPZ>(M, smem);
     double *rec = smem + 2 * 128 * CPZ + (size_t)wave * M.fast_slice;
     const int wpb = blockDim.x >> 6;
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
-        solve_fast<CPZ, CPG, 1>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
+    const int b = blockIdx.x * wpb + wave;
+    if (b < Bt.batch) solve_fast<CPZ, CPG, 1>(M, Bt, b, lane, rec, smem, glw(wsbase) + (size_t)b * M.wsld);
 }
 
 // The fused form as a persistent kernel: one workgroup of kPersistWaves wavefronts per CU loads the composed map into LDS once
@@ -844,6 +863,8 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
     double *Bf = Bv + (size_t)kin4 * 64;                           // [nz4][64]    f as MFMA B operands
     double *c0s = Bf + (size_t)nz4 * 64;                           // [16 wavefronts][16 instances]
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + kGroupWaves * 16);   // [16]
+    const int outld = 8 + ((nu + 1) & ~1);
+    double *outs = c0s + kGroupWaves * 16 + 16;                             // [16][8 + nu]: results of the sixteen instances
     fast_load_box<1>(M, lwuw);
     double *mine = slices + (size_t)wave * M.fast_slice;
     const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
@@ -852,10 +873,13 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
     double *sj = slices + (size_t)j * M.fast_slice;
     double *t0j = sj, *gt0j = sj + ZP, *lgj = gt0j + GPD, *ugj = lgj + GPD, *fj = ugj + GPD;
 
-    for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
+    {
+        const int b0 = blockIdx.x * 16;             // one batch of sixteen per workgroup, no loop (see lmpc_solve)
         const int bj = b0 + j;
         const int bc = bj < Bt.batch ? bj : Bt.batch - 1;
-        const long long ta0 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
+        // profiling aid: when the wavefront started its batch, when the first product was done, when the records were complete
+        auto gstamp = [&](int k) { if (Bt.dbg_cycles && lane == 0 && b0 + wave < Bt.batch) Bt.dbg_cycles[(size_t)(b0 + wave) * 8 + k] = (long long)__builtin_readcyclecounter(); };
+        gstamp(4);
         fast_init_pads<1, 1>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
         // vin operands: k-step kb holds rows 4kb + kq of instance j
         for (int kb = wave; kb < kin4; kb += kGroupWaves) {
@@ -877,13 +901,14 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
             const gdp Mt = MA + 16 * t + j;
             // every A operand of the tile requested at once: nothing else is resident on this CU to hide a chain of L2 round trips
             for (int kb = 0; kb < kin4; kb += kGroupKU) {
-                double a[kGroupKU], bq[kGroupKU];
+                double a[kGroupKU];
 #pragma unroll
                 for (int u = 0; u < kGroupKU; ++u) a[u] = Mt[(size_t)(4 * (kb + u < kin4 ? kb + u : kb) + kq) * M.rowsA];
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) bq[u] = kb + u < kin4 ? Bv[(kb + u < kin4 ? kb + u : kb) * 64 + lane] : 0.0;
-#pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+                for (int u = 0; u < kGroupKU; ++u) {
+                    const double bq = kb + u < kin4 ? Bv[(kb + u < kin4 ? kb + u : kb) * 64 + lane] : 0.0;      // (LDS: no need to hold them all)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq, acc, 0, 0, 0);
+                }
             }
             if (t < tg) {
                 // linear term: operand of the second product, and the instance's f
@@ -919,20 +944,21 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
         c0p += __shfl_xor(c0p, 32, 64);
         if (kq == 0) c0s[wave * 16 + j] = c0p;
         __syncthreads();
-        const long long ta1 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
+        gstamp(5);
 
         const int ntile2 = M.ldy16 >> 4;
         for (int t = wave; t < ntile2; t += kGroupWaves) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             const gdp Yt = Ym + 16 * t + j;
             for (int kb = 0; kb < nz4; kb += kGroupKU) {
-                double a[kGroupKU], bq[kGroupKU];
+                double a[kGroupKU];
 #pragma unroll
                 for (int u = 0; u < kGroupKU; ++u) a[u] = Yt[(size_t)(4 * (kb + u < nz4 ? kb + u : kb) + kq) * M.ldy16];
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) bq[u] = kb + u < nz4 ? Bf[(kb + u < nz4 ? kb + u : kb) * 64 + lane] : 0.0;
-#pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+                for (int u = 0; u < kGroupKU; ++u) {
+                    const double bq = kb + u < nz4 ? Bf[(kb + u < nz4 ? kb + u : kb) * 64 + lane] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq, acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -950,13 +976,32 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
         }
         __syncthreads();
         const int b = b0 + wave;
-        const long long ta2 = Bt.dbg_cycles ? (long long)__builtin_readcyclecounter() : 0;
-        if (b < Bt.batch) {
-            solve_fast<1, 1, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld);
-            // profiling aid: when the workgroup started this batch, when the first product was done, when the records were complete
-            if (Bt.dbg_cycles && lane == 0) { Bt.dbg_cycles[(size_t)b * 8 + 4] = ta0; Bt.dbg_cycles[(size_t)b * 8 + 5] = ta1; Bt.dbg_cycles[(size_t)b * 8 + 6] = ta2; }
-        }
+        gstamp(6);
+        if (b < Bt.batch) solve_fast<1, 1, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld);
         __syncthreads();
+        // the sixteen instances' results, written by neighbouring lanes: one transaction per array and workgroup instead of sixteen
+        {
+            const int t = threadIdx.x;
+            if (t < 16 && b0 + t < Bt.batch) {
+                const double *o = outs + t * outld;
+                const int bb = b0 + t;
+                const bool done = o[7] == 2.0;
+                glw(Bt.done)[bb] = done ? 2 : 0;
+                if (done) {
+                    if (Bt.cost) glw(Bt.cost)[bb] = o[0];
+                    if (Bt.status) glw(Bt.status)[bb] = (int)o[1];
+                    if (Bt.solver_status) glw(Bt.solver_status)[bb] = (int)o[2];
+                    if (Bt.is_feasible) glw(Bt.is_feasible)[bb] = (int)o[3];
+                    if (Bt.iterations) glw(Bt.iterations)[bb] = 0;
+                    if (Bt.polish_rounds) glw(Bt.polish_rounds)[bb] = (int)o[5];
+                    if (Bt.active_count) glw(Bt.active_count)[bb] = (int)o[6];
+                }
+            }
+            for (int e = t; e < 16 * nu; e += blockDim.x) {
+                const int ti = e / nu, jj = e - ti * nu;
+                if (b0 + ti < Bt.batch && outs[ti * outld + 7] == 2.0) glw(Bt.cmd)[(size_t)(b0 + ti) * nu + jj] = outs[ti * outld + 8 + jj];
+            }
+        }
     }
 }
 
@@ -983,22 +1028,19 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
         size_t prev = configured[devid].load(std::memory_order_relaxed);
         while (prev < ldsf && !configured[devid].compare_exchange_weak(prev, ldsf, std::memory_order_release)) {}
     }
-    int blocks = (b.batch + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int cap = 256 * 8;
-    if (blocks > cap) blocks = cap;
+    int blocks = (b.batch + kWavesPerBlock - 1) / kWavesPerBlock;      // one wavefront per instance: the grid covers the batch
     if (blocks < 1) blocks = 1;
     const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
     if (fused && b.fused >= 3) {
         // assemble + solve in one workgroup of sixteen wavefronts (one per CU)
-        const size_t ldsg = ((size_t)2 * 128 + (size_t)kGroupWaves * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + kGroupWaves * 16 + 16) * sizeof(double);
+        const size_t ldsg = ((size_t)2 * 128 + (size_t)kGroupWaves * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + kGroupWaves * 16 + 16 + 16 * (8 + ((m.nu + 1) & ~1))) * sizeof(double);
         if (ldsg > 160 * 1024) return -2;
         static std::atomic<int> gconf[64];
         if (!gconf[devid].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
             gconf[devid].store(1, std::memory_order_release);
         }
-        int wgs = (b.batch + 15) / 16;
-        if (wgs > 256) wgs = 256;
+        const int wgs = (b.batch + 15) / 16;
         hipLaunchKernelGGL(lmpc_solve_group, dim3(wgs), dim3(kGroupWaves * 64), ldsg, stream, m_dev, b, ws, b.fused - 3);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }

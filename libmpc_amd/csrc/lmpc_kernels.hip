@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const Lmp
         for (int c0 = (blockIdx.x * wpb + wave) * kFallbackChunk; c0 < Bt.batch; c0 += gridDim.x * wpb * kFallbackChunk) {
             const int bi = c0 + lane;
             const bool open = lane < kFallbackChunk && bi < Bt.batch &&
-                              glw(wsbase)[(size_t)bi * M.wsld + M.ldz + M.ldy + 2 * M.ldg + 1] != 2.0;
+                              (Bt.done ? gl(Bt.done)[bi] == 0 : glw(wsbase)[(size_t)bi * M.wsld + M.ldz + M.ldy + 2 * M.ldg + 1] != 2.0);
             unsigned long long todo = __ballot(open);
             while (todo) {
                 const int b = c0 + (int)__builtin_ctzll(todo);

@@ -62,6 +62,7 @@ struct mpcx_lmpc {
     int n_full_setups = 0, n_ref_refreshes = 0;      // how often each kind of set-up ran (mpcx_lmpc_debug_setup_counts)
     double *ws = nullptr;               // per-instance workspace between assemble and solve
     int *pcounter = nullptr;            // work counters of the persistent fused kernel (eight ints of its own)
+    int32_t *done = nullptr;            // [ws_cap] lmpc_solve_group: which instances it solved (the fallback kernel screens this instead of the records)
     size_t ws_cap = 0;                  // instances
     explicit mpcx_lmpc(const mpcx_dims &d) : ctl(d) {}
 
@@ -71,7 +72,8 @@ struct mpcx_lmpc {
         allocs.clear();
         if (ws) (void)hipFree(ws);
         if (pcounter) (void)hipFree(pcounter);
-        ws = nullptr; pcounter = nullptr; ws_cap = 0;
+        if (done) (void)hipFree(done);
+        ws = nullptr; pcounter = nullptr; done = nullptr; ws_cap = 0;
         warm_batch = 0;                 // row numbering may have changed with the model
     }
     void release_staging()
@@ -624,8 +626,10 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
     if ((size_t)b->batch > h->ws_cap) {
         // grows only when a larger batch than ever before arrives (not capturable in a graph)
         if (h->ws) (void)hipFree(h->ws);
-        h->ws = nullptr; h->ws_cap = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess)
+        if (h->done) (void)hipFree(h->done);
+        h->ws = nullptr; h->done = nullptr; h->ws_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&h->ws), (size_t)b->batch * h->dev.wsld * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&h->done), (size_t)b->batch * sizeof(int32_t)) != hipSuccess)
             return fail(MPCX_E_DEVICE, "workspace allocation failed");
         if (!h->pcounter) {
             if (hipMalloc(reinterpret_cast<void **>(&h->pcounter), 8 * sizeof(int)) != hipSuccess) return fail(MPCX_E_DEVICE, "workspace allocation failed");
@@ -640,7 +644,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) B.fused = fast + 3;
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
     else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
@@ -1037,7 +1041,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) B.fused = fast + 3;
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
     else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;

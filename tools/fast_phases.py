@@ -10,6 +10,7 @@ from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
 ph = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 c = quadrotor_lmpc(ph, device=0)
+c.debug_use_fused(0)          # the two-kernel form: lmpc_solve alone (the one-workgroup form files its own stamps in the same buffer)
 x0, u0, yref = quadrotor_batch(B)
 buf = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
 c._lib.mpcx_lmpc_debug_set_cycle_buffer(c._h, C.c_void_p(buf.data_ptr()))
