@@ -91,7 +91,7 @@ __device__ __forceinline__ double pivot_rcp(double d)
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // acc += M[:, 0..ncols) * xs.  M column-major, leading dimension ld, R (even) valid rows.
-template <int CP>
+template <int CP, int U = (CP == 1 ? 8 : (CP == 2 ? 4 : 2))>
 __device__ __forceinline__ void matvec_acc(gdp M, int ld, int R, int ncols, const double *xs,
                                            double (&acc)[2 * CP], int lane)
 {
@@ -104,7 +104,6 @@ __device__ __forceinline__ void matvec_acc(gdp M, int ld, int R, int ncols, cons
         t[2 * c] = 0; t[2 * c + 1] = 0;
     }
     // explicit software pipelining: issue a batch of column fetches, then consume them
-    constexpr int U = CP == 1 ? 8 : (CP == 2 ? 4 : 2);
     int j = 0;
     for (; j + U <= ncols; j += U) {
         d2 m[U][CP];

@@ -30,11 +30,35 @@ namespace {
 // =====================================================================================
 // assemble, generic form: one instance per wavefront
 // =====================================================================================
+// global -> registers -> LDS, K chunks of 64 elements per lane.  The loads are never predicated (an out-of-range lane re-reads element 0)
+// and every fetch of a group is issued before the first LDS store waits for one: the wave pays one memory latency per GROUP of arrays.
+// That is what this kernel's time is made of -- a dependent global load costs ~2.7k cycles on the loaded chip and the first form of this
+// function had ~80 of them in series (one per roll-out / adjoint step, one per reference element); now the dependent chains read LDS only.
+template <int K, class F>
+__device__ __forceinline__ void fetch(double (&v)[K], int n, int lane, F &&at)
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = lane + 64 * k;
+        v[k] = at(e < n ? e : 0);
+    }
+}
+template <int K, class F>
+__device__ __forceinline__ void put(double *dst, const double (&v)[K], int n, int lane, F &&at)
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = lane + 64 * k;
+        if (e < n) dst[e] = v[k];
+    }
+    for (int e = lane + 64 * K; e < n; e += 64) dst[e] = at(e);      // shapes past 64 K elements: the slow way
+}
+
 template <int CPZ, int CPG>
 __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
                              double *stage, double *arena, gdw ws)
 {
-    constexpr int NZS = 2 * CPZ, NGS = 2 * CPG;
+    constexpr int NZS = 2 * CPZ, NGS = 2 * CPG, CPY = CPZ + CPG, KF = 4;
     const int nx = M.nx, nu = M.nu, ny = M.ny, ndu = M.ndu, ph = M.ph;
     const int nz = M.nz, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
     const bool has_dist = M.has_dist != 0;
@@ -43,43 +67,91 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     const gdp gdm = gl(Bt.dmeas ? Bt.dmeas : M.dmeas_s), gyr = gl(Bt.yref ? Bt.yref : M.yref_s), gur = gl(Bt.uref ? Bt.uref : M.uref_s),
               gdr = gl(Bt.duref ? Bt.duref : M.duref_s);
 
+    // the wave's LDS plan (lmpc_lds_per_wave sizes it)
+    const int ney = (ph + 1) * ny, nuu = ph * nu;
     double *xb = arena;                       // free response, (ph+1) x nx
-    double *ey = xb + (ph + 1) * nx;          // weighted output error, (ph+1) x ny
-    double *pv = ey + (ph + 1) * ny;          // adjoint ping-pong, 2 x nx
-    double *u0s = pv + 2 * nx;                // lastU
-    // The model matrices in the wave's LDS slice: the roll-out and the adjoint pass are chains of ph dependent steps that read them in
-    // every step -- from L2 that is a memory latency per step, and in a heterogeneous batch (every instance its own model) from HBM
-    double *gA = u0s + ((nu + 1) & ~1), *gB = gA + nx * nx, *gC = gB + nx * nu, *gBd = gC + ny * nx, *gDd = gBd + nx * ndu;
-    {
-        const gdp mA = GP(A), mB = GP(B), mC = GP(C), mBd = GP(Bd), mDd = GP(Dd);
-        for (int e = lane; e < nx * nx; e += 64) gA[e] = mA[e];
-        for (int e = lane; e < nx * nu; e += 64) gB[e] = mB[e];
-        for (int e = lane; e < ny * nx; e += 64) gC[e] = mC[e];
-        if (has_dist) {
-            for (int e = lane; e < nx * ndu; e += 64) gBd[e] = mBd[e];
-            for (int e = lane; e < ny * ndu; e += 64) gDd[e] = mDd[e];
-        }
+    double *ey = xb + (ph + 1) * nx;          // output reference, then the weighted output error, (ph+1) x ny
+    double *wys = ey + ney;                   // output weights, (ph+1) x ny
+    double *pall = wys + ney;                 // adjoint states of every step, (ph+2) x nx (slot ph+1 = 0)
+    double *wur = pall + (ph + 2) * nx;       // Wu_i uref_{i-1}, then the input gradient of step i, ph x nu
+    double *dur = wur + nuu;                  // Wdu_i duref_{i-1}, ph x nu
+    double *u0s = dur + nuu;                  // lastU
+    double *sxu = u0s + nu;                   // the scalar row's coefficients, nx + nu
+    double *dms = sxu + nx + nu;              // measured disturbance of every step, ph x ndu
+    int *blks = reinterpret_cast<int *>(dms + ph * ndu);         // move-blocking map, ph+1 ints
+    // the model matrices: the roll-out and the adjoint pass are chains of ph dependent steps that read them in every step
+    double *gA = dms + ph * ndu + (ph + 2) / 2, *gB = gA + nx * nx, *gC = gB + nx * nu, *gBd = gC + ny * nx, *gDd = gBd + nx * ndu;
+
+    // ---- gather: everything this instance reads from global memory, in two groups of loads ----
+    const gdp mA = GP(A), mB = GP(B), mC = GP(C), mBd = GP(Bd), mDd = GP(Dd);
+    const gip gblk = GP(blk);
+    auto atA = [&](int e) { return mA[e]; };
+    auto atB = [&](int e) { return mB[e]; };
+    auto atC = [&](int e) { return mC[e]; };
+    auto atW = [&](int e) { return GP(Wy)[e]; };
+    auto atR = [&](int e) { const int i = e / ny, a = e - i * ny; return ref_at(gyr, Bt.yref_bs, Bt.yref_ks, b, i > 0 ? i - 1 : 0, a); };
+    auto atU = [&](int e) { const int k = e / nu, j = e - k * nu; return GP(Wu)[e + nu] * ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, k, j); };
+    auto atD = [&](int e) { const int i = e / nu, j = e - i * nu; return GP(Wdu)[e] * ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, i > 0 ? i - 1 : 0, j); };
+    double rA[KF], rB[KF], rC[KF];
+    fetch<KF>(rA, nx * nx, lane, atA);
+    fetch<KF>(rB, nx * nu, lane, atB);
+    fetch<KF>(rC, ny * nx, lane, atC);
+    const int lx = lane < nx ? lane : 0, lu = lane < nu ? lane : 0, ly = lane < ny ? lane : 0;
+    const double x0v = gl(Bt.x0)[(size_t)b * nx + lx], u0v = gl(Bt.u0)[(size_t)b * nu + lu];
+    const double lo0x = GP(lo0x)[lx], hi0x = GP(hi0x)[lx], lo0u = GP(lo0u)[lu], hi0u = GP(hi0u)[lu], lo0y = GP(lo0y)[ly], hi0y = GP(hi0y)[ly];
+    const double sxv = GP(sX)[lx], suv = GP(sU)[lu];
+    const double wu0 = GP(Wu)[lu], wdu0 = GP(Wdu)[lu];
+    const double ur0 = ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, 0, lu), dr0 = ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, 0, lu);
+    const int blkv = gblk[lane <= ph ? lane : 0];
+    double rW[KF], rR[KF], rU[KF], rD[KF];
+    fetch<KF>(rW, ney, lane, atW);
+    fetch<KF>(rR, ney, lane, atR);
+    fetch<KF>(rU, nuu, lane, atU);
+    fetch<KF>(rD, nuu, lane, atD);
+    int rkind[NGS], rstep[NGS], rcomp[NGS];
+    double rlg[NGS], rug[NGS];
+#pragma unroll
+    for (int s = 0; s < NGS; ++s) {
+        const int r = 128 * (s >> 1) + 2 * lane + (s & 1), rr = r < ldg ? r : 0;
+        rkind[s] = GP(g_kind)[rr]; rstep[s] = GP(g_step)[rr]; rcomp[s] = GP(g_comp)[rr];
+        rlg[s] = GP(lg0)[rr]; rug[s] = GP(ug0)[rr];
     }
-    if (lane < nx) xb[lane] = gl(Bt.x0)[(size_t)b * nx + lane];
-    if (lane < nu) u0s[lane] = gl(Bt.u0)[(size_t)b * nu + lane];
+
+    put<KF>(gA, rA, nx * nx, lane, atA);
+    put<KF>(gB, rB, nx * nu, lane, atB);
+    put<KF>(gC, rC, ny * nx, lane, atC);
+    if (lane < nx) { xb[lane] = x0v; sxu[lane] = sxv; pall[(ph + 1) * nx + lane] = 0.0; }
+    if (lane < nu) { u0s[lane] = u0v; sxu[nx + lane] = suv; }
+    if (lane <= ph) blks[lane] = blkv;
+    for (int e = lane + 64; e <= ph; e += 64) blks[e] = gblk[e];
+    put<KF>(wys, rW, ney, lane, atW);
+    put<KF>(ey, rR, ney, lane, atR);
+    put<KF>(wur, rU, nuu, lane, atU);
+    put<KF>(dur, rD, nuu, lane, atD);
+    if (has_dist) {
+        for (int e = lane; e < nx * ndu; e += 64) gBd[e] = mBd[e];
+        for (int e = lane; e < ny * ndu; e += 64) gDd[e] = mDd[e];
+        for (int e = lane; e < ph * ndu; e += 64) { const int k = e / ndu; dms[e] = ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, e - k * ndu); }
+    }
+    for (int e = lane; e < ldz; e += 64) stage[e] = 0.0;
     wave_sync();
 
-    auto dm = [&](int k, int dd) -> double { return ref_at(gdm, Bt.dmeas_bs, Bt.dmeas_ks, b, k, dd); };
+    auto dm = [&](int k, int dd) -> double { return dms[k * ndu + dd]; };
 
     // step-0 rows involve no decision variable: pure feasibility conditions on (x0, lastU)
     bool bad = false;
-    if (lane < nx) bad |= violates(xb[lane], GP(lo0x)[lane], GP(hi0x)[lane], ea, er);
-    if (lane < nu) bad |= violates(u0s[lane], GP(lo0u)[lane], GP(hi0u)[lane], ea, er);
+    if (lane < nx) bad |= violates(x0v, lo0x, hi0x, ea, er);
+    if (lane < nu) bad |= violates(u0v, lo0u, hi0u, ea, er);
     if (lane < ny) {
         double y0 = 0;
         for (int c = 0; c < nx; ++c) y0 = fma(gC[lane + c * ny], xb[c], y0);
         if (has_dist) for (int dd = 0; dd < ndu; ++dd) y0 = fma(gDd[lane + dd * ny], dm(0, dd), y0);
-        bad |= violates(y0, GP(lo0y)[lane], GP(hi0y)[lane], ea, er);
+        bad |= violates(y0, lo0y, hi0y, ea, er);
     }
     if (lane == 0) {
         double s0 = 0;
-        for (int c = 0; c < nx; ++c) s0 = fma(GP(sX)[c], xb[c], s0);
-        for (int c = 0; c < nu; ++c) s0 = fma(GP(sU)[c], u0s[c], s0);
+        for (int c = 0; c < nx; ++c) s0 = fma(sxu[c], xb[c], s0);
+        for (int c = 0; c < nu; ++c) s0 = fma(sxu[nx + c], u0s[c], s0);
         bad |= violates(s0, M.s0lo, M.s0hi, ea, er);
     }
 
@@ -96,21 +168,21 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
         wave_sync();
     }
     double c0 = 0;
-    for (int idx = lane; idx < (ph + 1) * ny; idx += 64) {
+    for (int idx = lane; idx < ney; idx += 64) {
         const int i = idx / ny, a = idx - i * ny, k = i > 0 ? i - 1 : 0;
         double cx = 0;
 #pragma unroll 4
         for (int c = 0; c < nx; ++c) cx = fma(gC[a + c * ny], xb[i * nx + c], cx);
-        double r = ref_at(gyr, Bt.yref_bs, Bt.yref_ks, b, k, a);
+        double r = ey[idx];
         if (has_dist) for (int dd = 0; dd < ndu; ++dd) r -= gDd[a + dd * ny] * dm(k, dd);
-        const double w = GP(Wy)[i * ny + a];
+        const double w = wys[idx];
         ey[idx] = w * (cx - r);
         c0 += w * (0.5 * cx * cx - r * cx);
     }
     if (lane < nu) {
-        const double u = u0s[lane];
-        c0 += GP(Wu)[lane] * (0.5 * u * u - ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, 0, lane) * u);
-        c0 += GP(Wdu)[lane] * (0.5 * u * u + ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, 0, lane) * u);
+        const double u = u0v;
+        c0 += wu0 * (0.5 * u * u - ur0 * u);
+        c0 += wdu0 * (0.5 * u * u + dr0 * u);
     }
     c0 = wave_sum(c0);
 
@@ -122,7 +194,7 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
         const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
         lg[s] = -INF; ug[s] = INF;
         if (r < ldg) {
-            const int kind = GP(g_kind)[r], st = GP(g_step)[r], cp = GP(g_comp)[r];
+            const int kind = rkind[s], st = rstep[s], cp = rcomp[s];
             double off;
             if (kind == 0) off = xb[st * nx + cp];
             else if (kind == 1) {
@@ -131,9 +203,9 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
                 if (has_dist) for (int dd = 0; dd < ndu; ++dd) off = fma(gDd[cp + dd * ny], dm(st - 1, dd), off);
             } else {
                 off = 0;
-                for (int c = 0; c < nx; ++c) off = fma(GP(sX)[c], xb[st * nx + c], off);
+                for (int c = 0; c < nx; ++c) off = fma(sxu[c], xb[st * nx + c], off);
             }
-            lg[s] = GP(lg0)[r] - off; ug[s] = GP(ug0)[r] - off;
+            lg[s] = rlg[s] - off; ug[s] = rug[s] - off;
         }
     }
     for (int idx = lane; idx < M.n_fixed; idx += 64) {
@@ -144,55 +216,55 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
             for (int c = 0; c < nx; ++c) v = fma(gC[cp + c * ny], xb[st * nx + c], v);
             if (has_dist) for (int dd = 0; dd < ndu; ++dd) v = fma(gDd[cp + dd * ny], dm(st - 1, dd), v);
         } else {
-            for (int c = 0; c < nx; ++c) v = fma(GP(sX)[c], xb[st * nx + c], v);
+            for (int c = 0; c < nx; ++c) v = fma(sxu[c], xb[st * nx + c], v);
         }
         bad |= violates(v, GP(f_lo)[idx], GP(f_hi)[idx], ea, er);
     }
     const bool infeasible0 = wave_any(bad);
+    wave_sync();                              // ey is complete
 
-    // adjoint pass -> linear term
-    for (int e = lane; e < ldz; e += 64) stage[e] = 0.0;
-    if (lane < nx) { pv[lane] = 0.0; pv[nx + lane] = 0.0; }
+    // adjoint pass -> linear term.  p_i = C' ey_i + A' p_{i+1}: the output terms of every step at once, then the chain of ph steps
+    // (one LDS mat-vec each), then the input gradients B' p_i of every step at once.
+    for (int e = lane; e < ph * nx; e += 64) {
+        const int i = e / nx + 1, r = e - (i - 1) * nx;
+        double s = 0;
+#pragma unroll 4
+        for (int a = 0; a < ny; ++a) s = fma(gC[a + r * ny], ey[i * ny + a], s);
+        pall[i * nx + r] = s;
+    }
     wave_sync();
-    {
-        const gip gblk = GP(blk);
-        int cur = 0;
-        for (int i = ph; i >= 1; --i) {
-            const double *pin = pv + cur * nx;
-            double *pout = pv + (1 - cur) * nx;
-            if (lane < nx) {
-                double s = 0;
+    for (int i = ph; i >= 1; --i) {
+        if (lane < nx) {
+            const double *pin = pall + (i + 1) * nx;
+            double s = pall[i * nx + lane];
 #pragma unroll 4
-                for (int a = 0; a < ny; ++a) s = fma(gC[a + lane * ny], ey[i * ny + a], s);
-#pragma unroll 4
-                for (int a = 0; a < nx; ++a) s = fma(gA[a + lane * nx], pin[a], s);
-                pout[lane] = s;
-            }
-            wave_sync();
-            if (lane < nu) {
-                double g = 0;
-#pragma unroll 4
-                for (int a = 0; a < nx; ++a) g = fma(gB[a + lane * nx], pout[a], g);
-                g -= GP(Wu)[i * nu + lane] * ref_at(gur, Bt.uref_bs, Bt.uref_ks, b, i - 1, lane);
-                stage[gblk[i] * nu + lane] += g;
-            }
-            cur = 1 - cur;
-            wave_sync();
-        }
-        if (lane < nu) {
-            const int j = lane;
-            stage[gblk[1] * nu + j] -= GP(Wdu)[j] * (u0s[j] + ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, 0, j));
-            for (int i = 1; i < ph; ++i) {
-                const int bn = gblk[i + 1], bp = gblk[i];
-                if (bn != bp) {
-                    const double t = -GP(Wdu)[i * nu + j] * ref_at(gdr, Bt.duref_bs, Bt.duref_ks, b, i - 1, j);
-                    stage[bn * nu + j] += t;
-                    stage[bp * nu + j] -= t;
-                }
-            }
+            for (int a = 0; a < nx; ++a) s = fma(gA[a + lane * nx], pin[a], s);
+            pall[i * nx + lane] = s;
         }
         wave_sync();
     }
+    for (int e = lane; e < nuu; e += 64) {
+        const int i = e / nu + 1, j = e - (i - 1) * nu;
+        double g = 0;
+#pragma unroll 4
+        for (int a = 0; a < nx; ++a) g = fma(gB[a + j * nx], pall[i * nx + a], g);
+        wur[e] = g - wur[e];
+    }
+    wave_sync();
+    if (lane < nu) {
+        const int j = lane;
+        for (int i = ph; i >= 1; --i) stage[blks[i] * nu + j] += wur[(i - 1) * nu + j];
+        stage[blks[1] * nu + j] -= wdu0 * (u0v + dr0);
+        for (int i = 1; i < ph; ++i) {
+            const int bn = blks[i + 1], bp = blks[i];
+            if (bn != bp) {
+                const double t = -dur[i * nu + j];
+                stage[bn * nu + j] += t;
+                stage[bp * nu + j] -= t;
+            }
+        }
+    }
+    wave_sync();
     double f[NZS], nf_[NZS];
 #pragma unroll
     for (int s = 0; s < NZS; ++s) {
@@ -204,26 +276,28 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     stage_store<CPZ>(stage, nf_, ldz, lane);
     wave_sync();
 
-    // unconstrained optimum t0 = -Hinv f and its image under the constraint rows
-    double t0[NZS], gt0[NGS];
+    // unconstrained optimum t0 = -Hinv f and its image under the constraint rows: the first nz columns of Y = [Hinv; G Hinv] in one pass
+    // (the record keeps t0 | gt0 back to back, as Y's rows are)
+    double tg[2 * CPY];
 #pragma unroll
-    for (int s = 0; s < NZS; ++s) t0[s] = 0;
-#pragma unroll
-    for (int s = 0; s < NGS; ++s) gt0[s] = 0;
-    matvec_acc<CPZ>(GP(Y), ldy, ldz, nz, stage, t0, lane);
-    matvec_acc<CPG>(GP(Y) + ldz, ldy, ldg, nz, stage, gt0, lane);
+    for (int s = 0; s < 2 * CPY; ++s) tg[s] = 0;
+    matvec_acc<CPY, (CPY <= 2 ? 8 : (CPY <= 4 ? 4 : 2))>(GP(Y), ldy, ldy, nz, stage, tg, lane);
 
     // workspace record: f | t0 | gt0 | lg | ug | c0, flag
 #pragma unroll
     for (int c = 0; c < CPZ; ++c) {
         const int e = 128 * c + 2 * lane;
-        if (e < ldz) { st2(ws + e, f[2 * c], f[2 * c + 1]); st2(ws + ldz + e, t0[2 * c], t0[2 * c + 1]); }
+        if (e < ldz) st2(ws + e, f[2 * c], f[2 * c + 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPY; ++c) {
+        const int e = 128 * c + 2 * lane;
+        if (e < ldy) st2(ws + ldz + e, tg[2 * c], tg[2 * c + 1]);
     }
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         const int r = 128 * c + 2 * lane;
         if (r < ldg) {
-            st2(ws + ldz + ldz + r, gt0[2 * c], gt0[2 * c + 1]);
             st2(ws + ldz + ldy + r, lg[2 * c], lg[2 * c + 1]);
             st2(ws + ldz + ldy + ldg + r, ug[2 * c], ug[2 * c + 1]);
         }
@@ -240,8 +314,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_assemble_generic(con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *stage = smem + (size_t)wave * M0.lds_per_wave;
     double *arena = stage + M0.stage_len + M0.ldy;
-    const int wpb = blockDim.x >> 6;
-    for (int b = blockIdx.x * wpb + wave; b < Bt.batch; b += gridDim.x * wpb)
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;             // one instance per wavefront; the grid covers the batch
+    if (b < Bt.batch)
         assemble_one<CPZ, CPG>(Mp[lmpc_model_of(Bt, b)], Bt, b, lane, stage, arena, glw(wsbase) + (size_t)b * M0.wsld);
 }
 
@@ -1378,7 +1452,7 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
             if (blocks1 > 4096) blocks1 = 4096;
             hipLaunchKernelGGL(lmpc_assemble_mfma, dim3(blocks1), dim3(256), lds1, stream, m_dev, b, ws, fast);
         } else {
-            hipLaunchKernelGGL(k1, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
+            hipLaunchKernelGGL(k1, dim3((b.batch + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWavesPerBlock * 64), lds, stream, m_dev, b, ws);
         }
     }
     if (which & 2) {
@@ -1424,8 +1498,8 @@ int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len)
 {
     int st = m.ldz > m.ldg ? m.ldz : m.ldg;
     st = (st + 1) / 2 * 2;
-    int a1 = (m.ph + 1) * (m.nx + m.ny) + 2 * m.nx + m.nu + 8 +
-             m.nx * m.nx + m.nx * m.nu + m.ny * m.nx + m.nx * m.ndu + m.ny * m.ndu;      // + the model matrices (assemble_one)
+    int a1 = (m.ph + 1) * (m.nx + 2 * m.ny) + (m.ph + 2) * m.nx + 2 * m.ph * m.nu + m.nu + (m.nx + m.nu) + m.ph * m.ndu + (m.ph + 2) / 2 + 8 +
+             m.nx * m.nx + m.nx * m.nu + m.ny * m.nx + m.nx * m.ndu + m.ny * m.ndu;      // assemble_one's plan, model matrices last
     int a2 = kMaxActive * kSld + 3 * kMaxActive + kMaxActive;      // S, lam, wsb, dg0, wsidx (ints)
     int ar = a1 > a2 ? a1 : a2;
     ar = (ar + 1) / 2 * 2;
