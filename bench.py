@@ -548,7 +548,7 @@ def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, bar
             "mean_iterations": float(it.mean()), "max_iterations": int(it.max()), "mean_active_rows": float(nact.mean()),
             "hbm_achieved_GBs": bytes_alg / (kern_ms * 1e-3) / 1e9, "hbm_frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "algorithmic_bytes_per_launch": bytes_alg, "workspace_bytes_per_instance": int(c.debug_workspace_bytes()),
-            "kernel_source_hash": kernel_source_hash()}
+            "kernel_source_hash": kernel_source_hash(), "counters": _sq_counters(dom, "%s_b%d" % (name, B))}
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
         ncores = _usable_cores()

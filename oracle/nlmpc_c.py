@@ -85,7 +85,7 @@ class NlmpcC:
                 {"type": "ineq", "fun": lambda z: -self.user_ineq(z, False)[0], "jac": lambda z: -self.user_ineq(z, True)[1]}]
         r = minimize(lambda z: self.objective(z, False)[0], z0, jac=lambda z: self.objective(z, True)[1], method="SLSQP",
                      bounds=list(zip(lo, hi)), constraints=cons, options={"maxiter": max_iter, "ftol": 1e-12})
-        return dict(z=r.x, cmd=r.x[ph * nx:ph * nx + nu].copy(), cost=float(r.fun), nit=int(r.nit), success=bool(r.success))
+        return dict(z=r.x, cmd=r.x[ph * nx:ph * nx + nu].copy(), cost=float(r.fun), nit=int(r.nit), success=bool(r.success), slsqp_mode=int(r.status))
 
 
 def make(name):

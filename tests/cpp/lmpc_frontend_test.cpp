@@ -3,6 +3,9 @@
 // once with compile-time sizes and once with run-time sizes (the reference builds every test both
 // ways, test/CMakeLists.txt:56-65).  Mode "api": setter return values and throwing calls only (runs
 // without a GPU, MPCX_DEVICE=-1).  Mode "solve": also the quadrotor known answer on the GPU.
+// A drop-in test has to make the reference's calls in the reference's order: the resemblance to its TEST_CASEs is the point.
+// The numeric literals (model matrices, weights, expected command) are data -- the same values tests/golden/
+// reference_known_answers.json holds for the Python suite; the harness, the controller and everything under it are this repository's.
 #include <mpc/LMPC.hpp>
 
 #include <cstdio>

@@ -4,6 +4,8 @@
 // lambdas are the capture list ([&] -> [=]: a device closure cannot hold references into the host's stack) and, for the
 // helper it calls, a functor with a __device__ call operator.  Also exercised: setHooks (all hooks at once, inlined),
 // setHookSources (bodies as text, hipRTC), user equalities, an output function, and the built-in model as the yardstick.
+// The lambda bodies are the example's on purpose (that a user's existing hooks run unchanged is what is being tested); nothing
+// else of the example is here.
 #include <cmath>
 #include <cstdio>
 #include <cstring>

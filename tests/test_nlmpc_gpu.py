@@ -242,27 +242,71 @@ def test_state_and_input_bounds_match_oracle():
     assert (r2["status"] == 0).all() and (r2["seq_input"].abs() <= 0.2 + 1e-9).all()
 
 
-def test_eight_oscillator_config_matches_golden_oracle_solutions():
-    """BASELINE config 5 (nz = 601, 480 equalities, 248 inequalities): the oracle needs ~50 s per instance, its solutions
-    are kept in tests/golden/nlmpc_oracle_solutions.json (generated by tests/golden/make_nlmpc_golden.py)"""
+def _golden(key):
     import json
     import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nlmpc_oracle_solutions.json")))[key]
+
+
+def _compare_with_golden(c, gold, label, cost_rtol):
+    """every golden instance in one batch; compared wherever the oracle's SLSQP ended at a usable point.  Returns (compared, other):
+    an instance where the two solvers stopped at different local optima is counted (with how its cost compares), not compared"""
     import torch
-    from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS8
-    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nlmpc_oracle_solutions.json")))["oscillators8_ph30_ch15"]
-    c = NLMPC(OSCILLATORS8, gold["ph"], gold["ch"], gold["Ts"])
-    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
     X0 = np.array([k["x0"] for k in gold["cases"]]); U0 = np.array([k["u0"] for k in gold["cases"]])
     r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0))
     torch.cuda.synchronize()
-    assert (r["status"] == 0).all(), (r["status"], r["solver_status"])
-    worst = 0.0
+    status, cost, cmd = r["status"].cpu().numpy(), r["cost"].cpu().numpy(), r["cmd"].cpu().numpy()
+    worst, worst_cost, compared, other, bad_cost = 0.0, 0.0, 0, [], []
+    # usable: scipy's SLSQP converged, or ended in its mode 8 (line search cannot improve: the step is below what its ftol of 1e-12
+    # resolves) at a feasible point -- how it ends most UGV solves.  Its diverged runs (cost 1e9 and more on config 5) are not.
+    usable = [k["success"] or (k["slsqp_mode"] == 8 and k["eq_violation"] < 1e-8 and k["ineq_violation"] < 1e-6) for k in gold["cases"]]
     for b, k in enumerate(gold["cases"]):
-        assert k["success"]
-        assert abs(r["cost"][b].item() - k["cost"]) <= 1e-8 * k["cost"]
-        worst = max(worst, np.abs(r["cmd"][b].cpu().numpy() - k["cmd"]).max() / max(1.0, np.abs(k["cmd"]).max()))
-        np.testing.assert_allclose(r["cmd"][b].cpu().numpy(), k["cmd"], rtol=1e-5, atol=1e-5)
-    print("parity 8 oscillators (config 5): max |cmd - oracle| / max(1, |cmd|) = %.2e over %d golden instances" % (worst, len(gold["cases"])))
+        if not usable[b]:
+            continue
+        assert status[b] != 3, (b, status[b])
+        if not np.allclose(cmd[b], k["cmd"], rtol=1e-5, atol=1e-5):
+            # another local optimum: the UGV's obstacle rows make the problem non-convex (from the example's own start x0 = 0 the two
+            # mirror-image paths cost the same to 1e-9 and round-off decides which one a solver takes; from other starts the two SLSQP
+            # implementations pass the obstacles on different sides).  Counted, not compared: the caller bounds how many there may be, and
+            # test_gpu_solution_satisfies_the_restated_kkt_conditions checks that the kernel's end points are KKT points.
+            assert status[b] == 0, (b, status[b])
+            other.append((b, "better" if cost[b] < k["cost"] * (1.0 - cost_rtol) else ("equal" if cost[b] <= k["cost"] * (1.0 + cost_rtol) else "worse")))
+            continue
+        if abs(cost[b] - k["cost"]) > cost_rtol * abs(k["cost"]):
+            bad_cost.append((b, cost[b], k["cost"], k["slsqp_mode"], k["ineq_violation"]))
+        worst_cost = max(worst_cost, abs(cost[b] - k["cost"]) / abs(k["cost"]))
+        compared += 1
+        worst = max(worst, np.abs(cmd[b] - k["cmd"]).max() / max(1.0, np.abs(k["cmd"]).max()))
+    print("parity %s: max |cmd - oracle| / max(1, |cmd|) = %.2e, max |cost - oracle| / cost = %.1e over %d golden instances (%d usable end points "
+          "of the oracle; %d at another local optimum: %s)" % (label, worst, worst_cost, compared, sum(usable), len(other),
+             {w: sum(1 for _, x in other if x == w) for w in ("better", "equal", "worse")}))
+    assert not bad_cost, bad_cost
+    return compared, other
+
+
+def test_eight_oscillator_config_matches_golden_oracle_solutions():
+    """BASELINE config 5 (nz = 601, 480 equalities, 248 inequalities): the oracle needs 60 ... 90 s per instance, its solutions on
+    the example's start and the first 31 instances of bench.py's batch are kept in tests/golden/nlmpc_oracle_solutions.json
+    (generated by tests/golden/make_nlmpc_golden.py)"""
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS8
+    gold = _golden("oscillators8_ph30_ch15")
+    assert len(gold["cases"]) >= 32
+    c = NLMPC(OSCILLATORS8, gold["ph"], gold["ch"], gold["Ts"])
+    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+    compared, other = _compare_with_golden(c, gold, "8 oscillators (config 5)", 1e-8)
+    assert compared >= 28 and not other                # one optimum here; scipy's SLSQP diverges on three of the 32 starts
+
+
+def test_ugv_config_matches_golden_oracle_solutions():
+    """BASELINE config 3 (ugv_ex.cpp, soft constraints): the example's start and the first 63 instances of bench.py's batch"""
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, UGV
+    gold = _golden("ugv_ph30_ch30")
+    assert len(gold["cases"]) >= 64
+    c = NLMPC(UGV, gold["ph"], gold["ch"], gold["Ts"])
+    c.setOptimizerParameters(NLParameters(maximum_iteration=150, hard_constraints=0))
+    # cost: scipy's mode-8 end points sit up to 1e-7 outside the obstacle rows (stored: ineq_violation), which buys them up to 5e-7 of cost
+    compared, other = _compare_with_golden(c, gold, "ugv (config 3)", 2e-6)
+    assert compared >= 48 and len(other) <= 8, (compared, other)
 
 
 def test_config5_properties_and_kkt_at_batch_256():
