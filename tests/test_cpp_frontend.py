@@ -60,3 +60,35 @@ def test_cpp_nlmpc_frontend_vanderpol_closed_loop():
     out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all C++ NLMPC front-end checks passed" in out.stdout
+
+
+BK_SRC = os.path.join(ROOT, "tests", "cpp", "ioptimizer_backend_test.cpp")
+BK_OUT = os.path.join(ROOT, "tests", "cpp", "build", "ioptimizer_backend_test")
+
+
+def _build_backend():
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    os.makedirs(os.path.dirname(BK_OUT), exist_ok=True)
+    lib = os.path.join(ROOT, "libmpc_amd")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           BK_SRC, "-o", BK_OUT, "-L" + lib, "-lmpcx", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    return BK_OUT
+
+
+def test_ioptimizer_shaped_backend_api_without_gpu():
+    """INTEGRATION.md section 2's binding (a backend of the shape of IOptimizer.hpp:24-58 over the C ABI), compiled"""
+    exe = _build_backend()
+    out = subprocess.run([exe, "api"], env=dict(os.environ, MPCX_DEVICE="-1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all IOptimizer backend checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_ioptimizer_shaped_backend_solves_like_the_front_end():
+    exe = _build_backend()
+    env = {k: v for k, v in os.environ.items() if k != "MPCX_DEVICE"}
+    out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all IOptimizer backend checks passed" in out.stdout
