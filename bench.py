@@ -139,8 +139,8 @@ def _traffic(dom, tag):
     if pm.get("kernel_source_hash") != kernel_source_hash():
         return None, os.path.basename(cand[-1]), "PMC summary is stale: kernel sources changed since it was measured"
     try:
-        # KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-        return (2.0 * pm["FETCH_SIZE"][dom]["mean"] + pm["WRITE_SIZE"][dom]["mean"]) * 1024.0, os.path.basename(cand[-1]), None
+        # KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; "a + b": two kernels timed as one slot
+        return sum((2.0 * pm["FETCH_SIZE"][k]["mean"] + pm["WRITE_SIZE"][k]["mean"]) * 1024.0 for k in dom.split(" + ")), os.path.basename(cand[-1]), None
     except KeyError:
         return None, os.path.basename(cand[-1]), "kernel %s not in the PMC summary" % dom
 
@@ -330,6 +330,11 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
     fl_admm = float(iters.sum() * info["flops_per_admm_iter"])
     if ms3[0] < 1e-3:      # one-kernel form (lmpc_solve_group: MFMA assemble into LDS + one wavefront per instance): both parts' flops
         kern = {"lmpc_solve_group": (ms3[1], fl_assemble + fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
+    elif ctl.debug_get("flags")[0] != 0:
+        # cost from its definition (ill-conditioned Hessians): lmpc_solve leaves w, lmpc_cost_mfma computes 0.5 w'Hw + f'w for
+        # sixteen instances per pass over H -- the two are launched and timed back to back as one slot
+        kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve + lmpc_cost_mfma": (ms3[1], fl_polish + B * (2.0 * nz * nz + 2.0 * nz)),
+                "lmpc_solve_admm": (ms3[2], fl_admm)}
     else:
         kern = {"lmpc_assemble_mfma": (ms3[0], fl_assemble), "lmpc_solve": (ms3[1], fl_polish), "lmpc_solve_admm": (ms3[2], fl_admm)}
     dom = max(kern, key=lambda k: kern[k][0])
@@ -349,7 +354,7 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
             "hbm_achieved_GBs": bytes_alg / (all_ms * 1e-3) / 1e9,
             "hbm_frac": bytes_alg / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "algorithmic_bytes_per_launch": bytes_alg, "kernel_source_hash": kernel_source_hash(),
-            "counters": _sq_counters(dom, "lmpc%d_b%d" % (ph, B))}
+            "counters": _sq_counters(dom.split(" + ")[0], "lmpc%d_b%d" % (ph, B))}
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
         # (i) one thread, every instance in turn -> per-solve latency and single-core rate; (ii) all host

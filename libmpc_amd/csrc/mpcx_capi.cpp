@@ -1139,7 +1139,10 @@ int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap)
                (double)h->dev.lds_per_wave, (double)(o.h_regularised ? 1 : 0)};
         v = &tmp;
     } else if (n == "MA0") v = &o.MA[0]; else if (n == "MA1") v = &o.MA[1];
-    else if (n == "dims_maps") {
+    else if (n == "flags") {           // which forms of the solve this controller can take: cost from its definition (lmpc_cost_mfma follows lmpc_solve), one-workgroup form, fused mat-vec form
+        tmp = {(double)h->dev.cost_direct, (double)h->dev.group_ok, (double)h->dev.fused_ok};
+        v = &tmp;
+    } else if (n == "dims_maps") {
         tmp = {(double)o.kin, (double)o.nxp, (double)o.nup, (double)o.nyp, (double)o.ione, (double)o.nz16, (double)o.mg16,
                (double)o.ns, (double)o.ns16, (double)o.kq16, (double)o.rowsA, (double)o.ldy16};
         v = &tmp;
