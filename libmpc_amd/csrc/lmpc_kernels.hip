@@ -276,24 +276,77 @@ __device__ void assemble_one(const LmpcDev &M, const LmpcBatchDev &Bt, const int
     stage_store<CPZ>(stage, nf_, ldz, lane);
     wave_sync();
 
-    // unconstrained optimum t0 = -Hinv f and its image under the constraint rows: the first nz columns of Y = [Hinv; G Hinv] in one pass
-    // (the record keeps t0 | gt0 back to back, as Y's rows are)
-    double tg[2 * CPY];
+    // unconstrained optimum t0 = -Hinv f and its image G t0 under the constraint rows
+    if (Bt.n_models > 0) {
+        // Every instance its own controller: the factors come from HBM, and G Hinv (ldg x nz) is 40 % of them.  G t0 needs no matrix:
+        // the rows of G are states, outputs and scalar rows of the response to the inputs, so G t0 is read off a roll-out
+        // x_i = A x_{i-1} + B t0[blk(i)] from x_0 = 0 with the model matrices that are in LDS already.  Only Hinv is fetched.
+        double t0[NZS];
 #pragma unroll
-    for (int s = 0; s < 2 * CPY; ++s) tg[s] = 0;
-    matvec_acc<CPY, (CPY <= 2 ? 8 : (CPY <= 4 ? 4 : 2))>(GP(Y), ldy, ldy, nz, stage, tg, lane);
-
+        for (int s = 0; s < NZS; ++s) t0[s] = 0;
+        matvec_acc<CPZ, (CPZ == 1 ? 16 : (CPZ == 2 ? 8 : 4))>(GP(Y), ldy, ldz, nz, stage, t0, lane);
+        wave_sync();                          // every lane is done with -f
+        stage_store<CPZ>(stage, t0, ldz, lane);
+        if (lane < nx) xb[lane] = 0.0;
+        wave_sync();
+        for (int i = 1; i <= ph; ++i) {
+            if (lane < nx) {
+                const double *xp = xb + (i - 1) * nx, *ui = stage + blks[i] * nu;
+                double s = 0;
+#pragma unroll 4
+                for (int c = 0; c < nx; ++c) s = fma(gA[lane + c * nx], xp[c], s);
+                for (int j = 0; j < nu; ++j) s = fma(gB[lane + j * nx], ui[j], s);
+                xb[i * nx + lane] = s;
+            }
+            wave_sync();
+        }
+        double gt0[NGS];
+#pragma unroll
+        for (int s = 0; s < NGS; ++s) {
+            const int r = 128 * (s >> 1) + 2 * lane + (s & 1);
+            gt0[s] = 0.0;
+            if (r < ldg) {
+                const int kind = rkind[s], st = rstep[s], cp = rcomp[s];
+                double v = 0;
+                if (kind == 0) v = xb[st * nx + cp];
+                else if (kind == 1) {
+                    for (int c = 0; c < nx; ++c) v = fma(gC[cp + c * ny], xb[st * nx + c], v);
+                } else {
+                    for (int c = 0; c < nx; ++c) v = fma(sxu[c], xb[st * nx + c], v);
+                    for (int j = 0; j < nu; ++j) v = fma(sxu[nx + j], stage[blks[st] * nu + j], v);
+                }
+                gt0[s] = v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldz) { st2(ws + e, f[2 * c], f[2 * c + 1]); st2(ws + ldz + e, t0[2 * c], t0[2 * c + 1]); }
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const int r = 128 * c + 2 * lane;
+            if (r < ldg) st2(ws + ldz + ldz + r, gt0[2 * c], gt0[2 * c + 1]);
+        }
+    } else {
+        // one controller for the batch: the first nz columns of Y = [Hinv; G Hinv] stream from L2 in one pass (the record keeps t0 | gt0
+        // back to back, as Y's rows are)
+        double tg[2 * CPY];
+#pragma unroll
+        for (int s = 0; s < 2 * CPY; ++s) tg[s] = 0;
+        matvec_acc<CPY, (CPY <= 2 ? 8 : (CPY <= 4 ? 4 : 2))>(GP(Y), ldy, ldy, nz, stage, tg, lane);
+#pragma unroll
+        for (int c = 0; c < CPZ; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldz) st2(ws + e, f[2 * c], f[2 * c + 1]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPY; ++c) {
+            const int e = 128 * c + 2 * lane;
+            if (e < ldy) st2(ws + ldz + e, tg[2 * c], tg[2 * c + 1]);
+        }
+    }
     // workspace record: f | t0 | gt0 | lg | ug | c0, flag
-#pragma unroll
-    for (int c = 0; c < CPZ; ++c) {
-        const int e = 128 * c + 2 * lane;
-        if (e < ldz) st2(ws + e, f[2 * c], f[2 * c + 1]);
-    }
-#pragma unroll
-    for (int c = 0; c < CPY; ++c) {
-        const int e = 128 * c + 2 * lane;
-        if (e < ldy) st2(ws + ldz + e, tg[2 * c], tg[2 * c + 1]);
-    }
 #pragma unroll
     for (int c = 0; c < CPG; ++c) {
         const int r = 128 * c + 2 * lane;
