@@ -436,17 +436,21 @@ def run_lmpc_hetero(args, ph, B, steps, warmup, world, rank, local, dev, gather,
     bytes_in = 8.0 * (nx * nx + nx * nu + ny * nx) + 8.0 * (ny + 2 * nu) * ph + 8.0 * 2 * (nx + ny + nu) * ph + 8.0 * (ny + 2 * nu) * ph + 8.0 * (nx + nu)
     bytes_alg = float(B) * (bytes_in + 8.0 * nu + 8.0)
     gbs = bytes_alg / (ms * 1e-3) / 1e9
-    gbs_read = float(B) * het.bytes_per_model / (ms * 1e-3) / 1e9
+    # the factors a solve fetches from its own controller: mpcx_lmpc_hetero_get_info counts the first nz columns of Y = [Hinv; G Hinv];
+    # the assemble kernel reads the Hinv rows only (G t0 comes from a roll-out of the model it has in LDS)
+    ti = het._template.info()
+    fbytes = het.bytes_per_model - 8.0 * ti["nz"] * ((ti["mg"] + 1) // 2 * 2)
+    gbs_read = float(B) * fbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src, traffic_note = _traffic("lmpc_assemble_generic", "lmpchetero%d_b%d" % (ph, B))
     roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
             "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
             "kernel": "lmpc_assemble_generic + lmpc_solve (every instance reads its own model's factors)", "all_kernels_ms": ms,
             "algorithmic_bytes_per_solve": bytes_in + 8.0 * nu + 8.0, "algorithmic_bytes_per_launch": bytes_alg,
-            "factor_bytes_read_per_solve": het.bytes_per_model, "factor_read_GBs": gbs_read, "factor_read_frac": gbs_read / PEAK_HBM_GBS,
+            "factor_bytes_read_per_solve": fbytes, "factor_read_GBs": gbs_read, "factor_read_frac": gbs_read / PEAK_HBM_GBS,
             "mean_polish_rounds": float(rounds.mean()),
             "note": "algorithmic = what the reference's ProblemBuilder consumes per solve (SURVEY 8d: 18 176 B at N = 20); this path reads the "
-                    "controller's precomputed factors instead (-Hinv, G Hinv: factor_bytes_read_per_solve) and pays the condensing once per "
+                    "controller's precomputed factors instead (-Hinv and the model matrices: factor_bytes_read_per_solve) and pays the condensing once per "
                     "model change (set_up below)",
             "kernel_source_hash": kernel_source_hash(), "counters": _sq_counters("lmpc_assemble_generic", "lmpchetero%d_b%d" % (ph, B))}
     setup = {"controllers": B, "condensed_on_device": bool(flags[1]), "condense_kernel_ms": float(flags[2]), "create_ms": float(flags[3]),
