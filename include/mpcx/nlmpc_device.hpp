@@ -36,6 +36,8 @@ struct NlmpcDev {
     int kw;                     // working-set capacity: min(kNlMaxWorking, rows, variables)
     int nl;                     // rows of the working set whose factor fits the LDS slice (beyond: factored in the workspace)
     int lds_per_wave;           // doubles
+    int lds_blocks;             // offset (doubles) in the wavefront's LDS slice of the LDS-resident dynamics blocks, operands of the sweeps:
+                                // jeq [ph nx (2nx+nu)] | einv [ph nx nx] | c [ph nx] | lamw [ph nx] | p [nr]; -1: they live in the workspace
     int continuous;             // hook models: 1 = the state function is dx/dt (setDiscretizationSamplingTime was called)
     int has_output;             // hook models: 1 = an output function was set (otherwise Y reads as zeros, Model.hpp:72-96)
     int vector_hooks;           // 1 = user hooks with the reference's whole-vector signatures (sizes the hook workspace)

@@ -45,6 +45,21 @@ namespace engine {
 using namespace models;
 
 typedef double __attribute__((address_space(1))) *gwp;      // a pointer known to point into HBM
+// The defects and the dynamics blocks: in HBM, or (BLK: small systems, nlmpc_plan) in the wavefront's LDS slice.  Either way the
+// pointer is re-derived so that the compiler knows the address space: flat accesses wait on both memory counters, i.e. for every
+// outstanding global load and store as well (measured: the LDS-resident blocks behind generic pointers bought nothing).
+template <bool BLK> struct BlockPtr {
+    typedef gwp type;
+    static __device__ __forceinline__ type make(double *p) { return (gwp)p; }
+};
+template <> struct BlockPtr<true> {
+    typedef double *type;
+    static __device__ __forceinline__ type make(double *p)
+    {
+        extern __shared__ __attribute__((aligned(16))) double lds_base[];
+        return lds_base + (p - lds_base);
+    }
+};
 
 __device__ __forceinline__ void nl_wave_sync()
 {
@@ -402,7 +417,7 @@ __device__ __forceinline__ void hook_constraints(const NlmpcDev &M, const double
 }
 
 // the transcription of one instance; any output may be null.  Xs/Us/Jm/Ys: this wave's LDS; hk: hook scratch (HBM).
-template <class Mdl>
+template <class Mdl, bool BLK = false>
 __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *x0, double *Xs, double *Us, double *Jm, double *Ys,
                               double *hk, int lane, double *cost, double *grad, double *ceq, double *jeq, double *cineq,
                               double *jineq, bool jin_fill = true, const double *prm_instance = nullptr)
@@ -480,7 +495,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
             for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
             if (c == 0) {
                 if (!ceq) continue;
-                gwp cv = (gwp)ceq + i * NX;
+                typename BlockPtr<BLK>::type cv = BlockPtr<BLK>::make(ceq) + i * NX;
                 call_f<Mdl>(fa, xk, uk, prm, i);
                 if (CT) {
                     call_f<Mdl>(fb, xk1, uk, prm, i);
@@ -491,7 +506,7 @@ __device__ void eval_instance(const NlmpcDev &M, const double *z, const double *
                 continue;
             }
             if (!jeq) continue;
-            gwp J = (gwp)jeq + (size_t)i * NX * W;          // [NX x W] row-major block of step i
+            typename BlockPtr<BLK>::type J = BlockPtr<BLK>::make(jeq) + (size_t)i * NX * W;          // [NX x W] row-major block of step i
             const int col = c - 1;
             auto cdiff = [&](const double *xx, const double *uu, int v, bool isu, double *out) {
                 double xp[NX], up[NU], f1[NX], f2[NX];
@@ -844,7 +859,7 @@ __device__ __attribute__((noinline)) bool chol_factor(int lp_off, int invd_off, 
 }
 
 // TWO: working sets may outgrow the LDS factor (M.kw > M.nl); otherwise that code is left out
-template <class Mdl, bool TWO = true>
+template <class Mdl, bool TWO = true, bool BLK = false>
 __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev &S)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = 2 * NX + NU;
@@ -891,6 +906,10 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
                *sv = w + M.ws.s, *p = w + M.ws.p, *qn = w + M.ws.qn, *qv = w + M.ws.qv, *Ssm = w + M.ws.qs, *Sbig = w + M.ws.qs2, *scal = w + M.ws.scal,
                *lamw = w + M.ws.lamw, *hk = w + M.ws.hook, *spv = w + M.ws.sp;
         int *spi = reinterpret_cast<int *>(spv + (size_t)mt * kNlSparse);   // entries 1.. of the sub-problem's sparse rows (entry 0: LDS)
+        if constexpr (BLK) {
+            // the dynamics blocks and the sweeps' right-hand sides live in the LDS slice (nlmpc_plan)
+            jeq = Xs + M.lds_blocks; einv = jeq + ph * NX * W; c = einv + ph * NX * NX; lamw = c + nxs; p = lamw + nxs;
+        }
         const double *x0 = S.x0 + (size_t)b * NX, *u0 = S.u0 + (size_t)b * NU;
         const double *prm = S.params_b ? S.params_b + (size_t)b * S.nparams : M.params;     // per-instance model parameters (built-in systems)
 
@@ -979,7 +998,7 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
         bool first_eval = true, final_eval = false;
         for (;;) {
             if (!first_eval) lap(4);
-            eval_instance<Mdl>(M, z, x0, Xs, Us, Jm, Ys, hk, lane, scal, final_eval ? nullptr : g, c, final_eval ? nullptr : jeq, gin,
+            eval_instance<Mdl, BLK>(M, z, x0, Xs, Us, Jm, Ys, hk, lane, scal, final_eval ? nullptr : g, c, final_eval ? nullptr : jeq, gin,
                                final_eval ? nullptr : jin, first_eval, prm);     // structural zeros are written once
             if (!first_eval) lap(5); else { MPCX_STAT(tstamp = __builtin_readcyclecounter();) }
             first_eval = false;
@@ -2076,8 +2095,9 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
 // sweeps and the finite differences), while the LDS slice of such a system already limits a CU to 3-6 wavefronts.  Large
 // systems therefore get the whole register file of a SIMD (512 VGPRs, one wavefront per SIMD) instead of spilling.
 template <class Mdl> constexpr int kSqpWavesPerSimd = Mdl::NX >= 12 ? 1 : 2;
-template <class Mdl, bool TWO>
-__global__ __launch_bounds__(256, kSqpWavesPerSimd<Mdl>) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl, TWO>(M, S); }
+template <class Mdl> constexpr bool kSqpLdsBlocks = Mdl::NX < 8 && !Mdl::VECTOR_HOOKS;     // instantiated with LDS-resident dynamics blocks as well
+template <class Mdl, bool TWO, bool BLK = false>
+__global__ __launch_bounds__(256, kSqpWavesPerSimd<Mdl>) void nlmpc_sqp(const NlmpcDev M, const NlmpcSolveDev S) { sqp_body<Mdl, TWO, BLK>(M, S); }
 
 // ---- host side: workspace plan and launchers -----------------------------------------------------------------------
 #if !defined(__HIPCC_RTC__)
@@ -2101,11 +2121,20 @@ inline void nlmpc_plan(NlmpcDev &m)
     const int tail_min = imax(imax((ph + 1) * (nx + nu) + ph * nu + 2 * nx * nx, kNlLdsWorking * (kNlLdsWorking + 1) / 2),
                               (m.nineq + m.nue) * ((ph * nx + 63) / 64));           // (the structure words of the reduction live there too)
     int cap = nx >= 12 ? 4992 : 2048;
+    // Small built-in systems whose whole slice still fits 2048 doubles (workgroups of four wavefronts, eight per CU, as before): the
+    // dynamics blocks and the sweeps' right-hand sides live in LDS for the whole solve -- the sweeps are chains of ph dependent steps run
+    // by a few lanes, and a dependent load from L2 costs ~2.7k cycles on the loaded chip.  (A larger budget costs occupancy: config 3 at
+    // six wavefronts per CU instead of eight lost more than it gained)
+    int jl = (nx < 8 && !m.vector_hooks) ? ((ph * nx * (2 * nx + nu) + ph * nx * nx + 2 * ph * nx + m.nr + 1) & ~1) : 0;
+    if (const char *e = getenv("MPCX_DEBUG_LDS_BLOCKS")) { if (atoi(e) == 0) jl = 0; }      // testing aid: A/B against the workspace form
+    if (jl > 0 && fixed + imax(tail_min, KW * (KW + 1) / 2) + jl <= 2048) cap = 2048 - jl; else jl = 0;
     if (const char *e = getenv("MPCX_DEBUG_LDS_CAP")) cap = atoi(e);          // testing aid
     const int tail = imax(tail_min, imin(KW * (KW + 1) / 2, cap - fixed));
     m.nl = 0;
     while (m.nl < KW && (m.nl + 1) * (m.nl + 2) / 2 <= tail) ++m.nl;
     m.lds_per_wave = (fixed + tail + 1) & ~1;
+    m.lds_blocks = -1;
+    if (jl > 0 && m.nl == KW) { m.lds_blocks = m.lds_per_wave; m.lds_per_wave += jl; }    // (a debug cap may have cut the factor: then not)
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     NlmpcWsLayout &w = m.ws;
@@ -2145,15 +2174,24 @@ int launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream
     const int blocks = (b->batch + wpb - 1) / wpb;
     const size_t lds = (size_t)wpb * m->lds_per_wave * sizeof(double);
     const bool two = m->kw > m->nl;                           // the working set can outgrow the LDS factor
-    if (getenv("MPCX_DEBUG_OCCUPANCY")) {                     // testing aid: resident blocks per CU as the runtime sees them
-        int nb = -1;
-        if (two) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl, true>, wpb * 64, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nlmpc_sqp<Mdl, false>, wpb * 64, lds);
-        fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; factor rows in LDS %d of %d\n",
-                blocks, wpb, lds, nb, m->nl, m->kw);
+    const bool blk = m->lds_blocks >= 0;                      // the dynamics blocks live in the LDS slice (nlmpc_plan; small built-in systems)
+    if (blk && !kSqpLdsBlocks<Mdl>) return -2;
+    auto go = [&](auto kern) {
+        if (getenv("MPCX_DEBUG_OCCUPANCY")) {                 // testing aid: resident blocks per CU as the runtime sees them
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, wpb * 64, lds);
+            fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; factor rows in LDS %d of %d; blocks in LDS %d\n",
+                    blocks, wpb, lds, nb, m->nl, m->kw, (int)blk);
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
+    };
+    if constexpr (kSqpLdsBlocks<Mdl>) {
+        // (the plan puts the blocks in LDS only where the whole factor fits too: no two-level instantiation of that form)
+        if (blk) { if (two) return -2; go(nlmpc_sqp<Mdl, false, true>); }
+        else { if (two) go(nlmpc_sqp<Mdl, true, false>); else go(nlmpc_sqp<Mdl, false, false>); }
+    } else {
+        if (two) go(nlmpc_sqp<Mdl, true, false>); else go(nlmpc_sqp<Mdl, false, false>);
     }
-    if (two) hipLaunchKernelGGL((nlmpc_sqp<Mdl, true>), dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
-    else hipLaunchKernelGGL((nlmpc_sqp<Mdl, false>), dim3(blocks), dim3(wpb * 64), lds, s, *m, *b);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 #endif   // !__HIPCC_RTC__
