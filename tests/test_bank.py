@@ -47,3 +47,18 @@ def test_bank_results_are_those_of_each_instance_s_own_controller():
         assert torch.equal(r.seq_state[sel], rk.seq_state)
     assert not torch.equal(r.cmd[torch.from_numpy(np.nonzero(model == 0)[0][:8]).cuda()],
                            r.cmd[torch.from_numpy(np.nonzero(model == 1)[0][:8]).cuda()])
+
+
+def test_hetero_bank_refuses_to_exist_without_a_device():
+    """mpcx_lmpc_hetero_create: the bank lives in HBM; host-only controllers configure it, nothing solves on the CPU"""
+    import pytest
+    import torch
+    from libmpc_amd import LMPCHetero, MpcxError
+    from libmpc_amd.workloads import quadrotor_lmpc
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: covered by tests/test_lmpc_hetero.py")
+    a = quadrotor_lmpc(10, device=-1)
+    with pytest.raises(MpcxError, match="no CPU fallback"):
+        LMPCHetero([a, a], device=0)
+    with pytest.raises(ValueError):
+        LMPCHetero([], device=0)
