@@ -681,3 +681,30 @@ def test_shards_equal_rows_of_the_unsharded_solve(name, kw, hard, iters):
         part = m.optimizeBatch(torch.from_numpy(X0[sl]), torch.from_numpy(U0[sl])); torch.cuda.synchronize()
         for key in ("cmd", "cost", "status", "z"):
             assert torch.equal(part[key], whole[key][sl]), (rk, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,hard,iters", [("vanderpol", dict(ph=10, ch=5, Ts=0.1), True, 200), ("ugv", dict(ph=12, ch=4), False, 150)])
+def test_lds_resident_blocks_agree_with_the_workspace_form(name, kw, hard, iters, monkeypatch):
+    """Small built-in systems keep the dynamics blocks and the sweeps' operands in the wavefront's LDS slice (nlmpc_plan,
+    NlmpcDev::lds_blocks); MPCX_DEBUG_LDS_BLOCKS=0 at set-up keeps them in the workspace as the larger systems do.  Same arithmetic, another
+    place: the two forms agree bit for bit."""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV
+    rng = np.random.default_rng(5)
+    B = 96
+    nx = 4 if name == "ugv" else 2
+    X0 = np.zeros((B, nx)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    U0 = np.zeros((B, 2 if name == "ugv" else 1))
+    out = []
+    for blocks in ("1", "0"):
+        monkeypatch.setenv("MPCX_DEBUG_LDS_BLOCKS", blocks)
+        c = NLMPC(dict(vanderpol=VANDERPOL, ugv=UGV)[name], kw["ph"], kw["ch"], kw.get("Ts", 0.1))
+        c.setOptimizerParameters(NLParameters(maximum_iteration=iters, hard_constraints=int(hard)))
+        r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0))
+        torch.cuda.synchronize()
+        out.append({k: r[k].cpu().numpy() for k in ("cmd", "cost", "status", "iterations", "z")})
+    a, b = out
+    assert (a["status"] == 0).all()
+    assert np.array_equal(a["iterations"], b["iterations"]) and np.array_equal(a["status"], b["status"])
+    assert np.array_equal(a["cmd"], b["cmd"]) and np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["z"], b["z"])
