@@ -437,10 +437,12 @@ int mpcx_lmpc_hetero_time_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batc
  * Not part of the reference-facing surface, but part of the exported ABI: bench.py's roofline block, tools/ and tests/ call
  * them, so they are declared (and kept) here.  "debug" in a name = may change between versions.                        */
 /* mean time (ms) of [0] the assemble kernel, [1] the solve kernel, [2] the ADMM fallback kernel of one batch, each timed alone
- * with HIP events on `stream` over `repeats` launches (one-kernel forms: [0] = 0, [1] = the whole step's kernel)          */
+ * with HIP events on `stream` over `repeats` launches (one-kernel forms: [0] = 0, [1] = the whole step's kernel; controllers whose
+ * cost comes from its definition -- "flags"[0] below -- : [1] = lmpc_solve + lmpc_cost_mfma, launched back to back)                */
 int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream, int repeats, float *ms3);
 /* condensed arrays of the host set-up by name ("H", "Kinv", "Gr", "Gc", "Y", "lw", "uw", "rho_b", "lg0", "ug0", "rho_g", "dims",
- * "dims_maps", "MA0", "MA1", "g_refrow", "g_step", "g_kind", "g_comp"); out = NULL returns the length                       */
+ * "dims_maps", "MA0", "MA1", "g_refrow", "g_step", "g_kind", "g_comp", "flags" = [cost from its definition, one-workgroup form
+ * available, fused mat-vec form available]); out = NULL returns the length                                                      */
 int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap);
 /* how many full set-ups (condensing + device rebuild) and how many reference-only refreshes have run on this handle */
 int mpcx_lmpc_debug_setup_counts(mpcx_lmpc_t h, int *full, int *refs);
