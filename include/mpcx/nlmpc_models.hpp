@@ -65,8 +65,11 @@ struct NoUserEq {
     __host__ __device__ static int neq_user(int) { return 0; }
     template <class XA, class UA>
     __device__ static double eq(int, const XA &, const UA &, int, const double *) { return 0.0; }
-    __device__ static bool eq_reads_x(int, int) { return true; }       // dense unless the model says otherwise
+    __host__ __device__ static bool eq_reads_x(int, int) { return true; }       // dense unless the model says otherwise
+    __host__ __device__ static bool eq_reads_u(int, int) { return true; }
     static constexpr bool INEQ_U_ROWS_DISJOINT = false;                 // true: ineq_rows_of_u(i) and ineq_rows_of_u(i') share no row for i != i'
+    static constexpr bool XFREE_ROWS_SPARSE = false;                    // true: a user row that reads no state has at most kNlSparse non-zero entries in the
+                                                                        // move-blocked inputs (+ slack); the workgroup form then keeps it as an (index, value) list
 };
 
 // ---- model zoo ----------------------------------------------------------------------------------
@@ -97,10 +100,11 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
     // structure of the inequality Jacobian: which rows of X / U constraint k reads (anything else differentiates to an exact 0)
     static constexpr bool INEQ_USES_SLACK = false;
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
-    __device__ static bool ineq_reads_x(int, int) { return false; }
-    __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
-    __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
-    __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i; count = 1; }
+    static constexpr bool XFREE_ROWS_SPARSE = true;
+    __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
+    __host__ __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
+    __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
+    __host__ __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i; count = 1; }
 };
 
 // The same system with the terminal equality x(ph) = 0: the textbook use of NLMPC::setEqConFunction (NLMPC.hpp:246-262).
@@ -148,10 +152,10 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
     }
     static constexpr bool INEQ_USES_SLACK = false;
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
-    __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
-    __device__ static bool ineq_reads_u(int, int) { return false; }
-    __device__ static void ineq_rows_of_x(int i, int &first, int &count) { first = 2 * i; count = 2; }
-    __device__ static void ineq_rows_of_u(int, int &first, int &count) { first = 0; count = 0; }
+    __host__ __device__ static bool ineq_reads_x(int k, int i) { return (k >> 1) == i; }
+    __host__ __device__ static bool ineq_reads_u(int, int) { return false; }
+    __host__ __device__ static void ineq_rows_of_x(int i, int &first, int &count) { first = 2 * i; count = 2; }
+    __host__ __device__ static void ineq_rows_of_u(int, int &first, int &count) { first = 0; count = 0; }
 };
 
 template <int N>
@@ -186,10 +190,11 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k / N, k % N) - 0.5; }
     static constexpr bool INEQ_USES_SLACK = false;
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
-    __device__ static bool ineq_reads_x(int, int) { return false; }
-    __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
-    __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
-    __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i * N; count = N; }
+    static constexpr bool XFREE_ROWS_SPARSE = true;
+    __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
+    __host__ __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
+    __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
+    __host__ __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = i * N; count = N; }
 };
 
 }  // namespace models

@@ -1,0 +1,1567 @@
+// nlmpc_sqp_wg: the SQP of nlmpc_engine.hpp as ONE WORKGROUP PER INSTANCE with the reduced problem resident in LDS.
+//
+// Replaces, like nlmpc_sqp, NLOptimizer::run (reference include/mpc/NLMPC/NLOptimizer.hpp:412-638) with its four NLopt callbacks
+// (:760-997 -> Objective.hpp:91-265, Constraints.hpp:211-316, 490-905, Mapping.hpp:174-211) for the built-in systems of
+// mpcx/nlmpc_models.hpp (component-wise functors with declared structure).  Same algorithm -- condensing of the dynamics equalities,
+// damped inverse BFGS, Goldfarb-Idnani dual active set in range-space form, l1 merit line search -- organised for the CU instead of for
+// one wavefront:
+//
+//   * 1, 2 or 4 wavefronts work on one instance (WAVES; the launcher picks by problem size), every loop is spread over all their lanes;
+//   * everything an iteration reads more than once lives in the workgroup's LDS for the whole solve: the iterate, the inverse BFGS matrix
+//     (symmetric, packed), the reduced constraint rows, the working set's Cholesky factor, the sparse rows' first entries, the small
+//     vectors; the folded dynamics blocks too where they fit (otherwise they stream through the workspace, written and read in
+//     whole coalesced blocks, one step ahead of the chain that consumes them).  The dense user Jacobian, the sensitivities Phi, B^-1 N'
+//     and the Schur complement of nlmpc_sqp's workspace do not exist any more:
+//       - the user Jacobian is kept as its declared non-zero blocks (one NX-vector per (row, state row it reads) pair);
+//       - Phi is never stored: the forward sweep that would form it (one column per lane, in registers) delivers the reduced gradient,
+//         the reduced constraint rows and their offsets as it goes; the state step is one more sweep with the input step applied;
+//       - the dynamics blocks are folded at evaluation time, [A_i | B_i | c_i] <- -E_i^-1 [A_i | B_i | c_i] (one Gauss-Jordan per step on
+//         [E | A B c | I], a column per lane), so that every sweep step is one matrix-vector product;
+//       - a row leaves the working set by a Givens down-date of the factor, so the Schur complement itself is not kept;
+//   * the phases (evaluate / condense / BFGS / sub-problem / step / merit / line search / update) are separate non-inlined functions
+//     whose only shared state is the LDS block: each gets its own register allocation and the loop around them carries a dozen scalars.
+//
+// Vector-valued user hooks (mpcx/nlmpc_hooks.hpp) keep going through nlmpc_sqp.
+#pragma once
+
+#include "nlmpc_engine.hpp"
+
+namespace mpcx {
+namespace engine {
+
+// ---- the plan: LDS and workspace layout of one instance (host-computed, a kernel argument) ------------------------------------------
+struct WgPlan {
+    int waves;                  // wavefronts per instance: 1, 2 or 4
+    int hard, nq;               // sub-problem variables: ch nu (+ slack when soft)
+    int kw;                     // working-set capacity
+    int nd, ndld, nd_user, nsb; // dense sub-problem rows (columns of art): user rows that read a state (or promise no sparsity), then bounds on states
+    int nsx;                    // (user row, state row) pairs with a non-zero Jacobian block
+    int needs_phi;              // some sub-problem row reads a state
+    int f_lds;                  // the folded dynamics blocks live in LDS
+    int lds_total;              // doubles
+    // LDS offsets (doubles)
+    int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
+        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_xq, o_np, o_vv, o_zd, o_wv, o_F;
+    int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
+    int o_L;                                              // overlay, inside the sub-problem: the packed factor
+    // workspace offsets (doubles) of one instance
+    int w_scal, w_F, w_einv, w_gx, w_hinv, w_sp;
+    int ws_total;
+};
+
+// The context block at the start of the workgroup's LDS: the three kernel arguments and this instance's pointers.  The phases read
+// what they need from here (uniform LDS reads) instead of carrying it through their calls.
+struct WgCtx {
+    NlmpcDev M;
+    NlmpcSolveDev S;
+    WgPlan P;
+    double *w;
+    const double *x0, *u0, *prm;
+    int b, pad;
+};
+constexpr int kWgCtxDoubles = (int)((sizeof(WgCtx) + 15) / 16) * 2;
+
+// slots of the scalar block st[] through which the phases hand results to the loop
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_ACC = 16, ST_TOTAL = 32 };
+
+#define MPCX_WG_PHASE __device__ __attribute__((noinline))
+
+__device__ __forceinline__ double *wg_lds()
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    return smem;
+}
+__device__ __forceinline__ const WgCtx &wg_ctx() { return *reinterpret_cast<const WgCtx *>(wg_lds()); }
+
+template <int P> __device__ __forceinline__ double group_sum(double v)      // over P adjacent lanes (P = 1, 2, 4, 8, 16), every lane gets the sum
+{
+    if constexpr (P >= 2) v += dpp_d<0xB1>(v);
+    if constexpr (P >= 4) v += dpp_d<0x4E>(v);
+    if constexpr (P >= 8) v += dpp_d<0x141>(v);
+    if constexpr (P >= 16) v += dpp_d<0x140>(v);
+    return v;
+}
+
+template <int WAVES> struct Team {
+    static constexpr int NT = 64 * WAVES;
+    static __device__ __forceinline__ void sync()
+    {
+        if constexpr (WAVES == 1) nl_wave_sync(); else __syncthreads();
+    }
+};
+
+// Reductions over the workgroup: a wave-level reduction, one LDS slot per wavefront, one barrier; the result is the same bits in every
+// thread (fixed order).  Two sets of slots alternate, so that consecutive reductions need no second barrier; a phase ends with a barrier.
+template <int WAVES> struct Red {
+    double *buf;
+    int par;
+    __device__ __forceinline__ explicit Red(double *b) : buf(b), par(0) {}
+    __device__ __forceinline__ double *slots() { double *s = buf + par * 8; par ^= 1; return s; }
+    __device__ __forceinline__ double sum(double v)
+    {
+        v = wave_sum(v);
+        if constexpr (WAVES == 1) return v;
+        else {
+            double *s = slots();
+            if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+            __syncthreads();
+            double r = s[0];
+#pragma unroll
+            for (int i = 1; i < WAVES; ++i) r += s[i];
+            return r;
+        }
+    }
+    __device__ __forceinline__ double max(double v)
+    {
+        v = wave_max(v);
+        if constexpr (WAVES == 1) return v;
+        else {
+            double *s = slots();
+            if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+            __syncthreads();
+            double r = s[0];
+#pragma unroll
+            for (int i = 1; i < WAVES; ++i) r = fmax(r, s[i]);
+            return r;
+        }
+    }
+    // largest value and the lowest index holding it
+    __device__ __forceinline__ void argmax(double &v, int &idx)
+    {
+        wave_argmax(v, idx);
+        if constexpr (WAVES > 1) {
+            double *s = slots();
+            if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s[4 + (threadIdx.x >> 6)] = (double)idx; }
+            __syncthreads();
+            v = s[0]; idx = (int)s[4];
+#pragma unroll
+            for (int i = 1; i < WAVES; ++i) {
+                const double ov = s[i]; const int oi = (int)s[4 + i];
+                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+            }
+        }
+    }
+};
+
+// dst = scale * H src for the symmetric matrix H packed by rows of its lower triangle (row r at r (r + 1) / 2), all in LDS;
+// P lanes share a row.  Every thread of the workgroup calls it; the caller synchronises.
+template <int P, int NT>
+__device__ __forceinline__ void hmul_rows(const double *hp, const double *src, double *dst, int n, double scale, int tid)
+{
+    const int part = tid & (P - 1);
+    for (int r0 = 0; r0 < n; r0 += NT / P) {
+        const int r = r0 + tid / P;
+        const bool live = r < n;
+        const int rr = live ? r : 0, ro = rr * (rr + 1) / 2;
+        double acc = 0.0;
+        for (int c = part; c < n; c += P) {
+            const double h = c <= rr ? hp[ro + c] : hp[c * (c + 1) / 2 + rr];
+            acc = fma(h, src[c], acc);
+        }
+        acc = group_sum<P>(acc);
+        if (live && part == 0) dst[r] = scale * acc;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void hmul(const double *hp, const double *src, double *dst, int n, double scale, int tid)
+{
+    if (4 * n <= NT) hmul_rows<4, NT>(hp, src, dst, n, scale, tid);
+    else if (2 * n <= NT) hmul_rows<2, NT>(hp, src, dst, n, scale, tid);
+    else hmul_rows<1, NT>(hp, src, dst, n, scale, tid);
+}
+__device__ __forceinline__ double hsym(const double *hp, int r, int c) { return r >= c ? hp[r * (r + 1) / 2 + c] : hp[c * (c + 1) / 2 + r]; }
+
+// (row, column) of element e of a packed lower triangle
+__device__ __forceinline__ void tri_index(int e, int &r, int &c)
+{
+    r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > e) --r;
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    c = e - r * (r + 1) / 2;
+}
+
+// ---- the working set's factor, one wavefront (rows lane and lane + 64) ------------------------------------------------------------------
+// S = L L' in place: Lp holds the lower triangle of S, packed by rows; right-looking, as chol_factor's LDS part
+__device__ __forceinline__ bool chol_inplace(double *Lp, double *invd, int n, int lane)
+{
+    double dmax = 0.0;
+    for (int r = lane; r < n; r += 64) dmax = fmax(dmax, Lp[r * (r + 1) / 2 + r]);
+    dmax = wave_max(dmax);
+    bool ok = true;
+    const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
+    for (int k = 0; k < n; ++k) {
+        const double dkk = Lp[k * (k + 1) / 2 + k];
+        ok &= dkk > 1e-13 * dmax;
+        const double dd = sqrt(dkk > 1e-13 * dmax ? dkk : 1e-13 * dmax + 1e-300), id = 1.0 / dd;
+        double l0 = 0.0, l1 = 0.0;
+        if (lane > k && lane < n) { l0 = Lp[o0 + k] * id; }
+        if (lane + 64 > k && lane + 64 < n) { l1 = Lp[o1 + k] * id; }
+        nl_wave_sync();                                           // everybody has read the pivot before it is overwritten
+        if (lane > k && lane < n) Lp[o0 + k] = l0;
+        if (lane + 64 > k && lane + 64 < n) Lp[o1 + k] = l1;
+        if (lane == 0) { Lp[k * (k + 1) / 2 + k] = dd; invd[k] = id; }
+        nl_wave_sync();
+        for (int j = k + 1; j < n; ++j) {
+            const double ljk = Lp[j * (j + 1) / 2 + k];
+            if (lane >= j && lane < n) Lp[o0 + j] = fma(-l0, ljk, Lp[o0 + j]);
+            if (lane + 64 >= j && lane + 64 < n) Lp[o1 + j] = fma(-l1, ljk, Lp[o1 + j]);
+        }
+        nl_wave_sync();
+    }
+    return ok;
+}
+// Row and column j leave S: row j of L is deleted, the rows below move up, and Givens rotations on the column pairs (r, r + 1),
+// r = j .. n - 2, restore the triangle.  Every lane streams along its own rows: it carries the rotated entry of column r + 1 into the
+// next rotation; the rotation itself comes from the row whose diagonal it creates.
+__device__ __forceinline__ void chol_delete(double *Lp, double *invd, int n, int j, int lane)
+{
+    const int r0 = lane, r1 = lane + 64;
+    const bool m0 = r0 > j && r0 < n, m1 = r1 > j && r1 < n;
+    const int s0 = r0 * (r0 + 1) / 2, s1 = r1 * (r1 + 1) / 2;                  // where the rows are
+    const int d0 = m0 ? (r0 - 1) * r0 / 2 : 0, d1 = m1 ? (r1 - 1) * r1 / 2 : 0; // where they go
+    double carry0 = m0 ? Lp[s0 + j] : 0.0, carry1 = m1 ? Lp[s1 + j] : 0.0;
+    // columns 0 .. j-1 move up unchanged, eight at a time: everybody reads before anybody writes
+    for (int c0 = 0; c0 < j; c0 += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = min(c0 + u, j - 1);
+            a[u] = m0 ? Lp[s0 + c] : 0.0; b[u] = m1 ? Lp[s1 + c] : 0.0;
+        }
+        nl_wave_sync();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u < j) { if (m0) Lp[d0 + c0 + u] = a[u]; if (m1) Lp[d1 + c0 + u] = b[u]; }
+        }
+        nl_wave_sync();
+    }
+    for (int r = j; r <= n - 2; ++r) {
+        const bool u0 = r0 >= r + 1 && r0 < n, u1 = r1 >= r + 1 && r1 < n;
+        const double y0 = u0 ? Lp[s0 + r + 1] : 0.0, y1 = u1 ? Lp[s1 + r + 1] : 0.0;
+        const int pl = (r + 1) & 63;
+        const double a = (r + 1) < 64 ? read_lane(carry0, pl) : read_lane(carry1, pl);
+        const double b = (r + 1) < 64 ? read_lane(y0, pl) : read_lane(y1, pl);
+        const double rho = sqrt(a * a + b * b), ir = 1.0 / rho, c = a * ir, s = b * ir;
+        const double n0 = c * carry0 + s * y0, n1 = c * carry1 + s * y1;
+        carry0 = c * y0 - s * carry0; carry1 = c * y1 - s * carry1;
+        if (u0) Lp[d0 + r] = n0;
+        if (u1) Lp[d1 + r] = n1;
+        if (lane == 0) invd[r] = ir;
+    }
+    nl_wave_sync();
+}
+
+// ---- the kernel's phases ----------------------------------------------------------------------------------------------------------------
+template <class Mdl, int WAVES>
+struct WgSqp {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1, NT = 64 * WAVES;
+    static constexpr bool CT = Mdl::CONTINUOUS;
+    static constexpr int GW = 3 * NX + NU + 1;                 // columns of the Gauss-Jordan tableau [E | A B c | I] of one step
+    using T = Team<WAVES>;
+
+    struct V {                                                 // the views of the LDS block a phase needs, re-derived from the context
+        const WgCtx &C;
+        double *sm;
+        __device__ __forceinline__ V() : C(wg_ctx()), sm(wg_lds()) {}
+        __device__ __forceinline__ double *at(int off) const { return sm + off; }
+        __device__ __forceinline__ int *iat(int off) const { return reinterpret_cast<int *>(sm + off); }
+    };
+    // the folded blocks: LDS or workspace, the pointer typed accordingly
+    template <bool FL> struct FP {
+        typedef typename BlockPtr<FL>::type type;
+        static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + v.C.P.o_F : v.C.w + v.C.P.w_F); }
+    };
+
+    // the sparse form of sub-problem row k (as in nlmpc_sqp): first entry and count in LDS, entries 1 .. 3 in the workspace
+    struct Sp {
+        const double *s1v; const int *s1m; const double *spv; const int *spi;
+        __device__ __forceinline__ explicit Sp(const V &v)
+            : s1v(v.at(v.C.P.o_s1v)), s1m(v.iat(v.C.P.o_s1m)), spv(v.C.w + v.C.P.w_sp),
+              spi(reinterpret_cast<const int *>(v.C.w + v.C.P.w_sp + (size_t)(v.C.M.nineq + v.C.M.nue + v.C.M.nbnd) * kNlSparse)) {}
+        __device__ __forceinline__ int count(int k) const { return s1m[k] >> 16; }
+        __device__ __forceinline__ int index(int k, int j) const { return j == 0 ? (s1m[k] & 0xffff) : spi[k * kNlSparse + j]; }
+        __device__ __forceinline__ double value(int k, int j) const { return j == 0 ? s1v[k] : spv[k * kNlSparse + j]; }
+        __device__ __forceinline__ double dot(int k, const double *x) const
+        {
+            const int mw = s1m[k];
+            if ((mw >> 16) == 0) return 0.0;
+            double acc = s1v[k] * x[mw & 0xffff];
+            for (int j = 1; j < (mw >> 16); ++j) acc = fma(spv[k * kNlSparse + j], x[spi[k * kNlSparse + j]], acc);
+            return acc;
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // start: initial guess (NLOptimizer.hpp:431-510), inverse Hessian estimate, structure tables
+    static MPCX_WG_PHASE void start()
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nzu = M.nzu, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd;
+        double *z = v.at(P.o_z), *hinv = v.at(P.o_hinv), *mu = v.at(P.o_mu), *st = v.at(P.o_st);
+        int *flag = v.iat(P.o_flag), *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *slot = v.iat(P.o_slot), *sbf = v.iat(P.o_sbf);
+        unsigned long long *xmask = reinterpret_cast<unsigned long long *>(v.at(P.o_xmask));
+        if (S.z_warm) {
+            const double *zw = S.z_warm + (size_t)C.b * nz;
+            for (int k = tid; k < nxs; k += NT) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
+            for (int k = tid; k < nzu; k += NT) {
+                const int bl = k / NU, j = k - bl * NU;
+                const int step = min(bl + 1, ph - 1);
+                z[nxs + k] = zw[nxs + min(step, ch - 1) * NU + j];
+            }
+            if (tid == 0) z[nz - 1] = zw[nz - 1];
+        } else {
+            for (int k = tid; k < nxs; k += NT) z[k] = C.x0[k % NX];
+            for (int k = tid; k < nzu; k += NT) z[nxs + k] = C.u0[k % NU];
+            if (tid == 0) z[nz - 1] = 0.0;
+        }
+        const int nh = nr * (nr + 1) / 2;
+        if (S.keep_curvature) {                               // the estimate the previous tick's solve left in the workspace
+            const double *hs = C.w + P.w_hinv;
+            for (int e = tid; e < nh; e += NT) hinv[e] = hs[e];
+        } else {
+            for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
+        }
+        for (int k = tid; k < mt; k += NT) { mu[k] = 0.0; flag[k] = 0; }
+        for (int k = tid; k < ST_TOTAL; k += NT) st[k] = 0.0;
+        T::sync();
+        // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
+        for (int k = tid; k < nz; k += NT) {
+            const double lo = M.zlb[k], hi = M.zub[k];
+            if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
+        }
+        // which state rows a user row reads (bit i-1: X row i, i = 1 .. ph; row 0 is x0, not a variable)
+        for (int k = tid; k < m; k += NT) {
+            unsigned long long mk = 0;
+            for (int i = 1; i <= ph; ++i)
+                if (k < mi ? Mdl::ineq_reads_x(k, i) : Mdl::eq_reads_x(k - mi, i)) mk |= 1ull << (i - 1);
+            xmask[k] = mk;
+        }
+        T::sync();
+        if (tid == 0) {                                       // prefix counts: Jacobian block slots and dense columns
+            int ns = 0, ndc = 0;
+            for (int k = 0; k < m; ++k) {
+                jxoff[k] = ns;
+                unsigned long long mk = xmask[k];
+                const bool dense = mk != 0ull || !Mdl::XFREE_ROWS_SPARSE;
+                dcol[k] = dense ? ndc++ : -1;
+                while (mk) { const int i = (int)__builtin_ctzll(mk) + 1; mk &= mk - 1; slot[ns++] = (k << 8) | i; }
+            }
+            jxoff[m] = ns;
+        }
+        // bounds: those on states come first in the table (ascending index) and are dense rows after the user's
+        for (int kb = tid; kb < M.nbnd; kb += NT) dcol[m + kb] = M.bnd_idx[kb] < nxs ? P.nd_user + kb : -1;
+        for (int i = tid; i <= ph; i += NT) {                 // first state bound of state row i + 1 (z entries i NX ..)
+            int f = 0;
+            while (f < P.nsb && M.bnd_idx[f] < i * NX) ++f;
+            sbf[i] = f;
+        }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // evaluate at z: cost (+ forward-difference gradient), dynamics defects (+ folded blocks), user constraints (+ Jacobian blocks,
+    // the sub-problem's rows as far as they do not depend on the sweep).  values_only: the last evaluation of a solve.
+    template <bool FL>
+    static MPCX_WG_PHASE void eval(int values_only)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nzu = M.nzu, mi = M.nineq, m = mi + M.nue;
+        const int nq = P.nq, ndld = P.ndld;
+        const double dv = kDv;
+        const double *prm = C.prm;
+        const Scale sc(M);
+        double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *Jm = v.at(P.o_Jm), *lam = v.at(P.o_lam), *st = v.at(P.o_st),
+               *gu = v.at(P.o_gu), *c = v.at(P.o_c), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br),
+               *s1v = v.at(P.o_s1v);
+        int *s1m = v.iat(P.o_s1m);
+        const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
+        const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
+        gwp gxg = (gwp)(C.w + P.w_gx);
+        // Mapping::unwrapVector
+        for (int k = tid; k < (ph + 1) * NX; k += NT) {
+            const int i = k / NX, j = k - i * NX;
+            Xs[k] = sc.over_ss(i == 0 ? C.x0[j] : z[(i - 1) * NX + j], j);
+        }
+        for (int k = tid; k < (ph + 1) * NU; k += NT) {
+            const int i = k / NU, j = k - i * NU;
+            Us[k] = sc.by_su(z[nxs + min(min(i, ph - 1), ch - 1) * NU + j], j);
+        }
+        T::sync();
+        const double e = z[nz - 1];
+        auto Xa = [&](int j) { const double a = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
+        auto Ua = [&](int j) { const double a = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
+        const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
+
+        // ---- Objective::evaluate + computeGradient (Objective.hpp:91-265)
+        {
+            const double f0 = Mdl::cost(X0, U0, e, ph, prm);
+            if (tid == 0) st[ST_COST] = f0;
+            if (!values_only) {
+                const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
+                const double de = fmax(dv, fabs(e)) * dv;
+                for (int idx = tid; idx < nall; idx += NT) {
+                    const bool isx = idx < nxv, isu = !isx && idx < nxv + nuv;
+                    const int kk = isx ? idx : idx - nxv;
+                    const int i = isx ? kk / NX : (isu ? kk / NU : 0), j = isx ? kk - i * NX : (isu ? kk - i * NU : 0);
+                    const double dx = dv * Xa(j), du = dv * Ua(j);
+                    const Pert Xp{Xs, NX, isx ? i + 1 : -1, -1, isx ? j : -1, isx ? dx : 0.0};       // no chain rule for the state scaling (Objective.hpp:107-144)
+                    const Pert Up{Us, NU, isu ? i : -1, (isu && i == ph - 1) ? ph : -1, isu ? j : -1, isu ? du : 0.0};   // the last row moves with its copy
+                    const double ee = idx == nall - 2 ? e + de : (idx == nall - 1 ? e - de : e);
+                    const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
+                    if (isx) { const double gk = (fp - f0) / dx; lam[kk] = gk; gxg[kk] = gk; }
+                    else if (isu) Jm[kk] = (fp - f0) / du;
+                    else st[idx == nall - 2 ? ST_FP : ST_FM] = fp;
+                }
+                T::sync();
+                for (int k = tid; k < nzu; k += NT) {
+                    const int bl = k / NU, j = k - bl * NU;
+                    double s = 0;
+                    for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
+                    gu[k] = sc.by_su(s, j);                                  // Iz2u' * vec(Jmv)
+                }
+                if (tid == 0) gu[nzu] = (st[ST_FP] - st[ST_FM]) / (2 * de);
+            }
+        }
+
+        // ---- Constraints::getStateEqConstraints (Constraints.hpp:490-905): defects, and the blocks folded with E^-1
+        const double h = 0.5 * M.Ts;
+        if (values_only) {
+            for (int i = tid; i < ph; i += NT) {
+                double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX];
+                for (int a = 0; a < NX; ++a) { xk[a] = Xs[i * NX + a]; xk1[a] = Xs[(i + 1) * NX + a]; }
+                for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
+                Mdl::f(fa, xk, uk, prm);
+                if (CT) {
+                    Mdl::f(fb, xk1, uk, prm);
+                    for (int a = 0; a < NX; ++a) c[i * NX + a] = sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a);
+                } else {
+                    for (int a = 0; a < NX; ++a) c[i * NX + a] = sc.over_ss(xk1[a] - fa[a], a);
+                }
+            }
+        } else if constexpr (!CT) {
+            // one-step models: E = I, the folded blocks are the negated Jacobian blocks; one lane per (step, column)
+            typename FP<FL>::type F = FP<FL>::get(v);
+            for (int k = tid; k < ph * FW; k += NT) {
+                const int i = k / FW, cc = k - i * FW;
+                double xk[NX], uk[NU], f1[NX], f2[NX];
+                for (int a = 0; a < NX; ++a) xk[a] = Xs[i * NX + a];
+                for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
+                if (cc == FW - 1) {
+                    Mdl::f(f1, xk, uk, prm);
+                    for (int a = 0; a < NX; ++a) {
+                        const double cv = sc.over_ss(Xs[(i + 1) * NX + a] - f1[a], a);
+                        c[i * NX + a] = cv; F[(size_t)(i * NX + a) * FW + cc] = -cv;
+                    }
+                    continue;
+                }
+                const bool isu = cc >= NX;
+                const int vv = isu ? cc - NX : cc;
+                const double base = isu ? uk[vv] : xk[vv];
+                const double d = dv * fmax(fabs(base), 1.0);
+                if (isu) uk[vv] = base + d; else xk[vv] = base + d;
+                Mdl::f(f1, xk, uk, prm);
+                if (isu) uk[vv] = base - d; else xk[vv] = base - d;
+                Mdl::f(f2, xk, uk, prm);
+                for (int a = 0; a < NX; ++a) {
+                    const double dcl = (f1[a] - f2[a]) / (2 * d);
+                    // Jacobian entries: -Sx A Tx (state columns), -Sx B su (input columns); folded: their negatives
+                    F[(size_t)(i * NX + a) * FW + cc] = isu ? sc.by_su(sc.over_ss(dcl, a), vv) : sc.over_ss(sc.by_ss(dcl, vv), a);
+                }
+            }
+        } else {
+            // collocation: per step a Gauss-Jordan on [E | A B c | I], one column per lane in registers; G steps per wavefront at a time
+            typename FP<FL>::type F = FP<FL>::get(v);
+            gwp einv = (gwp)(C.w + P.w_einv);
+            constexpr int G = 64 / GW > 0 ? 64 / GW : 1;
+            const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
+            for (int i0 = wave * G; i0 < ph; i0 += WAVES * G) {
+                const int i = i0 + g;
+                const bool live = g < G && i < ph;
+                const int ii = live ? i : ph - 1;
+                double xk[NX], xk1[NX], uk[NU], col[NX];
+                for (int a = 0; a < NX; ++a) { xk[a] = Xs[ii * NX + a]; xk1[a] = Xs[(ii + 1) * NX + a]; }
+                for (int a = 0; a < NU; ++a) uk[a] = Us[ii * NU + a];
+                // kind of column: 0 E (perturb x_{i+1}), 1 A (perturb x_i), 2 B (perturb u_i), 3 the defect, 4 identity
+                const int kind = cidx < NX ? 0 : (cidx < 2 * NX ? 1 : (cidx < 2 * NX + NU ? 2 : (cidx == 2 * NX + NU ? 3 : 4)));
+                const int vv = kind == 0 ? cidx : (kind == 1 ? cidx - NX : (kind == 2 ? cidx - 2 * NX : (kind == 4 ? cidx - (2 * NX + NU + 1) : 0)));
+                // two evaluations of the vector field per pass, the same call sites for every kind of column
+                auto pair = [&](const bool at_next, double (&o1)[NX], double (&o2)[NX], double &dstep) {
+                    double xp[NX], up[NU];
+                    for (int a = 0; a < NX; ++a) xp[a] = at_next ? xk1[a] : xk[a];
+                    for (int a = 0; a < NU; ++a) up[a] = uk[a];
+                    const bool isu = kind == 2, pert = kind <= 2;
+                    double bs = 0.0;
+                    for (int a = 0; a < NX; ++a) if (!isu && a == vv) bs = xp[a];
+                    for (int a = 0; a < NU; ++a) if (isu && a == vv) bs = up[a];
+                    const double d = pert ? dv * fmax(fabs(bs), 1.0) : 0.0;
+                    dstep = d;
+                    for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs + d;
+                    for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs + d;
+                    Mdl::f(o1, xp, up, prm);
+                    if (kind == 3) { for (int a = 0; a < NX; ++a) xp[a] = xk1[a]; }          // the defect's second evaluation is at x_{i+1}
+                    for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs - d;
+                    for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs - d;
+                    Mdl::f(o2, xp, up, prm);
+                };
+                double f1[NX], f2[NX], d1 = 0.0;
+                pair(kind == 0, f1, f2, d1);
+                if (kind == 0) for (int a = 0; a < NX; ++a) col[a] = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss((f1[a] - f2[a]) / (2 * d1), vv), a);
+                else if (kind == 1) for (int a = 0; a < NX; ++a) col[a] = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss((f1[a] - f2[a]) / (2 * d1), vv), a);
+                else if (kind == 3) {
+                    for (int a = 0; a < NX; ++a) col[a] = sc.over_ss(xk[a] + (h * (f1[a] + f2[a])) - xk1[a], a);
+                    if (live) for (int a = 0; a < NX; ++a) c[i * NX + a] = col[a];
+                } else if (kind == 4) for (int a = 0; a < NX; ++a) col[a] = a == vv ? 1.0 : 0.0;
+                {
+                    double g1[NX], g2[NX], d2 = 0.0;                      // the input columns need the pair at x_{i+1} too
+                    pair(true, g1, g2, d2);
+                    if (kind == 2) for (int a = 0; a < NX; ++a) col[a] = sc.by_su(h * sc.over_ss((f1[a] - f2[a]) / (2 * d1) + (g1[a] - g2[a]) / (2 * d2), a), vv);
+                }
+                // Gauss-Jordan with partial pivoting; the pivot column is lane base + k
+#pragma unroll
+                for (int k = 0; k < NX; ++k) {
+                    int pr = k;
+                    double best = fabs(col[k]);
+#pragma unroll
+                    for (int a = k + 1; a < NX; ++a) { const double av = fabs(col[a]); if (av > best) { best = av; pr = a; } }
+                    pr = __shfl(pr, base + k);
+                    double cp = col[k];
+#pragma unroll
+                    for (int a = k + 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[k]; }
+                    col[k] = cp;
+                    double mlt[NX];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) mlt[a] = __shfl(col[a], base + k);
+                    const double cs = col[k] / mlt[k];
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) col[a] = a == k ? cs : fma(-mlt[a], cs, col[a]);
+                }
+                if (live) {
+                    if (kind == 1) for (int a = 0; a < NX; ++a) F[(size_t)(i * NX + a) * FW + vv] = -col[a];
+                    else if (kind == 2) for (int a = 0; a < NX; ++a) F[(size_t)(i * NX + a) * FW + NX + vv] = -col[a];
+                    else if (kind == 3) for (int a = 0; a < NX; ++a) F[(size_t)(i * NX + a) * FW + FW - 1] = -col[a];
+                    else if (kind == 4) for (int a = 0; a < NX; ++a) einv[(size_t)(i * NX + a) * NX + vv] = col[a];
+                }
+            }
+        }
+
+        // ---- Constraints::evaluateIneq / evaluateEq (Constraints.hpp:211-442): values
+        for (int k = tid; k < mi; k += NT) gin[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
+        for (int k = tid; k < M.nue; k += NT) gin[mi + k] = Mdl::eq(k, X0, U0, ph, prm);
+        if (values_only) { T::sync(); return; }
+
+        // ---- their Jacobians (computeIneqJacobian :641-721, computeEqJacobian :731-832) as blocks: one NX-vector per (row, state row)
+        for (int t = tid; t < P.nsx * NX; t += NT) {
+            const int sl = t / NX, j = t - sl * NX, k = slot[sl] >> 8, i = slot[sl] & 0xff;
+            double val;
+            if (k < mi) {
+                const double dx = dv * Xa(j);
+                const Pert Xp{Xs, NX, i, -1, j, dx}, Xm{Xs, NX, i, -1, j, -dx};
+                val = (Mdl::ineq(k, Xp, U0, e, ph, prm) - Mdl::ineq(k, Xm, U0, e, ph, prm)) / (2 * dx);
+            } else {
+                const double dx = dv * fmax(fabs(Xs[i * NX + j]), 1.0);
+                const Pert Xp{Xs, NX, i, -1, j, dx}, Xm{Xs, NX, i, -1, j, -dx};
+                val = (Mdl::eq(k - mi, Xp, U0, ph, prm) - Mdl::eq(k - mi, Xm, U0, ph, prm)) / (2 * dx);
+            }
+            jx[t] = sc.by_ss(val, j);                            // the state columns are multiplied by the state scaling (Constraints.hpp:269-284)
+        }
+        // the input part, one lane per user row: into the row's column of art (dense rows) or its (index, value) list
+        gwp spv = (gwp)(C.w + P.w_sp);
+        int *spi = reinterpret_cast<int *>(C.w + P.w_sp + (size_t)(m + M.nbnd) * kNlSparse);
+        for (int k = tid; k < m; k += NT) {
+            const int dc = dcol[k];
+            const bool dense = dc >= 0;
+            if (dense) for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+            int cnt = 0, ix[kNlSparse + 1];
+            double ev[kNlSparse + 1];
+            for (int u = 0; u <= kNlSparse; ++u) { ix[u] = 0; ev[u] = 0.0; }
+            auto put = [&](int q, double val) {
+                if (q >= nq) return;
+                if (dense) { art[q * ndld + dc] += val; return; }
+                if (val == 0.0) return;                          // the finite differences leave exact zeros outside the structure
+                for (int u = 0; u < kNlSparse + 1; ++u) {
+                    if (u < cnt && ix[u] == q) { ev[u] += val; return; }
+                }
+                if (cnt <= kNlSparse) { for (int u = 0; u <= kNlSparse; ++u) if (u == cnt) { ix[u] = q; ev[u] = val; } }
+                ++cnt;
+            };
+            for (int i = 0; i < ph; ++i) {
+                if (!(k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i))) continue;
+                for (int j = 0; j < NU; ++j) {
+                    double val;
+                    if (k < mi) {
+                        const double du = dv * Ua(j);
+                        const Pert Up{Us, NU, i, -1, j, du}, Um{Us, NU, i, -1, j, -du};      // every input row on its own (no pairing here)
+                        val = (Mdl::ineq(k, X0, Up, e, ph, prm) - Mdl::ineq(k, X0, Um, e, ph, prm)) / (2 * du);
+                    } else {
+                        const double du = dv * fmax(fabs(Us[(ph - 1) * NU + j]), 1.0);      // row ph-1's magnitude for every step (Constraints.hpp:780,806)
+                        const Pert Up{Us, NU, i, i == ph - 1 ? ph : -1, j, du}, Um{Us, NU, i, i == ph - 1 ? ph : -1, j, -du};
+                        val = (Mdl::eq(k - mi, X0, Up, ph, prm) - Mdl::eq(k - mi, X0, Um, ph, prm)) / (2 * du);
+                    }
+                    put(min(i, ch - 1) * NU + j, sc.by_su(val, j));
+                }
+            }
+            if (Mdl::INEQ_USES_SLACK && k < mi) {
+                const double de = fmax(dv, fabs(e)) * dv;
+                put(nzu, (Mdl::ineq(k, X0, U0, e + de, ph, prm) - Mdl::ineq(k, X0, U0, e - de, ph, prm)) / (2 * de));
+            }
+            br[k] = gin[k];
+            if (!dense) {
+                if (cnt > kNlSparse) st[ST_ERR] = 1.0;           // the model's promise (XFREE_ROWS_SPARSE) does not hold
+                const int cn = min(cnt, kNlSparse);
+                s1v[k] = ev[0]; s1m[k] = (cn << 16) | ix[0];
+                for (int u = 0; u < kNlSparse; ++u) { spv[k * kNlSparse + u] = ev[u]; spi[k * kNlSparse + u] = ix[u]; }
+            } else {
+                s1v[k] = 0.0; s1m[k] = kSpDense;
+            }
+        }
+        // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): on an input one entry, on a state a row of Phi
+        for (int kb = tid; kb < M.nbnd; kb += NT) {
+            const int zi = M.bnd_idx[kb], k = m + kb;
+            const double sg = M.bnd_sign[kb];
+            br[k] = sg * (z[zi] - M.bnd_val[kb]);
+            if (zi < nxs) {
+                const int dc = dcol[k];
+                s1v[k] = 0.0; s1m[k] = kSpDense;
+                for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+            } else {
+                s1v[k] = sg; s1m[k] = (1 << 16) | (zi - nxs);
+                spv[k * kNlSparse] = sg; spi[k * kNlSparse] = zi - nxs;
+                for (int u = 1; u < kNlSparse; ++u) { spv[k * kNlSparse + u] = 0.0; spi[k * kNlSparse + u] = 0; }
+            }
+        }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // A chain over the horizon with one column: v_{i+1} = Abar_i v_i + rhs_i (forward) or l_i = -rhs_i + Abar_{i+1}' l_{i+1} (backward),
+    // in place in `io` (rhs in, result out), run by wavefront 0: four lanes share a row, the next step's entries are requested before this
+    // step computes.  Every thread of the workgroup calls it; the caller synchronises afterwards.
+    template <bool FL, bool BACKWARD>
+    static __device__ __forceinline__ void chain(const V &v, double *io, int tid)
+    {
+        if (tid >= 64) return;
+        const int ph = v.C.M.ph;
+        typename FP<FL>::type F = FP<FL>::get(v);
+        constexpr int RP = 16;                                  // rows per pass
+        constexpr int CH = (NX + 3) / 4;
+        const int part = tid & 3;
+        for (int step = 0; step < ph; ++step) {
+            const int i = BACKWARD ? ph - 1 - step : step;
+            // forward: v_i = io[(i-1) NX ..] (zero for i = 0), result to io[i NX ..]; backward: l_{i+1} = io[(i+1) NX ..] (zero at the end)
+            const bool has_prev = BACKWARD ? i + 1 < ph : i > 0;
+            const double *prev = io + (BACKWARD ? (i + 1) * NX : (i - 1) * NX);
+            const int blk = BACKWARD ? i + 1 : i;
+            double res[(NX + RP - 1) / RP];
+#pragma unroll
+            for (int a0 = 0; a0 < NX; a0 += RP) {
+                const int a = a0 + (tid >> 2);
+                const bool rowlive = a < NX;
+                const int aa = rowlive ? a : 0;
+                double s = 0.0;
+                if (has_prev) {
+                    double fv[CH], pv[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int bb = min(part + 4 * u, NX - 1);
+                        fv[u] = part + 4 * u < NX ? (BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb]) : 0.0;
+                        pv[u] = prev[bb];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) s = fma(fv[u], pv[u], s);
+                }
+                s = group_sum<4>(s);
+                const double rh = io[i * NX + aa];
+                res[a0 / RP] = BACKWARD ? s - rh : s + rh;
+            }
+            nl_wave_sync();
+#pragma unroll
+            for (int a0 = 0; a0 < NX; a0 += RP) {
+                const int a = a0 + (tid >> 2);
+                if (a < NX && part == 0) io[i * NX + a] = res[a0 / RP];
+            }
+            nl_wave_sync();
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // condense + reduce: the reduced gradient gr, the dense rows of the sub-problem (art, br) completed with their state part.
+    // Leaves the largest dynamics multiplier in st[ST_LAMDYN] where no row reads a state.
+    template <bool FL>
+    static MPCX_WG_PHASE void condense()
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, ch = M.ch, nxs = ph * NX, nzu = M.nzu, mi = M.nineq, m = mi + M.nue;
+        const int ndld = P.ndld;
+        double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *gr = v.at(P.o_gr), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br),
+               *st = v.at(P.o_st);
+        const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
+        const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
+        typename FP<FL>::type F = FP<FL>::get(v);
+        if (P.needs_phi) {
+            // One column of [Phi | r] per lane, in registers: dx_{i+1} = Abar_i dx_i + (Bbar_i e_q | cbar_i).  What the column is needed for
+            // is taken as the sweep passes: Phi' g_x, the rows of the user Jacobian and of the state bounds that read state row i + 1.
+            for (int q = tid; q <= nzu; q += NT) {
+                const bool isr = q == nzu;
+                const int bq = q / NU, jq = q - bq * NU;
+                double x[NX], t[NX], gacc = 0.0;
+#pragma unroll
+                for (int a = 0; a < NX; ++a) x[a] = 0.0;
+                for (int i = 0; i < ph; ++i) {
+                    const bool drives = !isr && min(i, ch - 1) == bq;
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) {
+                        double s = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+#pragma unroll
+                        for (int bb = 0; bb < NX; ++bb) s = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], s);
+                        t[a] = s;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) x[a] = t[a];
+                    if (!isr) {
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) gacc = fma(lam[i * NX + a], x[a], gacc);       // (lam still holds g_x)
+                    }
+                    auto row = [&](int k) {
+                        const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
+                        double s = 0.0;
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) s = fma(jx[sl * NX + a], x[a], s);
+                        if (isr) br[k] += s; else art[q * ndld + dcol[k]] += s;
+                    };
+                    int first, count;
+                    Mdl::ineq_rows_of_x(i + 1, first, count);
+                    for (int k = first; k < first + count; ++k) if ((xmask[k] >> i) & 1ull) row(k);
+                    for (int k = mi; k < m; ++k) if ((xmask[k] >> i) & 1ull) row(k);
+                    for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
+                        const int a = M.bnd_idx[kb] - i * NX;
+                        const double sg = M.bnd_sign[kb];
+                        double xa = 0.0;
+#pragma unroll
+                        for (int a2 = 0; a2 < NX; ++a2) if (a2 == a) xa = x[a2];
+                        if (isr) br[m + kb] += sg * xa; else art[q * ndld + dcol[m + kb]] = sg * xa;
+                    }
+                }
+                if (!isr) gr[q] = gu[q] + gacc;
+            }
+            if (tid == 0) gr[nzu] = gu[nzu];
+        } else {
+            // no row reads a state: Jx' lam = -g_x by one backward chain (lam holds g_x on entry, the chain's multipliers afterwards)
+            chain<FL, true>(v, lam, tid);
+            T::sync();
+            for (int q = tid; q <= nzu; q += NT) {
+                if (q == nzu) { gr[q] = gu[q]; continue; }
+                const int bq = q / NU, jq = q - bq * NU;
+                double s = gu[q];
+                for (int i = bq; i < (bq == ch - 1 ? ph : bq + 1); ++i) {
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) s = fma(-F[(size_t)(i * NX + a) * FW + NX + jq], lam[i * NX + a], s);
+                }
+                gr[q] = s;
+            }
+            // the multipliers of the defects themselves, for the merit weight: lam_i = E_i^-T (chain's value)
+            double lmax = 0.0;
+            if (CT) {
+                gwp einv = (gwp)(C.w + P.w_einv);
+                for (int k = tid; k < nxs; k += NT) {
+                    const int i = k / NX, a = k - i * NX;
+                    double s = 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < NX; ++bb) s = fma(einv[(size_t)(i * NX + bb) * NX + a], lam[i * NX + bb], s);
+                    lmax = fmax(lmax, fabs(s));
+                }
+            } else {
+                for (int k = tid; k < nxs; k += NT) lmax = fmax(lmax, fabs(lam[k]));
+            }
+            Red<WAVES> R(v.at(P.o_red));
+            lmax = R.max(lmax);
+            if (tid == 0) st[ST_LAMDYN] = lmax;
+        }
+        T::sync();
+    }
+
+    // sum_t coef[t] * (normal of working row t)[q], the working set as it stands in wq / sgq
+    static __device__ __forceinline__ double ws_combine(const V &v, const Sp &sp, int nw, const double *coef, int q)
+    {
+        const WgPlan &P = v.C.P;
+        const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
+        const double *sgq = v.at(P.o_sgq), *art = v.at(P.o_art);
+        double acc = 0.0;
+        for (int t = 0; t < nw; ++t) {
+            const int k = wq[t], dc = dcol[k];
+            const double ml = sgq[t] * coef[t];
+            if (dc >= 0) acc = fma(art[q * P.ndld + dc], ml, acc);
+            else {
+                const int cn = sp.count(k);
+                for (int j = 0; j < cn; ++j) if (sp.index(k, j) == q) acc = fma(sp.value(k, j), ml, acc);
+            }
+        }
+        return acc;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // damped BFGS update of the inverse Hessian estimate (Powell): s = a p, y = change of the reduced Lagrangian gradient
+    static MPCX_WG_PHASE void bfgs(double a_prev, int nw_keep)
+    {
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int nq = P.nq;
+        const Sp sp(v);
+        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq);
+        double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
+        Red<WAVES> R(v.at(P.o_red));
+        double sBs = 0, sy = 0;
+        for (int q = tid; q < nq; q += NT) {
+            const double gl = gr[q] + ws_combine(v, sp, nw_keep, uq, q);
+            const double y = gl - glold[q], Bs = -a_prev * glold[q];
+            v0[q] = y; v1[q] = Bs;
+            sBs += sv[q] * Bs; sy += sv[q] * y;
+        }
+        sBs = R.sum(sBs); sy = R.sum(sy);
+        if (sy < 0.2 * sBs) {
+            const double th = 0.8 * sBs / (sBs - sy);
+            for (int q = tid; q < nq; q += NT) v0[q] = th * v0[q] + (1 - th) * v1[q];
+            sy = th * sy + (1 - th) * sBs;
+        }
+        T::sync();
+        if (sy > 1e-300) {
+            const double rho = 1.0 / sy;
+            hmul<NT>(hinv, v0, v2, nq, 1.0, tid);
+            T::sync();
+            double yHy = 0;
+            for (int q = tid; q < nq; q += NT) yHy += v2[q] * v0[q];
+            yHy = R.sum(yHy);
+            const double cc = rho * rho * yHy + rho;
+            for (int e = tid; e < nq * (nq + 1) / 2; e += NT) {
+                int r, c;
+                tri_index(e, r, c);
+                hinv[e] += -rho * (sv[r] * v2[c] + v2[r] * sv[c]) + cc * sv[r] * sv[c];
+            }
+        }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // the normal n = sgn * (row k) of a sub-problem row and vv = B^-1 n, both into LDS (every thread calls; the caller synchronises)
+    static __device__ __forceinline__ void normal_and_hinv(const V &v, const Sp &sp, int k, double sgn, double *np_, double *vv, double *tmp, int tid)
+    {
+        const WgPlan &P = v.C.P;
+        const int nq = P.nq, dc = v.iat(P.o_dcol)[k];
+        const double *hinv = v.at(P.o_hinv), *art = v.at(P.o_art);
+        if (dc >= 0) {
+            for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * P.ndld + dc];
+            T::sync();
+            hmul<NT>(hinv, np_, vv, nq, 1.0, tid);
+        } else {
+            const int cn = sp.count(k);
+            for (int q = tid; q < nq; q += NT) {
+                double nvl = 0, hv = 0;
+                for (int j = 0; j < cn; ++j) {
+                    const int ix = sp.index(k, j);
+                    const double val = sgn * sp.value(k, j);
+                    if (ix == q) nvl += val;
+                    hv = fma(hsym(hinv, ix, q), val, hv);
+                }
+                np_[q] = nvl; vv[q] = hv;
+            }
+        }
+        (void)tmp;
+    }
+    // out[t] = (normal of working row t)' x for t < nw: four lanes share a row
+    static __device__ __forceinline__ void ws_dots(const V &v, const Sp &sp, int nw, const double *x, double *out, int tid)
+    {
+        const WgPlan &P = v.C.P;
+        const int nq = P.nq, part = tid & 3;
+        const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
+        const double *sgq = v.at(P.o_sgq), *art = v.at(P.o_art);
+        for (int t0 = 0; t0 < nw; t0 += NT / 4) {
+            const int t = t0 + (tid >> 2);
+            const bool live = t < nw;
+            const int k = wq[live ? t : 0], dc = dcol[k];
+            double acc = 0.0;
+            if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * P.ndld + dc], x[q], acc); }
+            else if (part == 0) acc = sp.dot(k, x);
+            acc = group_sum<4>(acc);
+            if (live && part == 0) out[t] = sgq[t] * acc;
+        }
+    }
+
+    // sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0 (equalities: = 0)   (Goldfarb-Idnani, range-space form on B^-1)
+    // returns the size of the final working set (>= 0) or a failure code (< 0)
+    static MPCX_WG_PHASE int qp(int nw_keep)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int nzu = M.nzu, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd;
+        const int nq = P.nq, KW = P.kw;
+        const Sp sp(v);
+        double *gr = v.at(P.o_gr), *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *mu = v.at(P.o_mu), *p = v.at(P.o_p),
+               *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq), *invd = v.at(P.o_invd), *Lp = v.at(P.o_L),
+               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art), *st = v.at(P.o_st);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        const int *dcol = v.iat(P.o_dcol);
+        Red<WAVES> R(v.at(P.o_red));
+        const Factor Fac{Lp, invd, nullptr, nullptr, KW, 0};
+        auto is_eq = [&](int k) { return k >= mi && k < m; };
+
+        for (int k = tid; k < mt; k += NT) flag[k] = 0;
+        hmul<NT>(hinv, gr, xq, nq, -1.0, tid);                  // the unconstrained minimiser x = -B^-1 gr
+        T::sync();
+        for (int t = tid; t < nw_keep; t += NT) flag[wq[t]] = 1;
+        T::sync();
+
+        // row t leaves the working set: the factor is down-dated, the lists close up
+        auto drop_row = [&](int kdrop, int nw) {
+            if (wave == 0) chol_delete(Lp, invd, nw, kdrop, lane);
+            int kq = 0; double sg = 0, u = 0;
+            const bool mv = tid > kdrop && tid < nw;             // (working sets hold at most 128 rows: one or two per thread)
+            const bool mv2 = tid + NT > kdrop && tid + NT < nw;
+            if (mv) { kq = wq[tid]; sg = sgq[tid]; u = uq[tid]; }
+            int kq2 = 0; double sg2 = 0, u2 = 0;
+            if (mv2) { kq2 = wq[tid + NT]; sg2 = sgq[tid + NT]; u2 = uq[tid + NT]; }
+            if (tid == 0) flag[wq[kdrop]] = 0;
+            T::sync();
+            if (mv) { wq[tid - 1] = kq; sgq[tid - 1] = sg; uq[tid - 1] = u; }
+            if (mv2) { wq[tid + NT - 1] = kq2; sgq[tid + NT - 1] = sg2; uq[tid + NT - 1] = u2; }
+            T::sync();
+        };
+        // tq <- S^-1 tq over the working set (wavefront 0); y = L^-1 tq stays in its registers: the factor's next row if the entering row joins
+        double y0 = 0, y1 = 0;
+        auto solve_ws = [&](int nw) {
+            if (wave == 0) {
+                double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
+                chol_forward<false>(Fac, nw, t0, t1, lane);
+                y0 = t0; y1 = t1;
+                chol_backward<false>(Fac, nw, t0, t1, lane);
+                if (lane < nw) tq[lane] = t0;
+                if (lane + 64 < nw) tq[lane + 64] = t1;
+            }
+            T::sync();
+        };
+
+        int nw = 0;
+        // ---- warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative
+        if (nw_keep > 0) {
+            nw = nw_keep;
+            // S = N B^-1 N' of the kept rows, straight into the factor's storage
+            int anyd = 0;
+            for (int t = tid; t < nw; t += NT) anyd |= dcol[wq[t]] >= 0 ? 1 : 0;
+            const bool any_dense = R.max((double)anyd) > 0.0;
+            if (!any_dense) {
+                for (int e = tid; e < nw * (nw + 1) / 2; e += NT) {
+                    int a, b2;
+                    tri_index(e, a, b2);
+                    const int ka = wq[a], kb = wq[b2];
+                    double s = 0.0;
+                    for (int ja = 0; ja < sp.count(ka); ++ja)
+                        for (int jb = 0; jb < sp.count(kb); ++jb)
+                            s = fma(sp.value(ka, ja) * sp.value(kb, jb), hsym(hinv, sp.index(ka, ja), sp.index(kb, jb)), s);
+                    Lp[e] = sgq[a] * sgq[b2] * s;
+                }
+            } else {
+                for (int b2 = 0; b2 < nw; ++b2) {
+                    normal_and_hinv(v, sp, wq[b2], sgq[b2], np_, vv, wv, tid);
+                    T::sync();
+                    ws_dots(v, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);      // row b2 of S: entries 0 .. b2
+                    T::sync();
+                }
+            }
+            T::sync();
+            int ok = 1;
+            if (wave == 0) ok = chol_inplace(Lp, invd, nw, lane) ? 1 : 0;
+            if (tid == 0) st[ST_R4] = (double)ok;
+            T::sync();
+            ok = (int)st[ST_R4];
+            if (!ok) {
+                for (int t = tid; t < nw; t += NT) flag[wq[t]] = 0;
+                nw = 0;
+                T::sync();
+            }
+            while (nw > 0) {
+                ws_dots(v, sp, nw, xq, tq, tid);
+                T::sync();
+                for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
+                T::sync();
+                solve_ws(nw);
+                // every row with a negative multiplier leaves at once; equalities stay
+                auto sheds = [&](int t) { return tq[t] < 0.0 && !is_eq(wq[t]); };
+                int neg = -1;
+                for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
+                if (neg < 0) break;
+                for (int t = nw - 1; t >= 0; --t) {
+                    if (sheds(t)) { drop_row(t, nw); --nw; }
+                }
+            }
+            if (nw > 0) {
+                for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(v, sp, nw, tq, q);
+                for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
+                T::sync();
+                hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
+                T::sync();
+                for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
+                T::sync();
+            }
+        }
+
+        // ---- the dual method
+        int fail = 0;
+        bool done = false;
+        for (int qit = 0; qit < 8 * (mt + nq) + 16 && !done && !fail; ++qit) {
+            // the most violated row outside the working set
+            double vmax = -1e300; int pidx = 0x7fffffff;
+            {
+                const int part = tid & 3;
+                for (int k0 = 0; k0 < mt; k0 += NT / 4) {
+                    const int k = k0 + (tid >> 2);
+                    const bool live = k < mt;
+                    const int kk = live ? k : 0, dc = dcol[kk];
+                    double acc = 0.0;
+                    if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * P.ndld + dc], xq[q], acc); }
+                    else if (part == 0) acc = sp.dot(kk, xq);
+                    acc = group_sum<4>(acc);
+                    double s = br[kk] + acc;
+                    if (is_eq(kk)) s = fabs(s);                          // an equality is violated on either side
+                    if (live && part == 0 && flag[kk] == 0 && s > vmax) { vmax = s; pidx = k; }
+                }
+            }
+            R.argmax(vmax, pidx);
+            if (mt == 0 || vmax <= 1e-12) { done = true; break; }        // primal feasible: optimal
+            if (nw >= KW) { fail = -3; break; }                          // working set full
+            // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
+            const bool p_is_eq = is_eq(pidx);
+            double sgn = 1.0;
+            if (p_is_eq) {
+                double part = 0;
+                const int dc = dcol[pidx];
+                if (dc >= 0) { for (int q = tid; q < nq; q += NT) part += art[q * P.ndld + dc] * xq[q]; }
+                else if (tid == 0) part = sp.dot(pidx, xq);
+                sgn = br[pidx] + R.sum(part) < 0.0 ? -1.0 : 1.0;
+            }
+            normal_and_hinv(v, sp, pidx, sgn, np_, vv, wv, tid);
+            T::sync();
+            double snn = 0, npn = 0;
+            for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
+            snn = R.sum(snn); npn = R.sum(npn);
+            double up = 0.0, spv_ = vmax;
+            bool added = false;
+            for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
+                // t = N_W v (the new column of S), rr = S^-1 t
+                if (nw > 0) {
+                    ws_dots(v, sp, nw, vv, tq, tid);
+                    T::sync();
+                    solve_ws(nw);
+                    for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(v, sp, nw, tq, q);
+                    T::sync();
+                    hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
+                    T::sync();
+                    for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
+                } else {
+                    y0 = 0; y1 = 0;
+                    for (int q = tid; q < nq; q += NT) zd[q] = vv[q];
+                }
+                T::sync();
+                double zn = 0;
+                for (int q = tid; q < nq; q += NT) zn += zd[q] * np_[q];
+                zn = R.sum(zn);
+                // dual ratio test: the smallest ratio, lowest slot on ties
+                double t1 = 1e300; int kdrop = -1;
+                {
+                    double tneg = -1e300; int tidx = 0x7fffffff;
+                    for (int t = tid; t < nw; t += NT) {
+                        const double rr = tq[t];
+                        if (rr > 1e-14 && !is_eq(wq[t])) { const double tj = uq[t] / rr; if (-tj > tneg) { tneg = -tj; tidx = t; } }
+                    }
+                    R.argmax(tneg, tidx);
+                    if (tneg > -1e300) { t1 = -tneg; kdrop = tidx; }
+                }
+                const bool can_move = zn > 1e-13 * fmax(1.0, npn);
+                const double t2 = can_move ? spv_ / zn : 1e300;
+                const double tt = fmin(t1, t2);
+                if (tt >= 1e300) {
+                    // no step: the row is a combination of working rows.  Violated by round-off only (a copy of an active row): set it
+                    // aside; violated for real: the linearised constraints are inconsistent.
+                    if (spv_ <= 1e-7 && !p_is_eq) { if (tid == 0) flag[pidx] = 2; T::sync(); added = true; break; }
+                    fail = -1; break;
+                }
+                if (can_move) {
+                    for (int q = tid; q < nq; q += NT) xq[q] -= tt * zd[q];
+                    spv_ -= tt * zn;
+                }
+                for (int t = tid; t < nw; t += NT) uq[t] -= tt * tq[t];
+                up += tt;
+                T::sync();
+                if (t2 <= t1) {                                          // full step: the row joins the working set
+                    if (wave == 0) chol_append<false>(Fac, nw, y0, y1, snn, snn, lane);
+                    if (tid == 0) { uq[nw] = up; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+                    ++nw; added = true;
+                } else {                                                 // a multiplier hit zero: that row leaves, try again
+                    drop_row(kdrop, nw);
+                    --nw;
+                }
+                T::sync();
+            }
+            if (!fail && !added) fail = -1;
+        }
+        if (!fail && !done) fail = -1;
+        if (fail) { T::sync(); return fail; }
+        for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
+        T::sync();
+        for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
+        for (int q = tid; q < nr; q += NT) p[q] = q < nq ? xq[q] : 0.0;
+        (void)nzu;
+        T::sync();
+        return nw;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // the full-space step d = [dx ; p] (dx by one forward chain with p applied) and the numbers of the convergence test
+    // st[R0..R3] = max |d|, max |defect|, g'd, max |z|
+    template <bool FL>
+    static MPCX_WG_PHASE void step()
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nr = M.nr, mi = M.nineq, m = mi + M.nue;
+        double *p = v.at(P.o_p), *dx = v.at(P.o_dx), *c = v.at(P.o_c), *z = v.at(P.o_z), *gu = v.at(P.o_gu), *gin = v.at(P.o_gin), *st = v.at(P.o_st);
+        typename FP<FL>::type F = FP<FL>::get(v);
+        gwp gxg = (gwp)(C.w + P.w_gx);
+        for (int k = tid; k < nxs; k += NT) {
+            const int i = k / NX, a = k - i * NX;
+            const double *pb = p + min(i, ch - 1) * NU;
+            double s = F[(size_t)k * FW + FW - 1];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) s = fma(F[(size_t)k * FW + NX + j], pb[j], s);
+            dx[k] = s;
+            (void)a;
+        }
+        T::sync();
+        chain<FL, false>(v, dx, tid);
+        T::sync();
+        Red<WAVES> R(v.at(P.o_red));
+        double dmax = 0, cmax = 0, gd = 0, zmax = 0;
+        for (int k = tid; k < nxs; k += NT) { dmax = fmax(dmax, fabs(dx[k])); gd += gxg[k] * dx[k]; cmax = fmax(cmax, fabs(c[k])); }
+        for (int q = tid; q < nr; q += NT) { dmax = fmax(dmax, fabs(p[q])); gd += gu[q] * p[q]; }
+        for (int k = tid; k < nz; k += NT) zmax = fmax(zmax, fabs(z[k]));
+        for (int k = mi + tid; k < m; k += NT) cmax = fmax(cmax, fabs(gin[k]));       // user equalities count as defects
+        dmax = R.max(dmax); cmax = R.max(cmax); gd = R.sum(gd); zmax = R.max(zmax);
+        if (tid == 0) { st[ST_R0] = dmax; st[ST_R1] = cmax; st[ST_R2] = gd; st[ST_R3] = zmax; }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // after the sub-problem: the BFGS memory, the largest multiplier (st[R0]) and the l1 violation at z (st[R1])
+    template <bool FL>
+    static MPCX_WG_PHASE void merit(int nw)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, nxs = ph * NX, mi = M.nineq, m = mi + M.nue;
+        const int nq = P.nq;
+        const Sp sp(v);
+        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *uq = v.at(P.o_uq), *lam = v.at(P.o_lam), *jx = v.at(P.o_jx), *c = v.at(P.o_c),
+               *gin = v.at(P.o_gin), *st = v.at(P.o_st), *sgq = v.at(P.o_sgq);
+        const int *wq = v.iat(P.o_wq), *jxoff = v.iat(P.o_jxoff);
+        const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
+        Red<WAVES> R(v.at(P.o_red));
+        // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
+        for (int q = tid; q < nq; q += NT) glold[q] = gr[q] + ws_combine(v, sp, nw, uq, q);
+        double lam_max;
+        if (P.needs_phi) {
+            // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward chain over the blocks
+            gwp gxg = (gwp)(C.w + P.w_gx);
+            for (int row = tid; row < nxs; row += NT) {
+                const int i = row / NX, a = row - i * NX;                   // entry a of state row i + 1
+                double s2 = gxg[row];
+                for (int t = 0; t < nw; ++t) {                              // mu lives on the working set
+                    const int k = wq[t];
+                    if (k < m) {
+                        if ((xmask[k] >> i) & 1ull) {
+                            const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
+                            s2 += jx[sl * NX + a] * (sgq[t] * uq[t]);
+                        }
+                    } else if (M.bnd_idx[k - m] == row) s2 += M.bnd_sign[k - m] * uq[t];
+                }
+                lam[row] = s2;
+            }
+            T::sync();
+            chain<FL, true>(v, lam, tid);
+            T::sync();
+            double lmax = 0.0;
+            if (CT) {
+                gwp einv = (gwp)(C.w + P.w_einv);
+                for (int k = tid; k < nxs; k += NT) {
+                    const int i = k / NX, a = k - i * NX;
+                    double s = 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < NX; ++bb) s = fma(einv[(size_t)(i * NX + bb) * NX + a], lam[i * NX + bb], s);
+                    lmax = fmax(lmax, fabs(s));
+                }
+            } else {
+                for (int k = tid; k < nxs; k += NT) lmax = fmax(lmax, fabs(lam[k]));
+            }
+            lam_max = lmax;
+        } else {
+            lam_max = tid == 0 ? st[ST_LAMDYN] : 0.0;
+        }
+        for (int t = tid; t < nw; t += NT) lam_max = fmax(lam_max, fabs(uq[t]));
+        lam_max = R.max(lam_max);
+        double viol = 0;
+        for (int k = tid; k < nxs; k += NT) viol += fabs(c[k]);
+        for (int k = tid; k < m; k += NT) viol += k < mi ? fmax(gin[k], 0.0) : fabs(gin[k]);
+        viol = R.sum(viol);
+        if (tid == 0) { st[ST_R0] = lam_max; st[ST_R1] = viol; }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // line search on the l1 merit function: eight step lengths a = 2^-(g + 8 round) at a time, NT / 8 lanes each.
+    // returns the accepted length, or -1 if none down to 2^-40
+    static MPCX_WG_PHASE double linesearch(double nu_pen, double phi0, double dphi)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, mi = M.nineq, m = mi + M.nue;
+        const double *prm = C.prm;
+        const Scale sc(M);
+        double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *dXs = v.at(P.o_dXs), *dUs = v.at(P.o_dUs), *dx = v.at(P.o_dx),
+               *p = v.at(P.o_p), *st = v.at(P.o_st);
+        for (int k = tid; k < (ph + 1) * NX; k += NT) {
+            const int i = k / NX, j = k - i * NX;
+            Xs[k] = sc.over_ss(i == 0 ? C.x0[j] : z[(i - 1) * NX + j], j);
+            dXs[k] = i == 0 ? 0.0 : sc.over_ss(dx[k - NX], j);
+        }
+        for (int k = tid; k < (ph + 1) * NU; k += NT) {
+            const int i = k / NU, j = k - i * NU, q = min(min(i, ph - 1), ch - 1) * NU + j;
+            Us[k] = sc.by_su(z[nxs + q], j);
+            dUs[k] = sc.by_su(p[q], j);
+        }
+        T::sync();
+        constexpr int GS = NT / kNlTrials;                       // lanes per trial point: 8, 16 or 32
+        const int grp = tid / GS, part = tid % GS;
+        const double h = 0.5 * M.Ts;
+        double a_step = -1.0;
+        for (int round = 0; round < 5 && a_step < 0.0; ++round) {
+            const double al = ldexp(1.0, -(grp + 8 * round));
+            const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
+            const double et = z[nz - 1] + al * p[M.nzu];
+            double mer = 0.0, vio = 0;
+            if (part == 0) mer = Mdl::cost(XL, UL, et, ph, prm);
+            for (int k = part; k < mi; k += GS) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+            for (int k = part; k < m - mi; k += GS) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
+            for (int i = part; i < ph; i += GS) {
+                double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX], s = 0;
+                for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
+                for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
+                Mdl::f(fa, xk, uk, prm);
+                if (CT) {
+                    Mdl::f(fb, xk1, uk, prm);
+                    for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
+                } else {
+                    for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk1[a] - fa[a], a));
+                }
+                vio += s;
+            }
+            mer += nu_pen * vio;
+            if constexpr (GS == 8) mer = group_sum<8>(mer);
+            else if constexpr (GS == 16) mer = group_sum<16>(mer);
+            else { mer = group_sum<16>(mer); mer += __shfl_xor(mer, 16); }
+            if (part == 0) st[ST_ACC + grp] = mer <= phi0 + 1e-4 * al * dphi ? 1.0 : 0.0;
+            T::sync();
+            for (int g = kNlTrials - 1; g >= 0; --g) if (st[ST_ACC + g] != 0.0) a_step = ldexp(1.0, -(g + 8 * round));
+            T::sync();
+        }
+        return a_step;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // z += a d; s = a p for the next BFGS update; the step's norms for nlopt's stopping rules: st[R0..R2] = |step|_1, |z|_1, max |step|
+    static MPCX_WG_PHASE void update(double a_step)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int nxs = M.ph * NX, nr = M.nr;
+        double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p), *sv = v.at(P.o_sv), *st = v.at(P.o_st);
+        Red<WAVES> R(v.at(P.o_red));
+        double s1 = 0, z1 = 0, smax = 0;
+        for (int q = tid; q < nr; q += NT) sv[q] = a_step * p[q];
+        for (int k = tid; k < nxs + nr; k += NT) {
+            const double dk = a_step * (k < nxs ? dx[k] : p[k - nxs]);
+            const double zn = z[k] + dk;
+            z[k] = zn;
+            s1 += fabs(dk); z1 += fabs(zn); smax = fmax(smax, fabs(dk));
+        }
+        s1 = R.sum(s1); z1 = R.sum(z1); smax = R.max(smax);
+        if (tid == 0) { st[ST_R0] = s1; st[ST_R1] = z1; st[ST_R2] = smax; }
+        T::sync();
+    }
+
+    // largest violation at z, for nlopt's stopping rules (applied to a step that ended at a feasible point)
+    static MPCX_WG_PHASE double violation()
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int nxs = M.ph * NX, mi = M.nineq, m = mi + M.nue;
+        const double *c = v.at(P.o_c), *gin = v.at(P.o_gin);
+        Red<WAVES> R(v.at(P.o_red));
+        double vmax = 0;
+        for (int k = tid; k < nxs; k += NT) vmax = fmax(vmax, fabs(c[k]));
+        for (int k = tid; k < m; k += NT) vmax = fmax(vmax, k < mi ? gin[k] : fabs(gin[k]));
+        vmax = R.max(vmax);
+        T::sync();
+        return vmax;
+    }
+
+    static MPCX_WG_PHASE void reset_hessian()
+    {
+        const V v; const WgPlan &P = v.C.P;
+        double *hinv = v.at(P.o_hinv);
+        const int nr = v.C.M.nr;
+        for (int e = threadIdx.x; e < nr * (nr + 1) / 2; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
+        T::sync();
+    }
+    static MPCX_WG_PHASE void take_last_step()
+    {
+        const V v; const WgPlan &P = v.C.P;
+        const int nxs = v.C.M.ph * NX, nr = v.C.M.nr;
+        double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p);
+        for (int k = threadIdx.x; k < nxs + nr; k += NT) z[k] += k < nxs ? dx[k] : p[k - nxs];
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // results (NLOptimizer.hpp:536-624): cmd = U.row(0), cost, status map, feasibility of the user constraints; Xs / Us hold the
+    // trajectory of the last evaluation
+    static MPCX_WG_PHASE void finish(int code, int it)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = M.ph, nz = M.nz, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd, b = C.b;
+        const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *gin = v.at(P.o_gin), *mu = v.at(P.o_mu), *hinv = v.at(P.o_hinv),
+                     *st = v.at(P.o_st);
+        const int *flag = v.iat(P.o_flag);
+        Red<WAVES> R(v.at(P.o_red));
+        double gmax = -1e300, hmax = 0.0;
+        for (int k = tid; k < m; k += NT) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
+        gmax = R.max(gmax); hmax = R.max(hmax);
+        const bool failed = code < 0;
+        if (S.cmd) for (int j = tid; j < NU; j += NT) S.cmd[(size_t)b * NU + j] = failed ? C.u0[j] : Us[j];
+        if (S.z_out) for (int k = tid; k < nz; k += NT) S.z_out[(size_t)b * nz + k] = z[k];
+        if (S.mu_out) for (int k = tid; k < mt; k += NT) S.mu_out[(size_t)b * mt + k] = mu[k];
+        if (S.seq_state) for (int k = tid; k < (ph + 1) * NX; k += NT) S.seq_state[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
+        if (S.seq_input) for (int k = tid; k < (ph + 1) * NU; k += NT) S.seq_input[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
+        if (S.seq_output)                                   // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
+            for (int i = tid; i <= ph; i += NT) {
+                double y[Mdl::NY > 0 ? Mdl::NY : 1];
+                for (int a = 0; a < Mdl::NY; ++a) y[a] = 0.0;
+                if (Mdl::HAS_OUTPUT && !failed) Mdl::out(y, Xs + i * NX, Us + i * NU, C.prm);
+                for (int a = 0; a < Mdl::NY; ++a) S.seq_output[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
+            }
+        // the curvature estimate stays in the workspace for a receding-horizon successor (keep_curvature)
+        gwp hs = (gwp)(C.w + P.w_hinv);
+        for (int e = tid; e < nr * (nr + 1) / 2; e += NT) hs[e] = hinv[e];
+        if (tid == 0) {
+            if (S.cost) S.cost[b] = failed ? __builtin_huge_val() : st[ST_COST];
+            if (S.solver_status) S.solver_status[b] = code;
+            if (S.status) S.status[b] = (code == 3 || code == 4) ? 0 : (code == 5 ? 1 : 3);     // SUCCESS / MAX_ITERATION / ERROR (NLOptimizer.hpp:729-750)
+            if (S.is_feasible) S.is_feasible[b] = ((mi == 0 || gmax <= S.ieq_tol) && hmax <= S.eq_tol) ? 1 : 0;    // Constraints.hpp:157-202
+            if (S.iterations) S.iterations[b] = it;
+            C.w[P.w_scal] = st[ST_COST];
+        }
+        (void)flag;
+        T::sync();
+    }
+};
+
+// one workgroup = one instance
+template <class Mdl, int WAVES, bool FL>
+__global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, const NlmpcSolveDev S, const WgPlan P)
+{
+    using K = WgSqp<Mdl, WAVES>;
+    using T = Team<WAVES>;
+    constexpr int NT = 64 * WAVES;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double *sm = wg_lds();
+    {
+        // the context block: the kernel's arguments and this instance's pointers, word by word
+        WgCtx *C = reinterpret_cast<WgCtx *>(sm);
+        if (tid == 0) {
+            C->M = M; C->S = S; C->P = P;
+            C->w = S.ws + (size_t)b * P.ws_total;
+            C->x0 = S.x0 + (size_t)b * Mdl::NX; C->u0 = S.u0 + (size_t)b * Mdl::NU;
+            C->prm = S.params_b ? S.params_b + (size_t)b * S.nparams : M.params;
+            C->b = b; C->pad = 0;
+        }
+        T::sync();
+    }
+    const double *st = sm + P.o_st;
+    K::start();
+    const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
+    double nu_pen = 0.0, a_prev = 0.0, f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;
+    bool have_old = false, stepped = false, final_eval = false;
+    int resets = 0, nw_keep = 0, it = 0, code = 5;       // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
+    for (;;) {
+        K::template eval<FL>(final_eval ? 1 : 0);
+        if (final_eval) break;
+        if (st[ST_ERR] != 0.0) { code = -3; break; }
+        if (stepped && tol_on) {
+            // nlopt's stopping rules (NLOptimizer.hpp:135-138), applied as SLSQP applies them: to a step that ended at a feasible point
+            const double vmax = K::violation();
+            if (vmax <= S.tol_con) {
+                const double fn = st[ST_COST], df = fabs(fn - f_prev);
+                const bool ft = (S.ftol_abs > 0 && df < S.ftol_abs) ||
+                                (S.ftol_rel > 0 && (df < S.ftol_rel * 0.5 * (fabs(fn) + fabs(f_prev)) || fn == f_prev));
+                const bool xt = (S.xtol_rel > 0 && step_l1 <= S.xtol_rel * z_l1) || (S.xtol_abs > 0 && step_max < S.xtol_abs);
+                if (ft) { code = 3; break; }
+                if (xt) { code = 4; break; }
+            }
+        }
+        stepped = false;
+        if (it >= S.max_iter) break;
+        K::template condense<FL>();
+        if (have_old) K::bfgs(a_prev, nw_keep);
+        const int nw = K::qp(nw_keep);
+        if (nw < 0) { code = nw; break; }
+        nw_keep = nw;
+        K::template step<FL>();
+        const double dmax = st[ST_R0], cmax = st[ST_R1], gd = st[ST_R2], zmax = st[ST_R3];
+        if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
+            // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
+            K::take_last_step();
+            code = 4; ++it;
+            final_eval = true;
+            continue;
+        }
+        T::sync();
+        K::template merit<FL>(nw);
+        const double lam_max = st[ST_R0], viol = st[ST_R1];
+        if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
+        const double phi0 = st[ST_COST] + nu_pen * viol;
+        const double dphi = fmin(gd - nu_pen * viol, 0.0);
+        T::sync();
+        const double a_step = K::linesearch(nu_pen, phi0, dphi);
+        if (a_step < 0.0) {                                  // no decrease left within 2^-40: the iteration has stalled
+            if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
+            if (resets >= 5) { code = -4; break; }
+            // far from a solution: the curvature estimate has gone bad -- forget it and try a steepest-descent-like step
+            ++resets;
+            K::reset_hessian();
+            have_old = false;
+            ++it;
+            continue;
+        }
+        f_prev = st[ST_COST];
+        T::sync();
+        K::update(a_step);
+        step_l1 = st[ST_R0]; z_l1 = st[ST_R1]; step_max = st[ST_R2];
+        T::sync();
+        a_prev = a_step; have_old = true; stepped = true;
+        ++it;
+    }
+    K::finish(code, it);
+    (void)NT;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+#if !defined(__HIPCC_RTC__)
+// the LDS / workspace plan of the workgroup form for controller m (dimensions, bounds) and the hard / soft flag; 0, or -2 if the
+// shape does not fit (the caller falls back to nlmpc_sqp)
+template <class Mdl>
+inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P)
+{
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
+    const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
+    if (ph > 64 || ph >= 255 || mu_ >= (1 << 23) || 3 * NX + NU + 1 > 64 || m.nr >= 0xffff) return -2;
+    P = WgPlan{};
+    P.hard = hard ? 1 : 0;
+    P.nq = hard ? m.nzu : nr;
+    // structure: dense columns and Jacobian block slots
+    int nsx = 0, ndu = 0;
+    bool reads_x = false;
+    for (int k = 0; k < mu_; ++k) {
+        int cnt = 0;
+        for (int i = 1; i <= ph; ++i) cnt += (k < mi ? Mdl::ineq_reads_x(k, i) : Mdl::eq_reads_x(k - mi, i)) ? 1 : 0;
+        nsx += cnt;
+        if (cnt > 0) reads_x = true;
+        if (cnt > 0 || !Mdl::XFREE_ROWS_SPARSE) ++ndu;
+    }
+    const int nsb = state_bounds;                          // finite bounds on states: the first rows of the bound table
+    P.nsx = nsx; P.nd_user = ndu; P.nsb = nsb; P.nd = ndu + nsb; P.ndld = (P.nd + 1) | 1;
+    P.needs_phi = (reads_x || nsb > 0) ? 1 : 0;
+    // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
+    auto imin = [](int a, int b) { return a < b ? a : b; };
+    auto imax = [](int a, int b) { return a > b ? a : b; };
+    P.kw = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
+    int waves = waves_wanted;
+    if (waves <= 0) waves = nz >= 96 ? 4 : (nz >= 48 ? 2 : 1);
+    if (waves != 1 && waves != 2 && waves != 4) return -2;
+    P.waves = waves;
+    for (int f_lds = 1; f_lds >= 0; --f_lds) {
+        int o = kWgCtxDoubles;
+        auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
+        P.f_lds = f_lds;
+        P.o_red = take(16); P.o_st = take(ST_TOTAL);
+        P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr); P.o_p = take(nr);
+        P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
+        P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
+        P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
+        P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = take(nr * P.ndld);
+        P.o_wq = take((P.kw + 1) / 2); P.o_sgq = take(P.kw); P.o_uq = take(P.kw); P.o_tq = take(P.kw); P.o_invd = take(P.kw);
+        P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
+        P.o_F = f_lds ? take(ph * NX * FW) : 0;
+        const int ov = o;
+        P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
+        P.o_Jm = take(ph * NU); P.o_lam = take(nxs); P.o_dx = take(nxs);
+        const int endA = o;
+        o = ov;
+        P.o_L = take(P.kw * (P.kw + 1) / 2);
+        P.lds_total = imax(endA, o);
+        if ((size_t)P.lds_total * sizeof(double) <= 160 * 1024) break;
+        if (f_lds == 0) return -2;
+    }
+    {
+        int o = 0;
+        auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
+        P.w_scal = take(16);
+        P.w_F = take(P.f_lds ? 0 : ph * NX * FW);
+        P.w_einv = take(Mdl::CONTINUOUS ? ph * NX * NX : 0);
+        P.w_gx = take(nxs);
+        P.w_hinv = take(nr * (nr + 1) / 2);
+        P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
+        P.ws_total = o;
+    }
+    return 0;
+}
+
+template <class Mdl>
+int launch_solve_wg(const NlmpcDev *m, const NlmpcSolveDev *b, const WgPlan *P, void *stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)P->lds_total * sizeof(double);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        if (getenv("MPCX_DEBUG_OCCUPANCY")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, P->waves * 64, lds);
+            fprintf(stderr, "nlmpc_sqp_wg: %d workgroups of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; blocks in LDS %d\n",
+                    b->batch, P->waves, lds, nb, P->f_lds);
+        }
+        hipLaunchKernelGGL(kern, dim3(b->batch), dim3(P->waves * 64), lds, s, *m, *b, *P);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    };
+    if (P->f_lds) {
+        if (P->waves == 4) return go(nlmpc_sqp_wg<Mdl, 4, true>);
+        if (P->waves == 2) return go(nlmpc_sqp_wg<Mdl, 2, true>);
+        return go(nlmpc_sqp_wg<Mdl, 1, true>);
+    }
+    if (P->waves == 4) return go(nlmpc_sqp_wg<Mdl, 4, false>);
+    if (P->waves == 2) return go(nlmpc_sqp_wg<Mdl, 2, false>);
+    return go(nlmpc_sqp_wg<Mdl, 1, false>);
+}
+#endif   // !__HIPCC_RTC__
+
+}  // namespace engine
+}  // namespace mpcx

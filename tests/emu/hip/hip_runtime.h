@@ -38,6 +38,8 @@ typedef struct ihipStream_t *hipStream_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 0; return hipSuccess; }
 
 extern "C" void hipemu_switch(void **save_sp, void *new_sp);
@@ -54,7 +56,7 @@ struct State {
     void *sp[kMaxThreads] = {};
     void *main_sp = nullptr;
     char *stacks = nullptr;
-    size_t stack_bytes = 512 * 1024;
+    size_t stack_bytes = 2048 * 1024;
     bool done[kMaxThreads] = {};
     const char *where[kMaxThreads] = {};
     long idle_switches = 0;

@@ -80,9 +80,12 @@ static int run(int argc, char **argv)
     const int mt = M.nineq + M.nue + M.nbnd;
     size_t ws_total = M.ws.total;
 #ifdef HIPEMU_WITH_WG
-    wg::WgPlan P{};
+    engine::WgPlan P{};
     if (form == "wg") {
-        if (wg::plan<Mdl>(M, hard, P) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
+        int nsb = 0;
+        for (int k = 0; k < M.nbnd; ++k) nsb += bidx[k] < nxs ? 1 : 0;
+        const int waves = getenv("HIPEMU_WAVES") ? atoi(getenv("HIPEMU_WAVES")) : 0;
+        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
         ws_total = P.ws_total;
         if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total);
     }
@@ -100,7 +103,7 @@ static int run(int argc, char **argv)
     auto solve = [&]() {
         int rc;
 #ifdef HIPEMU_WITH_WG
-        if (form == "wg") rc = wg::launch_solve_wg<Mdl>(&M, &S, &P, nullptr);
+        if (form == "wg") rc = engine::launch_solve_wg<Mdl>(&M, &S, &P, nullptr);
         else
 #endif
             rc = engine::launch_solve<Mdl>(nullptr, &M, &S, nullptr);
