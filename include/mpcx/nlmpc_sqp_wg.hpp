@@ -41,7 +41,7 @@ struct WgPlan {
     int lds_total;              // doubles
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
-        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_xq, o_np, o_vv, o_zd, o_wv, o_F;
+        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
@@ -72,6 +72,16 @@ __device__ __forceinline__ double *wg_lds()
     return smem;
 }
 __device__ __forceinline__ const WgCtx &wg_ctx() { return *reinterpret_cast<const WgCtx *>(wg_lds()); }
+
+// a value every lane holds (read from the context block in LDS) as a scalar: loop bounds and base addresses in SGPRs
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL> __device__ __forceinline__ double row_share(double v) { return dpp_d<CTRL>(v); }      // 0x150 + n: lane n of every row of 16
 
 template <int P> __device__ __forceinline__ double group_sum(double v)      // over P adjacent lanes (P = 1, 2, 4, 8, 16), every lane gets the sum
 {
@@ -262,22 +272,26 @@ struct WgSqp {
     struct V {                                                 // the views of the LDS block a phase needs, re-derived from the context
         const WgCtx &C;
         double *sm;
-        __device__ __forceinline__ V() : C(wg_ctx()), sm(wg_lds()) {}
-        __device__ __forceinline__ double *at(int off) const { return sm + off; }
-        __device__ __forceinline__ int *iat(int off) const { return reinterpret_cast<int *>(sm + off); }
+        double *w;                                             // this instance's workspace
+        int ph, ch, nz, nxs, nzu, nr, mi, m, mt, nq, ndld, kw; // (scalars)
+        __device__ __forceinline__ V()
+            : C(wg_ctx()), sm(wg_lds()), w(uni(C.w)), ph(uni(C.M.ph)), ch(uni(C.M.ch)), nz(uni(C.M.nz)), nxs(ph * NX), nzu(uni(C.M.nzu)),
+              nr(nzu + 1), mi(uni(C.M.nineq)), m(mi + uni(C.M.nue)), mt(m + uni(C.M.nbnd)), nq(uni(C.P.nq)), ndld(uni(C.P.ndld)), kw(uni(C.P.kw)) {}
+        __device__ __forceinline__ double *at(int off) const { return sm + uni(off); }
+        __device__ __forceinline__ int *iat(int off) const { return reinterpret_cast<int *>(sm + uni(off)); }
     };
     // the folded blocks: LDS or workspace, the pointer typed accordingly
     template <bool FL> struct FP {
         typedef typename BlockPtr<FL>::type type;
-        static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + v.C.P.o_F : v.C.w + v.C.P.w_F); }
+        static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + uni(v.C.P.o_F) : v.w + uni(v.C.P.w_F)); }
     };
 
     // the sparse form of sub-problem row k (as in nlmpc_sqp): first entry and count in LDS, entries 1 .. 3 in the workspace
     struct Sp {
         const double *s1v; const int *s1m; const double *spv; const int *spi;
         __device__ __forceinline__ explicit Sp(const V &v)
-            : s1v(v.at(v.C.P.o_s1v)), s1m(v.iat(v.C.P.o_s1m)), spv(v.C.w + v.C.P.w_sp),
-              spi(reinterpret_cast<const int *>(v.C.w + v.C.P.w_sp + (size_t)(v.C.M.nineq + v.C.M.nue + v.C.M.nbnd) * kNlSparse)) {}
+            : s1v(v.at(v.C.P.o_s1v)), s1m(v.iat(v.C.P.o_s1m)), spv(v.w + uni(v.C.P.w_sp)),
+              spi(reinterpret_cast<const int *>(v.w + uni(v.C.P.w_sp) + (size_t)v.mt * kNlSparse)) {}
         __device__ __forceinline__ int count(int k) const { return s1m[k] >> 16; }
         __device__ __forceinline__ int index(int k, int j) const { return j == 0 ? (s1m[k] & 0xffff) : spi[k * kNlSparse + j]; }
         __device__ __forceinline__ double value(int k, int j) const { return j == 0 ? s1v[k] : spv[k * kNlSparse + j]; }
@@ -297,12 +311,16 @@ struct WgSqp {
     {
         const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nzu = M.nzu, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd;
+        const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt;
+        const int nbnd = mt - m, nsb = uni(P.nsb), nd_user = uni(P.nd_user);
         double *z = v.at(P.o_z), *hinv = v.at(P.o_hinv), *mu = v.at(P.o_mu), *st = v.at(P.o_st);
         int *flag = v.iat(P.o_flag), *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *slot = v.iat(P.o_slot), *sbf = v.iat(P.o_sbf);
         unsigned long long *xmask = reinterpret_cast<unsigned long long *>(v.at(P.o_xmask));
-        if (S.z_warm) {
-            const double *zw = S.z_warm + (size_t)C.b * nz;
+        const double *x0 = uni(C.x0), *u0 = uni(C.u0), *zwarm = uni(S.z_warm);
+        const double *zlb = uni(M.zlb), *zub = uni(M.zub);
+        const int *bnd_idx = uni(M.bnd_idx);
+        if (zwarm) {
+            const double *zw = zwarm + (size_t)uni(C.b) * nz;
             for (int k = tid; k < nxs; k += NT) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
             for (int k = tid; k < nzu; k += NT) {
                 const int bl = k / NU, j = k - bl * NU;
@@ -311,13 +329,13 @@ struct WgSqp {
             }
             if (tid == 0) z[nz - 1] = zw[nz - 1];
         } else {
-            for (int k = tid; k < nxs; k += NT) z[k] = C.x0[k % NX];
-            for (int k = tid; k < nzu; k += NT) z[nxs + k] = C.u0[k % NU];
+            for (int k = tid; k < nxs; k += NT) z[k] = x0[k % NX];
+            for (int k = tid; k < nzu; k += NT) z[nxs + k] = u0[k % NU];
             if (tid == 0) z[nz - 1] = 0.0;
         }
         const int nh = nr * (nr + 1) / 2;
-        if (S.keep_curvature) {                               // the estimate the previous tick's solve left in the workspace
-            const double *hs = C.w + P.w_hinv;
+        if (uni(S.keep_curvature)) {                          // the estimate the previous tick's solve left in the workspace
+            const double *hs = v.w + uni(P.w_hinv);
             for (int e = tid; e < nh; e += NT) hinv[e] = hs[e];
         } else {
             for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
@@ -327,7 +345,7 @@ struct WgSqp {
         T::sync();
         // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
         for (int k = tid; k < nz; k += NT) {
-            const double lo = M.zlb[k], hi = M.zub[k];
+            const double lo = zlb[k], hi = zub[k];
             if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
         }
         // which state rows a user row reads (bit i-1: X row i, i = 1 .. ph; row 0 is x0, not a variable)
@@ -350,39 +368,32 @@ struct WgSqp {
             jxoff[m] = ns;
         }
         // bounds: those on states come first in the table (ascending index) and are dense rows after the user's
-        for (int kb = tid; kb < M.nbnd; kb += NT) dcol[m + kb] = M.bnd_idx[kb] < nxs ? P.nd_user + kb : -1;
+        for (int kb = tid; kb < nbnd; kb += NT) dcol[m + kb] = bnd_idx[kb] < nxs ? nd_user + kb : -1;
         for (int i = tid; i <= ph; i += NT) {                 // first state bound of state row i + 1 (z entries i NX ..)
             int f = 0;
-            while (f < P.nsb && M.bnd_idx[f] < i * NX) ++f;
+            while (f < nsb && bnd_idx[f] < i * NX) ++f;
             sbf[i] = f;
         }
         T::sync();
     }
 
     // ------------------------------------------------------------------------------------------------------------------------------
-    // evaluate at z: cost (+ forward-difference gradient), dynamics defects (+ folded blocks), user constraints (+ Jacobian blocks,
-    // the sub-problem's rows as far as they do not depend on the sweep).  values_only: the last evaluation of a solve.
-    template <bool FL>
-    static MPCX_WG_PHASE void eval(int values_only)
+    // Evaluation at z, in three parts.  values_only: the last evaluation of a solve.
+    // (1) Mapping::unwrapVector (Mapping.hpp:174-211), Objective::evaluate + computeGradient (Objective.hpp:91-265)
+    static MPCX_WG_PHASE void eval_cost(int values_only)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nzu = M.nzu, mi = M.nineq, m = mi + M.nue;
-        const int nq = P.nq, ndld = P.ndld;
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu;
         const double dv = kDv;
-        const double *prm = C.prm;
+        const double *prm = uni(C.prm), *x0 = uni(C.x0);
         const Scale sc(M);
         double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *Jm = v.at(P.o_Jm), *lam = v.at(P.o_lam), *st = v.at(P.o_st),
-               *gu = v.at(P.o_gu), *c = v.at(P.o_c), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br),
-               *s1v = v.at(P.o_s1v);
-        int *s1m = v.iat(P.o_s1m);
-        const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
-        const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
-        gwp gxg = (gwp)(C.w + P.w_gx);
-        // Mapping::unwrapVector
+               *gu = v.at(P.o_gu);
+        gwp gxg = (gwp)(v.w + uni(P.w_gx));
         for (int k = tid; k < (ph + 1) * NX; k += NT) {
             const int i = k / NX, j = k - i * NX;
-            Xs[k] = sc.over_ss(i == 0 ? C.x0[j] : z[(i - 1) * NX + j], j);
+            Xs[k] = sc.over_ss(i == 0 ? x0[j] : z[(i - 1) * NX + j], j);
         }
         for (int k = tid; k < (ph + 1) * NU; k += NT) {
             const int i = k / NU, j = k - i * NU;
@@ -393,39 +404,48 @@ struct WgSqp {
         auto Xa = [&](int j) { const double a = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
         auto Ua = [&](int j) { const double a = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
         const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
-
-        // ---- Objective::evaluate + computeGradient (Objective.hpp:91-265)
-        {
-            const double f0 = Mdl::cost(X0, U0, e, ph, prm);
-            if (tid == 0) st[ST_COST] = f0;
-            if (!values_only) {
-                const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
-                const double de = fmax(dv, fabs(e)) * dv;
-                for (int idx = tid; idx < nall; idx += NT) {
-                    const bool isx = idx < nxv, isu = !isx && idx < nxv + nuv;
-                    const int kk = isx ? idx : idx - nxv;
-                    const int i = isx ? kk / NX : (isu ? kk / NU : 0), j = isx ? kk - i * NX : (isu ? kk - i * NU : 0);
-                    const double dx = dv * Xa(j), du = dv * Ua(j);
-                    const Pert Xp{Xs, NX, isx ? i + 1 : -1, -1, isx ? j : -1, isx ? dx : 0.0};       // no chain rule for the state scaling (Objective.hpp:107-144)
-                    const Pert Up{Us, NU, isu ? i : -1, (isu && i == ph - 1) ? ph : -1, isu ? j : -1, isu ? du : 0.0};   // the last row moves with its copy
-                    const double ee = idx == nall - 2 ? e + de : (idx == nall - 1 ? e - de : e);
-                    const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
-                    if (isx) { const double gk = (fp - f0) / dx; lam[kk] = gk; gxg[kk] = gk; }
-                    else if (isu) Jm[kk] = (fp - f0) / du;
-                    else st[idx == nall - 2 ? ST_FP : ST_FM] = fp;
-                }
-                T::sync();
-                for (int k = tid; k < nzu; k += NT) {
-                    const int bl = k / NU, j = k - bl * NU;
-                    double s = 0;
-                    for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
-                    gu[k] = sc.by_su(s, j);                                  // Iz2u' * vec(Jmv)
-                }
-                if (tid == 0) gu[nzu] = (st[ST_FP] - st[ST_FM]) / (2 * de);
+        const double f0 = Mdl::cost(X0, U0, e, ph, prm);
+        if (tid == 0) st[ST_COST] = f0;
+        if (!values_only) {
+            const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
+            const double de = fmax(dv, fabs(e)) * dv;
+            for (int idx = tid; idx < nall; idx += NT) {
+                const bool isx = idx < nxv, isu = !isx && idx < nxv + nuv;
+                const int kk = isx ? idx : idx - nxv;
+                const int i = isx ? kk / NX : (isu ? kk / NU : 0), j = isx ? kk - i * NX : (isu ? kk - i * NU : 0);
+                const double dx = dv * Xa(j), du = dv * Ua(j);
+                const Pert Xp{Xs, NX, isx ? i + 1 : -1, -1, isx ? j : -1, isx ? dx : 0.0};       // no chain rule for the state scaling (Objective.hpp:107-144)
+                const Pert Up{Us, NU, isu ? i : -1, (isu && i == ph - 1) ? ph : -1, isu ? j : -1, isu ? du : 0.0};   // the last row moves with its copy
+                const double ee = idx == nall - 2 ? e + de : (idx == nall - 1 ? e - de : e);
+                const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
+                if (isx) { const double gk = (fp - f0) / dx; lam[kk] = gk; gxg[kk] = gk; }
+                else if (isu) Jm[kk] = (fp - f0) / du;
+                else st[idx == nall - 2 ? ST_FP : ST_FM] = fp;
             }
+            T::sync();
+            for (int k = tid; k < nzu; k += NT) {
+                const int bl = k / NU, j = k - bl * NU;
+                double s = 0;
+                for (int i = 0; i < ph; ++i) if (min(i, ch - 1) == bl) s += Jm[i * NU + j];
+                gu[k] = sc.by_su(s, j);                                  // Iz2u' * vec(Jmv)
+            }
+            if (tid == 0) gu[nzu] = (st[ST_FP] - st[ST_FM]) / (2 * de);
         }
+        T::sync();
+    }
 
-        // ---- Constraints::getStateEqConstraints (Constraints.hpp:490-905): defects, and the blocks folded with E^-1
+    // (2) Constraints::getStateEqConstraints (Constraints.hpp:490-905): the defects, and the Jacobian blocks folded with E^-1
+    template <bool FL>
+    static MPCX_WG_PHASE void eval_dyn(int values_only)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+        const int ph = v.ph;
+        const double dv = kDv;
+        const double *prm = uni(C.prm);
+        const Scale sc(M);
+        const double *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
+        double *c = v.at(P.o_c);
         const double h = 0.5 * M.Ts;
         if (values_only) {
             for (int i = tid; i < ph; i += NT) {
@@ -448,94 +468,106 @@ struct WgSqp {
                 double xk[NX], uk[NU], f1[NX], f2[NX];
                 for (int a = 0; a < NX; ++a) xk[a] = Xs[i * NX + a];
                 for (int a = 0; a < NU; ++a) uk[a] = Us[i * NU + a];
-                if (cc == FW - 1) {
-                    Mdl::f(f1, xk, uk, prm);
-                    for (int a = 0; a < NX; ++a) {
-                        const double cv = sc.over_ss(Xs[(i + 1) * NX + a] - f1[a], a);
-                        c[i * NX + a] = cv; F[(size_t)(i * NX + a) * FW + cc] = -cv;
-                    }
-                    continue;
-                }
-                const bool isu = cc >= NX;
+                const bool isv = cc == FW - 1, isu = cc >= NX;
                 const int vv = isu ? cc - NX : cc;
-                const double base = isu ? uk[vv] : xk[vv];
-                const double d = dv * fmax(fabs(base), 1.0);
-                if (isu) uk[vv] = base + d; else xk[vv] = base + d;
+                double base = 0.0;
+                for (int a = 0; a < NX; ++a) if (!isv && !isu && a == vv) base = xk[a];
+                for (int a = 0; a < NU; ++a) if (!isv && isu && a == vv) base = uk[a];
+                const double d = isv ? 0.0 : dv * fmax(fabs(base), 1.0);
+                for (int a = 0; a < NX; ++a) if (!isv && !isu && a == vv) xk[a] = base + d;
+                for (int a = 0; a < NU; ++a) if (!isv && isu && a == vv) uk[a] = base + d;
                 Mdl::f(f1, xk, uk, prm);
-                if (isu) uk[vv] = base - d; else xk[vv] = base - d;
+                for (int a = 0; a < NX; ++a) if (!isv && !isu && a == vv) xk[a] = base - d;
+                for (int a = 0; a < NU; ++a) if (!isv && isu && a == vv) uk[a] = base - d;
                 Mdl::f(f2, xk, uk, prm);
                 for (int a = 0; a < NX; ++a) {
-                    const double dcl = (f1[a] - f2[a]) / (2 * d);
-                    // Jacobian entries: -Sx A Tx (state columns), -Sx B su (input columns); folded: their negatives
-                    F[(size_t)(i * NX + a) * FW + cc] = isu ? sc.by_su(sc.over_ss(dcl, a), vv) : sc.over_ss(sc.by_ss(dcl, vv), a);
+                    double out;
+                    if (isv) {
+                        const double cv = sc.over_ss(Xs[(i + 1) * NX + a] - f1[a], a);
+                        c[i * NX + a] = cv; out = -cv;
+                    } else {
+                        const double dcl = (f1[a] - f2[a]) / (2 * d);
+                        // Jacobian entries: -Sx A Tx (state columns), -Sx B su (input columns); folded: their negatives
+                        out = isu ? sc.by_su(sc.over_ss(dcl, a), vv) : sc.over_ss(sc.by_ss(dcl, vv), a);
+                    }
+                    F[(size_t)(i * NX + a) * FW + cc] = out;
                 }
             }
         } else {
             // collocation: per step a Gauss-Jordan on [E | A B c | I], one column per lane in registers; G steps per wavefront at a time
             typename FP<FL>::type F = FP<FL>::get(v);
-            gwp einv = (gwp)(C.w + P.w_einv);
+            gwp einv = (gwp)(v.w + uni(P.w_einv));
             constexpr int G = 64 / GW > 0 ? 64 / GW : 1;
             const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
+            // kind of column: 0 E (perturb x_{i+1}), 1 A (perturb x_i), 2 B (perturb u_i), 3 the defect, 4 identity
+            const int kind = cidx < NX ? 0 : (cidx < 2 * NX ? 1 : (cidx < 2 * NX + NU ? 2 : (cidx == 2 * NX + NU ? 3 : 4)));
+            const int vv = kind == 0 ? cidx : (kind == 1 ? cidx - NX : (kind == 2 ? cidx - 2 * NX : (kind == 4 ? cidx - (2 * NX + NU + 1) : 0)));
             for (int i0 = wave * G; i0 < ph; i0 += WAVES * G) {
                 const int i = i0 + g;
                 const bool live = g < G && i < ph;
                 const int ii = live ? i : ph - 1;
-                double xk[NX], xk1[NX], uk[NU], col[NX];
-                for (int a = 0; a < NX; ++a) { xk[a] = Xs[ii * NX + a]; xk1[a] = Xs[(ii + 1) * NX + a]; }
-                for (int a = 0; a < NU; ++a) uk[a] = Us[ii * NU + a];
-                // kind of column: 0 E (perturb x_{i+1}), 1 A (perturb x_i), 2 B (perturb u_i), 3 the defect, 4 identity
-                const int kind = cidx < NX ? 0 : (cidx < 2 * NX ? 1 : (cidx < 2 * NX + NU ? 2 : (cidx == 2 * NX + NU ? 3 : 4)));
-                const int vv = kind == 0 ? cidx : (kind == 1 ? cidx - NX : (kind == 2 ? cidx - 2 * NX : (kind == 4 ? cidx - (2 * NX + NU + 1) : 0)));
-                // two evaluations of the vector field per pass, the same call sites for every kind of column
-                auto pair = [&](const bool at_next, double (&o1)[NX], double (&o2)[NX], double &dstep) {
-                    double xp[NX], up[NU];
-                    for (int a = 0; a < NX; ++a) xp[a] = at_next ? xk1[a] : xk[a];
-                    for (int a = 0; a < NU; ++a) up[a] = uk[a];
-                    const bool isu = kind == 2, pert = kind <= 2;
-                    double bs = 0.0;
-                    for (int a = 0; a < NX; ++a) if (!isu && a == vv) bs = xp[a];
-                    for (int a = 0; a < NU; ++a) if (isu && a == vv) bs = up[a];
-                    const double d = pert ? dv * fmax(fabs(bs), 1.0) : 0.0;
-                    dstep = d;
-                    for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs + d;
-                    for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs + d;
-                    Mdl::f(o1, xp, up, prm);
-                    if (kind == 3) { for (int a = 0; a < NX; ++a) xp[a] = xk1[a]; }          // the defect's second evaluation is at x_{i+1}
-                    for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs - d;
-                    for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs - d;
-                    Mdl::f(o2, xp, up, prm);
-                };
-                double f1[NX], f2[NX], d1 = 0.0;
-                pair(kind == 0, f1, f2, d1);
-                if (kind == 0) for (int a = 0; a < NX; ++a) col[a] = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss((f1[a] - f2[a]) / (2 * d1), vv), a);
-                else if (kind == 1) for (int a = 0; a < NX; ++a) col[a] = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss((f1[a] - f2[a]) / (2 * d1), vv), a);
-                else if (kind == 3) {
-                    for (int a = 0; a < NX; ++a) col[a] = sc.over_ss(xk[a] + (h * (f1[a] + f2[a])) - xk1[a], a);
-                    if (live) for (int a = 0; a < NX; ++a) c[i * NX + a] = col[a];
-                } else if (kind == 4) for (int a = 0; a < NX; ++a) col[a] = a == vv ? 1.0 : 0.0;
+                double col[NX];
                 {
-                    double g1[NX], g2[NX], d2 = 0.0;                      // the input columns need the pair at x_{i+1} too
-                    pair(true, g1, g2, d2);
-                    if (kind == 2) for (int a = 0; a < NX; ++a) col[a] = sc.by_su(h * sc.over_ss((f1[a] - f2[a]) / (2 * d1) + (g1[a] - g2[a]) / (2 * d2), a), vv);
+                    double xk[NX], xk1[NX], uk[NU];
+                    for (int a = 0; a < NX; ++a) { xk[a] = Xs[ii * NX + a]; xk1[a] = Xs[(ii + 1) * NX + a]; }
+                    for (int a = 0; a < NU; ++a) uk[a] = Us[ii * NU + a];
+                    // two passes of two evaluations of the vector field, the same call sites for every kind of column:
+                    // pass 0 at x_i (E: at x_{i+1}), pass 1 at x_{i+1} (used by the input columns and the defect only)
+                    double acc[NX];
+                    for (int a = 0; a < NX; ++a) acc[a] = 0.0;
+#pragma unroll 1
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const bool at_next = pass == 1 || kind == 0;
+                        double xp[NX], up[NU], o1[NX], o2[NX];
+                        for (int a = 0; a < NX; ++a) xp[a] = at_next ? xk1[a] : xk[a];
+                        for (int a = 0; a < NU; ++a) up[a] = uk[a];
+                        const bool isu = kind == 2, pert = kind <= 2;
+                        double bs = 0.0;
+                        for (int a = 0; a < NX; ++a) if (!isu && a == vv) bs = xp[a];
+                        for (int a = 0; a < NU; ++a) if (isu && a == vv) bs = up[a];
+                        const double d = pert ? dv * fmax(fabs(bs), 1.0) : 1.0;
+                        for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs + d;
+                        for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs + d;
+                        Mdl::f(o1, xp, up, prm);
+                        for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs - d;
+                        for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs - d;
+                        Mdl::f(o2, xp, up, prm);
+                        // derivative columns: the central difference; the defect: f(x_i, u_i) on pass 0, f(x_{i+1}, u_i) on pass 1
+                        const bool use = pass == 0 || kind >= 2;
+                        for (int a = 0; a < NX; ++a) acc[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) / (2 * d));
+                    }
+                    for (int a = 0; a < NX; ++a) {
+                        const double da = acc[a];
+                        double cv;
+                        if (kind == 0) cv = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
+                        else if (kind == 1) cv = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
+                        else if (kind == 2) cv = sc.by_su(h * sc.over_ss(da, a), vv);
+                        else if (kind == 3) cv = sc.over_ss(xk[a] + (h * da) - xk1[a], a);
+                        else cv = a == vv ? 1.0 : 0.0;
+                        col[a] = cv;
+                    }
+                    if (live && kind == 3) for (int a = 0; a < NX; ++a) c[i * NX + a] = col[a];
                 }
-                // Gauss-Jordan with partial pivoting; the pivot column is lane base + k
-#pragma unroll
+                // Gauss-Jordan with partial pivoting.  The rows rotate by one per step, so that the pivot row is always register 0 and
+                // the loop body is the same for every step (no unrolling over the steps); after NX steps they are back in place.
+#pragma unroll 1
                 for (int k = 0; k < NX; ++k) {
-                    int pr = k;
-                    double best = fabs(col[k]);
+                    int pr = 0;
+                    double best = fabs(col[0]);
 #pragma unroll
-                    for (int a = k + 1; a < NX; ++a) { const double av = fabs(col[a]); if (av > best) { best = av; pr = a; } }
-                    pr = __shfl(pr, base + k);
-                    double cp = col[k];
+                    for (int a = 1; a < NX; ++a) { const double av = fabs(col[a]); if (a < NX - k && av > best) { best = av; pr = a; } }
+                    pr = __shfl(pr, base + k);                           // the pivot column's choice
+                    double cp = col[0];
 #pragma unroll
-                    for (int a = k + 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[k]; }
-                    col[k] = cp;
-                    double mlt[NX];
+                    for (int a = 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[0]; }
+                    const double piv = __shfl(cp, base + k);
+                    const double cs = cp / piv;
+                    double nxt[NX];
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) mlt[a] = __shfl(col[a], base + k);
-                    const double cs = col[k] / mlt[k];
+                    for (int a = 1; a < NX; ++a) { const double ml = __shfl(col[a], base + k); nxt[a - 1] = fma(-ml, cs, col[a]); }
+                    nxt[NX - 1] = cs;
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) col[a] = a == k ? cs : fma(-mlt[a], cs, col[a]);
+                    for (int a = 0; a < NX; ++a) col[a] = nxt[a];
                 }
                 if (live) {
                     if (kind == 1) for (int a = 0; a < NX; ++a) F[(size_t)(i * NX + a) * FW + vv] = -col[a];
@@ -545,14 +577,34 @@ struct WgSqp {
                 }
             }
         }
+        T::sync();
+    }
 
-        // ---- Constraints::evaluateIneq / evaluateEq (Constraints.hpp:211-442): values
+    // (3) Constraints::evaluateIneq / evaluateEq (Constraints.hpp:211-442) and their Jacobians (computeIneqJacobian :641-721,
+    // computeEqJacobian :731-832) as blocks: one NX-vector per (row, state row) pair, the input part straight into the sub-problem's rows
+    static MPCX_WG_PHASE void eval_con(int values_only)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu, mi = v.mi, m = v.m, mt = v.mt, nq = v.nq, ndld = v.ndld;
+        const int nsx = uni(P.nsx);
+        const double dv = kDv;
+        const double *prm = uni(C.prm);
+        const Scale sc(M);
+        const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
+        double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
+        int *s1m = v.iat(P.o_s1m);
+        const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
+        const int *bnd_idx = uni(M.bnd_idx);
+        const double *bnd_sign = uni(M.bnd_sign), *bnd_val = uni(M.bnd_val);
+        const double e = z[nz - 1];
+        auto Xa = [&](int j) { const double a = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
+        auto Ua = [&](int j) { const double a = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
+        const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
         for (int k = tid; k < mi; k += NT) gin[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
-        for (int k = tid; k < M.nue; k += NT) gin[mi + k] = Mdl::eq(k, X0, U0, ph, prm);
+        for (int k = tid; k < m - mi; k += NT) gin[mi + k] = Mdl::eq(k, X0, U0, ph, prm);
         if (values_only) { T::sync(); return; }
-
-        // ---- their Jacobians (computeIneqJacobian :641-721, computeEqJacobian :731-832) as blocks: one NX-vector per (row, state row)
-        for (int t = tid; t < P.nsx * NX; t += NT) {
+        for (int t = tid; t < nsx * NX; t += NT) {
             const int sl = t / NX, j = t - sl * NX, k = slot[sl] >> 8, i = slot[sl] & 0xff;
             double val;
             if (k < mi) {
@@ -567,8 +619,8 @@ struct WgSqp {
             jx[t] = sc.by_ss(val, j);                            // the state columns are multiplied by the state scaling (Constraints.hpp:269-284)
         }
         // the input part, one lane per user row: into the row's column of art (dense rows) or its (index, value) list
-        gwp spv = (gwp)(C.w + P.w_sp);
-        int *spi = reinterpret_cast<int *>(C.w + P.w_sp + (size_t)(m + M.nbnd) * kNlSparse);
+        gwp spv = (gwp)(v.w + uni(P.w_sp));
+        int *spi = reinterpret_cast<int *>(v.w + uni(P.w_sp) + (size_t)mt * kNlSparse);
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
@@ -617,10 +669,10 @@ struct WgSqp {
             }
         }
         // rows of the bounds lb <= z + d <= ub (NLOptimizer::setStateBounds / setInputBounds): on an input one entry, on a state a row of Phi
-        for (int kb = tid; kb < M.nbnd; kb += NT) {
-            const int zi = M.bnd_idx[kb], k = m + kb;
-            const double sg = M.bnd_sign[kb];
-            br[k] = sg * (z[zi] - M.bnd_val[kb]);
+        for (int kb = tid; kb < mt - m; kb += NT) {
+            const int zi = bnd_idx[kb], k = m + kb;
+            const double sg = bnd_sign[kb];
+            br[k] = sg * (z[zi] - bnd_val[kb]);
             if (zi < nxs) {
                 const int dc = dcol[k];
                 s1v[k] = 0.0; s1m[k] = kSpDense;
@@ -637,72 +689,109 @@ struct WgSqp {
     // ------------------------------------------------------------------------------------------------------------------------------
     // A chain over the horizon with one column: v_{i+1} = Abar_i v_i + rhs_i (forward) or l_i = -rhs_i + Abar_{i+1}' l_{i+1} (backward),
     // in place in `io` (rhs in, result out), run by wavefront 0: four lanes share a row, the next step's entries are requested before this
-    // step computes.  Every thread of the workgroup calls it; the caller synchronises afterwards.
+    // step's are used.  Every thread of the workgroup calls it; the caller synchronises afterwards.
     template <bool FL, bool BACKWARD>
     static __device__ __forceinline__ void chain(const V &v, double *io, int tid)
     {
         if (tid >= 64) return;
-        const int ph = v.C.M.ph;
+        const int ph = v.ph;
         typename FP<FL>::type F = FP<FL>::get(v);
         constexpr int RP = 16;                                  // rows per pass
-        constexpr int CH = (NX + 3) / 4;
-        const int part = tid & 3;
+        constexpr int NP = (NX + RP - 1) / RP, CH = (NX + 3) / 4;
+        const int part = tid & 3, row = tid >> 2;
+        double fn[NP][CH];
+        auto fetch = [&](int blk) {                             // this lane's entries of block blk (or of its transpose)
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz) {
+                const int aa = min(pz * RP + row, NX - 1);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int bb = min(part + 4 * u, NX - 1);
+                    fn[pz][u] = BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb];
+                }
+            }
+        };
+        // forward: step i uses block i (from i = 1 on; v_0 = 0); backward: step i uses block i + 1 (up to i = ph - 2; l_ph = 0)
+        if (ph > 1) fetch(BACKWARD ? ph - 1 : 1);
         for (int step = 0; step < ph; ++step) {
             const int i = BACKWARD ? ph - 1 - step : step;
-            // forward: v_i = io[(i-1) NX ..] (zero for i = 0), result to io[i NX ..]; backward: l_{i+1} = io[(i+1) NX ..] (zero at the end)
-            const bool has_prev = BACKWARD ? i + 1 < ph : i > 0;
+            const bool has_prev = step > 0;
             const double *prev = io + (BACKWARD ? (i + 1) * NX : (i - 1) * NX);
-            const int blk = BACKWARD ? i + 1 : i;
-            double res[(NX + RP - 1) / RP];
+            double fc[NP][CH];
 #pragma unroll
-            for (int a0 = 0; a0 < NX; a0 += RP) {
-                const int a = a0 + (tid >> 2);
-                const bool rowlive = a < NX;
-                const int aa = rowlive ? a : 0;
+            for (int pz = 0; pz < NP; ++pz)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) fc[pz][u] = fn[pz][u];
+            if (step > 0 && step + 1 < ph) fetch(BACKWARD ? i : i + 1);
+            double res[NP];
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz) {
+                const int a = pz * RP + row;
+                const int aa = min(a, NX - 1);
                 double s = 0.0;
                 if (has_prev) {
-                    double fv[CH], pv[CH];
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) {
-                        const int bb = min(part + 4 * u, NX - 1);
-                        fv[u] = part + 4 * u < NX ? (BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb]) : 0.0;
-                        pv[u] = prev[bb];
-                    }
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) s = fma(fv[u], pv[u], s);
+                    for (int u = 0; u < CH; ++u) s = fma(part + 4 * u < NX ? fc[pz][u] : 0.0, prev[min(part + 4 * u, NX - 1)], s);
                 }
                 s = group_sum<4>(s);
                 const double rh = io[i * NX + aa];
-                res[a0 / RP] = BACKWARD ? s - rh : s + rh;
+                res[pz] = BACKWARD ? s - rh : s + rh;
             }
             nl_wave_sync();
 #pragma unroll
-            for (int a0 = 0; a0 < NX; a0 += RP) {
-                const int a = a0 + (tid >> 2);
-                if (a < NX && part == 0) io[i * NX + a] = res[a0 / RP];
+            for (int pz = 0; pz < NP; ++pz) {
+                const int a = pz * RP + row;
+                if (a < NX && part == 0) io[i * NX + a] = res[pz];
             }
             nl_wave_sync();
         }
     }
 
+    // the multipliers of the defects themselves from the chain's values, lam_i = E_i^-T l_i: this thread's share of max |lam|
+    static __device__ __forceinline__ double defect_multiplier_max(const V &v, const double *lam, int tid)
+    {
+        double lmax = 0.0;
+        if (CT) {
+            gwp einv = (gwp)(v.w + uni(v.C.P.w_einv));
+            for (int k = tid; k < v.nxs; k += NT) {
+                const int i = k / NX, a = k - i * NX;
+                double s = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < NX; ++bb) s = fma(einv[(size_t)(i * NX + bb) * NX + a], lam[i * NX + bb], s);
+                lmax = fmax(lmax, fabs(s));
+            }
+        } else {
+            for (int k = tid; k < v.nxs; k += NT) lmax = fmax(lmax, fabs(lam[k]));
+        }
+        return lmax;
+    }
+
     // ------------------------------------------------------------------------------------------------------------------------------
-    // condense + reduce: the reduced gradient gr, the dense rows of the sub-problem (art, br) completed with their state part.
-    // Leaves the largest dynamics multiplier in st[ST_LAMDYN] where no row reads a state.
+    // condense + reduce where a row of the sub-problem reads a state: one column of [Phi | r] per lane (NX <= 8: in registers) or per
+    // sixteen lanes (wider states: one entry per lane, the row products by DPP row_share), dx_{i+1} = Abar_i dx_i + (Bbar_i e_q | cbar_i).
+    // What the column is needed for is taken as the sweep passes: Phi' g_x, the rows of the user Jacobian and of the state bounds
+    // that read state row i + 1.
+    template <int BB> struct RowShare {
+        template <class FT> static __device__ __forceinline__ double dot(FT frow, double x, double acc)
+        {
+            if constexpr (BB < NX) return RowShare<BB + 1>::dot(frow, x, fma(frow[BB], row_share<0x150 + BB>(x), acc));
+            else return acc;
+        }
+    };
     template <bool FL>
-    static MPCX_WG_PHASE void condense()
+    static MPCX_WG_PHASE void condense_phi()
     {
         const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, ch = M.ch, nxs = ph * NX, nzu = M.nzu, mi = M.nineq, m = mi + M.nue;
-        const int ndld = P.ndld;
-        double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *gr = v.at(P.o_gr), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br),
-               *st = v.at(P.o_st);
+        const int ph = v.ph, ch = v.ch, nzu = v.nzu, mi = v.mi, m = v.m, ndld = v.ndld;
+        const double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *jx = v.at(P.o_jx);
+        double *gr = v.at(P.o_gr), *art = v.at(P.o_art), *br = v.at(P.o_br);
         const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
+        const int *bnd_idx = uni(M.bnd_idx);
+        const double *bnd_sign = uni(M.bnd_sign);
         typename FP<FL>::type F = FP<FL>::get(v);
-        if (P.needs_phi) {
-            // One column of [Phi | r] per lane, in registers: dx_{i+1} = Abar_i dx_i + (Bbar_i e_q | cbar_i).  What the column is needed for
-            // is taken as the sweep passes: Phi' g_x, the rows of the user Jacobian and of the state bounds that read state row i + 1.
+        if constexpr (NX <= 8) {
             for (int q = tid; q <= nzu; q += NT) {
                 const bool isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
@@ -736,8 +825,8 @@ struct WgSqp {
                     for (int k = first; k < first + count; ++k) if ((xmask[k] >> i) & 1ull) row(k);
                     for (int k = mi; k < m; ++k) if ((xmask[k] >> i) & 1ull) row(k);
                     for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
-                        const int a = M.bnd_idx[kb] - i * NX;
-                        const double sg = M.bnd_sign[kb];
+                        const int a = bnd_idx[kb] - i * NX;
+                        const double sg = bnd_sign[kb];
                         double xa = 0.0;
 #pragma unroll
                         for (int a2 = 0; a2 < NX; ++a2) if (a2 == a) xa = x[a2];
@@ -746,53 +835,89 @@ struct WgSqp {
                 }
                 if (!isr) gr[q] = gu[q] + gacc;
             }
-            if (tid == 0) gr[nzu] = gu[nzu];
         } else {
-            // no row reads a state: Jx' lam = -g_x by one backward chain (lam holds g_x on entry, the chain's multipliers afterwards)
-            chain<FL, true>(v, lam, tid);
-            T::sync();
-            for (int q = tid; q <= nzu; q += NT) {
-                if (q == nzu) { gr[q] = gu[q]; continue; }
+            static_assert(NX <= 16, "the workgroup form spreads a column over one DPP row");
+            const int a = tid & 15, aa = min(a, NX - 1);
+            const bool alive = a < NX;
+            for (int q0 = 0; q0 <= nzu; q0 += NT / 16) {
+                const int q = q0 + (tid >> 4);
+                const bool qlive = q <= nzu, isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
-                double s = gu[q];
-                for (int i = bq; i < (bq == ch - 1 ? ph : bq + 1); ++i) {
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) s = fma(-F[(size_t)(i * NX + a) * FW + NX + jq], lam[i * NX + a], s);
+                double x = 0.0, gacc = 0.0;
+                for (int i = 0; i < ph; ++i) {
+                    const bool drives = qlive && !isr && min(i, ch - 1) == bq;
+                    const double rh = !alive ? 0.0 : (isr ? F[(size_t)(i * NX + aa) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + aa) * FW + NX + jq] : 0.0));
+                    const double t = RowShare<0>::dot(F + (size_t)(i * NX + aa) * FW, x, rh);
+                    x = alive ? t : 0.0;
+                    gacc = fma(alive ? lam[i * NX + aa] : 0.0, x, gacc);
+                    auto row = [&](int k) {
+                        const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
+                        const double s = group_sum<16>(alive ? jx[sl * NX + aa] * x : 0.0);
+                        if (qlive && a == 0) { if (isr) br[k] += s; else art[q * ndld + dcol[k]] += s; }
+                    };
+                    int first, count;
+                    Mdl::ineq_rows_of_x(i + 1, first, count);
+                    for (int k = first; k < first + count; ++k) if ((xmask[k] >> i) & 1ull) row(k);
+                    for (int k = mi; k < m; ++k) if ((xmask[k] >> i) & 1ull) row(k);
+                    for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
+                        if (qlive && bnd_idx[kb] - i * NX == a) {
+                            const double sg = bnd_sign[kb];
+                            if (isr) br[m + kb] += sg * x; else art[q * ndld + dcol[m + kb]] = sg * x;
+                        }
+                    }
                 }
-                gr[q] = s;
+                gacc = group_sum<16>(gacc);
+                if (qlive && !isr && a == 0) gr[q] = gu[q] + gacc;
             }
-            // the multipliers of the defects themselves, for the merit weight: lam_i = E_i^-T (chain's value)
-            double lmax = 0.0;
-            if (CT) {
-                gwp einv = (gwp)(C.w + P.w_einv);
-                for (int k = tid; k < nxs; k += NT) {
-                    const int i = k / NX, a = k - i * NX;
-                    double s = 0.0;
-#pragma unroll
-                    for (int bb = 0; bb < NX; ++bb) s = fma(einv[(size_t)(i * NX + bb) * NX + a], lam[i * NX + bb], s);
-                    lmax = fmax(lmax, fabs(s));
-                }
-            } else {
-                for (int k = tid; k < nxs; k += NT) lmax = fmax(lmax, fabs(lam[k]));
-            }
-            Red<WAVES> R(v.at(P.o_red));
-            lmax = R.max(lmax);
-            if (tid == 0) st[ST_LAMDYN] = lmax;
         }
+        if (tid == 0) gr[nzu] = gu[nzu];
+        T::sync();
+    }
+    // ... and where none does: the reduced gradient through one backward chain (Jx' lam = -g_x; lam holds g_x on entry, the chain's
+    // multipliers afterwards).  Leaves the largest dynamics multiplier, which the merit weight has to dominate, in st[ST_LAMDYN].
+    template <bool FL>
+    static MPCX_WG_PHASE void condense_chain()
+    {
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int ph = v.ph, ch = v.ch, nzu = v.nzu;
+        double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *gr = v.at(P.o_gr), *st = v.at(P.o_st);
+        typename FP<FL>::type F = FP<FL>::get(v);
+        chain<FL, true>(v, lam, tid);
+        T::sync();
+        for (int q = tid; q <= nzu; q += NT) {
+            if (q == nzu) { gr[q] = gu[q]; continue; }
+            const int bq = q / NU, jq = q - bq * NU;
+            double s = gu[q];
+            for (int i = bq; i < (bq == ch - 1 ? ph : bq + 1); ++i) {
+#pragma unroll
+                for (int a = 0; a < NX; ++a) s = fma(-F[(size_t)(i * NX + a) * FW + NX + jq], lam[i * NX + a], s);
+            }
+            gr[q] = s;
+        }
+        Red<WAVES> R(v.at(P.o_red));
+        const double lmax = R.max(defect_multiplier_max(v, lam, tid));
+        if (tid == 0) st[ST_LAMDYN] = lmax;
         T::sync();
     }
 
-    // sum_t coef[t] * (normal of working row t)[q], the working set as it stands in wq / sgq
-    static __device__ __forceinline__ double ws_combine(const V &v, const Sp &sp, int nw, const double *coef, int q)
+    // the working set as it stands in LDS: row numbers, orientations, and where the rows' entries are (derived once per phase,
+    // outside any loop over lanes)
+    struct Ws {
+        const int *wq, *dcol;
+        const double *sgq, *art;
+        int ndld;
+        __device__ __forceinline__ explicit Ws(const V &v)
+            : wq(v.iat(v.C.P.o_wq)), dcol(v.iat(v.C.P.o_dcol)), sgq(v.at(v.C.P.o_sgq)), art(v.at(v.C.P.o_art)), ndld(v.ndld) {}
+    };
+    // sum_t coef[t] * (normal of working row t)[q]
+    static __device__ __forceinline__ double ws_combine(const Ws &W, const Sp &sp, int nw, const double *coef, int q)
     {
-        const WgPlan &P = v.C.P;
-        const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
-        const double *sgq = v.at(P.o_sgq), *art = v.at(P.o_art);
         double acc = 0.0;
         for (int t = 0; t < nw; ++t) {
-            const int k = wq[t], dc = dcol[k];
-            const double ml = sgq[t] * coef[t];
-            if (dc >= 0) acc = fma(art[q * P.ndld + dc], ml, acc);
+            const int k = W.wq[t], dc = W.dcol[k];
+            const double ml = W.sgq[t] * coef[t];
+            if (dc >= 0) acc = fma(W.art[q * W.ndld + dc], ml, acc);
             else {
                 const int cn = sp.count(k);
                 for (int j = 0; j < cn; ++j) if (sp.index(k, j) == q) acc = fma(sp.value(k, j), ml, acc);
@@ -807,14 +932,15 @@ struct WgSqp {
     {
         const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int nq = P.nq;
+        const int nq = v.nq;
         const Sp sp(v);
+        const Ws W(v);
         double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq);
         double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
         Red<WAVES> R(v.at(P.o_red));
         double sBs = 0, sy = 0;
         for (int q = tid; q < nq; q += NT) {
-            const double gl = gr[q] + ws_combine(v, sp, nw_keep, uq, q);
+            const double gl = gr[q] + ws_combine(W, sp, nw_keep, uq, q);
             const double y = gl - glold[q], Bs = -a_prev * glold[q];
             v0[q] = y; v1[q] = Bs;
             sBs += sv[q] * Bs; sy += sv[q] * y;
@@ -845,13 +971,13 @@ struct WgSqp {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // the normal n = sgn * (row k) of a sub-problem row and vv = B^-1 n, both into LDS (every thread calls; the caller synchronises)
-    static __device__ __forceinline__ void normal_and_hinv(const V &v, const Sp &sp, int k, double sgn, double *np_, double *vv, double *tmp, int tid)
+    static __device__ __forceinline__ void normal_and_hinv(const V &v, const Sp &sp, int k, double sgn, double *np_, double *vv, int tid)
     {
         const WgPlan &P = v.C.P;
-        const int nq = P.nq, dc = v.iat(P.o_dcol)[k];
+        const int nq = v.nq, dc = v.iat(P.o_dcol)[k];
         const double *hinv = v.at(P.o_hinv), *art = v.at(P.o_art);
         if (dc >= 0) {
-            for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * P.ndld + dc];
+            for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * v.ndld + dc];
             T::sync();
             hmul<NT>(hinv, np_, vv, nq, 1.0, tid);
         } else {
@@ -867,13 +993,12 @@ struct WgSqp {
                 np_[q] = nvl; vv[q] = hv;
             }
         }
-        (void)tmp;
     }
     // out[t] = (normal of working row t)' x for t < nw: four lanes share a row
     static __device__ __forceinline__ void ws_dots(const V &v, const Sp &sp, int nw, const double *x, double *out, int tid)
     {
         const WgPlan &P = v.C.P;
-        const int nq = P.nq, part = tid & 3;
+        const int nq = v.nq, part = tid & 3;
         const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
         const double *sgq = v.at(P.o_sgq), *art = v.at(P.o_art);
         for (int t0 = 0; t0 < nw; t0 += NT / 4) {
@@ -881,29 +1006,158 @@ struct WgSqp {
             const bool live = t < nw;
             const int k = wq[live ? t : 0], dc = dcol[k];
             double acc = 0.0;
-            if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * P.ndld + dc], x[q], acc); }
+            if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * v.ndld + dc], x[q], acc); }
             else if (part == 0) acc = sp.dot(k, x);
             acc = group_sum<4>(acc);
             if (live && part == 0) out[t] = sgq[t] * acc;
         }
     }
 
+    // tq <- S^-1 tq over the working set with its factor (wavefront 0); y = L^-1 tq is left in yv: the factor's next row if the entering
+    // row joins
+    static MPCX_WG_PHASE void ws_solve(int nw)
+    {
+        const V v; const WgPlan &P = v.C.P;
+        const int tid = threadIdx.x, lane = tid & 63;
+        double *tq = v.at(P.o_tq), *yv = v.at(P.o_yv);
+        if (tid < 64) {
+            const Factor Fac{v.at(P.o_L), v.at(P.o_invd), nullptr, nullptr, v.kw, 0};
+            double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
+            chol_forward<false>(Fac, nw, t0, t1, lane);
+            if (lane < nw) yv[lane] = t0;
+            if (lane + 64 < nw) yv[lane + 64] = t1;
+            chol_backward<false>(Fac, nw, t0, t1, lane);
+            if (lane < nw) tq[lane] = t0;
+            if (lane + 64 < nw) tq[lane + 64] = t1;
+        }
+        T::sync();
+    }
+    // row t leaves the working set of nw rows: the factor is down-dated, the lists close up
+    static MPCX_WG_PHASE void ws_drop(int kdrop, int nw)
+    {
+        const V v; const WgPlan &P = v.C.P;
+        const int tid = threadIdx.x, lane = tid & 63;
+        double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        if (tid < 64) chol_delete(v.at(P.o_L), v.at(P.o_invd), nw, kdrop, lane);
+        int kq = 0, kq2 = 0;
+        double sg = 0, u = 0, sg2 = 0, u2 = 0;
+        const bool mv = tid > kdrop && tid < nw;                 // (working sets hold at most 128 rows: one or two per thread)
+        const bool mv2 = tid + NT > kdrop && tid + NT < nw;
+        if (mv) { kq = wq[tid]; sg = sgq[tid]; u = uq[tid]; }
+        if (mv2) { kq2 = wq[tid + NT]; sg2 = sgq[tid + NT]; u2 = uq[tid + NT]; }
+        if (tid == 0) flag[wq[kdrop]] = 0;
+        T::sync();
+        if (mv) { wq[tid - 1] = kq; sgq[tid - 1] = sg; uq[tid - 1] = u; }
+        if (mv2) { wq[tid + NT - 1] = kq2; sgq[tid + NT - 1] = sg2; uq[tid + NT - 1] = u2; }
+        T::sync();
+    }
+    // the entering row joins as row nw of the factor (from yv) and of the lists
+    static MPCX_WG_PHASE void ws_append(int nw, int pidx, double sgn, double up, double snn)
+    {
+        const V v; const WgPlan &P = v.C.P;
+        const int tid = threadIdx.x, lane = tid & 63;
+        double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *yv = v.at(P.o_yv);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        if (tid < 64) {
+            const Factor Fac{v.at(P.o_L), v.at(P.o_invd), nullptr, nullptr, v.kw, 0};
+            const double y0 = lane < nw ? yv[lane] : 0.0, y1 = lane + 64 < nw ? yv[lane + 64] : 0.0;
+            chol_append<false>(Fac, nw, y0, y1, snn, snn, lane);
+        }
+        if (tid == 0) { uq[nw] = up; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+        T::sync();
+    }
+
+    // warm start of the sub-problem: the rows active in the previous one (wq, sgq) as long as their multipliers stay non-negative -- the
+    // minimiser on that set with u >= 0 is a valid state of the dual method.  xq holds -B^-1 gr on entry, the minimiser on the kept set
+    // on return; returns the number of rows kept.
+    static MPCX_WG_PHASE int ws_warm(int nw_keep)
+    {
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int mi = v.mi, m = v.m, nq = v.nq;
+        const Sp sp(v);
+        const Ws W(v);
+        double *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq), *invd = v.at(P.o_invd),
+               *Lp = v.at(P.o_L), *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        const int *dcol = v.iat(P.o_dcol);
+        Red<WAVES> R(v.at(P.o_red));
+        auto is_eq = [&](int k) { return k >= mi && k < m; };
+        int nw = nw_keep;
+        // S = N B^-1 N' of the kept rows, straight into the factor's storage
+        int anyd = 0;
+        for (int t = tid; t < nw; t += NT) anyd |= dcol[wq[t]] >= 0 ? 1 : 0;
+        const bool any_dense = R.max((double)anyd) > 0.0;
+        if (!any_dense) {
+            for (int e = tid; e < nw * (nw + 1) / 2; e += NT) {
+                int a, b2;
+                tri_index(e, a, b2);
+                const int ka = wq[a], kb = wq[b2];
+                double s = 0.0;
+                for (int ja = 0; ja < sp.count(ka); ++ja)
+                    for (int jb = 0; jb < sp.count(kb); ++jb)
+                        s = fma(sp.value(ka, ja) * sp.value(kb, jb), hsym(hinv, sp.index(ka, ja), sp.index(kb, jb)), s);
+                Lp[e] = sgq[a] * sgq[b2] * s;
+            }
+        } else {
+            for (int b2 = 0; b2 < nw; ++b2) {
+                normal_and_hinv(v, sp, wq[b2], sgq[b2], np_, vv, tid);
+                T::sync();
+                ws_dots(v, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);      // row b2 of S: entries 0 .. b2
+                T::sync();
+            }
+        }
+        T::sync();
+        if (tid < 64) { const bool ok = chol_inplace(Lp, invd, nw, lane); if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0; }
+        T::sync();
+        if (st[ST_R4] == 0.0) {                                  // dependent rows: start cold
+            for (int t = tid; t < nw; t += NT) flag[wq[t]] = 0;
+            T::sync();
+            return 0;
+        }
+        while (nw > 0) {
+            ws_dots(v, sp, nw, xq, tq, tid);
+            T::sync();
+            for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
+            T::sync();
+            ws_solve(nw);
+            // every row with a negative multiplier leaves at once; equalities stay
+            auto sheds = [&](int t) { return tq[t] < 0.0 && !is_eq(wq[t]); };
+            int neg = -1;
+            for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
+            if (neg < 0) break;
+            for (int t = nw - 1; t >= 0; --t) {
+                if (sheds(t)) { ws_drop(t, nw); --nw; }
+            }
+        }
+        if (nw > 0) {
+            for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(W, sp, nw, tq, q);
+            for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
+            T::sync();
+            hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
+            T::sync();
+            for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
+        }
+        T::sync();
+        return nw;
+    }
+
     // sub-problem: min 1/2 p'Bp + gr'p  s.t.  art' p + br <= 0 (equalities: = 0)   (Goldfarb-Idnani, range-space form on B^-1)
     // returns the size of the final working set (>= 0) or a failure code (< 0)
     static MPCX_WG_PHASE int qp(int nw_keep)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int nzu = M.nzu, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd;
-        const int nq = P.nq, KW = P.kw;
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const int tid = threadIdx.x;
+        const int nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, nq = v.nq, KW = v.kw;
         const Sp sp(v);
+        const Ws W(v);
         double *gr = v.at(P.o_gr), *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *mu = v.at(P.o_mu), *p = v.at(P.o_p),
-               *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq), *invd = v.at(P.o_invd), *Lp = v.at(P.o_L),
-               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art), *st = v.at(P.o_st);
+               *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq),
+               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         const int *dcol = v.iat(P.o_dcol);
         Red<WAVES> R(v.at(P.o_red));
-        const Factor Fac{Lp, invd, nullptr, nullptr, KW, 0};
         auto is_eq = [&](int k) { return k >= mi && k < m; };
 
         for (int k = tid; k < mt; k += NT) flag[k] = 0;
@@ -911,99 +1165,7 @@ struct WgSqp {
         T::sync();
         for (int t = tid; t < nw_keep; t += NT) flag[wq[t]] = 1;
         T::sync();
-
-        // row t leaves the working set: the factor is down-dated, the lists close up
-        auto drop_row = [&](int kdrop, int nw) {
-            if (wave == 0) chol_delete(Lp, invd, nw, kdrop, lane);
-            int kq = 0; double sg = 0, u = 0;
-            const bool mv = tid > kdrop && tid < nw;             // (working sets hold at most 128 rows: one or two per thread)
-            const bool mv2 = tid + NT > kdrop && tid + NT < nw;
-            if (mv) { kq = wq[tid]; sg = sgq[tid]; u = uq[tid]; }
-            int kq2 = 0; double sg2 = 0, u2 = 0;
-            if (mv2) { kq2 = wq[tid + NT]; sg2 = sgq[tid + NT]; u2 = uq[tid + NT]; }
-            if (tid == 0) flag[wq[kdrop]] = 0;
-            T::sync();
-            if (mv) { wq[tid - 1] = kq; sgq[tid - 1] = sg; uq[tid - 1] = u; }
-            if (mv2) { wq[tid + NT - 1] = kq2; sgq[tid + NT - 1] = sg2; uq[tid + NT - 1] = u2; }
-            T::sync();
-        };
-        // tq <- S^-1 tq over the working set (wavefront 0); y = L^-1 tq stays in its registers: the factor's next row if the entering row joins
-        double y0 = 0, y1 = 0;
-        auto solve_ws = [&](int nw) {
-            if (wave == 0) {
-                double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
-                chol_forward<false>(Fac, nw, t0, t1, lane);
-                y0 = t0; y1 = t1;
-                chol_backward<false>(Fac, nw, t0, t1, lane);
-                if (lane < nw) tq[lane] = t0;
-                if (lane + 64 < nw) tq[lane + 64] = t1;
-            }
-            T::sync();
-        };
-
-        int nw = 0;
-        // ---- warm start: the rows active in the previous sub-problem, as long as their multipliers stay non-negative
-        if (nw_keep > 0) {
-            nw = nw_keep;
-            // S = N B^-1 N' of the kept rows, straight into the factor's storage
-            int anyd = 0;
-            for (int t = tid; t < nw; t += NT) anyd |= dcol[wq[t]] >= 0 ? 1 : 0;
-            const bool any_dense = R.max((double)anyd) > 0.0;
-            if (!any_dense) {
-                for (int e = tid; e < nw * (nw + 1) / 2; e += NT) {
-                    int a, b2;
-                    tri_index(e, a, b2);
-                    const int ka = wq[a], kb = wq[b2];
-                    double s = 0.0;
-                    for (int ja = 0; ja < sp.count(ka); ++ja)
-                        for (int jb = 0; jb < sp.count(kb); ++jb)
-                            s = fma(sp.value(ka, ja) * sp.value(kb, jb), hsym(hinv, sp.index(ka, ja), sp.index(kb, jb)), s);
-                    Lp[e] = sgq[a] * sgq[b2] * s;
-                }
-            } else {
-                for (int b2 = 0; b2 < nw; ++b2) {
-                    normal_and_hinv(v, sp, wq[b2], sgq[b2], np_, vv, wv, tid);
-                    T::sync();
-                    ws_dots(v, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);      // row b2 of S: entries 0 .. b2
-                    T::sync();
-                }
-            }
-            T::sync();
-            int ok = 1;
-            if (wave == 0) ok = chol_inplace(Lp, invd, nw, lane) ? 1 : 0;
-            if (tid == 0) st[ST_R4] = (double)ok;
-            T::sync();
-            ok = (int)st[ST_R4];
-            if (!ok) {
-                for (int t = tid; t < nw; t += NT) flag[wq[t]] = 0;
-                nw = 0;
-                T::sync();
-            }
-            while (nw > 0) {
-                ws_dots(v, sp, nw, xq, tq, tid);
-                T::sync();
-                for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
-                T::sync();
-                solve_ws(nw);
-                // every row with a negative multiplier leaves at once; equalities stay
-                auto sheds = [&](int t) { return tq[t] < 0.0 && !is_eq(wq[t]); };
-                int neg = -1;
-                for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
-                if (neg < 0) break;
-                for (int t = nw - 1; t >= 0; --t) {
-                    if (sheds(t)) { drop_row(t, nw); --nw; }
-                }
-            }
-            if (nw > 0) {
-                for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(v, sp, nw, tq, q);
-                for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
-                T::sync();
-                hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
-                T::sync();
-                for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
-                T::sync();
-            }
-        }
+        int nw = nw_keep > 0 ? ws_warm(nw_keep) : 0;
 
         // ---- the dual method
         int fail = 0;
@@ -1018,7 +1180,7 @@ struct WgSqp {
                     const bool live = k < mt;
                     const int kk = live ? k : 0, dc = dcol[kk];
                     double acc = 0.0;
-                    if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * P.ndld + dc], xq[q], acc); }
+                    if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * v.ndld + dc], xq[q], acc); }
                     else if (part == 0) acc = sp.dot(kk, xq);
                     acc = group_sum<4>(acc);
                     double s = br[kk] + acc;
@@ -1035,11 +1197,11 @@ struct WgSqp {
             if (p_is_eq) {
                 double part = 0;
                 const int dc = dcol[pidx];
-                if (dc >= 0) { for (int q = tid; q < nq; q += NT) part += art[q * P.ndld + dc] * xq[q]; }
+                if (dc >= 0) { for (int q = tid; q < nq; q += NT) part += art[q * v.ndld + dc] * xq[q]; }
                 else if (tid == 0) part = sp.dot(pidx, xq);
                 sgn = br[pidx] + R.sum(part) < 0.0 ? -1.0 : 1.0;
             }
-            normal_and_hinv(v, sp, pidx, sgn, np_, vv, wv, tid);
+            normal_and_hinv(v, sp, pidx, sgn, np_, vv, tid);
             T::sync();
             double snn = 0, npn = 0;
             for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
@@ -1047,18 +1209,17 @@ struct WgSqp {
             double up = 0.0, spv_ = vmax;
             bool added = false;
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
-                // t = N_W v (the new column of S), rr = S^-1 t
+                // t = N_W v (the new column of S), rr = S^-1 t, zd = B^-1 (n - N_W' rr)
                 if (nw > 0) {
                     ws_dots(v, sp, nw, vv, tq, tid);
                     T::sync();
-                    solve_ws(nw);
-                    for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(v, sp, nw, tq, q);
+                    ws_solve(nw);
+                    for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(W, sp, nw, tq, q);
                     T::sync();
                     hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
                     T::sync();
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
                 } else {
-                    y0 = 0; y1 = 0;
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q];
                 }
                 T::sync();
@@ -1093,14 +1254,12 @@ struct WgSqp {
                 up += tt;
                 T::sync();
                 if (t2 <= t1) {                                          // full step: the row joins the working set
-                    if (wave == 0) chol_append<false>(Fac, nw, y0, y1, snn, snn, lane);
-                    if (tid == 0) { uq[nw] = up; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+                    ws_append(nw, pidx, sgn, up, snn);
                     ++nw; added = true;
                 } else {                                                 // a multiplier hit zero: that row leaves, try again
-                    drop_row(kdrop, nw);
+                    ws_drop(kdrop, nw);
                     --nw;
                 }
-                T::sync();
             }
             if (!fail && !added) fail = -1;
         }
@@ -1110,7 +1269,6 @@ struct WgSqp {
         T::sync();
         for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
         for (int q = tid; q < nr; q += NT) p[q] = q < nq ? xq[q] : 0.0;
-        (void)nzu;
         T::sync();
         return nw;
     }
@@ -1121,20 +1279,19 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void step()
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, nr = M.nr, mi = M.nineq, m = mi + M.nue;
+        const int ch = v.ch, nz = v.nz, nxs = v.nxs, nr = v.nr, mi = v.mi, m = v.m;
         double *p = v.at(P.o_p), *dx = v.at(P.o_dx), *c = v.at(P.o_c), *z = v.at(P.o_z), *gu = v.at(P.o_gu), *gin = v.at(P.o_gin), *st = v.at(P.o_st);
         typename FP<FL>::type F = FP<FL>::get(v);
-        gwp gxg = (gwp)(C.w + P.w_gx);
+        gwp gxg = (gwp)(v.w + uni(P.w_gx));
         for (int k = tid; k < nxs; k += NT) {
-            const int i = k / NX, a = k - i * NX;
+            const int i = k / NX;
             const double *pb = p + min(i, ch - 1) * NU;
             double s = F[(size_t)k * FW + FW - 1];
 #pragma unroll
             for (int j = 0; j < NU; ++j) s = fma(F[(size_t)k * FW + NX + j], pb[j], s);
             dx[k] = s;
-            (void)a;
         }
         T::sync();
         chain<FL, false>(v, dx, tid);
@@ -1157,20 +1314,22 @@ struct WgSqp {
     {
         const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, nxs = ph * NX, mi = M.nineq, m = mi + M.nue;
-        const int nq = P.nq;
+        const int nxs = v.nxs, mi = v.mi, m = v.m, nq = v.nq;
         const Sp sp(v);
+        const Ws W(v);
         double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *uq = v.at(P.o_uq), *lam = v.at(P.o_lam), *jx = v.at(P.o_jx), *c = v.at(P.o_c),
                *gin = v.at(P.o_gin), *st = v.at(P.o_st), *sgq = v.at(P.o_sgq);
         const int *wq = v.iat(P.o_wq), *jxoff = v.iat(P.o_jxoff);
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         Red<WAVES> R(v.at(P.o_red));
         // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
-        for (int q = tid; q < nq; q += NT) glold[q] = gr[q] + ws_combine(v, sp, nw, uq, q);
+        for (int q = tid; q < nq; q += NT) glold[q] = gr[q] + ws_combine(W, sp, nw, uq, q);
         double lam_max;
-        if (P.needs_phi) {
+        if (uni(P.needs_phi)) {
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward chain over the blocks
-            gwp gxg = (gwp)(C.w + P.w_gx);
+            gwp gxg = (gwp)(v.w + uni(P.w_gx));
+            const int *bnd_idx = uni(M.bnd_idx);
+            const double *bnd_sign = uni(M.bnd_sign);
             for (int row = tid; row < nxs; row += NT) {
                 const int i = row / NX, a = row - i * NX;                   // entry a of state row i + 1
                 double s2 = gxg[row];
@@ -1181,27 +1340,14 @@ struct WgSqp {
                             const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
                             s2 += jx[sl * NX + a] * (sgq[t] * uq[t]);
                         }
-                    } else if (M.bnd_idx[k - m] == row) s2 += M.bnd_sign[k - m] * uq[t];
+                    } else if (bnd_idx[k - m] == row) s2 += bnd_sign[k - m] * uq[t];
                 }
                 lam[row] = s2;
             }
             T::sync();
             chain<FL, true>(v, lam, tid);
             T::sync();
-            double lmax = 0.0;
-            if (CT) {
-                gwp einv = (gwp)(C.w + P.w_einv);
-                for (int k = tid; k < nxs; k += NT) {
-                    const int i = k / NX, a = k - i * NX;
-                    double s = 0.0;
-#pragma unroll
-                    for (int bb = 0; bb < NX; ++bb) s = fma(einv[(size_t)(i * NX + bb) * NX + a], lam[i * NX + bb], s);
-                    lmax = fmax(lmax, fabs(s));
-                }
-            } else {
-                for (int k = tid; k < nxs; k += NT) lmax = fmax(lmax, fabs(lam[k]));
-            }
-            lam_max = lmax;
+            lam_max = defect_multiplier_max(v, lam, tid);
         } else {
             lam_max = tid == 0 ? st[ST_LAMDYN] : 0.0;
         }
@@ -1217,19 +1363,65 @@ struct WgSqp {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // line search on the l1 merit function: eight step lengths a = 2^-(g + 8 round) at a time, NT / 8 lanes each.
+    // The three parts of a trial point's merit value, each this lane's share:
+    static __device__ __attribute__((noinline)) double ls_user_rows(double al, int part, int stride)
+    {
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const int ph = v.ph, mi = v.mi, m = v.m;
+        const double *prm = uni(C.prm);
+        const double *z = v.at(P.o_z), *p = v.at(P.o_p);
+        const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
+        const double et = z[v.nz - 1] + al * p[v.nzu];
+        double vio = 0.0;
+        for (int k = part; k < mi; k += stride) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
+        for (int k = part; k < m - mi; k += stride) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
+        return vio;
+    }
+    static __device__ __attribute__((noinline)) double ls_cost(double al)
+    {
+        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const double *z = v.at(P.o_z), *p = v.at(P.o_p);
+        const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
+        return Mdl::cost(XL, UL, z[v.nz - 1] + al * p[v.nzu], v.ph, uni(C.prm));
+    }
+    static __device__ __attribute__((noinline)) double ls_defects(double al, int part, int stride)
+    {
+        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const int ph = v.ph;
+        const double *prm = uni(C.prm);
+        const Scale sc(M);
+        const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
+        const double h = 0.5 * M.Ts;
+        double vio = 0.0;
+        for (int i = part; i < ph; i += stride) {
+            double xk[NX], xk1[NX], uk[NU], fa[NX], s = 0;
+            for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
+            for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
+            Mdl::f(fa, xk, uk, prm);
+            if (CT) {
+                double fb[NX];
+                Mdl::f(fb, xk1, uk, prm);
+                for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
+            } else {
+                for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk1[a] - fa[a], a));
+            }
+            vio += s;
+        }
+        return vio;
+    }
     // returns the accepted length, or -1 if none down to 2^-40
     static MPCX_WG_PHASE double linesearch(double nu_pen, double phi0, double dphi)
     {
         const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, ch = M.ch, nz = M.nz, nxs = ph * NX, mi = M.nineq, m = mi + M.nue;
-        const double *prm = C.prm;
+        const int ph = v.ph, ch = v.ch, nxs = v.nxs;
         const Scale sc(M);
+        const double *x0 = uni(C.x0);
         double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *dXs = v.at(P.o_dXs), *dUs = v.at(P.o_dUs), *dx = v.at(P.o_dx),
                *p = v.at(P.o_p), *st = v.at(P.o_st);
         for (int k = tid; k < (ph + 1) * NX; k += NT) {
             const int i = k / NX, j = k - i * NX;
-            Xs[k] = sc.over_ss(i == 0 ? C.x0[j] : z[(i - 1) * NX + j], j);
+            Xs[k] = sc.over_ss(i == 0 ? x0[j] : z[(i - 1) * NX + j], j);
             dXs[k] = i == 0 ? 0.0 : sc.over_ss(dx[k - NX], j);
         }
         for (int k = tid; k < (ph + 1) * NU; k += NT) {
@@ -1240,30 +1432,12 @@ struct WgSqp {
         T::sync();
         constexpr int GS = NT / kNlTrials;                       // lanes per trial point: 8, 16 or 32
         const int grp = tid / GS, part = tid % GS;
-        const double h = 0.5 * M.Ts;
         double a_step = -1.0;
         for (int round = 0; round < 5 && a_step < 0.0; ++round) {
             const double al = ldexp(1.0, -(grp + 8 * round));
-            const Lin XL{Xs, dXs, NX, al}, UL{Us, dUs, NU, al};
-            const double et = z[nz - 1] + al * p[M.nzu];
-            double mer = 0.0, vio = 0;
-            if (part == 0) mer = Mdl::cost(XL, UL, et, ph, prm);
-            for (int k = part; k < mi; k += GS) vio += fmax(Mdl::ineq(k, XL, UL, et, ph, prm), 0.0);
-            for (int k = part; k < m - mi; k += GS) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
-            for (int i = part; i < ph; i += GS) {
-                double xk[NX], xk1[NX], uk[NU], fa[NX], fb[NX], s = 0;
-                for (int a = 0; a < NX; ++a) { xk[a] = XL(i, a); xk1[a] = XL(i + 1, a); }
-                for (int a = 0; a < NU; ++a) uk[a] = UL(i, a);
-                Mdl::f(fa, xk, uk, prm);
-                if (CT) {
-                    Mdl::f(fb, xk1, uk, prm);
-                    for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk[a] + (h * (fa[a] + fb[a])) - xk1[a], a));
-                } else {
-                    for (int a = 0; a < NX; ++a) s += fabs(sc.over_ss(xk1[a] - fa[a], a));
-                }
-                vio += s;
-            }
-            mer += nu_pen * vio;
+            const double cst = ls_cost(al);                      // (every lane evaluates it: no divergence around the call)
+            const double vio = ls_user_rows(al, part, GS) + ls_defects(al, part, GS);
+            double mer = (part == 0 ? cst : 0.0) + nu_pen * vio;
             if constexpr (GS == 8) mer = group_sum<8>(mer);
             else if constexpr (GS == 16) mer = group_sum<16>(mer);
             else { mer = group_sum<16>(mer); mer += __shfl_xor(mer, 16); }
@@ -1279,9 +1453,9 @@ struct WgSqp {
     // z += a d; s = a p for the next BFGS update; the step's norms for nlopt's stopping rules: st[R0..R2] = |step|_1, |z|_1, max |step|
     static MPCX_WG_PHASE void update(double a_step)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const WgPlan &P = v.C.P;
         const int tid = threadIdx.x;
-        const int nxs = M.ph * NX, nr = M.nr;
+        const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p), *sv = v.at(P.o_sv), *st = v.at(P.o_st);
         Red<WAVES> R(v.at(P.o_red));
         double s1 = 0, z1 = 0, smax = 0;
@@ -1300,9 +1474,9 @@ struct WgSqp {
     // largest violation at z, for nlopt's stopping rules (applied to a step that ended at a feasible point)
     static MPCX_WG_PHASE double violation()
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const WgPlan &P = v.C.P;
         const int tid = threadIdx.x;
-        const int nxs = M.ph * NX, mi = M.nineq, m = mi + M.nue;
+        const int nxs = v.nxs, mi = v.mi, m = v.m;
         const double *c = v.at(P.o_c), *gin = v.at(P.o_gin);
         Red<WAVES> R(v.at(P.o_red));
         double vmax = 0;
@@ -1317,14 +1491,14 @@ struct WgSqp {
     {
         const V v; const WgPlan &P = v.C.P;
         double *hinv = v.at(P.o_hinv);
-        const int nr = v.C.M.nr;
+        const int nr = v.nr;
         for (int e = threadIdx.x; e < nr * (nr + 1) / 2; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
         T::sync();
     }
     static MPCX_WG_PHASE void take_last_step()
     {
         const V v; const WgPlan &P = v.C.P;
-        const int nxs = v.C.M.ph * NX, nr = v.C.M.nr;
+        const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p);
         for (int k = threadIdx.x; k < nxs + nr; k += NT) z[k] += k < nxs ? dx[k] : p[k - nxs];
         T::sync();
@@ -1335,41 +1509,42 @@ struct WgSqp {
     // trajectory of the last evaluation
     static MPCX_WG_PHASE void finish(int code, int it)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const V v; const WgCtx &C = v.C; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
         const int tid = threadIdx.x;
-        const int ph = M.ph, nz = M.nz, nr = M.nr, mi = M.nineq, m = mi + M.nue, mt = m + M.nbnd, b = C.b;
+        const int ph = v.ph, nz = v.nz, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, b = uni(C.b);
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *gin = v.at(P.o_gin), *mu = v.at(P.o_mu), *hinv = v.at(P.o_hinv),
                      *st = v.at(P.o_st);
-        const int *flag = v.iat(P.o_flag);
+        const double *u0 = uni(C.u0), *prm = uni(C.prm);
         Red<WAVES> R(v.at(P.o_red));
         double gmax = -1e300, hmax = 0.0;
         for (int k = tid; k < m; k += NT) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
         gmax = R.max(gmax); hmax = R.max(hmax);
         const bool failed = code < 0;
-        if (S.cmd) for (int j = tid; j < NU; j += NT) S.cmd[(size_t)b * NU + j] = failed ? C.u0[j] : Us[j];
-        if (S.z_out) for (int k = tid; k < nz; k += NT) S.z_out[(size_t)b * nz + k] = z[k];
-        if (S.mu_out) for (int k = tid; k < mt; k += NT) S.mu_out[(size_t)b * mt + k] = mu[k];
-        if (S.seq_state) for (int k = tid; k < (ph + 1) * NX; k += NT) S.seq_state[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
-        if (S.seq_input) for (int k = tid; k < (ph + 1) * NU; k += NT) S.seq_input[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
-        if (S.seq_output)                                   // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
+        double *o_cmd = uni(S.cmd), *o_z = uni(S.z_out), *o_mu = uni(S.mu_out), *o_sx = uni(S.seq_state), *o_su = uni(S.seq_input), *o_sy = uni(S.seq_output);
+        if (o_cmd) for (int j = tid; j < NU; j += NT) o_cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
+        if (o_z) for (int k = tid; k < nz; k += NT) o_z[(size_t)b * nz + k] = z[k];
+        if (o_mu) for (int k = tid; k < mt; k += NT) o_mu[(size_t)b * mt + k] = mu[k];
+        if (o_sx) for (int k = tid; k < (ph + 1) * NX; k += NT) o_sx[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
+        if (o_su) for (int k = tid; k < (ph + 1) * NU; k += NT) o_su[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
+        if (o_sy)                                           // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
             for (int i = tid; i <= ph; i += NT) {
                 double y[Mdl::NY > 0 ? Mdl::NY : 1];
                 for (int a = 0; a < Mdl::NY; ++a) y[a] = 0.0;
-                if (Mdl::HAS_OUTPUT && !failed) Mdl::out(y, Xs + i * NX, Us + i * NU, C.prm);
-                for (int a = 0; a < Mdl::NY; ++a) S.seq_output[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
+                if (Mdl::HAS_OUTPUT && !failed) Mdl::out(y, Xs + i * NX, Us + i * NU, prm);
+                for (int a = 0; a < Mdl::NY; ++a) o_sy[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
             }
         // the curvature estimate stays in the workspace for a receding-horizon successor (keep_curvature)
-        gwp hs = (gwp)(C.w + P.w_hinv);
+        gwp hs = (gwp)(v.w + uni(P.w_hinv));
         for (int e = tid; e < nr * (nr + 1) / 2; e += NT) hs[e] = hinv[e];
+        double *scal = v.w + uni(P.w_scal);
         if (tid == 0) {
             if (S.cost) S.cost[b] = failed ? __builtin_huge_val() : st[ST_COST];
             if (S.solver_status) S.solver_status[b] = code;
             if (S.status) S.status[b] = (code == 3 || code == 4) ? 0 : (code == 5 ? 1 : 3);     // SUCCESS / MAX_ITERATION / ERROR (NLOptimizer.hpp:729-750)
             if (S.is_feasible) S.is_feasible[b] = ((mi == 0 || gmax <= S.ieq_tol) && hmax <= S.eq_tol) ? 1 : 0;    // Constraints.hpp:157-202
             if (S.iterations) S.iterations[b] = it;
-            C.w[P.w_scal] = st[ST_COST];
+            scal[0] = st[ST_COST];
         }
-        (void)flag;
         T::sync();
     }
 };
@@ -1402,7 +1577,9 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
     bool have_old = false, stepped = false, final_eval = false;
     int resets = 0, nw_keep = 0, it = 0, code = 5;       // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
     for (;;) {
-        K::template eval<FL>(final_eval ? 1 : 0);
+        K::eval_cost(final_eval ? 1 : 0);
+        K::template eval_dyn<FL>(final_eval ? 1 : 0);
+        K::eval_con(final_eval ? 1 : 0);
         if (final_eval) break;
         if (st[ST_ERR] != 0.0) { code = -3; break; }
         if (stepped && tol_on) {
@@ -1419,7 +1596,7 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         }
         stepped = false;
         if (it >= S.max_iter) break;
-        K::template condense<FL>();
+        if (P.needs_phi) K::template condense_phi<FL>(); else K::template condense_chain<FL>();
         if (have_old) K::bfgs(a_prev, nw_keep);
         const int nw = K::qp(nw_keep);
         if (nw < 0) { code = nw; break; }
@@ -1507,7 +1684,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
         P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
         P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = take(nr * P.ndld);
-        P.o_wq = take((P.kw + 1) / 2); P.o_sgq = take(P.kw); P.o_uq = take(P.kw); P.o_tq = take(P.kw); P.o_invd = take(P.kw);
+        P.o_wq = take((P.kw + 1) / 2); P.o_sgq = take(P.kw); P.o_uq = take(P.kw); P.o_tq = take(P.kw); P.o_invd = take(P.kw); P.o_yv = take(P.kw);
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <execinfo.h>
 
 #define __device__
 #define __host__
@@ -59,6 +60,9 @@ struct State {
     size_t stack_bytes = 2048 * 1024;
     bool done[kMaxThreads] = {};
     const char *where[kMaxThreads] = {};
+    void *trace[kMaxThreads][8] = {};
+    int trace_n[kMaxThreads] = {};
+    bool tracing = false;
     long idle_switches = 0;
     Bar block_bar, wave_bar[kMaxThreads / kWave];
     uint64_t xbuf[kMaxThreads / kWave][2][kWave];
@@ -72,7 +76,11 @@ inline void report_deadlock()
     State &s = st();
     fprintf(stderr, "hipemu: deadlock in block %d -- a rendezvous was not reached by every thread of its scope\n", s.block);
     for (int t = 0; t < s.nthreads; ++t)
-        if (!s.done[t]) fprintf(stderr, "  thread %3d waits at %s\n", t, s.where[t] ? s.where[t] : "?");
+        if (!s.done[t]) {
+            fprintf(stderr, "  thread %3d waits at %s", t, s.where[t] ? s.where[t] : "?");
+            for (int i = 2; i < s.trace_n[t]; ++i) fprintf(stderr, " %p", s.trace[t][i]);      // HIPEMU_TRACE=1: return addresses (addr2line -e <binary>)
+            fprintf(stderr, "\n");
+        }
         else fprintf(stderr, "  thread %3d finished\n", t);
     abort();
 }
@@ -96,6 +104,7 @@ inline void rendezvous(Bar &b, int size, const char *what)
 {
     State &s = st();
     s.where[s.cur] = what;
+    if (s.tracing) s.trace_n[s.cur] = backtrace(s.trace[s.cur], 8);
     const unsigned gen = b.gen;
     if (++b.count == size) { b.count = 0; ++b.gen; s.idle_switches = 0; }
     else while (b.gen == gen) yield();
@@ -166,6 +175,7 @@ inline void run_block(int block, int nblocks, int nthreads, const std::function<
     State &s = st();
     if (nthreads > kMaxThreads) { fprintf(stderr, "hipemu: %d threads per block\n", nthreads); abort(); }
     if (const char *e = getenv("HIPEMU_ORDER")) s.reverse = !strcmp(e, "reverse");
+    s.tracing = getenv("HIPEMU_TRACE") != nullptr;
     s.nthreads = nthreads; s.block = block; s.nblocks = nblocks; s.alive = nthreads; s.body = body;
     s.block_bar = Bar{};
     for (auto &b : s.wave_bar) b = Bar{};
