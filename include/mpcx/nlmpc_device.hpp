@@ -49,6 +49,7 @@ struct NlmpcDev {
     // box bounds on the decision vector (NLOptimizer::lb / ub): all of them, and the finite ones as sub-problem rows
     const double *zlb, *zub;    // [nz]
     int nbnd;
+    int nbnd_state;             // how many of them bound a state: the first rows of the table (ascending index into z)
     const int *bnd_idx;         // [nbnd] index into z
     const double *bnd_sign;     // [nbnd] +1: z <= val, -1: z >= val
     const double *bnd_val;      // [nbnd]

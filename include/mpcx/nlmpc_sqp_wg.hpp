@@ -508,41 +508,50 @@ struct WgSqp {
                 const int ii = live ? i : ph - 1;
                 double col[NX];
                 {
-                    double xk[NX], xk1[NX], uk[NU];
-                    for (int a = 0; a < NX; ++a) { xk[a] = Xs[ii * NX + a]; xk1[a] = Xs[(ii + 1) * NX + a]; }
-                    for (int a = 0; a < NU; ++a) uk[a] = Us[ii * NU + a];
                     // two passes of two evaluations of the vector field, the same call sites for every kind of column:
-                    // pass 0 at x_i (E: at x_{i+1}), pass 1 at x_{i+1} (used by the input columns and the defect only)
-                    double acc[NX];
-                    for (int a = 0; a < NX; ++a) acc[a] = 0.0;
+                    // pass 0 at x_i (E: at x_{i+1}), pass 1 at x_{i+1} (used by the input columns and the defect only).
+                    // The point is read from LDS where it is needed: a column keeps one perturbed copy and two results at a time.
+                    const double *xr = Xs + ii * NX, *ur = Us + ii * NU;
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) col[a] = 0.0;
 #pragma unroll 1
                     for (int pass = 0; pass < 2; ++pass) {
                         const bool at_next = pass == 1 || kind == 0;
                         double xp[NX], up[NU], o1[NX], o2[NX];
-                        for (int a = 0; a < NX; ++a) xp[a] = at_next ? xk1[a] : xk[a];
-                        for (int a = 0; a < NU; ++a) up[a] = uk[a];
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) xp[a] = xr[(at_next ? NX : 0) + a];
+#pragma unroll
+                        for (int a = 0; a < NU; ++a) up[a] = ur[a];
                         const bool isu = kind == 2, pert = kind <= 2;
                         double bs = 0.0;
+#pragma unroll
                         for (int a = 0; a < NX; ++a) if (!isu && a == vv) bs = xp[a];
+#pragma unroll
                         for (int a = 0; a < NU; ++a) if (isu && a == vv) bs = up[a];
                         const double d = pert ? dv * fmax(fabs(bs), 1.0) : 1.0;
+#pragma unroll
                         for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs + d;
+#pragma unroll
                         for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs + d;
                         Mdl::f(o1, xp, up, prm);
+#pragma unroll
                         for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs - d;
+#pragma unroll
                         for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs - d;
                         Mdl::f(o2, xp, up, prm);
                         // derivative columns: the central difference; the defect: f(x_i, u_i) on pass 0, f(x_{i+1}, u_i) on pass 1
                         const bool use = pass == 0 || kind >= 2;
-                        for (int a = 0; a < NX; ++a) acc[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) / (2 * d));
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) col[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) / (2 * d));
                     }
+#pragma unroll
                     for (int a = 0; a < NX; ++a) {
-                        const double da = acc[a];
+                        const double da = col[a];
                         double cv;
                         if (kind == 0) cv = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
                         else if (kind == 1) cv = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
                         else if (kind == 2) cv = sc.by_su(h * sc.over_ss(da, a), vv);
-                        else if (kind == 3) cv = sc.over_ss(xk[a] + (h * da) - xk1[a], a);
+                        else if (kind == 3) cv = sc.over_ss(xr[a] + (h * da) - xr[NX + a], a);
                         else cv = a == vv ? 1.0 : 0.0;
                         col[a] = cv;
                     }

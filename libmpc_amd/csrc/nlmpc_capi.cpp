@@ -81,6 +81,8 @@ struct mpcx_nlmpc {
         }
         if (!ok) return MPCX_E_DEVICE;
         dev.zlb = d; dev.zub = d + nz; dev.bnd_val = dval; dev.bnd_sign = dsign; dev.bnd_idx = didx;
+        dev.nbnd_state = 0;
+        for (int k : idx) dev.nbnd_state += k < dev.ph * dev.nx ? 1 : 0;
         if (nb != dev.nbnd) {                       // the workspace layout depends on the number of rows
             dev.nbnd = nb;
             mpcx::nlmpc_plan_host(dev);

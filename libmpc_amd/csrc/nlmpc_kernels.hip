@@ -4,7 +4,11 @@
 // translation unit (mpcx/nlmpc_hooks.hpp) or in a run-time compiled module (nlmpc_jit.cpp).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "mpcx/nlmpc_engine.hpp"
+#include "mpcx/nlmpc_sqp_wg.hpp"
 
 namespace mpcx {
 namespace {
@@ -42,9 +46,23 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
     return dispatch_model(m->model_id, [&](auto mdl) { return engine::launch_evaluate<decltype(mdl)>(nullptr, m, b, stream); });
 }
 
+// The built-in systems solve in the workgroup form (mpcx/nlmpc_sqp_wg.hpp: one workgroup per instance, the reduced problem in LDS).
+// A shape its LDS plan does not take (horizons beyond 64 steps, more than 160 KB) goes through nlmpc_sqp, one wavefront per instance;
+// MPCX_NLMPC_FORM=wave forces that form (A/B measurements), MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance.
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
-    return dispatch_model(m->model_id, [&](auto mdl) { return engine::launch_solve<decltype(mdl)>(nullptr, m, b, stream); });
+    return dispatch_model(m->model_id, [&](auto mdl) {
+        using Mdl = decltype(mdl);
+        const char *form = getenv("MPCX_NLMPC_FORM");
+        if (!(form && !strcmp(form, "wave"))) {
+            engine::WgPlan P;
+            const char *wv = getenv("MPCX_NLMPC_WAVES");
+            if (engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P) == 0 && P.ws_total <= m->ws.total)
+                return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
+            if (form && !strcmp(form, "wg")) return -2;
+        }
+        return engine::launch_solve<Mdl>(nullptr, m, b, stream);
+    });
 }
 
 }  // namespace mpcx

@@ -65,7 +65,7 @@ static int run(int argc, char **argv)
         if (lb[k] > -1e30) { bidx.push_back(k); bsign.push_back(-1.0); bval.push_back(lb[k]); }
     }
     bidx.push_back(0); bsign.push_back(0); bval.push_back(0);
-    M.zlb = lb.data(); M.zub = ub.data(); M.nbnd = (int)bidx.size() - 1; M.bnd_idx = bidx.data(); M.bnd_sign = bsign.data(); M.bnd_val = bval.data();
+    M.zlb = lb.data(); M.zub = ub.data(); M.nbnd = (int)bidx.size() - 1; M.nbnd_state = 0; for (int k = 0; k < M.nbnd; ++k) M.nbnd_state += bidx[k] < nxs ? 1 : 0; M.bnd_idx = bidx.data(); M.bnd_sign = bsign.data(); M.bnd_val = bval.data();
     engine::nlmpc_plan(M);
 
     std::vector<double> X0, U0;
