@@ -75,6 +75,7 @@ struct NoUserEq {
 // ---- model zoo ----------------------------------------------------------------------------------
 struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.cpp:33-65
     static constexpr int NX = 2, NU = 1, NY = 2;
+    static constexpr int NPARAMS = 1;                              // (none used; the library keeps one)
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return ph + 1; }
     __device__ static void f(double *dx, const double *x, const double *u, const double *)
@@ -117,6 +118,7 @@ struct VanDerPolTerminal : VanDerPol {
 
 struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
     static constexpr int NX = 4, NU = 2, NY = 4;
+    static constexpr int NPARAMS = 9;
     static constexpr bool CONTINUOUS = false;
     static constexpr bool HAS_OUTPUT = true;                       // y = Cd x + Dd u with C = I, D = 0 (ugv_ex.cpp:34-77)
     __device__ static void out(double *y, const double *x, const double *, const double *) { for (int a = 0; a < 4; ++a) y[a] = x[a]; }
@@ -161,6 +163,7 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
 template <int N>
 struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_oscillators_ex.cpp:17-76; params: [mu, k]
     static constexpr int NX = 2 * N, NU = N, NY = 2 * N;
+    static constexpr int NPARAMS = 2;
     static constexpr bool CONTINUOUS = true;
     __host__ __device__ static int nineq(int ph) { return (ph + 1) * N; }
     __device__ static void f(double *dx, const double *x, const double *u, const double *p)

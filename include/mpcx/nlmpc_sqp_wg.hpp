@@ -41,11 +41,12 @@ struct WgPlan {
     int lds_total;              // doubles
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
-        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F;
+        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F, o_prm, o_cd, o_yd,
+        o_bidx, o_bsign, o_bval;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
-    int w_scal, w_F, w_einv, w_gx, w_hinv, w_sp;
+    int w_scal, w_F, w_einv, w_gx, w_hinv, w_sp;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
     int ws_total;
 };
 
@@ -154,7 +155,9 @@ template <int WAVES> struct Red {
 };
 
 // dst = scale * H src for the symmetric matrix H packed by rows of its lower triangle (row r at r (r + 1) / 2), all in LDS;
-// P lanes share a row.  Every thread of the workgroup calls it; the caller synchronises.
+// P lanes share a row: the row's own part (entries left of the diagonal, contiguous) and the column part below it (entry (c, r) at
+// c (c + 1) / 2 + r: the offset grows by c + 1 per step), four independent partial sums each.  Every thread of the workgroup calls it;
+// the caller synchronises.
 template <int P, int NT>
 __device__ __forceinline__ void hmul_rows(const double *hp, const double *src, double *dst, int n, double scale, int tid)
 {
@@ -162,13 +165,25 @@ __device__ __forceinline__ void hmul_rows(const double *hp, const double *src, d
     for (int r0 = 0; r0 < n; r0 += NT / P) {
         const int r = r0 + tid / P;
         const bool live = r < n;
-        const int rr = live ? r : 0, ro = rr * (rr + 1) / 2;
-        double acc = 0.0;
-        for (int c = part; c < n; c += P) {
-            const double h = c <= rr ? hp[ro + c] : hp[c * (c + 1) / 2 + rr];
-            acc = fma(h, src[c], acc);
+        const int rr = live ? r : 0;
+        const double *row = hp + rr * (rr + 1) / 2;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int c = part;
+        for (; c + 3 * P <= rr; c += 4 * P) {
+            a0 = fma(row[c], src[c], a0); a1 = fma(row[c + P], src[c + P], a1);
+            a2 = fma(row[c + 2 * P], src[c + 2 * P], a2); a3 = fma(row[c + 3 * P], src[c + 3 * P], a3);
         }
-        acc = group_sum<P>(acc);
+        for (; c <= rr; c += P) a0 = fma(row[c], src[c], a0);
+        // c is now the first column beyond the diagonal that this lane takes
+        int off = c * (c + 1) / 2 + rr;
+        for (; c + 3 * P < n; c += 4 * P) {
+            const int o1 = off + P * c + P * (P + 1) / 2, o2 = o1 + P * (c + P) + P * (P + 1) / 2, o3 = o2 + P * (c + 2 * P) + P * (P + 1) / 2;
+            a0 = fma(hp[off], src[c], a0); a1 = fma(hp[o1], src[c + P], a1);
+            a2 = fma(hp[o2], src[c + 2 * P], a2); a3 = fma(hp[o3], src[c + 3 * P], a3);
+            off = o3 + P * (c + 3 * P) + P * (P + 1) / 2;
+        }
+        for (; c < n; c += P) { a1 = fma(hp[off], src[c], a1); off += P * c + P * (P + 1) / 2; }
+        const double acc = group_sum<P>((a0 + a1) + (a2 + a3));
         if (live && part == 0) dst[r] = scale * acc;
     }
 }
@@ -319,6 +334,15 @@ struct WgSqp {
         const double *x0 = uni(C.x0), *u0 = uni(C.u0), *zwarm = uni(S.z_warm);
         const double *zlb = uni(M.zlb), *zub = uni(M.zub);
         const int *bnd_idx = uni(M.bnd_idx);
+        {
+            // the model's parameters and the bound table into LDS: every model function reads parameters, and a read from HBM in the
+            // middle of a dependent chain costs a memory latency each time
+            const double *prm_g = uni(C.prm), *bs = uni(M.bnd_sign), *bv = uni(M.bnd_val);
+            double *prm_l = v.at(P.o_prm), *bsl = v.at(P.o_bsign), *bvl = v.at(P.o_bval);
+            int *bil = v.iat(P.o_bidx);
+            for (int k = tid; k < Mdl::NPARAMS; k += NT) prm_l[k] = prm_g[k];
+            for (int k = tid; k < nbnd; k += NT) { bil[k] = bnd_idx[k]; bsl[k] = bs[k]; bvl[k] = bv[k]; }
+        }
         if (zwarm) {
             const double *zw = zwarm + (size_t)uni(C.b) * nz;
             for (int k = tid; k < nxs; k += NT) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
@@ -386,7 +410,7 @@ struct WgSqp {
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu;
         const double dv = kDv;
-        const double *prm = uni(C.prm), *x0 = uni(C.x0);
+        const double *prm = v.at(P.o_prm), *x0 = uni(C.x0);
         const Scale sc(M);
         double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *Jm = v.at(P.o_Jm), *lam = v.at(P.o_lam), *st = v.at(P.o_st),
                *gu = v.at(P.o_gu);
@@ -442,7 +466,7 @@ struct WgSqp {
         const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
         const int ph = v.ph;
         const double dv = kDv;
-        const double *prm = uni(C.prm);
+        const double *prm = v.at(P.o_prm);
         const Scale sc(M);
         const double *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
         double *c = v.at(P.o_c);
@@ -598,14 +622,14 @@ struct WgSqp {
         const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu, mi = v.mi, m = v.m, mt = v.mt, nq = v.nq, ndld = v.ndld;
         const int nsx = uni(P.nsx);
         const double dv = kDv;
-        const double *prm = uni(C.prm);
+        const double *prm = v.at(P.o_prm);
         const Scale sc(M);
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
         double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
         int *s1m = v.iat(P.o_s1m);
         const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
-        const int *bnd_idx = uni(M.bnd_idx);
-        const double *bnd_sign = uni(M.bnd_sign), *bnd_val = uni(M.bnd_val);
+        const int *bnd_idx = v.iat(P.o_bidx);
+        const double *bnd_sign = v.at(P.o_bsign), *bnd_val = v.at(P.o_bval);
         const double e = z[nz - 1];
         auto Xa = [&](int j) { const double a = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
         auto Ua = [&](int j) { const double a = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
@@ -797,8 +821,8 @@ struct WgSqp {
         double *gr = v.at(P.o_gr), *art = v.at(P.o_art), *br = v.at(P.o_br);
         const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
-        const int *bnd_idx = uni(M.bnd_idx);
-        const double *bnd_sign = uni(M.bnd_sign);
+        const int *bnd_idx = v.iat(P.o_bidx);
+        const double *bnd_sign = v.at(P.o_bsign);
         typename FP<FL>::type F = FP<FL>::get(v);
         if constexpr (NX <= 8) {
             for (int q = tid; q <= nzu; q += NT) {
@@ -910,29 +934,85 @@ struct WgSqp {
         T::sync();
     }
 
+    // The dense rows of the sub-problem are the columns of art [nq x nd] (row q contiguous).  Products with the whole matrix replace
+    // loops over the working set: their cost does not depend on how many rows are active, the loads are contiguous and independent.
+    // yd[dc] = (column dc of art)' x for every dense column (four lanes share a column).  Every thread calls; the caller synchronises.
+    static __device__ __forceinline__ void art_tmul(const V &v, const double *x, double *yd, int tid)
+    {
+        const WgPlan &P = v.C.P;
+        const int nd = uni(P.nd), nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const double *art = v.at(P.o_art);
+        for (int d0 = 0; d0 < nd; d0 += NT / 4) {
+            const int dc = d0 + (tid >> 2);
+            const bool live = dc < nd;
+            const double *col = art + (live ? dc : 0);
+            double a0 = 0.0, a1 = 0.0;
+            int q = part;
+            for (; q + 4 < nq; q += 8) { a0 = fma(col[q * ndld], x[q], a0); a1 = fma(col[(q + 4) * ndld], x[q + 4], a1); }
+            for (; q < nq; q += 4) a0 = fma(col[q * ndld], x[q], a0);
+            const double acc = group_sum<4>(a0 + a1);
+            if (live && part == 0) yd[dc] = acc;
+        }
+    }
+    // out[q] (+)= sum_dc art[q][dc] cd[dc] (four lanes share a row)
+    template <bool ACCUMULATE>
+    static __device__ __forceinline__ void art_mul(const V &v, const double *cd, double *out, int tid)
+    {
+        const WgPlan &P = v.C.P;
+        const int nd = uni(P.nd), nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const double *art = v.at(P.o_art);
+        for (int q0 = 0; q0 < nq; q0 += NT / 4) {
+            const int q = q0 + (tid >> 2);
+            const bool live = q < nq;
+            const double *row = art + (live ? q : 0) * ndld;
+            double a0 = 0.0, a1 = 0.0;
+            int dc = part;
+            for (; dc + 4 < nd; dc += 8) { a0 = fma(row[dc], cd[dc], a0); a1 = fma(row[dc + 4], cd[dc + 4], a1); }
+            for (; dc < nd; dc += 4) a0 = fma(row[dc], cd[dc], a0);
+            const double acc = group_sum<4>(a0 + a1);
+            if (live && part == 0) out[q] = ACCUMULATE ? out[q] + acc : acc;
+        }
+    }
     // the working set as it stands in LDS: row numbers, orientations, and where the rows' entries are (derived once per phase,
     // outside any loop over lanes)
     struct Ws {
         const int *wq, *dcol;
-        const double *sgq, *art;
-        int ndld;
+        const double *sgq;
+        double *cd, *yd;
+        int nd;
         __device__ __forceinline__ explicit Ws(const V &v)
-            : wq(v.iat(v.C.P.o_wq)), dcol(v.iat(v.C.P.o_dcol)), sgq(v.at(v.C.P.o_sgq)), art(v.at(v.C.P.o_art)), ndld(v.ndld) {}
+            : wq(v.iat(v.C.P.o_wq)), dcol(v.iat(v.C.P.o_dcol)), sgq(v.at(v.C.P.o_sgq)), cd(v.at(v.C.P.o_cd)), yd(v.at(v.C.P.o_yd)), nd(uni(v.C.P.nd)) {}
     };
-    // sum_t coef[t] * (normal of working row t)[q]
-    static __device__ __forceinline__ double ws_combine(const Ws &W, const Sp &sp, int nw, const double *coef, int q)
+    // out[q] = sum_t coef[t] * (oriented normal of working row t)[q] for q < nq: the sparse rows scatter their few entries (an LDS atomic
+    // add each: two rows on one variable add up in either order to the same bits), the dense rows go through art.  Every thread
+    // calls; synchronised on return.
+    static __device__ __forceinline__ void ws_nt_mul(const V &v, const Ws &W, const Sp &sp, int nw, const double *coef, double *out, int tid)
     {
-        double acc = 0.0;
-        for (int t = 0; t < nw; ++t) {
+        const int nq = v.nq;
+        for (int q = tid; q < nq; q += NT) out[q] = 0.0;
+        for (int dc = tid; dc < W.nd; dc += NT) W.cd[dc] = 0.0;
+        T::sync();
+        for (int t = tid; t < nw; t += NT) {
             const int k = W.wq[t], dc = W.dcol[k];
             const double ml = W.sgq[t] * coef[t];
-            if (dc >= 0) acc = fma(W.art[q * W.ndld + dc], ml, acc);
+            if (dc >= 0) W.cd[dc] = ml;
             else {
                 const int cn = sp.count(k);
-                for (int j = 0; j < cn; ++j) if (sp.index(k, j) == q) acc = fma(sp.value(k, j), ml, acc);
+                for (int j = 0; j < cn; ++j) atomicAdd(out + sp.index(k, j), sp.value(k, j) * ml);
             }
         }
-        return acc;
+        T::sync();
+        if (W.nd > 0) { art_mul<true>(v, W.cd, out, tid); T::sync(); }
+    }
+    // out[t] = (oriented normal of working row t)' x for t < nw.  Every thread calls; synchronised on return.
+    static __device__ __forceinline__ void ws_n_mul(const V &v, const Ws &W, const Sp &sp, int nw, const double *x, double *out, int tid)
+    {
+        if (W.nd > 0) { art_tmul(v, x, W.yd, tid); T::sync(); }
+        for (int t = tid; t < nw; t += NT) {
+            const int k = W.wq[t], dc = W.dcol[k];
+            out[t] = W.sgq[t] * (dc >= 0 ? W.yd[dc] : sp.dot(k, x));
+        }
+        T::sync();
     }
 
     // ------------------------------------------------------------------------------------------------------------------------------
@@ -948,8 +1028,9 @@ struct WgSqp {
         double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
         Red<WAVES> R(v.at(P.o_red));
         double sBs = 0, sy = 0;
+        ws_nt_mul(v, W, sp, nw_keep, uq, v2, tid);               // N' u with the previous multipliers and this point's rows
         for (int q = tid; q < nq; q += NT) {
-            const double gl = gr[q] + ws_combine(W, sp, nw_keep, uq, q);
+            const double gl = gr[q] + v2[q];
             const double y = gl - glold[q], Bs = -a_prev * glold[q];
             v0[q] = y; v1[q] = Bs;
             sBs += sv[q] * Bs; sy += sv[q] * y;
@@ -1003,25 +1084,6 @@ struct WgSqp {
             }
         }
     }
-    // out[t] = (normal of working row t)' x for t < nw: four lanes share a row
-    static __device__ __forceinline__ void ws_dots(const V &v, const Sp &sp, int nw, const double *x, double *out, int tid)
-    {
-        const WgPlan &P = v.C.P;
-        const int nq = v.nq, part = tid & 3;
-        const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
-        const double *sgq = v.at(P.o_sgq), *art = v.at(P.o_art);
-        for (int t0 = 0; t0 < nw; t0 += NT / 4) {
-            const int t = t0 + (tid >> 2);
-            const bool live = t < nw;
-            const int k = wq[live ? t : 0], dc = dcol[k];
-            double acc = 0.0;
-            if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * v.ndld + dc], x[q], acc); }
-            else if (part == 0) acc = sp.dot(k, x);
-            acc = group_sum<4>(acc);
-            if (live && part == 0) out[t] = sgq[t] * acc;
-        }
-    }
-
     // tq <- S^-1 tq over the working set with its factor (wavefront 0); y = L^-1 tq is left in yv: the factor's next row if the entering
     // row joins
     static MPCX_WG_PHASE void ws_solve(int nw)
@@ -1113,8 +1175,7 @@ struct WgSqp {
             for (int b2 = 0; b2 < nw; ++b2) {
                 normal_and_hinv(v, sp, wq[b2], sgq[b2], np_, vv, tid);
                 T::sync();
-                ws_dots(v, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);      // row b2 of S: entries 0 .. b2
-                T::sync();
+                ws_n_mul(v, W, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);  // row b2 of S: entries 0 .. b2
             }
         }
         T::sync();
@@ -1126,8 +1187,7 @@ struct WgSqp {
             return 0;
         }
         while (nw > 0) {
-            ws_dots(v, sp, nw, xq, tq, tid);
-            T::sync();
+            ws_n_mul(v, W, sp, nw, xq, tq, tid);
             for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
             T::sync();
             ws_solve(nw);
@@ -1139,11 +1199,11 @@ struct WgSqp {
             for (int t = nw - 1; t >= 0; --t) {
                 if (sheds(t)) { ws_drop(t, nw); --nw; }
             }
+            T::sync();                                           // (the next round overwrites tq)
         }
         if (nw > 0) {
-            for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(W, sp, nw, tq, q);
+            ws_nt_mul(v, W, sp, nw, tq, wv, tid);
             for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
-            T::sync();
             hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
             T::sync();
             for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
@@ -1163,7 +1223,7 @@ struct WgSqp {
         const Ws W(v);
         double *gr = v.at(P.o_gr), *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *mu = v.at(P.o_mu), *p = v.at(P.o_p),
                *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq),
-               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art);
+               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         const int *dcol = v.iat(P.o_dcol);
         Red<WAVES> R(v.at(P.o_red));
@@ -1177,38 +1237,28 @@ struct WgSqp {
         int nw = nw_keep > 0 ? ws_warm(nw_keep) : 0;
 
         // ---- the dual method
-        int fail = 0;
+        int fail = 0, nsteps = 0;
         bool done = false;
         for (int qit = 0; qit < 8 * (mt + nq) + 16 && !done && !fail; ++qit) {
             // the most violated row outside the working set
             double vmax = -1e300; int pidx = 0x7fffffff;
-            {
-                const int part = tid & 3;
-                for (int k0 = 0; k0 < mt; k0 += NT / 4) {
-                    const int k = k0 + (tid >> 2);
-                    const bool live = k < mt;
-                    const int kk = live ? k : 0, dc = dcol[kk];
-                    double acc = 0.0;
-                    if (dc >= 0) { for (int q = part; q < nq; q += 4) acc = fma(art[q * v.ndld + dc], xq[q], acc); }
-                    else if (part == 0) acc = sp.dot(kk, xq);
-                    acc = group_sum<4>(acc);
-                    double s = br[kk] + acc;
-                    if (is_eq(kk)) s = fabs(s);                          // an equality is violated on either side
-                    if (live && part == 0 && flag[kk] == 0 && s > vmax) { vmax = s; pidx = k; }
-                }
+            if (W.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
+            for (int k = tid; k < mt; k += NT) {
+                const int dc = dcol[k];
+                double s = br[k] + (dc >= 0 ? W.yd[dc] : sp.dot(k, xq));
+                if (is_eq(k)) s = fabs(s);                               // an equality is violated on either side
+                if (flag[k] == 0 && s > vmax) { vmax = s; pidx = k; }
             }
             R.argmax(vmax, pidx);
             if (mt == 0 || vmax <= 1e-12) { done = true; break; }        // primal feasible: optimal
+            ++nsteps;
             if (nw >= KW) { fail = -3; break; }                          // working set full
             // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
             const bool p_is_eq = is_eq(pidx);
             double sgn = 1.0;
             if (p_is_eq) {
-                double part = 0;
                 const int dc = dcol[pidx];
-                if (dc >= 0) { for (int q = tid; q < nq; q += NT) part += art[q * v.ndld + dc] * xq[q]; }
-                else if (tid == 0) part = sp.dot(pidx, xq);
-                sgn = br[pidx] + R.sum(part) < 0.0 ? -1.0 : 1.0;
+                sgn = br[pidx] + (dc >= 0 ? W.yd[dc] : sp.dot(pidx, xq)) < 0.0 ? -1.0 : 1.0;
             }
             normal_and_hinv(v, sp, pidx, sgn, np_, vv, tid);
             T::sync();
@@ -1220,11 +1270,9 @@ struct WgSqp {
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S), rr = S^-1 t, zd = B^-1 (n - N_W' rr)
                 if (nw > 0) {
-                    ws_dots(v, sp, nw, vv, tq, tid);
-                    T::sync();
+                    ws_n_mul(v, W, sp, nw, vv, tq, tid);
                     ws_solve(nw);
-                    for (int q = tid; q < nq; q += NT) wv[q] = ws_combine(W, sp, nw, tq, q);
-                    T::sync();
+                    ws_nt_mul(v, W, sp, nw, tq, wv, tid);
                     hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
                     T::sync();
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
@@ -1273,6 +1321,7 @@ struct WgSqp {
             if (!fail && !added) fail = -1;
         }
         if (!fail && !done) fail = -1;
+        if (tid == 0) st[ST_R5] += (double)nsteps;
         if (fail) { T::sync(); return fail; }
         for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
         T::sync();
@@ -1332,27 +1381,34 @@ struct WgSqp {
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         Red<WAVES> R(v.at(P.o_red));
         // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
-        for (int q = tid; q < nq; q += NT) glold[q] = gr[q] + ws_combine(W, sp, nw, uq, q);
+        ws_nt_mul(v, W, sp, nw, uq, glold, tid);
+        for (int q = tid; q < nq; q += NT) glold[q] += gr[q];
         double lam_max;
         if (uni(P.needs_phi)) {
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward chain over the blocks
             gwp gxg = (gwp)(v.w + uni(P.w_gx));
-            const int *bnd_idx = uni(M.bnd_idx);
-            const double *bnd_sign = uni(M.bnd_sign);
+            const int *bnd_idx = v.iat(P.o_bidx);
+            const double *bnd_sign = v.at(P.o_bsign);
+            const double *mu = v.at(P.o_mu);                                // (the sub-problem left mu[k] = orientation * multiplier, zero off the working set)
+            const int *sbf = v.iat(P.o_sbf);
+            const int ph = v.ph;
             for (int row = tid; row < nxs; row += NT) {
                 const int i = row / NX, a = row - i * NX;                   // entry a of state row i + 1
                 double s2 = gxg[row];
-                for (int t = 0; t < nw; ++t) {                              // mu lives on the working set
-                    const int k = wq[t];
-                    if (k < m) {
-                        if ((xmask[k] >> i) & 1ull) {
-                            const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
-                            s2 += jx[sl * NX + a] * (sgq[t] * uq[t]);
-                        }
-                    } else if (bnd_idx[k - m] == row) s2 += bnd_sign[k - m] * uq[t];
-                }
+                auto add = [&](int k) {
+                    if (((xmask[k] >> i) & 1ull) && mu[k] != 0.0) {
+                        const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
+                        s2 = fma(jx[sl * NX + a], mu[k], s2);
+                    }
+                };
+                int first, count;
+                Mdl::ineq_rows_of_x(i + 1, first, count);
+                for (int k = first; k < first + count; ++k) add(k);
+                for (int k = mi; k < m; ++k) add(k);
+                for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) if (bnd_idx[kb] == row) s2 = fma(bnd_sign[kb], mu[m + kb], s2);
                 lam[row] = s2;
             }
+            (void)ph;
             T::sync();
             chain<FL, true>(v, lam, tid);
             T::sync();
@@ -1377,7 +1433,7 @@ struct WgSqp {
     {
         const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
         const int ph = v.ph, mi = v.mi, m = v.m;
-        const double *prm = uni(C.prm);
+        const double *prm = v.at(P.o_prm);
         const double *z = v.at(P.o_z), *p = v.at(P.o_p);
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
         const double et = z[v.nz - 1] + al * p[v.nzu];
@@ -1391,13 +1447,13 @@ struct WgSqp {
         const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
         const double *z = v.at(P.o_z), *p = v.at(P.o_p);
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
-        return Mdl::cost(XL, UL, z[v.nz - 1] + al * p[v.nzu], v.ph, uni(C.prm));
+        return Mdl::cost(XL, UL, z[v.nz - 1] + al * p[v.nzu], v.ph, v.at(P.o_prm));
     }
     static __device__ __attribute__((noinline)) double ls_defects(double al, int part, int stride)
     {
         const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
         const int ph = v.ph;
-        const double *prm = uni(C.prm);
+        const double *prm = v.at(P.o_prm);
         const Scale sc(M);
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
         const double h = 0.5 * M.Ts;
@@ -1523,7 +1579,7 @@ struct WgSqp {
         const int ph = v.ph, nz = v.nz, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, b = uni(C.b);
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *gin = v.at(P.o_gin), *mu = v.at(P.o_mu), *hinv = v.at(P.o_hinv),
                      *st = v.at(P.o_st);
-        const double *u0 = uni(C.u0), *prm = uni(C.prm);
+        const double *u0 = uni(C.u0), *prm = v.at(P.o_prm);
         Red<WAVES> R(v.at(P.o_red));
         double gmax = -1e300, hmax = 0.0;
         for (int k = tid; k < m; k += NT) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
@@ -1572,7 +1628,7 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         WgCtx *C = reinterpret_cast<WgCtx *>(sm);
         if (tid == 0) {
             C->M = M; C->S = S; C->P = P;
-            C->w = S.ws + (size_t)b * P.ws_total;
+            C->w = S.ws + (size_t)b * M.ws.total;
             C->x0 = S.x0 + (size_t)b * Mdl::NX; C->u0 = S.u0 + (size_t)b * Mdl::NU;
             C->prm = S.params_b ? S.params_b + (size_t)b * S.nparams : M.params;
             C->b = b; C->pad = 0;
@@ -1580,15 +1636,22 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         T::sync();
     }
     const double *st = sm + P.o_st;
+    // shader-clock cycles per phase (tools/nlmpc_phases.py): evaluate (cost, dynamics, constraints), condense, BFGS, sub-problem, step, merit, line search, update
+    long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
+    auto lap = [&](int k) { const long long now = __builtin_readcyclecounter(); cyc[k] += now - tstamp; tstamp = now; };
     K::start();
+    lap(9);
     const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
     double nu_pen = 0.0, a_prev = 0.0, f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;
     bool have_old = false, stepped = false, final_eval = false;
     int resets = 0, nw_keep = 0, it = 0, code = 5;       // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
     for (;;) {
         K::eval_cost(final_eval ? 1 : 0);
+        lap(0);
         K::template eval_dyn<FL>(final_eval ? 1 : 0);
+        lap(1);
         K::eval_con(final_eval ? 1 : 0);
+        lap(2);
         if (final_eval) break;
         if (st[ST_ERR] != 0.0) { code = -3; break; }
         if (stepped && tol_on) {
@@ -1606,11 +1669,15 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         stepped = false;
         if (it >= S.max_iter) break;
         if (P.needs_phi) K::template condense_phi<FL>(); else K::template condense_chain<FL>();
+        lap(3);
         if (have_old) K::bfgs(a_prev, nw_keep);
+        lap(4);
         const int nw = K::qp(nw_keep);
+        lap(5);
         if (nw < 0) { code = nw; break; }
         nw_keep = nw;
         K::template step<FL>();
+        lap(6);
         const double dmax = st[ST_R0], cmax = st[ST_R1], gd = st[ST_R2], zmax = st[ST_R3];
         if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
             // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
@@ -1621,12 +1688,14 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         }
         T::sync();
         K::template merit<FL>(nw);
+        lap(7);
         const double lam_max = st[ST_R0], viol = st[ST_R1];
         if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
         const double phi0 = st[ST_COST] + nu_pen * viol;
         const double dphi = fmin(gd - nu_pen * viol, 0.0);
         T::sync();
         const double a_step = K::linesearch(nu_pen, phi0, dphi);
+        lap(8);
         if (a_step < 0.0) {                                  // no decrease left within 2^-40: the iteration has stalled
             if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
             if (resets >= 5) { code = -4; break; }
@@ -1640,12 +1709,18 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, con
         f_prev = st[ST_COST];
         T::sync();
         K::update(a_step);
+        lap(9);
         step_l1 = st[ST_R0]; z_l1 = st[ST_R1]; step_max = st[ST_R2];
         T::sync();
         a_prev = a_step; have_old = true; stepped = true;
         ++it;
     }
     K::finish(code, it);
+    if (tid == 0) {
+        double *scal = S.ws + (size_t)b * M.ws.total + P.w_scal;
+        scal[1] = st[ST_R5];
+        for (int k = 0; k < 10; ++k) scal[2 + k] = (double)cyc[k];
+    }
     (void)NT;
 }
 
@@ -1695,6 +1770,8 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = take(nr * P.ndld);
         P.o_wq = take((P.kw + 1) / 2); P.o_sgq = take(P.kw); P.o_uq = take(P.kw); P.o_tq = take(P.kw); P.o_invd = take(P.kw); P.o_yv = take(P.kw);
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
+        P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
+        P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;
         P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
@@ -1709,13 +1786,15 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     {
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
-        P.w_scal = take(16);
         P.w_F = take(P.f_lds ? 0 : ph * NX * FW);
         P.w_einv = take(Mdl::CONTINUOUS ? ph * NX * NX : 0);
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);
         P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
         P.ws_total = o;
+        // the instances keep the stride of the controller's workspace (NlmpcWsLayout), the statistics block its place in it
+        P.w_scal = m.ws.scal;
+        if (P.ws_total > m.ws.scal || m.ws.scal + 16 > m.ws.total) return -2;
     }
     return 0;
 }

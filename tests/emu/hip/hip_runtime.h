@@ -215,6 +215,7 @@ struct Idx { unsigned x, y, z; };
     } while (0)
 
 inline void __syncthreads() { hipemu::sync_block(); }
+inline double atomicAdd(double *p, double v) { const double o = *p; *p = o + v; return o; }     // (fibres run one at a time)
 
 using std::max;
 using std::min;

@@ -12,17 +12,26 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 c, x0, u0 = make(name, B)
 r = c.optimizeBatch(x0, u0); torch.cuda.synchronize()
 it = r["iterations"].cpu().numpy()
-acc = np.zeros(6)
+import os
+wg = os.environ.get("MPCX_NLMPC_FORM") != "wave"
+acc = np.zeros(10 if wg else 6)
 qst = np.zeros(8)
+dual = 0.0
 for i in range(0, B, max(1, B // 16)):
     sc = c.debug_workspace(i)["scal"]
-    acc += sc[2:8]
-    qst += sc[8:16] / max(1, it[i])
+    if wg:              # the workgroup form (nlmpc_sqp_wg): ten phases, dual steps of the whole solve in slot 1
+        acc += sc[2:12]; dual += sc[1] / max(1, it[i])
+    else:
+        acc += sc[2:8]
+        qst += sc[8:16] / max(1, it[i])
 qst /= len(range(0, B, max(1, B // 16)))
-names = ["condense", "reduce(gr,Ar,br)", "bfgs", "qp", "step+linesearch", "evaluate"]
+names = (["evaluate: cost+gradient", "evaluate: dynamics", "evaluate: constraints", "condense", "bfgs", "sub-problem", "step", "merit", "line search", "update+start"]
+         if wg else ["condense", "reduce(gr,Ar,br)", "bfgs", "qp", "step+linesearch", "evaluate"])
 tot = acc.sum()
 for n, v in zip(names, acc):
     print("%-18s %5.1f %%" % (n, 100 * v / tot))
+if wg:
+    print("dual steps per SQP iteration: %.2f" % (dual / len(range(0, B, max(1, B // 16)))))
 print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
 if qst.any():       # only a build with -DMPCX_NL_STATS (make -C libmpc_amd/csrc stats; MPCX_LIBRARY=libmpc_amd/libmpcx_stats.so) fills these
     print("sub-problem, per SQP iteration: steps %.1f, inner passes %.1f, rows at the end %.1f (max %d over the solve), rows kept %.1f, shed at the warm start %.1f,"
