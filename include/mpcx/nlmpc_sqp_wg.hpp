@@ -504,13 +504,14 @@ struct WgSqp {
                 for (int a = 0; a < NX; ++a) if (!isv && !isu && a == vv) xk[a] = base - d;
                 for (int a = 0; a < NU; ++a) if (!isv && isu && a == vv) uk[a] = base - d;
                 Mdl::f(f2, xk, uk, prm);
+                const double i2d = isv ? 0.0 : 1.0 / (2 * d);
                 for (int a = 0; a < NX; ++a) {
                     double out;
                     if (isv) {
                         const double cv = sc.over_ss(Xs[(i + 1) * NX + a] - f1[a], a);
                         c[i * NX + a] = cv; out = -cv;
                     } else {
-                        const double dcl = (f1[a] - f2[a]) / (2 * d);
+                        const double dcl = (f1[a] - f2[a]) * i2d;
                         // Jacobian entries: -Sx A Tx (state columns), -Sx B su (input columns); folded: their negatives
                         out = isu ? sc.by_su(sc.over_ss(dcl, a), vv) : sc.over_ss(sc.by_ss(dcl, vv), a);
                     }
@@ -565,8 +566,9 @@ struct WgSqp {
                         Mdl::f(o2, xp, up, prm);
                         // derivative columns: the central difference; the defect: f(x_i, u_i) on pass 0, f(x_{i+1}, u_i) on pass 1
                         const bool use = pass == 0 || kind >= 2;
+                        const double i2d = 1.0 / (2 * d);                 // (one division per column; the quotient's last bit is below the differences' noise)
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) col[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) / (2 * d));
+                        for (int a = 0; a < NX; ++a) col[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) * i2d);
                     }
 #pragma unroll
                     for (int a = 0; a < NX; ++a) {
@@ -721,63 +723,57 @@ struct WgSqp {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // A chain over the horizon with one column: v_{i+1} = Abar_i v_i + rhs_i (forward) or l_i = -rhs_i + Abar_{i+1}' l_{i+1} (backward),
-    // in place in `io` (rhs in, result out), run by wavefront 0: four lanes share a row, the next step's entries are requested before this
-    // step's are used.  Every thread of the workgroup calls it; the caller synchronises afterwards.
+    // in place in `io` (rhs in, result out), run by wavefront 0.  The column never leaves the registers: lane a of a group of NXP lanes
+    // (a quad for NX <= 4, a DPP row of sixteen beyond) holds entry a, the others' entries reach it by DPP broadcasts, its row (column, backward)
+    // of the next block is requested before this step's is used; LDS only receives the results.  Every thread of the workgroup
+    // calls it; the caller synchronises afterwards.
+    static constexpr int NXP = NX <= 4 ? 4 : 16;
+    template <int B> static __device__ __forceinline__ double chain_bcast(double x)
+    {
+        if constexpr (NXP == 4) return dpp_d<B * 0x55>(x);        // quad_perm [B, B, B, B]
+        else return row_share<0x150 + B>(x);
+    }
+    template <int B> struct ChainDot {
+        static __device__ __forceinline__ double run(const double (&f)[NX], double x, double acc)
+        {
+            if constexpr (B < NX) return ChainDot<B + 1>::run(f, x, fma(f[B], chain_bcast<B>(x), acc));
+            else return acc;
+        }
+    };
     template <bool FL, bool BACKWARD>
     static __device__ __forceinline__ void chain(const V &v, double *io, int tid)
     {
+        static_assert(NX <= 16, "a chain's column lives in one DPP row");
         if (tid >= 64) return;
         const int ph = v.ph;
         typename FP<FL>::type F = FP<FL>::get(v);
-        constexpr int RP = 16;                                  // rows per pass
-        constexpr int NP = (NX + RP - 1) / RP, CH = (NX + 3) / 4;
-        const int part = tid & 3, row = tid >> 2;
-        double fn[NP][CH];
-        auto fetch = [&](int blk) {                             // this lane's entries of block blk (or of its transpose)
+        const int a = tid & (NXP - 1), aa = min(a, NX - 1);
+        const bool alive = a < NX, writes = alive && tid < NXP;
+        double fn[NX];
+        auto fetch = [&](int blk) {                             // this lane's row of block blk (its column, backward)
 #pragma unroll
-            for (int pz = 0; pz < NP; ++pz) {
-                const int aa = min(pz * RP + row, NX - 1);
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int bb = min(part + 4 * u, NX - 1);
-                    fn[pz][u] = BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb];
-                }
-            }
+            for (int bb = 0; bb < NX; ++bb) fn[bb] = !alive ? 0.0 : (BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb]);
         };
         // forward: step i uses block i (from i = 1 on; v_0 = 0); backward: step i uses block i + 1 (up to i = ph - 2; l_ph = 0)
-        if (ph > 1) fetch(BACKWARD ? ph - 1 : 1);
+#pragma unroll
+        for (int bb = 0; bb < NX; ++bb) fn[bb] = 0.0;
+        double x = 0.0;
+        double rh = alive ? io[(BACKWARD ? ph - 1 : 0) * NX + aa] : 0.0;
         for (int step = 0; step < ph; ++step) {
             const int i = BACKWARD ? ph - 1 - step : step;
-            const bool has_prev = step > 0;
-            const double *prev = io + (BACKWARD ? (i + 1) * NX : (i - 1) * NX);
-            double fc[NP][CH];
+            double fc[NX];
 #pragma unroll
-            for (int pz = 0; pz < NP; ++pz)
-#pragma unroll
-                for (int u = 0; u < CH; ++u) fc[pz][u] = fn[pz][u];
-            if (step > 0 && step + 1 < ph) fetch(BACKWARD ? i : i + 1);
-            double res[NP];
-#pragma unroll
-            for (int pz = 0; pz < NP; ++pz) {
-                const int a = pz * RP + row;
-                const int aa = min(a, NX - 1);
-                double s = 0.0;
-                if (has_prev) {
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) s = fma(part + 4 * u < NX ? fc[pz][u] : 0.0, prev[min(part + 4 * u, NX - 1)], s);
-                }
-                s = group_sum<4>(s);
-                const double rh = io[i * NX + aa];
-                res[pz] = BACKWARD ? s - rh : s + rh;
+            for (int bb = 0; bb < NX; ++bb) fc[bb] = fn[bb];
+            const double rc = rh;
+            if (step + 1 < ph) {
+                fetch(BACKWARD ? i : i + 1);
+                rh = alive ? io[(BACKWARD ? i - 1 : i + 1) * NX + aa] : 0.0;
             }
-            nl_wave_sync();
-#pragma unroll
-            for (int pz = 0; pz < NP; ++pz) {
-                const int a = pz * RP + row;
-                if (a < NX && part == 0) io[i * NX + a] = res[pz];
-            }
-            nl_wave_sync();
+            const double s = ChainDot<0>::run(fc, x, 0.0);       // (zero on the first step: fc = 0)
+            x = alive ? (BACKWARD ? s - rc : s + rc) : 0.0;
+            if (writes) io[i * NX + aa] = x;
         }
+        nl_wave_sync();
     }
 
     // the multipliers of the defects themselves from the chain's values, lam_i = E_i^-T l_i: this thread's share of max |lam|
@@ -825,20 +821,46 @@ struct WgSqp {
         const double *bnd_sign = v.at(P.o_bsign);
         typename FP<FL>::type F = FP<FL>::get(v);
         if constexpr (NX <= 8) {
+            constexpr bool PF = NX <= 4;                         // the next step's block is requested while this one's is used (registers for it: small states)
             for (int q = tid; q <= nzu; q += NT) {
                 const bool isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
                 double x[NX], t[NX], gacc = 0.0;
-#pragma unroll
-                for (int a = 0; a < NX; ++a) x[a] = 0.0;
-                for (int i = 0; i < ph; ++i) {
-                    const bool drives = !isr && min(i, ch - 1) == bq;
+                double fb[PF ? NX * (NX + 1) : 1];
+                auto fetch = [&](int i) {
+                    const bool drv = !isr && min(i, ch - 1) == bq;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) {
-                        double s = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
 #pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) s = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], s);
-                        t[a] = s;
+                        for (int bb = 0; bb < NX; ++bb) fb[a * (NX + 1) + bb] = F[(size_t)(i * NX + a) * FW + bb];
+                        fb[a * (NX + 1) + NX] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+                    }
+                };
+#pragma unroll
+                for (int a = 0; a < NX; ++a) x[a] = 0.0;
+                if constexpr (PF) fetch(0);
+                for (int i = 0; i < ph; ++i) {
+                    if constexpr (PF) {
+                        double fcur[NX * (NX + 1)];
+#pragma unroll
+                        for (int e = 0; e < NX * (NX + 1); ++e) fcur[e] = fb[e];
+                        if (i + 1 < ph) fetch(i + 1);
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double s = fcur[a * (NX + 1) + NX];
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) s = fma(fcur[a * (NX + 1) + bb], x[bb], s);
+                            t[a] = s;
+                        }
+                    } else {
+                        const bool drives = !isr && min(i, ch - 1) == bq;
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double s = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) s = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], s);
+                            t[a] = s;
+                        }
                     }
 #pragma unroll
                     for (int a = 0; a < NX; ++a) x[a] = t[a];
@@ -1753,22 +1775,22 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
     auto imin = [](int a, int b) { return a < b ? a : b; };
     auto imax = [](int a, int b) { return a > b ? a : b; };
-    P.kw = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
+    const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
     int waves = waves_wanted;
     if (waves <= 0) waves = nz >= 96 ? 4 : (nz >= 48 ? 2 : 1);
     if (waves != 1 && waves != 2 && waves != 4) return -2;
     P.waves = waves;
-    for (int f_lds = 1; f_lds >= 0; --f_lds) {
+    auto layout = [&](int kw, int f_lds) {
         int o = kWgCtxDoubles;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
-        P.f_lds = f_lds;
+        P.kw = kw; P.f_lds = f_lds;
         P.o_red = take(16); P.o_st = take(ST_TOTAL);
         P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr); P.o_p = take(nr);
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
         P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
         P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = take(nr * P.ndld);
-        P.o_wq = take((P.kw + 1) / 2); P.o_sgq = take(P.kw); P.o_uq = take(P.kw); P.o_tq = take(P.kw); P.o_invd = take(P.kw); P.o_yv = take(P.kw);
+        P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw); P.o_yv = take(kw);
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
@@ -1778,11 +1800,29 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_Jm = take(ph * NU); P.o_lam = take(nxs); P.o_dx = take(nxs);
         const int endA = o;
         o = ov;
-        P.o_L = take(P.kw * (P.kw + 1) / 2);
+        P.o_L = take(kw * (kw + 1) / 2);
         P.lds_total = imax(endA, o);
-        if ((size_t)P.lds_total * sizeof(double) <= 160 * 1024) break;
-        if (f_lds == 0) return -2;
+        return (size_t)P.lds_total * sizeof(double);
+    };
+    // How many workgroups a CU holds is decided by the LDS block (160 KB per CU): with one wavefront per SIMD nothing hides the latency of
+    // a dependent LDS access, a second or third workgroup does.  The plan therefore takes the smallest budget (most workgroups per CU, up to
+    // the 32 wavefronts a CU runs) that holds the whole problem; where only the factor of the largest possible working set stands in the
+    // way of one more workgroup per CU, its capacity is cut -- not below 48 rows: a working set that outgrows it ends the solve with
+    // nlopt's OUT_OF_MEMORY code (status ERROR), as one beyond kNlMaxWorking always did.
+    const int kw_floor = imin(kw_full, 48);
+    bool placed = false;
+    const int max_wg = imin(8, 32 / waves);
+    for (int per_cu = max_wg; per_cu >= 1 && !placed; --per_cu) {
+        const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)15;
+        for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
+            if (layout(kw_full, f_lds) <= budget) { placed = true; break; }
+            if (per_cu == 1) continue;                          // (alone on the CU the factor keeps its full capacity)
+            int kw = kw_full;
+            while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
+            if (layout(kw, f_lds) <= budget) { placed = true; break; }
+        }
     }
+    if (!placed) return -2;
     {
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
