@@ -164,6 +164,7 @@ struct Scale {
     const double *su, *ss, *iss;
     bool on;
     __device__ __forceinline__ explicit Scale(const NlmpcDev &M) : su(M.su), ss(M.ss), iss(M.iss), on(M.scaled != 0) {}
+    __device__ __forceinline__ Scale(const double *su_, const double *ss_, const double *iss_, bool on_) : su(su_), ss(ss_), iss(iss_), on(on_) {}
     __device__ __forceinline__ double by_su(double v, int j) const { return on ? v * su[j] : v; }
     __device__ __forceinline__ double by_ss(double v, int j) const { return on ? v * ss[j] : v; }
     __device__ __forceinline__ double over_ss(double v, int j) const { return on ? v * iss[j] : v; }

@@ -50,17 +50,15 @@ struct WgPlan {
     int ws_total;
 };
 
-// The context block at the start of the workgroup's LDS: the three kernel arguments and this instance's pointers.  The phases read
-// what they need from here (uniform LDS reads) instead of carrying it through their calls.
-struct WgCtx {
+// The kernel's one argument.  The phases read what they need from it where it lies -- the kernarg segment, constant address space:
+// scalar loads, every dimension, offset and base pointer in SGPRs -- instead of carrying it through their calls.
+struct WgArgs {
     NlmpcDev M;
     NlmpcSolveDev S;
     WgPlan P;
-    double *w;
-    const double *x0, *u0, *prm;
-    int b, pad;
 };
-constexpr int kWgCtxDoubles = (int)((sizeof(WgCtx) + 15) / 16) * 2;
+typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
+constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
 enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_ACC = 16, ST_TOTAL = 32 };
@@ -72,16 +70,8 @@ __device__ __forceinline__ double *wg_lds()
     extern __shared__ __attribute__((aligned(16))) double smem[];
     return smem;
 }
-__device__ __forceinline__ const WgCtx &wg_ctx() { return *reinterpret_cast<const WgCtx *>(wg_lds()); }
+__device__ __forceinline__ WgArgsPtr wg_args() { return (WgArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
 
-// a value every lane holds (read from the context block in LDS) as a scalar: loop bounds and base addresses in SGPRs
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <class T> __device__ __forceinline__ T *uni(T *p)
-{
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
-}
 template <int CTRL> __device__ __forceinline__ double row_share(double v) { return dpp_d<CTRL>(v); }      // 0x150 + n: lane n of every row of 16
 
 template <int P> __device__ __forceinline__ double group_sum(double v)      // over P adjacent lanes (P = 1, 2, 4, 8, 16), every lane gets the sum
@@ -103,55 +93,60 @@ template <int WAVES> struct Team {
 
 // Reductions over the workgroup: a wave-level reduction, one LDS slot per wavefront, one barrier; the result is the same bits in every
 // thread (fixed order).  Two sets of slots alternate, so that consecutive reductions need no second barrier; a phase ends with a barrier.
+// The bodies are out of line: a solve passes through some forty reductions per iteration, and what bounds a wavefront that walks a long
+// instruction stream once per iteration is the instruction cache (64 KB for two CUs) -- every helper below exists once per kernel.
+#define MPCX_WG_CALL __device__ __attribute__((noinline))
+template <int WAVES> MPCX_WG_CALL double wg_red_sum(double v, double *s)
+{
+    v = wave_sum(v);
+    if constexpr (WAVES == 1) return v;
+    else {
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double r = s[0];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) r += s[i];
+        return r;
+    }
+}
+template <int WAVES> MPCX_WG_CALL double wg_red_max(double v, double *s)
+{
+    v = wave_max(v);
+    if constexpr (WAVES == 1) return v;
+    else {
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double r = s[0];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) r = fmax(r, s[i]);
+        return r;
+    }
+}
+// largest value and the lowest index holding it
+struct WgArgmax { double v; int idx; };
+template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, double *s)
+{
+    wave_argmax(v, idx);
+    if constexpr (WAVES > 1) {
+        if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s[4 + (threadIdx.x >> 6)] = (double)idx; }
+        __syncthreads();
+        v = s[0]; idx = (int)s[4];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) {
+            const double ov = s[i]; const int oi = (int)s[4 + i];
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+    }
+    return WgArgmax{v, idx};
+}
 template <int WAVES> struct Red {
     double *buf;
     int par;
     __device__ __forceinline__ explicit Red(double *b) : buf(b), par(0) {}
     __device__ __forceinline__ double *slots() { double *s = buf + par * 8; par ^= 1; return s; }
-    __device__ __forceinline__ double sum(double v)
-    {
-        v = wave_sum(v);
-        if constexpr (WAVES == 1) return v;
-        else {
-            double *s = slots();
-            if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-            __syncthreads();
-            double r = s[0];
-#pragma unroll
-            for (int i = 1; i < WAVES; ++i) r += s[i];
-            return r;
-        }
-    }
-    __device__ __forceinline__ double max(double v)
-    {
-        v = wave_max(v);
-        if constexpr (WAVES == 1) return v;
-        else {
-            double *s = slots();
-            if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-            __syncthreads();
-            double r = s[0];
-#pragma unroll
-            for (int i = 1; i < WAVES; ++i) r = fmax(r, s[i]);
-            return r;
-        }
-    }
-    // largest value and the lowest index holding it
-    __device__ __forceinline__ void argmax(double &v, int &idx)
-    {
-        wave_argmax(v, idx);
-        if constexpr (WAVES > 1) {
-            double *s = slots();
-            if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s[4 + (threadIdx.x >> 6)] = (double)idx; }
-            __syncthreads();
-            v = s[0]; idx = (int)s[4];
-#pragma unroll
-            for (int i = 1; i < WAVES; ++i) {
-                const double ov = s[i]; const int oi = (int)s[4 + i];
-                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-            }
-        }
-    }
+    __device__ __forceinline__ double sum(double v) { return wg_red_sum<WAVES>(v, slots()); }
+    __device__ __forceinline__ double max(double v) { return wg_red_max<WAVES>(v, slots()); }
+    __device__ __forceinline__ void argmax(double &v, int &idx) { const WgArgmax r = wg_red_argmax<WAVES>(v, idx, slots()); v = r.v; idx = r.idx; }
 };
 
 // dst = scale * H src for the symmetric matrix H packed by rows of its lower triangle (row r at r (r + 1) / 2), all in LDS;
@@ -284,29 +279,33 @@ struct WgSqp {
     static constexpr int GW = 3 * NX + NU + 1;                 // columns of the Gauss-Jordan tableau [E | A B c | I] of one step
     using T = Team<WAVES>;
 
-    struct V {                                                 // the views of the LDS block a phase needs, re-derived from the context
-        const WgCtx &C;
+    struct V {                                                 // what a phase needs of the arguments and of the LDS block (scalars throughout)
+        WgArgsPtr A;
         double *sm;
-        double *w;                                             // this instance's workspace
-        int ph, ch, nz, nxs, nzu, nr, mi, m, mt, nq, ndld, kw; // (scalars)
+        int b;                                                 // this workgroup's instance
+        double *w;                                             // its workspace
+        int ph, ch, nz, nxs, nzu, nr, mi, m, mt, nq, ndld, kw;
         __device__ __forceinline__ V()
-            : C(wg_ctx()), sm(wg_lds()), w(uni(C.w)), ph(uni(C.M.ph)), ch(uni(C.M.ch)), nz(uni(C.M.nz)), nxs(ph * NX), nzu(uni(C.M.nzu)),
-              nr(nzu + 1), mi(uni(C.M.nineq)), m(mi + uni(C.M.nue)), mt(m + uni(C.M.nbnd)), nq(uni(C.P.nq)), ndld(uni(C.P.ndld)), kw(uni(C.P.kw)) {}
-        __device__ __forceinline__ double *at(int off) const { return sm + uni(off); }
-        __device__ __forceinline__ int *iat(int off) const { return reinterpret_cast<int *>(sm + uni(off)); }
+            : A(wg_args()), sm(wg_lds()), b(blockIdx.x), w(A->S.ws + (size_t)b * A->M.ws.total), ph(A->M.ph), ch(A->M.ch), nz(A->M.nz),
+              nxs(ph * NX), nzu(A->M.nzu), nr(nzu + 1), mi(A->M.nineq), m(mi + A->M.nue), mt(m + A->M.nbnd), nq(A->P.nq), ndld(A->P.ndld), kw(A->P.kw) {}
+        __device__ __forceinline__ double *at(int off) const { return sm + off; }
+        __device__ __forceinline__ int *iat(int off) const { return reinterpret_cast<int *>(sm + off); }
+        __device__ __forceinline__ const double *x0() const { return A->S.x0 + (size_t)b * NX; }
+        __device__ __forceinline__ const double *u0() const { return A->S.u0 + (size_t)b * NU; }
+        __device__ __forceinline__ Scale scale() const { return Scale(A->M.su, A->M.ss, A->M.iss, A->M.scaled != 0); }
     };
     // the folded blocks: LDS or workspace, the pointer typed accordingly
     template <bool FL> struct FP {
         typedef typename BlockPtr<FL>::type type;
-        static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + uni(v.C.P.o_F) : v.w + uni(v.C.P.w_F)); }
+        static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + v.A->P.o_F : v.w + v.A->P.w_F); }
     };
 
     // the sparse form of sub-problem row k (as in nlmpc_sqp): first entry and count in LDS, entries 1 .. 3 in the workspace
     struct Sp {
         const double *s1v; const int *s1m; const double *spv; const int *spi;
         __device__ __forceinline__ explicit Sp(const V &v)
-            : s1v(v.at(v.C.P.o_s1v)), s1m(v.iat(v.C.P.o_s1m)), spv(v.w + uni(v.C.P.w_sp)),
-              spi(reinterpret_cast<const int *>(v.w + uni(v.C.P.w_sp) + (size_t)v.mt * kNlSparse)) {}
+            : s1v(v.at(v.A->P.o_s1v)), s1m(v.iat(v.A->P.o_s1m)), spv(v.w + v.A->P.w_sp),
+              spi(reinterpret_cast<const int *>(v.w + v.A->P.w_sp + (size_t)v.mt * kNlSparse)) {}
         __device__ __forceinline__ int count(int k) const { return s1m[k] >> 16; }
         __device__ __forceinline__ int index(int k, int j) const { return j == 0 ? (s1m[k] & 0xffff) : spi[k * kNlSparse + j]; }
         __device__ __forceinline__ double value(int k, int j) const { return j == 0 ? s1v[k] : spv[k * kNlSparse + j]; }
@@ -324,27 +323,27 @@ struct WgSqp {
     // start: initial guess (NLOptimizer.hpp:431-510), inverse Hessian estimate, structure tables
     static MPCX_WG_PHASE void start()
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &S = v.A->S; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt;
-        const int nbnd = mt - m, nsb = uni(P.nsb), nd_user = uni(P.nd_user);
+        const int nbnd = mt - m, nsb = P.nsb, nd_user = P.nd_user;
         double *z = v.at(P.o_z), *hinv = v.at(P.o_hinv), *mu = v.at(P.o_mu), *st = v.at(P.o_st);
         int *flag = v.iat(P.o_flag), *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *slot = v.iat(P.o_slot), *sbf = v.iat(P.o_sbf);
         unsigned long long *xmask = reinterpret_cast<unsigned long long *>(v.at(P.o_xmask));
-        const double *x0 = uni(C.x0), *u0 = uni(C.u0), *zwarm = uni(S.z_warm);
-        const double *zlb = uni(M.zlb), *zub = uni(M.zub);
-        const int *bnd_idx = uni(M.bnd_idx);
+        const double *x0 = v.x0(), *u0 = v.u0(), *zwarm = S.z_warm;
+        const double *zlb = M.zlb, *zub = M.zub;
+        const int *bnd_idx = M.bnd_idx;
         {
             // the model's parameters and the bound table into LDS: every model function reads parameters, and a read from HBM in the
             // middle of a dependent chain costs a memory latency each time
-            const double *prm_g = uni(C.prm), *bs = uni(M.bnd_sign), *bv = uni(M.bnd_val);
+            const double *prm_g = S.params_b ? S.params_b + (size_t)v.b * S.nparams : M.params, *bs = M.bnd_sign, *bv = M.bnd_val;
             double *prm_l = v.at(P.o_prm), *bsl = v.at(P.o_bsign), *bvl = v.at(P.o_bval);
             int *bil = v.iat(P.o_bidx);
             for (int k = tid; k < Mdl::NPARAMS; k += NT) prm_l[k] = prm_g[k];
             for (int k = tid; k < nbnd; k += NT) { bil[k] = bnd_idx[k]; bsl[k] = bs[k]; bvl[k] = bv[k]; }
         }
         if (zwarm) {
-            const double *zw = zwarm + (size_t)uni(C.b) * nz;
+            const double *zw = zwarm + (size_t)v.b * nz;
             for (int k = tid; k < nxs; k += NT) { const int i = k / NX; z[k] = zw[i == ph - 1 ? k : k + NX]; }
             for (int k = tid; k < nzu; k += NT) {
                 const int bl = k / NU, j = k - bl * NU;
@@ -358,8 +357,8 @@ struct WgSqp {
             if (tid == 0) z[nz - 1] = 0.0;
         }
         const int nh = nr * (nr + 1) / 2;
-        if (uni(S.keep_curvature)) {                          // the estimate the previous tick's solve left in the workspace
-            const double *hs = v.w + uni(P.w_hinv);
+        if (S.keep_curvature) {                          // the estimate the previous tick's solve left in the workspace
+            const double *hs = v.w + P.w_hinv;
             for (int e = tid; e < nh; e += NT) hinv[e] = hs[e];
         } else {
             for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
@@ -406,15 +405,15 @@ struct WgSqp {
     // (1) Mapping::unwrapVector (Mapping.hpp:174-211), Objective::evaluate + computeGradient (Objective.hpp:91-265)
     static MPCX_WG_PHASE void eval_cost(int values_only)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu;
         const double dv = kDv;
-        const double *prm = v.at(P.o_prm), *x0 = uni(C.x0);
-        const Scale sc(M);
+        const double *prm = v.at(P.o_prm), *x0 = v.x0();
+        const Scale sc = v.scale();
         double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *Jm = v.at(P.o_Jm), *lam = v.at(P.o_lam), *st = v.at(P.o_st),
                *gu = v.at(P.o_gu);
-        gwp gxg = (gwp)(v.w + uni(P.w_gx));
+        gwp gxg = (gwp)(v.w + P.w_gx);
         for (int k = tid; k < (ph + 1) * NX; k += NT) {
             const int i = k / NX, j = k - i * NX;
             Xs[k] = sc.over_ss(i == 0 ? x0[j] : z[(i - 1) * NX + j], j);
@@ -462,12 +461,12 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void eval_dyn(int values_only)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
-        const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int ph = v.ph;
         const double dv = kDv;
         const double *prm = v.at(P.o_prm);
-        const Scale sc(M);
+        const Scale sc = v.scale();
         const double *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
         double *c = v.at(P.o_c);
         const double h = 0.5 * M.Ts;
@@ -521,7 +520,7 @@ struct WgSqp {
         } else {
             // collocation: per step a Gauss-Jordan on [E | A B c | I], one column per lane in registers; G steps per wavefront at a time
             typename FP<FL>::type F = FP<FL>::get(v);
-            gwp einv = (gwp)(v.w + uni(P.w_einv));
+            gwp einv = (gwp)(v.w + P.w_einv);
             constexpr int G = 64 / GW > 0 ? 64 / GW : 1;
             const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
             // kind of column: 0 E (perturb x_{i+1}), 1 A (perturb x_i), 2 B (perturb u_i), 3 the defect, 4 identity
@@ -619,13 +618,13 @@ struct WgSqp {
     // computeEqJacobian :731-832) as blocks: one NX-vector per (row, state row) pair, the input part straight into the sub-problem's rows
     static MPCX_WG_PHASE void eval_con(int values_only)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nz = v.nz, nxs = v.nxs, nzu = v.nzu, mi = v.mi, m = v.m, mt = v.mt, nq = v.nq, ndld = v.ndld;
-        const int nsx = uni(P.nsx);
+        const int nsx = P.nsx;
         const double dv = kDv;
         const double *prm = v.at(P.o_prm);
-        const Scale sc(M);
+        const Scale sc = v.scale();
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
         double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
         int *s1m = v.iat(P.o_s1m);
@@ -654,8 +653,8 @@ struct WgSqp {
             jx[t] = sc.by_ss(val, j);                            // the state columns are multiplied by the state scaling (Constraints.hpp:269-284)
         }
         // the input part, one lane per user row: into the row's column of art (dense rows) or its (index, value) list
-        gwp spv = (gwp)(v.w + uni(P.w_sp));
-        int *spi = reinterpret_cast<int *>(v.w + uni(P.w_sp) + (size_t)mt * kNlSparse);
+        gwp spv = (gwp)(v.w + P.w_sp);
+        int *spi = reinterpret_cast<int *>(v.w + P.w_sp + (size_t)mt * kNlSparse);
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
@@ -781,7 +780,7 @@ struct WgSqp {
     {
         double lmax = 0.0;
         if (CT) {
-            gwp einv = (gwp)(v.w + uni(v.C.P.w_einv));
+            gwp einv = (gwp)(v.w + v.A->P.w_einv);
             for (int k = tid; k < v.nxs; k += NT) {
                 const int i = k / NX, a = k - i * NX;
                 double s = 0.0;
@@ -810,7 +809,7 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void condense_phi()
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nzu = v.nzu, mi = v.mi, m = v.m, ndld = v.ndld;
         const double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *jx = v.at(P.o_jx);
@@ -933,7 +932,7 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void condense_chain()
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nzu = v.nzu;
         double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *gr = v.at(P.o_gr), *st = v.at(P.o_st);
@@ -961,8 +960,8 @@ struct WgSqp {
     // yd[dc] = (column dc of art)' x for every dense column (four lanes share a column).  Every thread calls; the caller synchronises.
     static __device__ __forceinline__ void art_tmul(const V &v, const double *x, double *yd, int tid)
     {
-        const WgPlan &P = v.C.P;
-        const int nd = uni(P.nd), nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const auto &P = v.A->P;
+        const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
         const double *art = v.at(P.o_art);
         for (int d0 = 0; d0 < nd; d0 += NT / 4) {
             const int dc = d0 + (tid >> 2);
@@ -980,8 +979,8 @@ struct WgSqp {
     template <bool ACCUMULATE>
     static __device__ __forceinline__ void art_mul(const V &v, const double *cd, double *out, int tid)
     {
-        const WgPlan &P = v.C.P;
-        const int nd = uni(P.nd), nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const auto &P = v.A->P;
+        const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
         const double *art = v.at(P.o_art);
         for (int q0 = 0; q0 < nq; q0 += NT / 4) {
             const int q = q0 + (tid >> 2);
@@ -1003,14 +1002,17 @@ struct WgSqp {
         double *cd, *yd;
         int nd;
         __device__ __forceinline__ explicit Ws(const V &v)
-            : wq(v.iat(v.C.P.o_wq)), dcol(v.iat(v.C.P.o_dcol)), sgq(v.at(v.C.P.o_sgq)), cd(v.at(v.C.P.o_cd)), yd(v.at(v.C.P.o_yd)), nd(uni(v.C.P.nd)) {}
+            : wq(v.iat(v.A->P.o_wq)), dcol(v.iat(v.A->P.o_dcol)), sgq(v.at(v.A->P.o_sgq)), cd(v.at(v.A->P.o_cd)), yd(v.at(v.A->P.o_yd)), nd(v.A->P.nd) {}
     };
     // out[q] = sum_t coef[t] * (oriented normal of working row t)[q] for q < nq: the sparse rows scatter their few entries (an LDS atomic
-    // add each: two rows on one variable add up in either order to the same bits), the dense rows go through art.  Every thread
-    // calls; synchronised on return.
-    static __device__ __forceinline__ void ws_nt_mul(const V &v, const Ws &W, const Sp &sp, int nw, const double *coef, double *out, int tid)
+    // add each: two rows on one variable add up in either order to the same bits), the dense rows go through art.  Arrays by their LDS
+    // offsets; every thread calls; synchronised on return.  (Out of line, like everything the sub-problem uses more than once.)
+    static MPCX_WG_CALL void ws_nt_mul(int nw, int coef_off, int out_off)
     {
-        const int nq = v.nq;
+        const V v; const Sp sp(v); const Ws W(v);
+        const int tid = threadIdx.x, nq = v.nq;
+        const double *coef = v.at(coef_off);
+        double *out = v.at(out_off);
         for (int q = tid; q < nq; q += NT) out[q] = 0.0;
         for (int dc = tid; dc < W.nd; dc += NT) W.cd[dc] = 0.0;
         T::sync();
@@ -1026,9 +1028,13 @@ struct WgSqp {
         T::sync();
         if (W.nd > 0) { art_mul<true>(v, W.cd, out, tid); T::sync(); }
     }
-    // out[t] = (oriented normal of working row t)' x for t < nw.  Every thread calls; synchronised on return.
-    static __device__ __forceinline__ void ws_n_mul(const V &v, const Ws &W, const Sp &sp, int nw, const double *x, double *out, int tid)
+    // out[t] = (oriented normal of working row t)' x for t < nw
+    static MPCX_WG_CALL void ws_n_mul(int nw, int x_off, int out_off)
     {
+        const V v; const Sp sp(v); const Ws W(v);
+        const int tid = threadIdx.x;
+        const double *x = v.at(x_off);
+        double *out = v.at(out_off);
         if (W.nd > 0) { art_tmul(v, x, W.yd, tid); T::sync(); }
         for (int t = tid; t < nw; t += NT) {
             const int k = W.wq[t], dc = W.dcol[k];
@@ -1036,58 +1042,20 @@ struct WgSqp {
         }
         T::sync();
     }
-
-    // ------------------------------------------------------------------------------------------------------------------------------
-    // damped BFGS update of the inverse Hessian estimate (Powell): s = a p, y = change of the reduced Lagrangian gradient
-    static MPCX_WG_PHASE void bfgs(double a_prev, int nw_keep)
+    // dst = scale * B^-1 src
+    static MPCX_WG_CALL void hmul_call(int src_off, int dst_off, double scale)
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
-        const int tid = threadIdx.x;
-        const int nq = v.nq;
-        const Sp sp(v);
-        const Ws W(v);
-        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq);
-        double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
-        Red<WAVES> R(v.at(P.o_red));
-        double sBs = 0, sy = 0;
-        ws_nt_mul(v, W, sp, nw_keep, uq, v2, tid);               // N' u with the previous multipliers and this point's rows
-        for (int q = tid; q < nq; q += NT) {
-            const double gl = gr[q] + v2[q];
-            const double y = gl - glold[q], Bs = -a_prev * glold[q];
-            v0[q] = y; v1[q] = Bs;
-            sBs += sv[q] * Bs; sy += sv[q] * y;
-        }
-        sBs = R.sum(sBs); sy = R.sum(sy);
-        if (sy < 0.2 * sBs) {
-            const double th = 0.8 * sBs / (sBs - sy);
-            for (int q = tid; q < nq; q += NT) v0[q] = th * v0[q] + (1 - th) * v1[q];
-            sy = th * sy + (1 - th) * sBs;
-        }
-        T::sync();
-        if (sy > 1e-300) {
-            const double rho = 1.0 / sy;
-            hmul<NT>(hinv, v0, v2, nq, 1.0, tid);
-            T::sync();
-            double yHy = 0;
-            for (int q = tid; q < nq; q += NT) yHy += v2[q] * v0[q];
-            yHy = R.sum(yHy);
-            const double cc = rho * rho * yHy + rho;
-            for (int e = tid; e < nq * (nq + 1) / 2; e += NT) {
-                int r, c;
-                tri_index(e, r, c);
-                hinv[e] += -rho * (sv[r] * v2[c] + v2[r] * sv[c]) + cc * sv[r] * sv[c];
-            }
-        }
+        const V v;
+        hmul<NT>(v.at(v.A->P.o_hinv), v.at(src_off), v.at(dst_off), v.nq, scale, threadIdx.x);
         T::sync();
     }
-
-    // ------------------------------------------------------------------------------------------------------------------------------
-    // the normal n = sgn * (row k) of a sub-problem row and vv = B^-1 n, both into LDS (every thread calls; the caller synchronises)
-    static __device__ __forceinline__ void normal_and_hinv(const V &v, const Sp &sp, int k, double sgn, double *np_, double *vv, int tid)
+    // the oriented normal n = sgn * (row k) of a sub-problem row into np and vv = B^-1 n
+    static MPCX_WG_CALL void normal_call(int k, double sgn)
     {
-        const WgPlan &P = v.C.P;
-        const int nq = v.nq, dc = v.iat(P.o_dcol)[k];
+        const V v; const auto &P = v.A->P; const Sp sp(v);
+        const int tid = threadIdx.x, nq = v.nq, dc = v.iat(P.o_dcol)[k];
         const double *hinv = v.at(P.o_hinv), *art = v.at(P.o_art);
+        double *np_ = v.at(P.o_np), *vv = v.at(P.o_vv);
         if (dc >= 0) {
             for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * v.ndld + dc];
             T::sync();
@@ -1105,12 +1073,78 @@ struct WgSqp {
                 np_[q] = nvl; vv[q] = hv;
             }
         }
+        T::sync();
     }
+    // the most violated row outside the working set at xq (an equality is violated on either side); yd keeps art' xq
+    static MPCX_WG_CALL WgArgmax scan_call()
+    {
+        const V v; const auto &P = v.A->P; const Sp sp(v); const Ws W(v);
+        const int tid = threadIdx.x, mi = v.mi, m = v.m, mt = v.mt;
+        const double *xq = v.at(P.o_xq), *br = v.at(P.o_br);
+        const int *flag = v.iat(P.o_flag);
+        if (W.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
+        double vmax = -1e300; int pidx = 0x7fffffff;
+        for (int k = tid; k < mt; k += NT) {
+            const int dc = W.dcol[k];
+            double s = br[k] + (dc >= 0 ? W.yd[dc] : sp.dot(k, xq));
+            if (k >= mi && k < m) s = fabs(s);
+            if (flag[k] == 0 && s > vmax) { vmax = s; pidx = k; }
+        }
+        Red<WAVES> R(v.at(P.o_red));
+        R.argmax(vmax, pidx);
+        T::sync();
+        return WgArgmax{vmax, pidx};
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // damped BFGS update of the inverse Hessian estimate (Powell): s = a p, y = change of the reduced Lagrangian gradient
+    static MPCX_WG_PHASE void bfgs(double a_prev, int nw_keep)
+    {
+        const V v; const auto &P = v.A->P;
+        const int tid = threadIdx.x;
+        const int nq = v.nq;
+        const Sp sp(v);
+        const Ws W(v);
+        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq);
+        double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
+        Red<WAVES> R(v.at(P.o_red));
+        double sBs = 0, sy = 0;
+        ws_nt_mul(nw_keep, P.o_uq, P.o_vv);                      // N' u with the previous multipliers and this point's rows
+        for (int q = tid; q < nq; q += NT) {
+            const double gl = gr[q] + v2[q];
+            const double y = gl - glold[q], Bs = -a_prev * glold[q];
+            v0[q] = y; v1[q] = Bs;
+            sBs += sv[q] * Bs; sy += sv[q] * y;
+        }
+        sBs = R.sum(sBs); sy = R.sum(sy);
+        if (sy < 0.2 * sBs) {
+            const double th = 0.8 * sBs / (sBs - sy);
+            for (int q = tid; q < nq; q += NT) v0[q] = th * v0[q] + (1 - th) * v1[q];
+            sy = th * sy + (1 - th) * sBs;
+        }
+        T::sync();
+        if (sy > 1e-300) {
+            const double rho = 1.0 / sy;
+            hmul_call(P.o_xq, P.o_vv, 1.0);
+            double yHy = 0;
+            for (int q = tid; q < nq; q += NT) yHy += v2[q] * v0[q];
+            yHy = R.sum(yHy);
+            const double cc = rho * rho * yHy + rho;
+            for (int e = tid; e < nq * (nq + 1) / 2; e += NT) {
+                int r, c;
+                tri_index(e, r, c);
+                hinv[e] += -rho * (sv[r] * v2[c] + v2[r] * sv[c]) + cc * sv[r] * sv[c];
+            }
+        }
+        T::sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
     // tq <- S^-1 tq over the working set with its factor (wavefront 0); y = L^-1 tq is left in yv: the factor's next row if the entering
     // row joins
     static MPCX_WG_PHASE void ws_solve(int nw)
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x, lane = tid & 63;
         double *tq = v.at(P.o_tq), *yv = v.at(P.o_yv);
         if (tid < 64) {
@@ -1128,7 +1162,7 @@ struct WgSqp {
     // row t leaves the working set of nw rows: the factor is down-dated, the lists close up
     static MPCX_WG_PHASE void ws_drop(int kdrop, int nw)
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x, lane = tid & 63;
         double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
@@ -1148,7 +1182,7 @@ struct WgSqp {
     // the entering row joins as row nw of the factor (from yv) and of the lists
     static MPCX_WG_PHASE void ws_append(int nw, int pidx, double sgn, double up, double snn)
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x, lane = tid & 63;
         double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *yv = v.at(P.o_yv);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
@@ -1166,7 +1200,7 @@ struct WgSqp {
     // on return; returns the number of rows kept.
     static MPCX_WG_PHASE int ws_warm(int nw_keep)
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x, lane = tid & 63;
         const int mi = v.mi, m = v.m, nq = v.nq;
         const Sp sp(v);
@@ -1195,9 +1229,8 @@ struct WgSqp {
             }
         } else {
             for (int b2 = 0; b2 < nw; ++b2) {
-                normal_and_hinv(v, sp, wq[b2], sgq[b2], np_, vv, tid);
-                T::sync();
-                ws_n_mul(v, W, sp, b2 + 1, vv, Lp + b2 * (b2 + 1) / 2, tid);  // row b2 of S: entries 0 .. b2
+                normal_call(wq[b2], sgq[b2]);
+                ws_n_mul(b2 + 1, P.o_vv, P.o_L + b2 * (b2 + 1) / 2);        // row b2 of S: entries 0 .. b2
             }
         }
         T::sync();
@@ -1209,7 +1242,7 @@ struct WgSqp {
             return 0;
         }
         while (nw > 0) {
-            ws_n_mul(v, W, sp, nw, xq, tq, tid);
+            ws_n_mul(nw, P.o_xq, P.o_tq);
             for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
             T::sync();
             ws_solve(nw);
@@ -1224,10 +1257,9 @@ struct WgSqp {
             T::sync();                                           // (the next round overwrites tq)
         }
         if (nw > 0) {
-            ws_nt_mul(v, W, sp, nw, tq, wv, tid);
+            ws_nt_mul(nw, P.o_tq, P.o_wv);
             for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
-            hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
-            T::sync();
+            hmul_call(P.o_wv, P.o_zd, 1.0);
             for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
         }
         T::sync();
@@ -1238,7 +1270,7 @@ struct WgSqp {
     // returns the size of the final working set (>= 0) or a failure code (< 0)
     static MPCX_WG_PHASE int qp(int nw_keep)
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, nq = v.nq, KW = v.kw;
         const Sp sp(v);
@@ -1252,8 +1284,7 @@ struct WgSqp {
         auto is_eq = [&](int k) { return k >= mi && k < m; };
 
         for (int k = tid; k < mt; k += NT) flag[k] = 0;
-        hmul<NT>(hinv, gr, xq, nq, -1.0, tid);                  // the unconstrained minimiser x = -B^-1 gr
-        T::sync();
+        hmul_call(P.o_gr, P.o_xq, -1.0);                        // the unconstrained minimiser x = -B^-1 gr
         for (int t = tid; t < nw_keep; t += NT) flag[wq[t]] = 1;
         T::sync();
         int nw = nw_keep > 0 ? ws_warm(nw_keep) : 0;
@@ -1263,15 +1294,9 @@ struct WgSqp {
         bool done = false;
         for (int qit = 0; qit < 8 * (mt + nq) + 16 && !done && !fail; ++qit) {
             // the most violated row outside the working set
-            double vmax = -1e300; int pidx = 0x7fffffff;
-            if (W.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
-            for (int k = tid; k < mt; k += NT) {
-                const int dc = dcol[k];
-                double s = br[k] + (dc >= 0 ? W.yd[dc] : sp.dot(k, xq));
-                if (is_eq(k)) s = fabs(s);                               // an equality is violated on either side
-                if (flag[k] == 0 && s > vmax) { vmax = s; pidx = k; }
-            }
-            R.argmax(vmax, pidx);
+            const WgArgmax worst = scan_call();
+            const double vmax = worst.v;
+            const int pidx = worst.idx;
             if (mt == 0 || vmax <= 1e-12) { done = true; break; }        // primal feasible: optimal
             ++nsteps;
             if (nw >= KW) { fail = -3; break; }                          // working set full
@@ -1282,8 +1307,7 @@ struct WgSqp {
                 const int dc = dcol[pidx];
                 sgn = br[pidx] + (dc >= 0 ? W.yd[dc] : sp.dot(pidx, xq)) < 0.0 ? -1.0 : 1.0;
             }
-            normal_and_hinv(v, sp, pidx, sgn, np_, vv, tid);
-            T::sync();
+            normal_call(pidx, sgn);
             double snn = 0, npn = 0;
             for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
             snn = R.sum(snn); npn = R.sum(npn);
@@ -1292,11 +1316,10 @@ struct WgSqp {
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S), rr = S^-1 t, zd = B^-1 (n - N_W' rr)
                 if (nw > 0) {
-                    ws_n_mul(v, W, sp, nw, vv, tq, tid);
+                    ws_n_mul(nw, P.o_vv, P.o_tq);
                     ws_solve(nw);
-                    ws_nt_mul(v, W, sp, nw, tq, wv, tid);
-                    hmul<NT>(hinv, wv, zd, nq, 1.0, tid);
-                    T::sync();
+                    ws_nt_mul(nw, P.o_tq, P.o_wv);
+                    hmul_call(P.o_wv, P.o_zd, 1.0);
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
                 } else {
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q];
@@ -1359,12 +1382,12 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void step()
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ch = v.ch, nz = v.nz, nxs = v.nxs, nr = v.nr, mi = v.mi, m = v.m;
         double *p = v.at(P.o_p), *dx = v.at(P.o_dx), *c = v.at(P.o_c), *z = v.at(P.o_z), *gu = v.at(P.o_gu), *gin = v.at(P.o_gin), *st = v.at(P.o_st);
         typename FP<FL>::type F = FP<FL>::get(v);
-        gwp gxg = (gwp)(v.w + uni(P.w_gx));
+        gwp gxg = (gwp)(v.w + P.w_gx);
         for (int k = tid; k < nxs; k += NT) {
             const int i = k / NX;
             const double *pb = p + min(i, ch - 1) * NU;
@@ -1392,7 +1415,7 @@ struct WgSqp {
     template <bool FL>
     static MPCX_WG_PHASE void merit(int nw)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int nxs = v.nxs, mi = v.mi, m = v.m, nq = v.nq;
         const Sp sp(v);
@@ -1403,12 +1426,12 @@ struct WgSqp {
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         Red<WAVES> R(v.at(P.o_red));
         // reduced Lagrangian gradient at this point with the new multipliers: the BFGS memory
-        ws_nt_mul(v, W, sp, nw, uq, glold, tid);
+        ws_nt_mul(nw, P.o_uq, P.o_glold);
         for (int q = tid; q < nq; q += NT) glold[q] += gr[q];
         double lam_max;
-        if (uni(P.needs_phi)) {
+        if (P.needs_phi) {
             // multipliers of the dynamics equalities: Jx' lam = -(g_x + Jin_x' mu), a backward chain over the blocks
-            gwp gxg = (gwp)(v.w + uni(P.w_gx));
+            gwp gxg = (gwp)(v.w + P.w_gx);
             const int *bnd_idx = v.iat(P.o_bidx);
             const double *bnd_sign = v.at(P.o_bsign);
             const double *mu = v.at(P.o_mu);                                // (the sub-problem left mu[k] = orientation * multiplier, zero off the working set)
@@ -1453,7 +1476,7 @@ struct WgSqp {
     // The three parts of a trial point's merit value, each this lane's share:
     static __device__ __attribute__((noinline)) double ls_user_rows(double al, int part, int stride)
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const int ph = v.ph, mi = v.mi, m = v.m;
         const double *prm = v.at(P.o_prm);
         const double *z = v.at(P.o_z), *p = v.at(P.o_p);
@@ -1466,17 +1489,17 @@ struct WgSqp {
     }
     static __device__ __attribute__((noinline)) double ls_cost(double al)
     {
-        const V v; const WgCtx &C = v.C; const WgPlan &P = C.P;
+        const V v; const auto &P = v.A->P;
         const double *z = v.at(P.o_z), *p = v.at(P.o_p);
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
         return Mdl::cost(XL, UL, z[v.nz - 1] + al * p[v.nzu], v.ph, v.at(P.o_prm));
     }
     static __device__ __attribute__((noinline)) double ls_defects(double al, int part, int stride)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int ph = v.ph;
         const double *prm = v.at(P.o_prm);
-        const Scale sc(M);
+        const Scale sc = v.scale();
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
         const double h = 0.5 * M.Ts;
         double vio = 0.0;
@@ -1499,11 +1522,11 @@ struct WgSqp {
     // returns the accepted length, or -1 if none down to 2^-40
     static MPCX_WG_PHASE double linesearch(double nu_pen, double phi0, double dphi)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcDev &M = C.M; const WgPlan &P = C.P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nxs = v.nxs;
-        const Scale sc(M);
-        const double *x0 = uni(C.x0);
+        const Scale sc = v.scale();
+        const double *x0 = v.x0();
         double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *dXs = v.at(P.o_dXs), *dUs = v.at(P.o_dUs), *dx = v.at(P.o_dx),
                *p = v.at(P.o_p), *st = v.at(P.o_st);
         for (int k = tid; k < (ph + 1) * NX; k += NT) {
@@ -1540,7 +1563,7 @@ struct WgSqp {
     // z += a d; s = a p for the next BFGS update; the step's norms for nlopt's stopping rules: st[R0..R2] = |step|_1, |z|_1, max |step|
     static MPCX_WG_PHASE void update(double a_step)
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p), *sv = v.at(P.o_sv), *st = v.at(P.o_st);
@@ -1561,7 +1584,7 @@ struct WgSqp {
     // largest violation at z, for nlopt's stopping rules (applied to a step that ended at a feasible point)
     static MPCX_WG_PHASE double violation()
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int nxs = v.nxs, mi = v.mi, m = v.m;
         const double *c = v.at(P.o_c), *gin = v.at(P.o_gin);
@@ -1576,7 +1599,7 @@ struct WgSqp {
 
     static MPCX_WG_PHASE void reset_hessian()
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         double *hinv = v.at(P.o_hinv);
         const int nr = v.nr;
         for (int e = threadIdx.x; e < nr * (nr + 1) / 2; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
@@ -1584,7 +1607,7 @@ struct WgSqp {
     }
     static MPCX_WG_PHASE void take_last_step()
     {
-        const V v; const WgPlan &P = v.C.P;
+        const V v; const auto &P = v.A->P;
         const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p);
         for (int k = threadIdx.x; k < nxs + nr; k += NT) z[k] += k < nxs ? dx[k] : p[k - nxs];
@@ -1596,18 +1619,18 @@ struct WgSqp {
     // trajectory of the last evaluation
     static MPCX_WG_PHASE void finish(int code, int it)
     {
-        const V v; const WgCtx &C = v.C; const NlmpcSolveDev &S = C.S; const WgPlan &P = C.P;
+        const V v; const auto &S = v.A->S; const auto &P = v.A->P;
         const int tid = threadIdx.x;
-        const int ph = v.ph, nz = v.nz, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, b = uni(C.b);
+        const int ph = v.ph, nz = v.nz, nr = v.nr, mi = v.mi, m = v.m, mt = v.mt, b = v.b;
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *gin = v.at(P.o_gin), *mu = v.at(P.o_mu), *hinv = v.at(P.o_hinv),
                      *st = v.at(P.o_st);
-        const double *u0 = uni(C.u0), *prm = v.at(P.o_prm);
+        const double *u0 = v.u0(), *prm = v.at(P.o_prm);
         Red<WAVES> R(v.at(P.o_red));
         double gmax = -1e300, hmax = 0.0;
         for (int k = tid; k < m; k += NT) { if (k < mi) gmax = fmax(gmax, gin[k]); else hmax = fmax(hmax, fabs(gin[k])); }
         gmax = R.max(gmax); hmax = R.max(hmax);
         const bool failed = code < 0;
-        double *o_cmd = uni(S.cmd), *o_z = uni(S.z_out), *o_mu = uni(S.mu_out), *o_sx = uni(S.seq_state), *o_su = uni(S.seq_input), *o_sy = uni(S.seq_output);
+        double *o_cmd = S.cmd, *o_z = S.z_out, *o_mu = S.mu_out, *o_sx = S.seq_state, *o_su = S.seq_input, *o_sy = S.seq_output;
         if (o_cmd) for (int j = tid; j < NU; j += NT) o_cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
         if (o_z) for (int k = tid; k < nz; k += NT) o_z[(size_t)b * nz + k] = z[k];
         if (o_mu) for (int k = tid; k < mt; k += NT) o_mu[(size_t)b * mt + k] = mu[k];
@@ -1621,9 +1644,9 @@ struct WgSqp {
                 for (int a = 0; a < Mdl::NY; ++a) o_sy[((size_t)b * (ph + 1) + i) * Mdl::NY + a] = y[a];
             }
         // the curvature estimate stays in the workspace for a receding-horizon successor (keep_curvature)
-        gwp hs = (gwp)(v.w + uni(P.w_hinv));
+        gwp hs = (gwp)(v.w + P.w_hinv);
         for (int e = tid; e < nr * (nr + 1) / 2; e += NT) hs[e] = hinv[e];
-        double *scal = v.w + uni(P.w_scal);
+        double *scal = v.w + P.w_scal;
         if (tid == 0) {
             if (S.cost) S.cost[b] = failed ? __builtin_huge_val() : st[ST_COST];
             if (S.solver_status) S.solver_status[b] = code;
@@ -1638,25 +1661,16 @@ struct WgSqp {
 
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const NlmpcDev M, const NlmpcSolveDev S, const WgPlan P)
+__global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const WgArgs A)
 {
     using K = WgSqp<Mdl, WAVES>;
     using T = Team<WAVES>;
     constexpr int NT = 64 * WAVES;
+    const auto &M = wg_args()->M;
+    const auto &S = wg_args()->S;
+    const auto &P = wg_args()->P;
     const int tid = threadIdx.x, b = blockIdx.x;
     double *sm = wg_lds();
-    {
-        // the context block: the kernel's arguments and this instance's pointers, word by word
-        WgCtx *C = reinterpret_cast<WgCtx *>(sm);
-        if (tid == 0) {
-            C->M = M; C->S = S; C->P = P;
-            C->w = S.ws + (size_t)b * M.ws.total;
-            C->x0 = S.x0 + (size_t)b * Mdl::NX; C->u0 = S.u0 + (size_t)b * Mdl::NU;
-            C->prm = S.params_b ? S.params_b + (size_t)b * S.nparams : M.params;
-            C->b = b; C->pad = 0;
-        }
-        T::sync();
-    }
     const double *st = sm + P.o_st;
     // shader-clock cycles per phase (tools/nlmpc_phases.py): evaluate (cost, dynamics, constraints), condense, BFGS, sub-problem, step, merit, line search, update
     long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
@@ -1854,7 +1868,8 @@ int launch_solve_wg(const NlmpcDev *m, const NlmpcSolveDev *b, const WgPlan *P, 
             fprintf(stderr, "nlmpc_sqp_wg: %d workgroups of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; blocks in LDS %d\n",
                     b->batch, P->waves, lds, nb, P->f_lds);
         }
-        hipLaunchKernelGGL(kern, dim3(b->batch), dim3(P->waves * 64), lds, s, *m, *b, *P);
+        const WgArgs A{*m, *b, *P};
+        hipLaunchKernelGGL(kern, dim3(b->batch), dim3(P->waves * 64), lds, s, A);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     };
     if (P->f_lds) {
