@@ -70,7 +70,13 @@ __device__ __forceinline__ double *wg_lds()
     extern __shared__ __attribute__((aligned(16))) double smem[];
     return smem;
 }
-__device__ __forceinline__ WgArgsPtr wg_args() { return (WgArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+// (Inside a function that is not the kernel the kernarg segment pointer itself is not an input; the pointer to the implicit arguments,
+// which follow the explicit ones at the next multiple of eight bytes, is.)
+__device__ __forceinline__ WgArgsPtr wg_args()
+{
+    typedef const char __attribute__((address_space(4))) *cptr;
+    return (WgArgsPtr)((cptr)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(WgArgs) + 7) & ~(size_t)7));
+}
 
 template <int CTRL> __device__ __forceinline__ double row_share(double v) { return dpp_d<CTRL>(v); }      // 0x150 + n: lane n of every row of 16
 

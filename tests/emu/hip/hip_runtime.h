@@ -67,7 +67,8 @@ struct State {
     Bar block_bar, wave_bar[kMaxThreads / kWave];
     uint64_t xbuf[kMaxThreads / kWave][2][kWave];
     std::function<void()> body;
-    const void *kernarg = nullptr;          // the first kernel argument of the launch in progress (__builtin_amdgcn_kernarg_segment_ptr)
+    const void *kernarg = nullptr;          // the first kernel argument of the launch in progress
+    size_t kernarg_bytes = 0;
     long n_block_syncs = 0, n_wave_syncs = 0;
 };
 inline State &st() { static State s; return s; }
@@ -198,6 +199,8 @@ inline void run_block(int block, int nblocks, int nthreads, const std::function<
 struct Idx { unsigned x, y, z; };
 inline const void *first_arg_ptr() { return nullptr; }
 template <class A0, class... R> inline const void *first_arg_ptr(const A0 &a, const R &...) { return &a; }
+inline size_t first_arg_bytes() { return 0; }
+template <class A0, class... R> inline size_t first_arg_bytes(const A0 &, const R &...) { return sizeof(A0); }
 
 }  // namespace hipemu
 
@@ -215,6 +218,7 @@ template <class A0, class... R> inline const void *first_arg_ptr(const A0 &a, co
         const dim3 g_ = (grid), b_ = (block);                                                                     \
         (void)(lds); (void)(stream);                                                                              \
         hipemu::st().kernarg = hipemu::first_arg_ptr(__VA_ARGS__);                                                \
+        hipemu::st().kernarg_bytes = hipemu::first_arg_bytes(__VA_ARGS__);                                        \
         for (unsigned blk_ = 0; blk_ < g_.x; ++blk_) hipemu::run_block((int)blk_, (int)g_.x, (int)b_.x, [&]() { kern(__VA_ARGS__); }); \
     } while (0)
 
@@ -240,6 +244,8 @@ inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_s_barrier() { hipemu::sync_block(); }
 inline unsigned long long __builtin_amdgcn_read_exec() { return ~0ull; }
 inline void *__builtin_amdgcn_kernarg_segment_ptr() { return const_cast<void *>(hipemu::st().kernarg); }
+// the implicit arguments follow the explicit ones (here: one struct) at the next multiple of eight bytes
+inline void *__builtin_amdgcn_implicitarg_ptr() { return (char *)const_cast<void *>(hipemu::st().kernarg) + ((hipemu::st().kernarg_bytes + 7) & ~(size_t)7); }
 inline long long __builtin_readcyclecounter() { return 0; }
 inline int __builtin_amdgcn_readlane(int v, int l) { return (int)(uint32_t)hipemu::exchange((uint32_t)v, l, "v_readlane"); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::exchange((uint32_t)v, 0, "v_readfirstlane"); }
