@@ -42,7 +42,7 @@ struct WgPlan {
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
         o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F, o_prm, o_cd, o_yd,
-        o_bidx, o_bsign, o_bval;
+        o_bidx, o_bsign, o_bval, o_xrf, o_xre;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
@@ -61,7 +61,14 @@ typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
 constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
-enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_ACC = 16, ST_TOTAL = 32 };
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
+// -DMPCX_NL_STATS (libmpcx_stats.so): shader-clock cycles of the sub-problem's parts in st[ST_QSTAT ..]: unconstrained minimiser, warm start (the kept
+// rows' Schur complement, its factor, the shedding rounds), and per dual step: scan, entering row, N_W v, solve, N_W' r, B^-1 w, the rest
+#ifdef MPCX_NL_STATS
+#define MPCX_QLAP(k) do { const long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) st[ST_QSTAT + (k)] += (double)(now_ - qt_); qt_ = now_; } while (0)
+#else
+#define MPCX_QLAP(k) do { } while (0)
+#endif
 
 #define MPCX_WG_PHASE __device__ __attribute__((noinline))
 
@@ -395,6 +402,15 @@ struct WgSqp {
                 while (mk) { const int i = (int)__builtin_ctzll(mk) + 1; mk &= mk - 1; slot[ns++] = (k << 8) | i; }
             }
             jxoff[m] = ns;
+            // the same pairs grouped by state row: what the sweep consumes as it passes state row i + 1 (entry: row << 12 | block slot)
+            int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
+            int ne = 0;
+            for (int i = 1; i <= ph; ++i) {
+                xrf[i - 1] = ne;
+                for (int k = 0; k < m; ++k)
+                    if ((xmask[k] >> (i - 1)) & 1ull) xre[ne++] = (k << 12) | (jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << (i - 1)) - 1ull)));
+            }
+            xrf[ph] = ne;
         }
         // bounds: those on states come first in the table (ascending index) and are dense rows after the user's
         for (int kb = tid; kb < nbnd; kb += NT) dcol[m + kb] = bnd_idx[kb] < nxs ? nd_user + kb : -1;
@@ -827,6 +843,7 @@ struct WgSqp {
         typename FP<FL>::type F = FP<FL>::get(v);
         if constexpr (NX <= 8) {
             constexpr bool PF = NX <= 4;                         // the next step's block is requested while this one's is used (registers for it: small states)
+            const int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
             for (int q = tid; q <= nzu; q += NT) {
                 const bool isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
@@ -841,49 +858,20 @@ struct WgSqp {
                         fb[a * (NX + 1) + NX] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
                     }
                 };
-#pragma unroll
-                for (int a = 0; a < NX; ++a) x[a] = 0.0;
-                if constexpr (PF) fetch(0);
-                for (int i = 0; i < ph; ++i) {
-                    if constexpr (PF) {
-                        double fcur[NX * (NX + 1)];
-#pragma unroll
-                        for (int e = 0; e < NX * (NX + 1); ++e) fcur[e] = fb[e];
-                        if (i + 1 < ph) fetch(i + 1);
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double s = fcur[a * (NX + 1) + NX];
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) s = fma(fcur[a * (NX + 1) + bb], x[bb], s);
-                            t[a] = s;
-                        }
-                    } else {
-                        const bool drives = !isr && min(i, ch - 1) == bq;
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double s = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) s = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], s);
-                            t[a] = s;
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) x[a] = t[a];
+                // what state row i + 1 (held in x) is needed for; issued before the next step's products so that its LDS round trips and
+                // theirs overlap: neither depends on the other
+                auto consume = [&](int i) {
                     if (!isr) {
 #pragma unroll
                         for (int a = 0; a < NX; ++a) gacc = fma(lam[i * NX + a], x[a], gacc);       // (lam still holds g_x)
                     }
-                    auto row = [&](int k) {
-                        const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
-                        double s = 0.0;
+                    for (int e = xrf[i]; e < xrf[i + 1]; ++e) {
+                        const int k = xre[e] >> 12, sl = xre[e] & 0xfff;
+                        double sacc = 0.0;
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) s = fma(jx[sl * NX + a], x[a], s);
-                        if (isr) br[k] += s; else art[q * ndld + dcol[k]] += s;
-                    };
-                    int first, count;
-                    Mdl::ineq_rows_of_x(i + 1, first, count);
-                    for (int k = first; k < first + count; ++k) if ((xmask[k] >> i) & 1ull) row(k);
-                    for (int k = mi; k < m; ++k) if ((xmask[k] >> i) & 1ull) row(k);
+                        for (int a = 0; a < NX; ++a) sacc = fma(jx[sl * NX + a], x[a], sacc);
+                        if (isr) br[k] += sacc; else art[q * ndld + dcol[k]] += sacc;
+                    }
                     for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
                         const int a = bnd_idx[kb] - i * NX;
                         const double sg = bnd_sign[kb];
@@ -892,7 +880,38 @@ struct WgSqp {
                         for (int a2 = 0; a2 < NX; ++a2) if (a2 == a) xa = x[a2];
                         if (isr) br[m + kb] += sg * xa; else art[q * ndld + dcol[m + kb]] = sg * xa;
                     }
+                };
+#pragma unroll
+                for (int a = 0; a < NX; ++a) x[a] = 0.0;
+                if constexpr (PF) fetch(0);
+                for (int i = 0; i < ph; ++i) {
+                    if (i > 0) consume(i - 1);
+                    if constexpr (PF) {
+                        double fcur[NX * (NX + 1)];
+#pragma unroll
+                        for (int e = 0; e < NX * (NX + 1); ++e) fcur[e] = fb[e];
+                        if (i + 1 < ph) fetch(i + 1);
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double sacc = fcur[a * (NX + 1) + NX];
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * (NX + 1) + bb], x[bb], sacc);
+                            t[a] = sacc;
+                        }
+                    } else {
+                        const bool drives = !isr && min(i, ch - 1) == bq;
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            double sacc = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+#pragma unroll
+                            for (int bb = 0; bb < NX; ++bb) sacc = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], sacc);
+                            t[a] = sacc;
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) x[a] = t[a];
                 }
+                consume(ph - 1);
                 if (!isr) gr[q] = gu[q] + gacc;
             }
         } else {
@@ -1218,6 +1237,9 @@ struct WgSqp {
         Red<WAVES> R(v.at(P.o_red));
         auto is_eq = [&](int k) { return k >= mi && k < m; };
         int nw = nw_keep;
+#ifdef MPCX_NL_STATS
+        long long qt_ = __builtin_readcyclecounter();
+#endif
         // S = N B^-1 N' of the kept rows, straight into the factor's storage
         int anyd = 0;
         for (int t = tid; t < nw; t += NT) anyd |= dcol[wq[t]] >= 0 ? 1 : 0;
@@ -1240,8 +1262,10 @@ struct WgSqp {
             }
         }
         T::sync();
+        MPCX_QLAP(1);
         if (tid < 64) { const bool ok = chol_inplace(Lp, invd, nw, lane); if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0; }
         T::sync();
+        MPCX_QLAP(2);
         if (st[ST_R4] == 0.0) {                                  // dependent rows: start cold
             for (int t = tid; t < nw; t += NT) flag[wq[t]] = 0;
             T::sync();
@@ -1269,6 +1293,7 @@ struct WgSqp {
             for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
         }
         T::sync();
+        MPCX_QLAP(3);
         return nw;
     }
 
@@ -1289,11 +1314,18 @@ struct WgSqp {
         Red<WAVES> R(v.at(P.o_red));
         auto is_eq = [&](int k) { return k >= mi && k < m; };
 
+#ifdef MPCX_NL_STATS
+        long long qt_ = __builtin_readcyclecounter();
+#endif
         for (int k = tid; k < mt; k += NT) flag[k] = 0;
         hmul_call(P.o_gr, P.o_xq, -1.0);                        // the unconstrained minimiser x = -B^-1 gr
         for (int t = tid; t < nw_keep; t += NT) flag[wq[t]] = 1;
         T::sync();
+        MPCX_QLAP(0);
         int nw = nw_keep > 0 ? ws_warm(nw_keep) : 0;
+#ifdef MPCX_NL_STATS
+        qt_ = __builtin_readcyclecounter();
+#endif
 
         // ---- the dual method
         int fail = 0, nsteps = 0;
@@ -1301,6 +1333,7 @@ struct WgSqp {
         for (int qit = 0; qit < 8 * (mt + nq) + 16 && !done && !fail; ++qit) {
             // the most violated row outside the working set
             const WgArgmax worst = scan_call();
+            MPCX_QLAP(4);
             const double vmax = worst.v;
             const int pidx = worst.idx;
             if (mt == 0 || vmax <= 1e-12) { done = true; break; }        // primal feasible: optimal
@@ -1314,6 +1347,7 @@ struct WgSqp {
                 sgn = br[pidx] + (dc >= 0 ? W.yd[dc] : sp.dot(pidx, xq)) < 0.0 ? -1.0 : 1.0;
             }
             normal_call(pidx, sgn);
+            MPCX_QLAP(5);
             double snn = 0, npn = 0;
             for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
             snn = R.sum(snn); npn = R.sum(npn);
@@ -1322,10 +1356,15 @@ struct WgSqp {
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S), rr = S^-1 t, zd = B^-1 (n - N_W' rr)
                 if (nw > 0) {
+                    MPCX_QLAP(10);
                     ws_n_mul(nw, P.o_vv, P.o_tq);
+                    MPCX_QLAP(6);
                     ws_solve(nw);
+                    MPCX_QLAP(7);
                     ws_nt_mul(nw, P.o_tq, P.o_wv);
+                    MPCX_QLAP(8);
                     hmul_call(P.o_wv, P.o_zd, 1.0);
+                    MPCX_QLAP(9);
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
                 } else {
                     for (int q = tid; q < nq; q += NT) zd[q] = vv[q];
@@ -1370,15 +1409,17 @@ struct WgSqp {
                 }
             }
             if (!fail && !added) fail = -1;
+            MPCX_QLAP(10);
         }
         if (!fail && !done) fail = -1;
-        if (tid == 0) st[ST_R5] += (double)nsteps;
+        if (tid == 0) { st[ST_R5] += (double)nsteps; st[ST_R5 + 1] = fmax(st[ST_R5 + 1], (double)nw); }
         if (fail) { T::sync(); return fail; }
         for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
         T::sync();
         for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
         for (int q = tid; q < nr; q += NT) p[q] = q < nq ? xq[q] : 0.0;
         T::sync();
+        MPCX_QLAP(10);
         return nw;
     }
 
@@ -1761,6 +1802,10 @@ __global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const WgArgs A)
     if (tid == 0) {
         double *scal = S.ws + (size_t)b * M.ws.total + P.w_scal;
         scal[1] = st[ST_R5];
+        scal[12] = st[ST_R5 + 1];                                // the largest working set of the solve
+#ifdef MPCX_NL_STATS
+        for (int k = 0; k < 12; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
+#endif
         for (int k = 0; k < 10; ++k) scal[2 + k] = (double)cyc[k];
     }
     (void)NT;
@@ -1775,7 +1820,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
-    if (ph > 64 || ph >= 255 || mu_ >= (1 << 23) || 3 * NX + NU + 1 > 64 || m.nr >= 0xffff) return -2;
+    if (ph > 64 || ph >= 255 || mu_ >= (1 << 19) || 3 * NX + NU + 1 > 64 || m.nr >= 0xffff) return -2;
     P = WgPlan{};
     P.hard = hard ? 1 : 0;
     P.nq = hard ? m.nzu : nr;
@@ -1790,6 +1835,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         if (cnt > 0 || !Mdl::XFREE_ROWS_SPARSE) ++ndu;
     }
     const int nsb = state_bounds;                          // finite bounds on states: the first rows of the bound table
+    if (nsx >= 4096) return -2;
     P.nsx = nsx; P.nd_user = ndu; P.nsb = nsb; P.nd = ndu + nsb; P.ndld = (P.nd + 1) | 1;
     P.needs_phi = (reads_x || nsb > 0) ? 1 : 0;
     // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
@@ -1814,6 +1860,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
+        P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2);
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;
         P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
