@@ -243,6 +243,102 @@ __device__ __forceinline__ bool chol_inplace(double *Lp, double *invd, int n, in
     }
     return ok;
 }
+// L y = t and L' x = y on the leading n rows of the packed factor (rows lane and, TWO, lane + 64), column by column: once an unknown is
+// known every remaining row loses its term; an element is scaled by its reciprocal diagonal when it is handed on and, for the result,
+// once at the end -- no per-step predicates on "my own element", the entries beyond a row's end are masked after the load.
+template <bool TWO>
+__device__ __forceinline__ void tri_forward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+{
+    const int o0 = lane * (lane + 1) / 2, o1 = (lane + 64) * (lane + 65) / 2;
+    const int h0 = lane < n ? lane : -1, h1 = (TWO && lane + 64 < n) ? lane + 64 : -1;      // a row takes part in step k while k < its number
+    double a0 = 0 < h0 ? Lp[o0] : 0.0, a1 = TWO ? (0 < h1 ? Lp[o1] : 0.0) : 0.0, id = invd[0];
+    const int n0 = TWO ? min(n, 64) : n;
+    for (int k = 0; k < n0; ++k) {
+        const int kn = k + 1;
+        const double a0n = Lp[o0 + kn], idn = invd[min(kn, n - 1)];
+        double a1n = 0.0;
+        if constexpr (TWO) a1n = Lp[o1 + kn];
+        const double yk = read_lane(t0, k) * id;
+        t0 = fma(-a0, yk, t0);
+        if constexpr (TWO) t1 = fma(-a1, yk, t1);
+        a0 = kn < h0 ? a0n : 0.0; id = idn;
+        if constexpr (TWO) a1 = kn < h1 ? a1n : 0.0;
+    }
+    if constexpr (TWO) {
+        for (int k = 64; k < n; ++k) {
+            const int kn = k + 1;
+            const double a1n = Lp[o1 + kn], idn = invd[min(kn, n - 1)];
+            const double yk = read_lane(t1, k - 64) * id;
+            t1 = fma(-a1, yk, t1);
+            a1 = kn < h1 ? a1n : 0.0; id = idn;
+        }
+    }
+    t0 *= lane < n ? invd[lane] : 0.0;
+    if constexpr (TWO) t1 *= lane + 64 < n ? invd[lane + 64] : 0.0;
+}
+template <bool TWO>
+__device__ __forceinline__ void tri_backward(const double *Lp, const double *invd, int n, double &t0, double &t1, int lane)
+{
+    // column k of L' is row k of L: entries 0 .. k-1 contiguous at k (k + 1) / 2
+    int k = n - 1;
+    double id = invd[k];
+    double a0 = lane < k ? Lp[k * (k + 1) / 2 + lane] : 0.0, a1 = (TWO && lane + 64 < k) ? Lp[k * (k + 1) / 2 + lane + 64] : 0.0;
+    if constexpr (TWO) {
+        for (; k >= 64; --k) {
+            const int kn = k - 1, on = kn * (kn + 1) / 2;
+            const double a0n = Lp[on + lane], a1n = Lp[on + lane + 64], idn = invd[kn];
+            const double xk = read_lane(t1, k - 64) * id;
+            t0 = fma(-a0, xk, t0); t1 = fma(-a1, xk, t1);
+            a0 = lane < kn ? a0n : 0.0; a1 = lane + 64 < kn ? a1n : 0.0; id = idn;
+        }
+    }
+    for (; k >= 0; --k) {
+        const int kn = max(k - 1, 0), on = kn * (kn + 1) / 2;
+        const double a0n = Lp[on + lane], idn = invd[kn];
+        const double xk = read_lane(t0, k) * id;
+        t0 = fma(-a0, xk, t0);
+        a0 = lane < kn ? a0n : 0.0; id = idn;
+    }
+    t0 *= lane < n ? invd[lane] : 0.0;
+    if constexpr (TWO) t1 *= lane + 64 < n ? invd[lane + 64] : 0.0;
+}
+// S = L L' in place by the whole workgroup: per column the pivot, the column's scaling (one row per thread), and the trailing update
+// spread over the threads in two dimensions (four threads share a row) -- the one-wavefront form walks each row's update serially.
+template <int WAVES>
+__device__ __forceinline__ bool chol_inplace_wg(double *Lp, double *invd, double *flagslot, int n, int tid)
+{
+    constexpr int NT = 64 * WAVES;
+    using T = Team<WAVES>;
+    double dmax = 0.0;
+    for (int r = tid; r < n; r += NT) dmax = fmax(dmax, Lp[r * (r + 1) / 2 + r]);
+    dmax = wave_max(dmax);
+    if constexpr (WAVES > 1) {
+        if ((tid & 63) == 0) flagslot[1 + (tid >> 6)] = dmax;
+        T::sync();
+        dmax = flagslot[1];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) dmax = fmax(dmax, flagslot[1 + w]);
+    }
+    bool ok = true;
+    for (int k = 0; k < n; ++k) {
+        T::sync();                                               // the previous column's trailing update is complete
+        const double dkk = Lp[k * (k + 1) / 2 + k];
+        ok &= dkk > 1e-13 * dmax;
+        const double dd = sqrt(dkk > 1e-13 * dmax ? dkk : 1e-13 * dmax + 1e-300), id = 1.0 / dd;
+        T::sync();                                               // everybody has read the pivot
+        for (int r = k + 1 + tid; r < n; r += NT) Lp[r * (r + 1) / 2 + k] *= id;
+        if (tid == 0) { Lp[k * (k + 1) / 2 + k] = dd; invd[k] = id; }
+        T::sync();
+        const int part = tid & 3;
+        for (int r = k + 1 + (tid >> 2); r < n; r += NT / 4) {
+            const int ro = r * (r + 1) / 2;
+            const double lrk = Lp[ro + k];
+            for (int j = k + 1 + part; j <= r; j += 4) Lp[ro + j] = fma(-lrk, Lp[j * (j + 1) / 2 + k], Lp[ro + j]);
+        }
+    }
+    T::sync();
+    return ok;
+}
 // Row and column j leave S: row j of L is deleted, the rows below move up, and Givens rotations on the column pairs (r, r + 1),
 // r = j .. n - 2, restore the triangle.  Every lane streams along its own rows: it carries the rotated entry of column r + 1 into the
 // next rotation; the rotation itself comes from the row whose diagonal it creates.
@@ -1173,12 +1269,18 @@ struct WgSqp {
         const int tid = threadIdx.x, lane = tid & 63;
         double *tq = v.at(P.o_tq), *yv = v.at(P.o_yv);
         if (tid < 64) {
-            const Factor Fac{v.at(P.o_L), v.at(P.o_invd), nullptr, nullptr, v.kw, 0};
+            const double *Lp = v.at(P.o_L), *invd = v.at(P.o_invd);
             double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
-            chol_forward<false>(Fac, nw, t0, t1, lane);
-            if (lane < nw) yv[lane] = t0;
-            if (lane + 64 < nw) yv[lane + 64] = t1;
-            chol_backward<false>(Fac, nw, t0, t1, lane);
+            if (v.kw <= 64) {
+                tri_forward<false>(Lp, invd, nw, t0, t1, lane);
+                if (lane < nw) yv[lane] = t0;
+                tri_backward<false>(Lp, invd, nw, t0, t1, lane);
+            } else {
+                tri_forward<true>(Lp, invd, nw, t0, t1, lane);
+                if (lane < nw) yv[lane] = t0;
+                if (lane + 64 < nw) yv[lane + 64] = t1;
+                tri_backward<true>(Lp, invd, nw, t0, t1, lane);
+            }
             if (lane < nw) tq[lane] = t0;
             if (lane + 64 < nw) tq[lane + 64] = t1;
         }
@@ -1263,7 +1365,10 @@ struct WgSqp {
         }
         T::sync();
         MPCX_QLAP(1);
-        if (tid < 64) { const bool ok = chol_inplace(Lp, invd, nw, lane); if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0; }
+        {
+            const bool ok = chol_inplace_wg<WAVES>(Lp, invd, v.at(P.o_red), nw, tid);
+            if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0;
+        }
         T::sync();
         MPCX_QLAP(2);
         if (st[ST_R4] == 0.0) {                                  // dependent rows: start cold
@@ -1708,7 +1813,7 @@ struct WgSqp {
 
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES) void nlmpc_sqp_wg(const WgArgs A)
+__global__ __launch_bounds__(64 * WAVES, 2) void nlmpc_sqp_wg(const WgArgs A)
 {
     using K = WgSqp<Mdl, WAVES>;
     using T = Team<WAVES>;
