@@ -1813,7 +1813,7 @@ struct WgSqp {
 
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES, 2) void nlmpc_sqp_wg(const WgArgs A)
+__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 4 : 2) void nlmpc_sqp_wg(const WgArgs A)
 {
     using K = WgSqp<Mdl, WAVES>;
     using T = Team<WAVES>;

@@ -46,20 +46,26 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
     return dispatch_model(m->model_id, [&](auto mdl) { return engine::launch_evaluate<decltype(mdl)>(nullptr, m, b, stream); });
 }
 
-// The built-in systems solve in the workgroup form (mpcx/nlmpc_sqp_wg.hpp: one workgroup per instance, the reduced problem in LDS).
-// A shape its LDS plan does not take (horizons beyond 64 steps, more than 160 KB) goes through nlmpc_sqp, one wavefront per instance;
-// MPCX_NLMPC_FORM=wave forces that form (A/B measurements), MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance.
+// Two forms of the SQP for the built-in systems (mpcx_nlmpc_solve_batch):
+//   * nlmpc_sqp_wg (mpcx/nlmpc_sqp_wg.hpp): one workgroup per instance, the reduced problem in LDS, no streaming of a workspace through HBM;
+//   * nlmpc_sqp (mpcx/nlmpc_engine.hpp): one wavefront per instance, the reduced problem in a per-instance HBM workspace.
+// Which one is faster is a matter of how many instances a CU holds at once -- both are bound by the issue latency of dependent
+// instructions at one or two wavefronts per SIMD (tools/micro/latency.hip): the LDS-resident form holds 160 KB /
+// (its LDS block) instances per CU, the workspace form eight.  Measured on MI355X (profiles/r04_nlmpc_forms.txt): the workgroup form wins
+// where an instance needs one wavefront and a few KB of LDS (config 1), the wavefront form where the LDS block is tens of KB (configs 3, 5).
+// The default follows that; MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
     return dispatch_model(m->model_id, [&](auto mdl) {
         using Mdl = decltype(mdl);
         const char *form = getenv("MPCX_NLMPC_FORM");
-        if (!(form && !strcmp(form, "wave"))) {
+        const bool force_wave = form && !strcmp(form, "wave"), force_wg = form && !strcmp(form, "wg");
+        if (!force_wave) {
             engine::WgPlan P;
             const char *wv = getenv("MPCX_NLMPC_WAVES");
-            if (engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P) == 0 && P.ws_total <= m->ws.total)
-                return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
-            if (form && !strcmp(form, "wg")) return -2;
+            const bool fits = engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P) == 0 && P.ws_total <= m->ws.total;
+            if (fits && (force_wg || P.waves == 1)) return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
+            if (force_wg) return -2;
         }
         return engine::launch_solve<Mdl>(nullptr, m, b, stream);
     });

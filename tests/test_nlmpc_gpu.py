@@ -702,6 +702,7 @@ def test_lds_resident_blocks_agree_with_the_workspace_form(name, kw, hard, iters
     X0 = np.zeros((B, nx)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
     U0 = np.zeros((B, 2 if name == "ugv" else 1))
     out = []
+    monkeypatch.setenv("MPCX_NLMPC_FORM", "wave")          # (both variants are variants of the one-wavefront form)
     for blocks in ("1", "0"):
         monkeypatch.setenv("MPCX_DEBUG_LDS_BLOCKS", blocks)
         c = NLMPC(dict(vanderpol=VANDERPOL, ugv=UGV)[name], kw["ph"], kw["ch"], kw.get("Ts", 0.1))
