@@ -32,6 +32,7 @@ namespace engine {
 // ---- the plan: LDS and workspace layout of one instance (host-computed, a kernel argument) ------------------------------------------
 struct WgPlan {
     int waves;                  // wavefronts per instance: 1, 2 or 4
+    int per_cu;                 // workgroups of this plan a CU's LDS holds
     int hard, nq;               // sub-problem variables: ch nu (+ slack when soft)
     int kw;                     // working-set capacity
     int nd, ndld, nd_user, nsb; // dense sub-problem rows (columns of art): user rows that read a state (or promise no sparsity), then bounds on states
@@ -1948,9 +1949,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     auto imax = [](int a, int b) { return a > b ? a : b; };
     const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
     int waves = waves_wanted;
-    if (waves <= 0) waves = nz >= 96 ? 4 : (nz >= 48 ? 2 : 1);
-    if (waves != 1 && waves != 2 && waves != 4) return -2;
-    P.waves = waves;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4) return -2;
     auto layout = [&](int kw, int f_lds) {
         int o = kWgCtxDoubles;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
@@ -1983,16 +1982,30 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     // nlopt's OUT_OF_MEMORY code (status ERROR), as one beyond kNlMaxWorking always did.
     const int kw_floor = imin(kw_full, 48);
     bool placed = false;
-    const int max_wg = imin(8, 32 / waves);
-    for (int per_cu = max_wg; per_cu >= 1 && !placed; --per_cu) {
-        const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)15;
-        for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
-            if (layout(kw_full, f_lds) <= budget) { placed = true; break; }
-            if (per_cu == 1) continue;                          // (alone on the CU the factor keeps its full capacity)
-            int kw = kw_full;
-            while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
-            if (layout(kw, f_lds) <= budget) { placed = true; break; }
+    auto place = [&]() {
+        placed = false;
+        const int max_wg = imin(16, 32 / P.waves);
+        for (int per_cu = max_wg; per_cu >= 1 && !placed; --per_cu) {
+            const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)15;
+            for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
+                if (layout(kw_full, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
+                if (per_cu == 1) continue;                      // (alone on the CU the factor keeps its full capacity)
+                int kw = kw_full;
+                while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
+                if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
+            }
         }
+    };
+    // Wavefronts per instance.  What a CU delivers is instances in flight: a small problem (eight or more blocks per CU at one wavefront each)
+    // gets one wavefront per instance and fills the CU with instances; a larger one, whose LDS block leaves room for one or two
+    // instances, gets four wavefronts (two for a medium one) -- that form is for latency, the launcher prefers nlmpc_sqp for throughput.
+    if (waves == 0) {
+        P.waves = 1;
+        place();
+        if (!placed || P.per_cu < 8) { P.waves = nz >= 96 ? 4 : 2; place(); }
+    } else {
+        P.waves = waves;
+        place();
     }
     if (!placed) return -2;
     {

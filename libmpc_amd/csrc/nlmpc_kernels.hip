@@ -53,7 +53,8 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // instructions at one or two wavefronts per SIMD (tools/micro/latency.hip): the LDS-resident form holds 160 KB /
 // (its LDS block) instances per CU, the workspace form eight.  Measured on MI355X (profiles/r04_nlmpc_forms.txt): the workgroup form wins
 // where an instance needs one wavefront and a few KB of LDS (config 1), the wavefront form where the LDS block is tens of KB (configs 3, 5).
-// The default follows that; MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
+// The default follows that, and takes the workgroup form for a batch that it holds resident all at once (latency: each instance on its own
+// wavefronts); MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
     return dispatch_model(m->model_id, [&](auto mdl) {
@@ -64,7 +65,10 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
             engine::WgPlan P;
             const char *wv = getenv("MPCX_NLMPC_WAVES");
             const bool fits = engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P) == 0 && P.ws_total <= m->ws.total;
-            if (fits && (force_wg || P.waves == 1)) return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
+            // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
+            // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form
+            const bool resident = (long)b->batch <= 256L * P.per_cu;
+            if (fits && (force_wg || P.waves == 1 || resident)) return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
             if (force_wg) return -2;
         }
         return engine::launch_solve<Mdl>(nullptr, m, b, stream);
