@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=None, help="LMPC prediction horizon (overrides the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--nlmpc-extra", type=int, default=1, help="default (LMPC) workload: append the NLMPC configs' quick figures as the `nlmpc` key (0 = skip)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the timed steps rotate over (each with its own controller handle, workspace and outputs); "
                          "1 = strictly serial steps (default: what `value`, the roofline and the rocprof trace refer to)")
@@ -398,6 +399,8 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
            "pipelined": pipelined,
            "solved_fraction": float((status == 0).mean()),
            "roofline": roof, "cpu_baseline": cpu}
+    if world == 1 and args.nlmpc_extra:
+        out["nlmpc"] = nlmpc_extra(local)
     print(json.dumps(out))
 
 
@@ -523,6 +526,28 @@ def nl_flops(c, name, it, nact):
     return float((it * (ev + cond + red + bfgs + step + ls) + it * qp).sum())
 
 
+def nlmpc_extra(local):
+    """Configs 1, 3 and 5 in the line the driver runs (outside `value` and the timed region, ~1 s of GPU time): solves/s of a few steps at the
+    quoted batches, and the time of one batched solve at a batch the workgroup form holds resident (the latency a controller sees)."""
+    import ctypes as C
+    from libmpc_amd._capi import check
+    res = {}
+    stream = torch.cuda.current_stream(local)
+    for key, name, B, steps in (("config1_vanderpol_b4096", "vanderpol", 4096, 10), ("config3_ugv_b4096", "ugv", 4096, 2), ("config5_osc8_b1024", "osc8", 1024, 1),
+                                ("config3_ugv_b256_latency", "ugv", 256, 2), ("config5_osc8_b256_latency", "osc8", 256, 1)):
+        c, x0, u0 = nl_make(name, B, device=local)
+        b, out = c.make_batch(torch.from_numpy(x0), torch.from_numpy(u0))
+        check(c._lib.mpcx_nlmpc_solve_batch(c._h, C.byref(b), stream.cuda_stream)); torch.cuda.synchronize()      # warm-up
+        ms = c.time_launches(b, steps, stream.cuda_stream)
+        torch.cuda.synchronize()
+        st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy()
+        form = int(c._lib.mpcx_nlmpc_debug_last_form())
+        res[key] = {"solves_per_s": B / (ms * 1e-3), "kernel_ms": ms, "kernel": "nlmpc_sqp_wg" if form > 0 else "nlmpc_sqp",
+                    "wavefronts_per_instance": form if form > 0 else 1, "mean_iterations": float(it.mean()),
+                    "solved_fraction": float(np.isin(st, (3, 4)).mean())}
+    return res
+
+
 def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, barrier):
     c, x0, u0 = nl_make(name, B, first=rank * 7919, device=local)
     x0t, u0t = torch.from_numpy(x0), torch.from_numpy(u0)
@@ -547,13 +572,16 @@ def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, bar
     flops = nl_flops(c, name, it, nact)
     bytes_alg = float(B) * 8.0 * (c.nx + c.nu + c.nu + 1 + 2)
     ach = flops / (kern_ms * 1e-3) / 1e12
-    dom = "nlmpc_sqp"
+    form = int(c._lib.mpcx_nlmpc_debug_last_form())
+    dom = "nlmpc_sqp_wg" if form > 0 else "nlmpc_sqp"
     traffic, traffic_src, traffic_note = _traffic(dom, "%s_b%d" % (name, B))
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
             "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
             "kernel": dom, "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops,
-            "note": "f64 SQP, one instance per wavefront, latency-bound dependent iterations; flop model in DESIGN.md section 6",
+            "note": ("f64 SQP, one workgroup of %d wavefront(s) per instance, the reduced problem in LDS" % form if form > 0 else
+                     "f64 SQP, one instance per wavefront, the reduced problem in an HBM workspace") + "; bound by the issue latency of dependent instructions; flop model in DESIGN.md section 6",
+            "form": {"kernel": dom, "wavefronts_per_instance": form if form > 0 else 1},
             "mean_iterations": float(it.mean()), "max_iterations": int(it.max()), "mean_active_rows": float(nact.mean()),
             "hbm_achieved_GBs": bytes_alg / (kern_ms * 1e-3) / 1e9, "hbm_frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "algorithmic_bytes_per_launch": bytes_alg, "workspace_bytes_per_instance": int(c.debug_workspace_bytes()),

@@ -756,7 +756,8 @@ struct WgSqp {
         const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
         for (int k = tid; k < mi; k += NT) gin[k] = Mdl::ineq(k, X0, U0, e, ph, prm);
         for (int k = tid; k < m - mi; k += NT) gin[mi + k] = Mdl::eq(k, X0, U0, ph, prm);
-        if (values_only) { T::sync(); return; }
+        T::sync();                                               // (an equality's value is read below by the thread that owns its row)
+        if (values_only) return;
         for (int t = tid; t < nsx * NX; t += NT) {
             const int sl = t / NX, j = t - sl * NX, k = slot[sl] >> 8, i = slot[sl] & 0xff;
             double val;

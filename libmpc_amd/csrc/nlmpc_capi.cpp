@@ -15,6 +15,7 @@ int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq
 void nlmpc_plan_host(NlmpcDev &m);
 int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream);
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream);
+int nlmpc_last_form();
 // run-time compiled hooks (nlmpc_jit.cpp)
 void nlmpc_jit_release(void *jit);
 }
@@ -423,6 +424,10 @@ extern "C" int mpcx_discretize_batch(int device, int nx, int nu, int batch, cons
     if (rc != 0) return capi_fail(MPCX_E_DEVICE, "discretisation kernel launch failed");
     return MPCX_OK;
 }
+
+// Which kernel the last solve of a built-in system went through (bench.py names it): 0 = nlmpc_sqp (one wavefront per instance),
+// 1 | 2 | 4 = nlmpc_sqp_wg with that many wavefronts per instance, -1 = none yet
+extern "C" int mpcx_nlmpc_debug_last_form(void) { return mpcx::nlmpc_last_form(); }
 
 // Experiment knob (not part of include/mpcx.h): the step / defect thresholds of the solver's own convergence test
 extern "C" int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_con)

@@ -55,6 +55,10 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // where an instance needs one wavefront and a few KB of LDS (config 1), the wavefront form where the LDS block is tens of KB (configs 3, 5).
 // The default follows that, and takes the workgroup form for a batch that it holds resident all at once (latency: each instance on its own
 // wavefronts); MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
+// which form the last launch of a built-in system took: 0 = nlmpc_sqp, 1 | 2 | 4 = nlmpc_sqp_wg with that many wavefronts per instance
+static int g_last_form = -1;
+int nlmpc_last_form() { return g_last_form; }
+
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
     return dispatch_model(m->model_id, [&](auto mdl) {
@@ -68,9 +72,10 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
             // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
             // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form
             const bool resident = (long)b->batch <= 256L * P.per_cu;
-            if (fits && (force_wg || P.waves == 1 || resident)) return engine::launch_solve_wg<Mdl>(m, b, &P, stream);
+            if (fits && (force_wg || P.waves == 1 || resident)) { g_last_form = P.waves; return engine::launch_solve_wg<Mdl>(m, b, &P, stream); }
             if (force_wg) return -2;
         }
+        g_last_form = 0;
         return engine::launch_solve<Mdl>(nullptr, m, b, stream);
     });
 }

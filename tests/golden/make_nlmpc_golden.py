@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-N_OSC8, N_UGV = 32, 64
+N_OSC8, N_UGV = 64, 256
 
 
 def _solve(job):
@@ -42,7 +42,7 @@ def main():
     Xu = np.zeros((4096, 4)); Xu[:, :2] = rng.uniform(-0.5, 0.5, size=(4096, 2))   # bench.py nl_make("ugv")
     xu = [np.zeros(4)] + [Xu[i] for i in range(N_UGV - 1)]                    # ugv_ex.cpp's own start first
     jobs = [("osc8", x, np.zeros(8), 200, True) for x in x8] + [("ugv", x, np.zeros(2), 150, False) for x in xu]
-    with mp.Pool(os.cpu_count()) as pool:
+    with mp.Pool(max(1, (os.cpu_count() or 2) - 2)) as pool:
         res = pool.map(_solve, jobs, chunksize=1)
     out = {"oscillators8_ph30_ch15": dict(model="oscillators", N=8, ph=30, ch=15, Ts=0.1, hard=True, cases=res[:N_OSC8]),
            "ugv_ph30_ch30": dict(model="ugv", ph=30, ch=30, Ts=0.1, hard=False, cases=res[N_OSC8:])}

@@ -1,0 +1,76 @@
+"""The NLMPC solve kernels stepped through on the host by the lock-step interpreter of tests/emu (TEST INFRASTRUCTURE: fibres per thread,
+rendezvous for DPP / readlane / shuffles / barriers -- see tests/emu/hip/hip_runtime.h): the device sources of include/mpcx/ are compiled
+unchanged with g++ and must reach the oracle's optimum, in both forms of the kernel and in both orders in which the interpreter may run the
+threads of a workgroup between two rendezvous (an exchange through LDS that lacks its barrier gives different results in the two orders,
+a wave-level operation inside divergent control flow a reported deadlock).  No GPU, nothing of libmpcx.so."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import nlmpc_numpy as ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def runner(tmp_path_factory):
+    if not shutil.which("g++"):
+        pytest.skip("g++ not installed")
+    exe = str(tmp_path_factory.mktemp("emu") / "run_nlmpc")
+    subprocess.run(["g++", "-O1", "-std=c++20", "-DHIPEMU_WITH_WG", "-I" + EMU, "-I" + os.path.join(ROOT, "include"), "-fpermissive", "-w", "-o", exe,
+                    os.path.join(EMU, "run_nlmpc.cpp"), os.path.join(EMU, "hipemu_switch.S")], check=True)
+
+    def run(args, inst, env=None):
+        e = dict(os.environ); e.update(env or {})
+        inp = "\n".join(" ".join(repr(float(x)) for x in row) for row in inst) + "\n"
+        r = subprocess.run([exe] + [str(a) for a in args], input=inp, capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[:2000]
+        return [json.loads(l) for l in r.stdout.splitlines()]
+    return run
+
+
+@pytest.mark.parametrize("form,env", [("wg", {}), ("wg", {"HIPEMU_ORDER": "reverse"}), ("wg", {"HIPEMU_WAVES": "4"}), ("wave", {}), ("wave", {"HIPEMU_ORDER": "reverse"})])
+def test_vanderpol_reaches_the_oracle_optimum_through_the_interpreter(runner, form, env):
+    rng = np.random.default_rng(11)
+    X0 = rng.uniform(-1.0, 1.0, size=(4, 2)); X0[0] = [0.0, 1.0]          # examples/vanderpol_ex.cpp:67
+    r = runner(["vanderpol", 10, 5, 0.1, 1, 200, form], np.hstack([X0, np.zeros((4, 1))]), env)
+    m = ref.vanderpol(ph=10, ch=5, Ts=0.1)
+    for b, y in enumerate(r):
+        o = m.solve(X0[b], np.zeros(1), max_iter=1000)
+        assert o["success"] and y["status"] == 0 and y["solver_status"] == 4
+        np.testing.assert_allclose(y["cmd"], o["cmd"], rtol=1e-5, atol=1e-5)
+        assert abs(y["cost"] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"]))
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPEMU_ORDER": "reverse"}])
+def test_workgroup_form_with_bounds_equalities_and_dense_rows(runner, env):
+    """rows through the sensitivities (state bounds, the UGV's obstacle rows, a terminal equality), sparse rows (input bounds), infeasible
+    starts: the workgroup form against the one-wavefront form, instance by instance"""
+    rng = np.random.default_rng(21)
+    X0 = rng.uniform(-0.7, 0.7, size=(6, 2)); X0[0] = [0.0, 1.0]
+    cases = [(["vanderpol", 10, 5, 0.1, 1, 200], np.hstack([X0, np.zeros((6, 1))]), ["lbu=-0.3", "ubu=0.3", "lbx0=-0.8", "ubx0=0.8"]),
+             (["vanderpol_terminal", 10, 5, 0.1, 1, 300], np.hstack([0.15 * X0[:3], np.zeros((3, 1))]), []),
+             (["ugv", 12, 4, 0.1, 0, 150], np.hstack([np.c_[0.4 * X0[:3], np.zeros((3, 2))], np.zeros((3, 2))]), [])]
+    for args, inst, extra in cases:
+        a = runner(args + ["wave"] + extra, inst)
+        b = runner(args + ["wg"] + extra, inst, env)
+        for x, y in zip(a, b):
+            assert x["status"] == y["status"] and x["solver_status"] == y["solver_status"], (args[0], x["b"])
+            if x["status"] == 0:
+                np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-5, atol=1e-5)
+                assert abs(x["iterations"] - y["iterations"]) <= 3
+
+
+def test_config3_golden_instances_through_the_interpreter(runner):
+    """the first golden instances of BASELINE config 3 (tests/golden/nlmpc_oracle_solutions.json) in the workgroup form, four wavefronts"""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nlmpc_oracle_solutions.json")))["ugv_ph30_ch30"]
+    cases = gold["cases"][1:5]
+    r = runner(["ugv", 30, 30, 0.1, 0, 150, "wg"], np.array([k["x0"] + k["u0"] for k in cases]))
+    for k, y in zip(cases, r):
+        assert y["status"] == 0
+        np.testing.assert_allclose(y["cmd"], k["cmd"], rtol=1e-5, atol=1e-5)
