@@ -465,7 +465,8 @@ int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_
 int mpcx_nlmpc_debug_last_form(void);
 /* one instance's slice of the SQP workspace copied to the host, with the offsets of its arrays (NlmpcWsLayout) */
 int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, int *layout, int nlayout);
-/* user hooks given as source: the translation unit the run-time compiler is fed / a compile-only check (0 = it builds) */
+/* user hooks given as source: the translation unit the run-time compiler is fed / a compile-only check (> 0: it builds, the size of the
+ * code object; a negative MPCX_E_* code otherwise, the compiler's log through mpcx_last_error()) */
 int mpcx_nlmpc_debug_generated_source(const mpcx_nlmpc_source *src, char *out, int cap);
 int mpcx_nlmpc_debug_compile_source(const mpcx_nlmpc_source *src);
 /* one O(n^3) array ("H", "Kinv", "Gr", "Gc", "Y", "rho_b", "rho_g"; "flags" = [cost_direct, condensed on the device]) of controller k

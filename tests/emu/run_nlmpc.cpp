@@ -99,8 +99,23 @@ static int run(int argc, char **argv)
     S.cmd = cmd.data(); S.cost = cost.data(); S.z_out = zout.data(); S.status = status.data(); S.solver_status = sstat.data();
     S.is_feasible = feas.data(); S.iterations = iters.data(); S.seq_state = sx.data(); S.seq_input = su_.data(); S.seq_output = sy.data();
     S.mu_out = mu.data();
+    // form "wave-blk2": the one-wavefront kernel with the dynamics blocks in LDS AND a two-level factor -- a combination the product's plan
+    // never selects (it returned wrong results on the GPU for a reason that was not found); here to look for that reason
+    const bool blk2 = form == "wave-blk2";
+    if (blk2) {
+        const int jl = (ph * NX * (2 * NX + NU) + ph * NX * NX + 2 * ph * NX + M.nr + 1) & ~1;
+        if (M.lds_blocks < 0) { M.lds_blocks = M.lds_per_wave; M.lds_per_wave += jl; }
+        if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wave-blk2: kw %d nl %d lds_per_wave %d blocks at %d\n", M.kw, M.nl, M.lds_per_wave, M.lds_blocks);
+    }
     auto solve = [&]() {
         int rc;
+        if (blk2) {
+            if constexpr (engine::kSqpLdsBlocks<Mdl>) {
+                const int wpb = nlmpc_waves_per_block(M);
+                hipLaunchKernelGGL((engine::nlmpc_sqp<Mdl, true, true>), dim3((S.batch + wpb - 1) / wpb), dim3(wpb * 64), 0, nullptr, M, S);
+                return;
+            } else { fprintf(stderr, "no LDS-block form for this model\n"); exit(5); }
+        }
 #ifdef HIPEMU_WITH_WG
         if (form == "wg") rc = engine::launch_solve_wg<Mdl>(&M, &S, &P, nullptr);
         else

@@ -66,15 +66,15 @@ BK_SRC = os.path.join(ROOT, "tests", "cpp", "ioptimizer_backend_test.cpp")
 BK_OUT = os.path.join(ROOT, "tests", "cpp", "build", "ioptimizer_backend_test")
 
 
-def _build_backend():
+def _build_backend(src=BK_SRC, out=BK_OUT):
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
-    os.makedirs(os.path.dirname(BK_OUT), exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = os.path.join(ROOT, "libmpc_amd")
     subprocess.check_call(["g++", "-std=c++20", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
-                           BK_SRC, "-o", BK_OUT, "-L" + lib, "-lmpcx", "-L/opt/rocm/lib", "-lamdhip64",
+                           src, "-o", out, "-L" + lib, "-lmpcx", "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
-    return BK_OUT
+    return out
 
 
 def test_ioptimizer_shaped_backend_api_without_gpu():
@@ -92,3 +92,27 @@ def test_ioptimizer_shaped_backend_solves_like_the_front_end():
     out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all IOptimizer backend checks passed" in out.stdout
+
+
+NLBK_SRC = os.path.join(ROOT, "tests", "cpp", "nloptimizer_backend_test.cpp")
+NLBK_OUT = os.path.join(ROOT, "tests", "cpp", "build", "nloptimizer_backend_test")
+
+
+def test_nloptimizer_shaped_backend_api_without_gpu():
+    """INTEGRATION.md section 6's binding (a backend of the shape of NLOptimizer.hpp:30-404 over the C ABI), compiled; its hook sources
+    cross-compile for gfx950 without a device"""
+    if not os.path.exists("/opt/rocm/lib/libhiprtc.so") and not any(f.startswith("libhiprtc.so") for f in os.listdir("/opt/rocm/lib")):
+        pytest.skip("hipRTC not installed")
+    exe = _build_backend(NLBK_SRC, NLBK_OUT)
+    out = subprocess.run([exe, "api"], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all NLOptimizer backend checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_nloptimizer_shaped_backend_solves_like_the_front_end():
+    exe = _build_backend(NLBK_SRC, NLBK_OUT)
+    env = {k: v for k, v in os.environ.items() if k != "MPCX_DEVICE"}
+    out = subprocess.run([exe, "solve"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all NLOptimizer backend checks passed" in out.stdout
