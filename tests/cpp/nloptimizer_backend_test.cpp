@@ -70,8 +70,8 @@ public:
     void setModel(const std::string &state_fn, const std::string &output_fn, double Ts) { f_ = state_fn; out_ = output_fn; has_out_ = !output_fn.empty(); ts_ = Ts; bound_ = false; }
     // NLOptimizer::bindObjective / bindUserIneq / bindUserEq (:204-344): what Objective / Constraints evaluate
     bool bindObjective(const std::string &objective_fn) { obj_ = objective_fn; bound_ = false; return !obj_.empty(); }
-    bool bindUserIneq(const std::string &ineq_fn) { ineq_src_ = ineq_fn; has_ineq_ = true; bound_ = false; return ineq_ > 0; }
-    bool bindUserEq(const std::string &eq_fn) { eq_src_ = eq_fn; has_eq_ = true; bound_ = false; return eq_ > 0; }
+    bool bindUserIneq(const std::string &ineq_fn) { if (ineq_ <= 0) return false; ineq_src_ = ineq_fn; has_ineq_ = true; bound_ = false; return true; }
+    bool bindUserEq(const std::string &eq_fn) { if (eq_ <= 0) return false; eq_src_ = eq_fn; has_eq_ = true; bound_ = false; return true; }
     // NLOptimizer::bindEq (:231-259): the dynamics equalities are the engine's own transcription (Constraints.hpp:490-905) -- nothing to hand over
     bool bindEq() { return !f_.empty(); }
     // compile-only check of what has been bound (no device needed)
