@@ -420,7 +420,12 @@ int mpcx_allgather_u(mpcx_comm_t c, const double *u_local, int rows_per_rank, in
  * 642-825).  A bank is K configured controllers (host-only handles are enough) with the same dimensions and the same pattern
  * of finite bounds, solved together: instance b of a batch uses controller model_index[b] (device array; NULL: controller b,
  * batch = K).  "Shared" references mean each controller's own setReferences / setExogenousInputs values.  The bank copies what
- * it needs: the controllers may be destroyed or changed afterwards (changes do not reach the bank).                          */
+ * it needs: the controllers may be destroyed or changed afterwards (changes do not reach the bank).
+ * Preconditions the library does not check on the device: every model_index[b] lies in [0, K) (an index outside reads another
+ * controller's -- or no -- factors); a HIP graph captured from a solve holds the handle's workspace pointers, which a later solve
+ * with a LARGER batch re-allocates: re-capture after growing the batch.
+ * Set-up errors name the controller: MPCX_E_NUMERIC (its condensed Hessian or ADMM matrix does not factor), MPCX_E_INVALID (its
+ * constraint structure differs from controller 0's, e.g. a constraint row that does not depend on the inputs in one of the two). */
 typedef struct mpcx_lmpc_hetero *mpcx_lmpc_hetero_t;
 int mpcx_lmpc_hetero_create(const mpcx_lmpc_t *controllers, int count, int device, mpcx_lmpc_hetero_t *out);
 /* condense_on_host = 1: every controller's prediction matrices, Hessian, factors and dual Hessian on the host cores (what a single
@@ -447,7 +452,8 @@ int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap);
 /* how many full set-ups (condensing + device rebuild) and how many reference-only refreshes have run on this handle */
 int mpcx_lmpc_debug_setup_counts(mpcx_lmpc_t h, int *full, int *refs);
 /* solve path: 0 = assemble and solve as two kernels; 1 = the record computed inside the solve kernel by one mat-vec (persistent
- * form from 1024 instances on); 2 = assemble + solve in one workgroup of sixteen wavefronts; -1 = automatic (the default)   */
+ * form from 1024 instances on); 2 = assemble + solve in one workgroup of sixteen wavefronts; -1 = automatic (the default: the
+ * workgroup form up to 4096 instances, two kernels beyond; the fused forms only on request)                                   */
 int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int mode);
 /* 1 = always the generic (roll-out) assemble kernel, whatever the reference layout */
 int mpcx_lmpc_debug_force_generic(mpcx_lmpc_t h, int on);

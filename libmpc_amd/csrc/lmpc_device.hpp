@@ -26,6 +26,9 @@ struct LmpcDev {
     // solver parameters
     int max_iter, polish, check_every, polish_rounds0, polish_rounds;
     int cost_direct;                             // 1: cost from its definition (regularised Hessian), 0: from the multipliers
+    int cond_status;                             // device-side condensing (lmpc_condense_models): 0 fine; bit 0: the condensed Hessian is not positive
+                                                 // semidefinite; bit 1: the ADMM matrix is not positive definite; bit 2: a kept row of G is identically
+                                                 // zero (the controller's constraint structure differs from controller 0's)
     int strict_infeasible;                       // 1: report INFEASIBLE / NaN; 0: behave as the reference does
     double alpha, sigma, eps_abs, eps_rel, eps_prim_inf;
     int adaptive_rho; double rho_user;            // LParameters::adaptive_rho / rho (the ADMM step sizes of the set-up)

@@ -90,10 +90,12 @@ __device__ void tri_inverse_lds(const double *L, double *Q, const int n, const i
 __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev *models, const int count, const int NP, const int NQ)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int flag;
+    __shared__ int flag, cstat;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = threadIdx.x;
     for (int mdl = blockIdx.x; mdl < count; mdl += gridDim.x) {
         LmpcDev &M = models[mdl];
+        if (threadIdx.x == 0) cstat = 0;
+        __syncthreads();
         const int nx = M.nx, nu = M.nu, ny = M.ny, ph = M.ph, nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
         const int ld = NP + 1;
         double *P = smem, *Q = P + (size_t)NP * ld, *Sx0 = Q + (size_t)NQ * ld, *Sx1 = Sx0 + (size_t)nx * ld, *CS = Sx1 + (size_t)nx * ld;
@@ -228,7 +230,14 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
             __syncthreads();
             for (int e = t; e < nz * nz; e += blockDim.x) { const int q = e / nz, p = e - q * nz; P[p * ld + q] = oH[(size_t)q * ldz + p] + (p == q ? delta : 0.0); }
             __syncthreads();
-            (void)chol_lds(P, nz, ld, 0.0, &flag);
+            if (!chol_lds(P, nz, ld, 0.0, &flag)) {
+                // LmpcController::condense on the host: "condensed Hessian is not positive semidefinite".  Recorded for the caller; the
+                // factor is replaced by the identity so that what follows stays finite (the model is never solved: create fails)
+                if (t == 0) cstat |= 1;
+                __syncthreads();
+                for (int e = t; e < nz * nz; e += blockDim.x) { const int q = e / nz, p = e - q * nz; P[p * ld + q] = p == q ? 1.0 : 0.0; }
+                __syncthreads();
+            }
         }
         tri_inverse_lds(P, Q, nz, ld);
         // Hinv = Q' Q into P and into Y's leading block
@@ -299,12 +308,27 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
                          if (row < nz && col < nz) P[row * ld + col] = v + oH[(size_t)col * ldz + row] + (row == col ? M.sigma + rb[row] : 0.0);
                      }, wave, lane);
         __syncthreads();
-        (void)chol_lds(P, nz, ld, 0.0, &flag);
+        if (!chol_lds(P, nz, ld, 0.0, &flag)) {                  // host: "ADMM matrix is not positive definite"
+            if (t == 0) cstat |= 2;
+            __syncthreads();
+            for (int e = t; e < nz * nz; e += blockDim.x) { const int q = e / nz, p = e - q * nz; P[p * ld + q] = p == q ? 1.0 : 0.0; }
+            __syncthreads();
+        }
         tri_inverse_lds(P, Q, nz, ld);
         mfma_product(npt, npt, (nz + 3) >> 2,
                      [&](int row, int k) { return (row < nz && k < nz) ? Q[k * ld + row] : 0.0; },
                      [&](int k, int col) { return (col < nz && k < nz) ? Q[k * ld + col] : 0.0; },
                      [&](int row, int col, double v) { if (row < nz && col < nz) oK[(size_t)col * ldz + row] = v; }, wave, lane);
+        __syncthreads();
+        // a kept row of G that is identically zero: on the host that row would have been a feasibility-only (fixed) row -- the split into
+        // fixed and general rows was taken from controller 0, so this controller's constraint structure differs from it
+        for (int r0 = t; r0 < mg; r0 += blockDim.x) {
+            double amax = 0.0;
+            for (int q = 0; q < nz; ++q) amax = fmax(amax, fabs(oGr[(size_t)r0 * ldz + q]));
+            if (!(amax > 0.0)) atomicOr(&cstat, 4);
+        }
+        __syncthreads();
+        if (t == 0) M.cond_status = cstat;
         __syncthreads();
     }
 }

@@ -52,7 +52,8 @@ struct mpcx_lmpc {
     // being handed over through the HBM workspace (3 MB instead of 25 MB of traffic per 4096 instances), but the hardest-first
     // dispatch order of the two-kernel path is lost -- worth 22 us of its 70 us at 4096 instances, nothing at large batches.
     // Measured (quadrotor N = 20, ms per step, two kernels / fused): 4096: 0.097 / 0.125; 16384: 0.309 / 0.300; 65536: 1.10 / 1.00.
-    // -1 = automatic (fused from 16384 instances on), 0 = never, 1 = wherever the dimensions allow (mpcx_lmpc_debug_use_fused)
+    // -1 = automatic (lmpc_solve_group up to group_max instances, assemble + solve as two kernels beyond; the fused / persistent mat-vec forms
+    // only on request), 0 = always two kernels, 1 = the fused form wherever the dimensions allow, 2 = the group form (mpcx_lmpc_debug_use_fused)
     int use_fused = -1;
     int group_max = 4096;               // automatic mode: batches up to this size take lmpc_solve_group (assemble + solve in one workgroup)
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
@@ -168,7 +169,10 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
     // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
     D.fused_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && o.rowsF <= 384 && !D.cost_direct) ? 1 : 0;
     // assemble + solve in one workgroup (lmpc_solve_group): the one-chunk variant, cost from the multipliers
-    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct) ? 1 : 0;
+    // lmpc_solve_group's LDS block: two box-bound vectors, sixteen per-instance slices, the staged operands, the result records -- one CU's worth at most
+    // (otherwise the two-kernel path, which handled such a controller before the group form existed, takes it)
+    const size_t ldsg = ((size_t)2 * 128 + (size_t)16 * D.fast_slice + (size_t)(D.kin / 4 + D.nz16 / 4) * 64 + 16 * 16 + 16 + 16 * (8 + ((D.nu + 1) & ~1))) * sizeof(double);
+    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct && ldsg <= 160 * 1024) ? 1 : 0;
     D.slo = U.up(o.slo, rc); D.shi = U.up(o.shi, rc);
 }
 
@@ -910,6 +914,16 @@ int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int de
         if (lr != 0) return fail(MPCX_E_DEVICE, "the device condensing kernel could not be launched (" + std::to_string(lr) + ")");
         const hipError_t es = hipDeviceSynchronize();
         if (es != hipSuccess) return fail(MPCX_E_DEVICE, std::string("the device condensing kernel failed: ") + hipGetErrorString(es));
+        // what LmpcController::condense reports on the host (MPCX_E_NUMERIC for a Hessian / ADMM matrix that does not factor), and what the
+        // host path reports as "differs from controller 0" (a constraint row that vanishes in one controller but not in the first)
+        if (hipMemcpy(devs.data(), f->models_d, sizeof(mpcx::LmpcDev) * (size_t)count, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(MPCX_E_DEVICE, "could not read the bank's model table back");
+        for (int k = 0; k < count; ++k) {
+            const int cs = devs[(size_t)k].cond_status;
+            if (cs & 1) return fail(MPCX_E_NUMERIC, "controller " + std::to_string(k) + ": condensed Hessian is not positive semidefinite");
+            if (cs & 2) return fail(MPCX_E_NUMERIC, "controller " + std::to_string(k) + ": ADMM matrix is not positive definite");
+            if (cs & 4) return fail(MPCX_E_INVALID, "controller " + std::to_string(k) + " differs from controller 0: one of its constraint rows does not depend on the inputs");
+        }
     }
     f->condensed_on_device = on_device;
     f->setup_total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

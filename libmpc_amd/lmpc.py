@@ -297,7 +297,8 @@ class LMPC:
     def debug_use_fused(self, on=True):
         """experiment / testing knob: False / 0 = assemble and solve as two kernels, True / 1 = the record computed inside the solve
         kernel by one mat-vec (persistent form from 1024 instances on), 2 = assemble + solve in one workgroup of sixteen
-        wavefronts (lmpc_solve_group), -1 = automatic (the default: the workgroup form up to 8192 instances, two kernels beyond)"""
+        wavefronts (lmpc_solve_group), -1 = automatic (the default: the workgroup form up to 4096 instances, two kernels beyond; the fused
+        forms only on request)"""
         check(self._lib.mpcx_lmpc_debug_use_fused(self._h, -1 if on is None else int(on)))
 
     def _torch(self):

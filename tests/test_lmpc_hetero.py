@@ -141,3 +141,31 @@ def test_device_condensing_matches_the_host_set_up(family):
     np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=1e-8, atol=1e-8)
     assert torch.equal(ra.active_lower, rb.active_lower) and torch.equal(ra.active_upper, rb.active_upper)
+
+
+def _two_state_controller(b1, hessian_weight=1.0):
+    """x = [p, q]: p driven by the input, q driven by the input only through b1; q carries a bound, so its rows of the condensed G
+    vanish identically when b1 = 0"""
+    from libmpc_amd import LMPC, LParameters
+    c = LMPC(2, 1, 0, 2, 6, 6, device=-1)
+    c.setStateSpaceModel(np.array([[0.9, 0.0], [0.0, 0.8]]), np.array([[0.5], [b1]]), np.eye(2))
+    c.setObjectiveWeights([hessian_weight, hessian_weight], [0.1], [0.0], (0, 6))
+    c.setStateBounds([-np.inf, -1.0], [np.inf, 1.0], (0, 6))
+    c.setInputBounds([-1.0], [1.0], (0, 6))
+    c.setReferences([0.5, 0.0], [0.0], [0.0], (0, 6))
+    c.setOptimizerParameters(LParameters(maximum_iteration=500))
+    return c
+
+
+@pytest.mark.parametrize("on_host", [False, True])
+def test_a_bank_whose_constraint_structure_differs_from_controller_0_is_refused_on_both_condensing_paths(on_host):
+    """the split into feasibility-only and general rows is taken from controller 0; a controller in which a bounded state does not depend on
+    the inputs has that row identically zero in G -- the host path reports it, and so does the device condensing (cond_status), instead of
+    condensing a singular row into the dual Hessian"""
+    from libmpc_amd import LMPCHetero
+    good = [_two_state_controller(0.3), _two_state_controller(0.25)]
+    het = LMPCHetero(good, device=0, condense_on_host=on_host)
+    assert het.count == 2
+    with pytest.raises(Exception) as ei:
+        LMPCHetero([_two_state_controller(0.3), _two_state_controller(0.0)], device=0, condense_on_host=on_host)
+    assert "differs from controller 0" in str(ei.value) or "controller 1" in str(ei.value), str(ei.value)
