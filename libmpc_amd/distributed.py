@@ -100,3 +100,67 @@ def allgather_controls(cmd_local: torch.Tensor, total: int | None = None, group=
     out = collect(pad)
     parts = [out[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
+
+
+class OverlappedGather:
+    """Double buffering of the one exchange of the data path: step k's solve writes its optimal controls into buffer k % 2 on the solve
+    stream while step k-1's all-gather (buffer (k-1) % 2) is still travelling on a second stream.  At a 50 us step an all-gather issued in
+    series on the solve stream (latency-bound: tens of microseconds over xGMI) would be a large part of every step; behind an event on its
+    own stream it costs the solve stream nothing.
+
+    Ordering, per buffer i: solve(k) waits for the gather of step k-2 (the last reader of buffer i) -> `done[i]` -> gather(k) on the
+    gather stream -> `free[i]`.  `gathered(k)` is the [world * n, nu] result of step k, valid until step k+2 is launched.
+
+    CUDA tensors: two HIP streams and events, the collective through `ControlGather` (RCCL behind the C ABI).  CPU tensors (the gloo
+    tests): the same rotation with torch's collective and no streams -- what is tested there is that the results of step k are what is
+    gathered as step k, and that they survive the launch of step k+1."""
+
+    def __init__(self, n: int, nu: int, device, gather: ControlGather | None = None, group=None, solve_stream=None, world: int | None = None):
+        self.gather, self.group = gather, group
+        self.world = gather.world if gather is not None else (world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1))
+        dev = torch.device(device)
+        self.cuda = dev.type == "cuda"
+        self.cmd = [torch.zeros((n, nu), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.all = [torch.zeros((self.world * n, nu), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.k_of = [-1, -1]                                   # which step's results each buffer holds
+        if self.cuda:
+            self.solve_stream = solve_stream if solve_stream is not None else torch.cuda.current_stream(dev)
+            self.gather_stream = torch.cuda.Stream(device=dev)
+            self.done = [torch.cuda.Event() for _ in range(2)]
+            self.free = [torch.cuda.Event() for _ in range(2)]
+            for e in self.free:
+                e.record(self.solve_stream)
+
+    def step(self, k: int, launch):
+        """launch(i, stream) enqueues (CUDA) or performs (CPU) the solve of step k with its controls going to `self.cmd[i]`"""
+        i = k % 2
+        if self.cuda:
+            self.solve_stream.wait_event(self.free[i])         # buffer i's previous all-gather has read it
+            launch(i, self.solve_stream)
+            self.done[i].record(self.solve_stream)
+            self.gather_stream.wait_event(self.done[i])
+            if self.gather is not None:
+                self.gather.allgather(self.cmd[i], out=self.all[i], stream=self.gather_stream.cuda_stream)
+            else:
+                with torch.cuda.stream(self.gather_stream):
+                    self.all[i].copy_(self.cmd[i].repeat(self.world, 1) if self.world > 1 else self.cmd[i])
+            self.free[i].record(self.gather_stream)
+        else:
+            launch(i, None)
+            if dist.is_initialized() and self.world > 1:
+                dist.all_gather_into_tensor(self.all[i], self.cmd[i].contiguous(), group=self.group)
+            else:
+                self.all[i].copy_(self.cmd[i])
+        self.k_of[i] = k
+
+    def gathered(self, k: int) -> torch.Tensor:
+        i = k % 2
+        if self.k_of[i] != k:
+            raise RuntimeError("step %d is no longer (or not yet) in its buffer: it holds step %d" % (k, self.k_of[i]))
+        if self.cuda:
+            self.free[i].synchronize()
+        return self.all[i]
+
+    def finish(self):
+        if self.cuda:
+            self.gather_stream.synchronize()

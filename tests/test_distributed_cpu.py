@@ -46,3 +46,48 @@ def test_allgather_controls_gloo(total):
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (total, nu) for _, _, shape in res)
+
+
+def _overlap_worker(rank, world, port, n, nu, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libmpc_amd.distributed import OverlappedGather
+    og = OverlappedGather(n, nu, "cpu")
+
+    def value(r, k):                                             # what rank r's solve of step k "returns"
+        return (1000.0 * k + 10.0 * r) + torch.arange(n * nu, dtype=torch.float64).reshape(n, nu)
+
+    ok = True
+    for k in range(steps):
+        og.step(k, lambda i, stream: og.cmd[i].copy_(value(rank, k)))
+        want = torch.cat([value(r, k) for r in range(world)], dim=0)
+        ok &= torch.equal(og.gathered(k), want)                  # the results of step k are what was gathered as step k ...
+        if k >= 1:
+            prev = torch.cat([value(r, k - 1) for r in range(world)], dim=0)
+            ok &= torch.equal(og.gathered(k - 1), prev)          # ... and step k-1's survive the launch of step k (two buffers)
+        if k >= 2:
+            try:
+                og.gathered(k - 2)
+                ok = False                                       # its buffer holds step k by now: refused, not returned stale
+            except RuntimeError:
+                pass
+    og.finish()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_double_buffered_gather_keeps_step_order_gloo():
+    """bench.py --gpus N overlaps step k's all-gather with step k+1's solve (libmpc_amd.distributed.OverlappedGather); the rotation of the
+    two buffers on a world-size-2 gloo group"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, 6, 4, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

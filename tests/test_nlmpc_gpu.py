@@ -259,14 +259,16 @@ def _golden(key):
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nlmpc_oracle_solutions.json")))[key]
 
 
-def _compare_with_golden(c, gold, label, cost_rtol):
+def _compare_with_golden(c, gold, label, cost_rtol, oracle_model=None, hard=True):
     """every golden instance in one batch; compared wherever the oracle's SLSQP ended at a usable point.  Returns (compared, other):
-    an instance where the two solvers stopped at different local optima is counted (with how its cost compares), not compared"""
+    an instance where the two solvers stopped at different local optima is counted (with how its cost compares), not compared -- and one
+    that ended WORSE than the oracle's has to be a KKT point of the restated problem all the same (oracle callbacks, the kernel's multipliers)"""
     import torch
     X0 = np.array([k["x0"] for k in gold["cases"]]); U0 = np.array([k["u0"] for k in gold["cases"]])
-    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0))
+    r = c.optimizeBatch(torch.from_numpy(X0), torch.from_numpy(U0), multipliers=True)
     torch.cuda.synchronize()
     status, cost, cmd = r["status"].cpu().numpy(), r["cost"].cpu().numpy(), r["cmd"].cpu().numpy()
+    zs, mus = r["z"].cpu().numpy(), r["multipliers"].cpu().numpy()
     worst, worst_cost, compared, other, bad_cost = 0.0, 0.0, 0, [], []
     # usable: scipy's SLSQP converged, or ended in its mode 8 (line search cannot improve: the step is below what its ftol of 1e-12
     # resolves) at a feasible point -- how it ends most UGV solves.  Its diverged runs (cost 1e9 and more on config 5) are not.
@@ -278,10 +280,13 @@ def _compare_with_golden(c, gold, label, cost_rtol):
         if not np.allclose(cmd[b], k["cmd"], rtol=1e-5, atol=1e-5):
             # another local optimum: the UGV's obstacle rows make the problem non-convex (from the example's own start x0 = 0 the two
             # mirror-image paths cost the same to 1e-9 and round-off decides which one a solver takes; from other starts the two SLSQP
-            # implementations pass the obstacles on different sides).  Counted, not compared: the caller bounds how many there may be, and
-            # test_gpu_solution_satisfies_the_restated_kkt_conditions checks that the kernel's end points are KKT points.
+            # implementations pass the obstacles on different sides).  Counted, not compared: the caller bounds how many there may be.
             assert status[b] == 0, (b, status[b])
-            other.append((b, "better" if cost[b] < k["cost"] * (1.0 - cost_rtol) else ("equal" if cost[b] <= k["cost"] * (1.0 + cost_rtol) else "worse")))
+            how = "better" if cost[b] < k["cost"] * (1.0 - cost_rtol) else ("equal" if cost[b] <= k["cost"] * (1.0 + cost_rtol) else "worse")
+            if how == "worse" and oracle_model is not None:
+                stat, viol, comp, neg = _kkt_report(oracle_model, zs[b], X0[b], mus[b], hard)
+                assert stat <= 2e-5 and viol <= 1e-7 and comp <= 1e-5 and neg >= -1e-7, (b, stat, viol, comp, neg)
+            other.append((b, how))
             continue
         if abs(cost[b] - k["cost"]) > cost_rtol * abs(k["cost"]):
             bad_cost.append((b, cost[b], k["cost"], k["slsqp_mode"], k["ineq_violation"]))
@@ -301,23 +306,25 @@ def test_eight_oscillator_config_matches_golden_oracle_solutions():
     (generated by tests/golden/make_nlmpc_golden.py)"""
     from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS8
     gold = _golden("oscillators8_ph30_ch15")
-    assert len(gold["cases"]) >= 32
+    assert len(gold["cases"]) >= 64
     c = NLMPC(OSCILLATORS8, gold["ph"], gold["ch"], gold["Ts"])
     c.setOptimizerParameters(NLParameters(maximum_iteration=200))
     compared, other = _compare_with_golden(c, gold, "8 oscillators (config 5)", 1e-8)
-    assert compared >= 28 and not other                # one optimum here; scipy's SLSQP diverges on three of the 32 starts
+    assert compared >= 56 and not other                # one optimum here; scipy's SLSQP diverges on a few of the 64 starts
 
 
 def test_ugv_config_matches_golden_oracle_solutions():
     """BASELINE config 3 (ugv_ex.cpp, soft constraints): the example's start and the first 63 instances of bench.py's batch"""
     from libmpc_amd.nlmpc import NLMPC, NLParameters, UGV
     gold = _golden("ugv_ph30_ch30")
-    assert len(gold["cases"]) >= 64
+    assert len(gold["cases"]) >= 256
     c = NLMPC(UGV, gold["ph"], gold["ch"], gold["Ts"])
     c.setOptimizerParameters(NLParameters(maximum_iteration=150, hard_constraints=0))
     # cost: scipy's mode-8 end points sit up to 1e-7 outside the obstacle rows (stored: ineq_violation), which buys them up to 5e-7 of cost
-    compared, other = _compare_with_golden(c, gold, "ugv (config 3)", 2e-6)
-    assert compared >= 48 and len(other) <= 8, (compared, other)
+    # measured: 224 of the 231 usable end points agree, 7 sit at another local optimum (1 of equal cost, 6 worse -- each of them a KKT point
+    # of the restated problem, checked inside); the allowance is that count + 2
+    compared, other = _compare_with_golden(c, gold, "ugv (config 3)", 2e-6, oracle_model=ref.ugv(ph=gold["ph"], ch=gold["ch"]), hard=False)
+    assert compared >= 218 and len(other) <= 9, (compared, other)
 
 
 def test_config5_properties_and_kkt_at_batch_256():
