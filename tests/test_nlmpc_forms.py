@@ -134,15 +134,18 @@ def test_the_two_forms_agree_with_each_other(monkeypatch):
         assert np.array_equal(a["multipliers"][ok] > 1e-9, b["multipliers"][ok] > 1e-9)
 
 
-def test_default_form_is_the_measured_choice(monkeypatch, capfd):
-    """csrc/nlmpc_kernels.hip: the workgroup form where an instance takes one wavefront (config 1), the wavefront form for the larger systems;
-    MPCX_DEBUG_OCCUPANCY makes the launchers say which one ran"""
+def test_default_form_is_the_measured_choice(monkeypatch):
+    """csrc/nlmpc_kernels.hip: the workgroup form where an instance takes one wavefront (config 1: a CU full of instances) and for a batch it
+    holds resident all at once (latency: every instance on its own four wavefronts), the wavefront form for large batches of the larger
+    systems (throughput); mpcx_nlmpc_debug_last_form says which one ran"""
+    from libmpc_amd import _capi
     from libmpc_amd.nlmpc import VANDERPOL, UGV
     monkeypatch.delenv("MPCX_NLMPC_FORM", raising=False)
     monkeypatch.delenv("MPCX_NLMPC_WAVES", raising=False)
-    monkeypatch.setenv("MPCX_DEBUG_OCCUPANCY", "1")
-    _solve(VANDERPOL, 10, 5, 0.1, np.array([[0.0, 1.0]]), np.zeros((1, 1)), True, 50)
-    assert "nlmpc_sqp_wg" in capfd.readouterr().err
-    _solve(UGV, 30, 30, 0.1, np.zeros((1, 4)), np.zeros((1, 2)), False, 5)
-    err = capfd.readouterr().err
-    assert "nlmpc_sqp:" in err and "nlmpc_sqp_wg" not in err
+    last = _capi.lib().mpcx_nlmpc_debug_last_form
+    _solve(VANDERPOL, 10, 5, 0.1, np.tile([[0.0, 1.0]], (4096, 1)), np.zeros((4096, 1)), True, 50)
+    assert last() == 1
+    _solve(UGV, 30, 30, 0.1, np.zeros((8, 4)), np.zeros((8, 2)), False, 5)
+    assert last() == 4
+    _solve(UGV, 30, 30, 0.1, np.zeros((4096, 4)), np.zeros((4096, 2)), False, 2)
+    assert last() == 0

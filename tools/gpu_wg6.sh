@@ -13,5 +13,5 @@ PY
 ( MPCX_FORCE_DIST=1 timeout 200 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --pipeline-streams 0 --nlmpc-extra 0 ) 2> $O/${T}_bench_rccl1.err | grep "^{" > $O/${T}_bench_rccl1.json; python - <<PY
 import json
 d=json.loads(open("$O/${T}_bench_rccl1.json").read().strip().splitlines()[-1])
-print("one-rank RCCL path: overlapped", d["value"], "in series", d["allgather_in_series"])
+print("one-rank RCCL path: in series", d["value"], "overlapped", d["allgather_overlapped"])
 PY
