@@ -1813,9 +1813,13 @@ struct WgSqp {
     }
 };
 
+// Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
+// block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
+// for the smallest systems at one wavefront per instance, whose 4 KB blocks let sixteen instances share a CU.
+template <class Mdl, int WAVES> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : 2;
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 4 : 2) void nlmpc_sqp_wg(const WgArgs A)
+__global__ __launch_bounds__(64 * WAVES, kWgWavesPerSimd<Mdl, WAVES>) void nlmpc_sqp_wg(const WgArgs A)
 {
     using K = WgSqp<Mdl, WAVES>;
     using T = Team<WAVES>;
