@@ -1819,7 +1819,7 @@ struct WgSqp {
 template <class Mdl, int WAVES> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : 2;
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES, kWgWavesPerSimd<Mdl, WAVES>) void nlmpc_sqp_wg(const WgArgs A)
+__global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlmpc_sqp_wg(const WgArgs A)
 {
     using K = WgSqp<Mdl, WAVES>;
     using T = Team<WAVES>;
