@@ -77,6 +77,30 @@ def _cpu_worker(job):
     return done, time.perf_counter() - t0
 
 
+def _hetero_cpu_worker(job):
+    """heterogeneous LMPC CPU baseline, one host core's share: instance k on the C oracle configured as controller quadrotor_variant(k) -- one
+    controller object per problem, configured once outside the timed loop (LMPC.hpp:751), the set-up inside every solve as LOptimizer::run
+    pays it -- until the budget is used"""
+    ph, first, x0, u0, yref, budget = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import OracleFrontEnd
+    from libmpc_amd.workloads import quadrotor_variant
+    from oracle.lmpc_oracle import default_params
+    ctrls = []
+    for t in range(x0.shape[0]):
+        f = OracleFrontEnd(12, 4, 4, 12, ph, ph)
+        quadrotor_variant(first + t, ph, into=f)
+        f.o.params = default_params(maximum_iteration=250)
+        ctrls.append(f.o)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for t, o in enumerate(ctrls):
+            o.solve_batch_constref(x0[t:t + 1], u0[t:t + 1], yref[t:t + 1])
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                return done, time.perf_counter() - t0
+
+
 def _nl_cpu_worker(job):
     """NLMPC CPU baseline, one host core's share: the reference's callbacks in C (oracle/nlmpc_callbacks.c) driving scipy's SLSQP
     (Kraft's compiled code, what NLopt's LD_SLSQP translates) on instances of the batch, until the time budget is used"""
@@ -487,6 +511,21 @@ def run_lmpc_hetero(args, ph, B, steps, warmup, world, rank, local, dev, gather,
              "mfma_frac": (B * flags[4] / (flags[2] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS) if flags[2] > 0 else None,
              "note": "lmpc_condense_models: one workgroup per controller, prediction matrices / Hessian / dual Hessian / ADMM matrix on "
                      "v_mfma_f64_16x16x4_f64, Cholesky and triangular inverses in LDS; flops = the host set-up's count"}
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        import multiprocessing as mp
+        ncores = _usable_cores()
+        per_core = max(8, min(64, B // ncores))
+        x0n, u0n, yrn = (np.asarray(a.cpu().numpy() if hasattr(a, "cpu") else a) for a in (x0, u0, yref))
+        jobs = [(ph, (i * per_core) % B, x0n[(i * per_core) % B:][:per_core], u0n[(i * per_core) % B:][:per_core], yrn[(i * per_core) % B:][:per_core],
+                 0.5 * args.cpu_seconds) for i in range(ncores)]
+        with mp.get_context("fork").Pool(ncores) as pool:
+            res_cpu = pool.map(_hetero_cpu_worker, jobs)
+        done = sum(r[0] for r in res_cpu); t_all = max(r[1] for r in res_cpu)
+        cpu = {"value": done / t_all, "unit": "solves/s", "cores": ncores, "kind": "port",
+               "sample": f"{done} solves in {t_all:.1f} s: {ncores} worker processes (one per host core), each on its own {per_core} instances of the same "
+                         f"batch, every instance on the C oracle of its own controller (one controller object per problem, configured outside the "
+                         f"timed loop; set-up per solve as LOptimizer::run)"}
     total = world * B * steps
     out = {"metric": "MPC solves/sec (whole node), quadrotor LMPC N=%d, every instance its own controller, batch=%d" % (ph, B),
            "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -494,7 +533,7 @@ def run_lmpc_hetero(args, ph, B, steps, warmup, world, rank, local, dev, gather,
            "config": {"workload": "quadrotor LMPC nx=12 nu=4 ny=12 ph=ch=%d, %d controllers (quadrotor_variant: own dynamics, weights, limits), one "
                                   "instance each per GPU, SplitMix64 x0/u0/yref" % (ph, B),
                       "parallelism": ("batch-sharded x%d" % world) if gather else "single GPU", "rccl_ranks": gather.world if gather else 0},
-           "solved_fraction": float((status == 0).mean()), "roofline": roof, "set_up": setup, "cpu_baseline": None}
+           "solved_fraction": float((status == 0).mean()), "roofline": roof, "set_up": setup, "cpu_baseline": cpu}
     print(json.dumps(out))
 
 

@@ -349,7 +349,8 @@ int mpcx_nlmpc_set_input_bounds_slice(mpcx_nlmpc_t h, const double *lo, const do
 /* One batched NLOptimizer::run (NLOptimizer.hpp:412-638).  Device pointers.  Outputs other than
  * cmd may be NULL.  status uses MPCX_STATUS_* (ResultStatus), solver_status nlopt's result codes
  * (3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE = inconsistent linearised constraints,
- * -3 OUT_OF_MEMORY = more than 128 rows active at once, -4 ROUNDOFF_LIMITED = line search stalled far from a solution) as mapped at NLOptimizer.hpp:729-750; on failure
+ * -3 OUT_OF_MEMORY = more than 128 rows active at once, -4 ROUNDOFF_LIMITED = line search stalled far from a solution,
+ * -5 FORCED_STOP = the kernel's own consistency guard tripped: a wavefront reached a phase boundary with lanes missing -- never seen, tests assert it) as mapped at NLOptimizer.hpp:729-750; on failure
  * cmd = u0 and cost = inf as at :613-624.  is_feasible = every user inequality <= 1e-10 and every user
  * equality within 1e-10 (Constraints.hpp:157-202, tolerances NLMPC.hpp:166, 262).                 */
 typedef struct mpcx_nlmpc_batch {

@@ -47,7 +47,7 @@ struct WgPlan {
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
-    int w_scal, w_F, w_einv, w_gx, w_hinv, w_sp;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
+    int w_scal, w_F, w_art, w_einv, w_gx, w_hinv, w_sp;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
     int ws_total;
 };
 
@@ -382,7 +382,7 @@ __device__ __forceinline__ void chol_delete(double *Lp, double *invd, int n, int
 }
 
 // ---- the kernel's phases ----------------------------------------------------------------------------------------------------------------
-template <class Mdl, int WAVES>
+template <class Mdl, int WAVES, bool FL>
 struct WgSqp {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1, NT = 64 * WAVES;
     static constexpr bool CT = Mdl::CONTINUOUS;
@@ -405,10 +405,14 @@ struct WgSqp {
         __device__ __forceinline__ Scale scale() const { return Scale(A->M.su, A->M.ss, A->M.iss, A->M.scaled != 0); }
     };
     // the folded blocks: LDS or workspace, the pointer typed accordingly
-    template <bool FL> struct FP {
+    struct FP {
         typedef typename BlockPtr<FL>::type type;
         static __device__ __forceinline__ type get(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + v.A->P.o_F : v.w + v.A->P.w_F); }
     };
+
+    // the dense reduced rows art [nq x ndld]: where the folded blocks are -- in LDS (FL), or in the workspace, from where whole-matrix products
+    // fetch them in bulk (contiguous, a dozen loads per lane in flight) and where a CU's L2 keeps the few resident instances' copies
+    static __device__ __forceinline__ typename FP::type art_of(const V &v) { return BlockPtr<FL>::make(FL ? v.sm + v.A->P.o_art : v.w + v.A->P.w_art); }
 
     // the sparse form of sub-problem row k (as in nlmpc_sqp): first entry and count in LDS, entries 1 .. 3 in the workspace
     struct Sp {
@@ -499,13 +503,15 @@ struct WgSqp {
                 while (mk) { const int i = (int)__builtin_ctzll(mk) + 1; mk &= mk - 1; slot[ns++] = (k << 8) | i; }
             }
             jxoff[m] = ns;
-            // the same pairs grouped by state row: what the sweep consumes as it passes state row i + 1 (entry: row << 12 | block slot)
+            // the same pairs grouped by state row: what the sweep consumes as it passes state row i + 1 (entry: row << 12 | block slot;
+            // bit 31: the pair is all there is to the row's reduced entries -- one state row, no input -- and is stored, not added)
             int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
             int ne = 0;
             for (int i = 1; i <= ph; ++i) {
                 xrf[i - 1] = ne;
                 for (int k = 0; k < m; ++k)
-                    if ((xmask[k] >> (i - 1)) & 1ull) xre[ne++] = (k << 12) | (jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << (i - 1)) - 1ull)));
+                    if ((xmask[k] >> (i - 1)) & 1ull)
+                        xre[ne++] = (k << 12) | (jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << (i - 1)) - 1ull))) | (sole_state_row(k, xmask[k], mi, ph) ? (int)0x80000000 : 0);
             }
             xrf[ph] = ne;
         }
@@ -577,7 +583,6 @@ struct WgSqp {
     }
 
     // (2) Constraints::getStateEqConstraints (Constraints.hpp:490-905): the defects, and the Jacobian blocks folded with E^-1
-    template <bool FL>
     static MPCX_WG_PHASE void eval_dyn(int values_only)
     {
         const V v; const auto &M = v.A->M; const auto &P = v.A->P;
@@ -604,7 +609,7 @@ struct WgSqp {
             }
         } else if constexpr (!CT) {
             // one-step models: E = I, the folded blocks are the negated Jacobian blocks; one lane per (step, column)
-            typename FP<FL>::type F = FP<FL>::get(v);
+            typename FP::type F = FP::get(v);
             for (int k = tid; k < ph * FW; k += NT) {
                 const int i = k / FW, cc = k - i * FW;
                 double xk[NX], uk[NU], f1[NX], f2[NX];
@@ -638,7 +643,7 @@ struct WgSqp {
             }
         } else {
             // collocation: per step a Gauss-Jordan on [E | A B c | I], one column per lane in registers; G steps per wavefront at a time
-            typename FP<FL>::type F = FP<FL>::get(v);
+            typename FP::type F = FP::get(v);
             gwp einv = (gwp)(v.w + P.w_einv);
             constexpr int G = 64 / GW > 0 ? 64 / GW : 1;
             const int g = lane / GW, cidx = lane - g * GW, base = g * GW;
@@ -733,6 +738,15 @@ struct WgSqp {
         T::sync();
     }
 
+    // a user row whose reduced entries come from one state row alone (no input enters it): the condensing sweep stores them
+    static __device__ __forceinline__ bool sole_state_row(int k, unsigned long long mk, int mi, int ph)
+    {
+        if (NX > 8 || __builtin_popcountll(mk) != 1) return false;     // (the sixteen-lane sweep of wide states adds throughout)
+        for (int i = 0; i < ph; ++i)
+            if (k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i)) return false;
+        return true;
+    }
+
     // (3) Constraints::evaluateIneq / evaluateEq (Constraints.hpp:211-442) and their Jacobians (computeIneqJacobian :641-721,
     // computeEqJacobian :731-832) as blocks: one NX-vector per (row, state row) pair, the input part straight into the sub-problem's rows
     static MPCX_WG_PHASE void eval_con(int values_only)
@@ -745,9 +759,11 @@ struct WgSqp {
         const double *prm = v.at(P.o_prm);
         const Scale sc = v.scale();
         const double *z = v.at(P.o_z), *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us);
-        double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *art = v.at(P.o_art), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
+        double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
+        typename FP::type art = art_of(v);
         int *s1m = v.iat(P.o_s1m);
         const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
+        const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         const int *bnd_idx = v.iat(P.o_bidx);
         const double *bnd_sign = v.at(P.o_bsign), *bnd_val = v.at(P.o_bval);
         const double e = z[nz - 1];
@@ -778,7 +794,7 @@ struct WgSqp {
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
-            if (dense) for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+            if (dense) for (int q = sole_state_row(k, xmask[k], mi, ph) ? nzu : 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
             int cnt = 0, ix[kNlSparse + 1];
             double ev[kNlSparse + 1];
             for (int u = 0; u <= kNlSparse; ++u) { ix[u] = 0; ev[u] = 0.0; }
@@ -859,13 +875,13 @@ struct WgSqp {
             else return acc;
         }
     };
-    template <bool FL, bool BACKWARD>
+    template <bool BACKWARD>
     static __device__ __forceinline__ void chain(const V &v, double *io, int tid)
     {
         static_assert(NX <= 16, "a chain's column lives in one DPP row");
         if (tid >= 64) return;
         const int ph = v.ph;
-        typename FP<FL>::type F = FP<FL>::get(v);
+        typename FP::type F = FP::get(v);
         const int a = tid & (NXP - 1), aa = min(a, NX - 1);
         const bool alive = a < NX, writes = alive && tid < NXP;
         double fn[NX];
@@ -926,19 +942,19 @@ struct WgSqp {
             else return acc;
         }
     };
-    template <bool FL>
     static MPCX_WG_PHASE void condense_phi()
     {
         const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nzu = v.nzu, mi = v.mi, m = v.m, ndld = v.ndld;
         const double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *jx = v.at(P.o_jx);
-        double *gr = v.at(P.o_gr), *art = v.at(P.o_art), *br = v.at(P.o_br);
+        double *gr = v.at(P.o_gr), *br = v.at(P.o_br);
+        typename FP::type art = art_of(v);
         const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         const int *bnd_idx = v.iat(P.o_bidx);
         const double *bnd_sign = v.at(P.o_bsign);
-        typename FP<FL>::type F = FP<FL>::get(v);
+        typename FP::type F = FP::get(v);
         if constexpr (NX <= 8) {
             constexpr bool PF = NX <= 4;                         // the next step's block is requested while this one's is used (registers for it: small states)
             const int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
@@ -946,14 +962,12 @@ struct WgSqp {
                 const bool isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
                 double x[NX], t[NX], gacc = 0.0;
-                double fb[PF ? NX * (NX + 1) : 1];
+                double fb[PF ? NX * NX : 1];
                 auto fetch = [&](int i) {
-                    const bool drv = !isr && min(i, ch - 1) == bq;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) {
 #pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) fb[a * (NX + 1) + bb] = F[(size_t)(i * NX + a) * FW + bb];
-                        fb[a * (NX + 1) + NX] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+                        for (int bb = 0; bb < NX; ++bb) fb[a * NX + bb] = F[(size_t)(i * NX + a) * FW + bb];
                     }
                 };
                 // what state row i + 1 (held in x) is needed for; issued before the next step's products so that its LDS round trips and
@@ -964,11 +978,13 @@ struct WgSqp {
                         for (int a = 0; a < NX; ++a) gacc = fma(lam[i * NX + a], x[a], gacc);       // (lam still holds g_x)
                     }
                     for (int e = xrf[i]; e < xrf[i + 1]; ++e) {
-                        const int k = xre[e] >> 12, sl = xre[e] & 0xfff;
+                        const int k = (xre[e] & 0x7fffffff) >> 12, sl = xre[e] & 0xfff;
                         double sacc = 0.0;
 #pragma unroll
                         for (int a = 0; a < NX; ++a) sacc = fma(jx[sl * NX + a], x[a], sacc);
-                        if (isr) br[k] += sacc; else art[q * ndld + dcol[k]] += sacc;
+                        if (isr) br[k] += sacc;
+                        else if (xre[e] < 0) art[q * ndld + dcol[k]] = sacc;
+                        else art[q * ndld + dcol[k]] += sacc;
                     }
                     for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
                         const int a = bnd_idx[kb] - i * NX;
@@ -985,16 +1001,21 @@ struct WgSqp {
                 for (int i = 0; i < ph; ++i) {
                     if (i > 0) consume(i - 1);
                     if constexpr (PF) {
-                        double fcur[NX * (NX + 1)];
+                        // this step's block was requested a step ago; its right-hand side column (the lane's own: B e_q or c) is requested now and
+                        // added after the products, the next block behind it
+                        double fcur[NX * NX], rh[NX];
+                        const bool drv = !isr && min(i, ch - 1) == bq;
 #pragma unroll
-                        for (int e = 0; e < NX * (NX + 1); ++e) fcur[e] = fb[e];
+                        for (int a = 0; a < NX; ++a) rh[a] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+#pragma unroll
+                        for (int e = 0; e < NX * NX; ++e) fcur[e] = fb[e];
                         if (i + 1 < ph) fetch(i + 1);
 #pragma unroll
                         for (int a = 0; a < NX; ++a) {
-                            double sacc = fcur[a * (NX + 1) + NX];
+                            double sacc = 0.0;
 #pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * (NX + 1) + bb], x[bb], sacc);
-                            t[a] = sacc;
+                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * NX + bb], x[bb], sacc);
+                            t[a] = sacc + rh[a];
                         }
                     } else {
                         const bool drives = !isr && min(i, ch - 1) == bq;
@@ -1052,15 +1073,14 @@ struct WgSqp {
     }
     // ... and where none does: the reduced gradient through one backward chain (Jx' lam = -g_x; lam holds g_x on entry, the chain's
     // multipliers afterwards).  Leaves the largest dynamics multiplier, which the merit weight has to dominate, in st[ST_LAMDYN].
-    template <bool FL>
     static MPCX_WG_PHASE void condense_chain()
     {
         const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ph = v.ph, ch = v.ch, nzu = v.nzu;
         double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *gr = v.at(P.o_gr), *st = v.at(P.o_st);
-        typename FP<FL>::type F = FP<FL>::get(v);
-        chain<FL, true>(v, lam, tid);
+        typename FP::type F = FP::get(v);
+        chain<true>(v, lam, tid);
         T::sync();
         for (int q = tid; q <= nzu; q += NT) {
             if (q == nzu) { gr[q] = gu[q]; continue; }
@@ -1085,11 +1105,11 @@ struct WgSqp {
     {
         const auto &P = v.A->P;
         const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
-        const double *art = v.at(P.o_art);
+        typename FP::type art = art_of(v);
         for (int d0 = 0; d0 < nd; d0 += NT / 4) {
             const int dc = d0 + (tid >> 2);
             const bool live = dc < nd;
-            const double *col = art + (live ? dc : 0);
+            typename FP::type col = art + (live ? dc : 0);
             double a0 = 0.0, a1 = 0.0;
             int q = part;
             for (; q + 4 < nq; q += 8) { a0 = fma(col[q * ndld], x[q], a0); a1 = fma(col[(q + 4) * ndld], x[q + 4], a1); }
@@ -1104,11 +1124,11 @@ struct WgSqp {
     {
         const auto &P = v.A->P;
         const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
-        const double *art = v.at(P.o_art);
+        typename FP::type art = art_of(v);
         for (int q0 = 0; q0 < nq; q0 += NT / 4) {
             const int q = q0 + (tid >> 2);
             const bool live = q < nq;
-            const double *row = art + (live ? q : 0) * ndld;
+            typename FP::type row = art + (live ? q : 0) * ndld;
             double a0 = 0.0, a1 = 0.0;
             int dc = part;
             for (; dc + 4 < nd; dc += 8) { a0 = fma(row[dc], cd[dc], a0); a1 = fma(row[dc + 4], cd[dc + 4], a1); }
@@ -1177,7 +1197,8 @@ struct WgSqp {
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
         const int tid = threadIdx.x, nq = v.nq, dc = v.iat(P.o_dcol)[k];
-        const double *hinv = v.at(P.o_hinv), *art = v.at(P.o_art);
+        const double *hinv = v.at(P.o_hinv);
+        typename FP::type art = art_of(v);
         double *np_ = v.at(P.o_np), *vv = v.at(P.o_vv);
         if (dc >= 0) {
             for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * v.ndld + dc];
@@ -1415,7 +1436,7 @@ struct WgSqp {
         const Ws W(v);
         double *gr = v.at(P.o_gr), *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *mu = v.at(P.o_mu), *p = v.at(P.o_p),
                *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq),
-               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *art = v.at(P.o_art), *st = v.at(P.o_st);
+               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         const int *dcol = v.iat(P.o_dcol);
         Red<WAVES> R(v.at(P.o_red));
@@ -1533,14 +1554,13 @@ struct WgSqp {
     // ------------------------------------------------------------------------------------------------------------------------------
     // the full-space step d = [dx ; p] (dx by one forward chain with p applied) and the numbers of the convergence test
     // st[R0..R3] = max |d|, max |defect|, g'd, max |z|
-    template <bool FL>
     static MPCX_WG_PHASE void step()
     {
         const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int ch = v.ch, nz = v.nz, nxs = v.nxs, nr = v.nr, mi = v.mi, m = v.m;
         double *p = v.at(P.o_p), *dx = v.at(P.o_dx), *c = v.at(P.o_c), *z = v.at(P.o_z), *gu = v.at(P.o_gu), *gin = v.at(P.o_gin), *st = v.at(P.o_st);
-        typename FP<FL>::type F = FP<FL>::get(v);
+        typename FP::type F = FP::get(v);
         gwp gxg = (gwp)(v.w + P.w_gx);
         for (int k = tid; k < nxs; k += NT) {
             const int i = k / NX;
@@ -1551,7 +1571,7 @@ struct WgSqp {
             dx[k] = s;
         }
         T::sync();
-        chain<FL, false>(v, dx, tid);
+        chain<false>(v, dx, tid);
         T::sync();
         Red<WAVES> R(v.at(P.o_red));
         double dmax = 0, cmax = 0, gd = 0, zmax = 0;
@@ -1566,7 +1586,6 @@ struct WgSqp {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // after the sub-problem: the BFGS memory, the largest multiplier (st[R0]) and the l1 violation at z (st[R1])
-    template <bool FL>
     static MPCX_WG_PHASE void merit(int nw)
     {
         const V v; const auto &M = v.A->M; const auto &P = v.A->P;
@@ -1609,7 +1628,7 @@ struct WgSqp {
             }
             (void)ph;
             T::sync();
-            chain<FL, true>(v, lam, tid);
+            chain<true>(v, lam, tid);
             T::sync();
             lam_max = defect_multiplier_max(v, lam, tid);
         } else {
@@ -1816,12 +1835,14 @@ struct WgSqp {
 // Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
 // block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
 // for the smallest systems at one wavefront per instance, whose 4 KB blocks let sixteen instances share a CU.
-template <class Mdl, int WAVES> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : 2;
+// A problem of several wavefronts whose blocks and reduced rows live in the workspace (FL = false) is built for three workgroups per CU
+// (170 registers): its LDS block is a third of a CU's, and the third workgroup is what pays for the global fetches.
+template <class Mdl, int WAVES, bool FL = true> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : (WAVES == 4 && !FL && Mdl::NX <= 4) ? 3 : 2;
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
-__global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlmpc_sqp_wg(const WgArgs A)
+__global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void nlmpc_sqp_wg(const WgArgs A)
 {
-    using K = WgSqp<Mdl, WAVES>;
+    using K = WgSqp<Mdl, WAVES, FL>;
     using T = Team<WAVES>;
     constexpr int NT = 64 * WAVES;
     const auto &M = wg_args()->M;
@@ -1842,7 +1863,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlm
     for (;;) {
         K::eval_cost(final_eval ? 1 : 0);
         lap(0);
-        K::template eval_dyn<FL>(final_eval ? 1 : 0);
+        K::eval_dyn(final_eval ? 1 : 0);
         lap(1);
         K::eval_con(final_eval ? 1 : 0);
         lap(2);
@@ -1862,7 +1883,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlm
         }
         stepped = false;
         if (it >= S.max_iter) break;
-        if (P.needs_phi) K::template condense_phi<FL>(); else K::template condense_chain<FL>();
+        if (P.needs_phi) K::condense_phi(); else K::condense_chain();
         lap(3);
         if (have_old) K::bfgs(a_prev, nw_keep);
         lap(4);
@@ -1870,7 +1891,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlm
         lap(5);
         if (nw < 0) { code = nw; break; }
         nw_keep = nw;
-        K::template step<FL>();
+        K::step();
         lap(6);
         const double dmax = st[ST_R0], cmax = st[ST_R1], gd = st[ST_R2], zmax = st[ST_R3];
         if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
@@ -1881,7 +1902,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlm
             continue;
         }
         T::sync();
-        K::template merit<FL>(nw);
+        K::merit(nw);
         lap(7);
         const double lam_max = st[ST_R0], viol = st[ST_R1];
         if (1.1 * lam_max > nu_pen) nu_pen = 1.5 * lam_max;
@@ -1927,7 +1948,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES>)) void nlm
 // the LDS / workspace plan of the workgroup form for controller m (dimensions, bounds) and the hard / soft flag; 0, or -2 if the
 // shape does not fit (the caller falls back to nlmpc_sqp)
 template <class Mdl>
-inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P)
+inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
@@ -1964,7 +1985,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
         P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
-        P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = take(nr * P.ndld);
+        P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = f_lds ? take(nr * P.ndld) : 0;
         P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw); P.o_yv = take(kw);
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
@@ -1989,10 +2010,13 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     bool placed = false;
     auto place = [&]() {
         placed = false;
-        const int max_wg = imin(16, 32 / P.waves);
-        for (int per_cu = max_wg; per_cu >= 1 && !placed; --per_cu) {
+        for (int per_cu = imin(16, 32 / P.waves); per_cu >= 1 && !placed; --per_cu) {
             const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)15;
             for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
+                if (blocks_wanted >= 0 && f_lds != (blocks_wanted ? 1 : 0)) continue;
+                // the registers of the variant (kWgWavesPerSimd) bound the workgroups per CU as well
+                const int by_regs = 4 * (P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
+                if (per_cu > by_regs) continue;
                 if (layout(kw_full, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
                 if (per_cu == 1) continue;                      // (alone on the CU the factor keeps its full capacity)
                 int kw = kw_full;
@@ -2017,6 +2041,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         P.w_F = take(P.f_lds ? 0 : ph * NX * FW);
+        P.w_art = take(P.f_lds ? 0 : nr * P.ndld);
         P.w_einv = take(Mdl::CONTINUOUS ? ph * NX * NX : 0);
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);

@@ -67,12 +67,16 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
         const bool force_wave = form && !strcmp(form, "wave"), force_wg = form && !strcmp(form, "wg");
         if (!force_wave) {
             engine::WgPlan P;
-            const char *wv = getenv("MPCX_NLMPC_WAVES");
-            const bool fits = engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P) == 0 && P.ws_total <= m->ws.total;
+            const char *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");   // (BLOCKS=1|0: folded blocks and reduced rows in LDS | workspace)
+            auto plan = [&](int blocks) { return engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P, blocks) == 0 && P.ws_total <= m->ws.total; };
             // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
-            // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form
-            const bool resident = (long)b->batch <= 256L * P.per_cu;
-            if (fits && (force_wg || P.waves == 1 || resident)) { g_last_form = P.waves; return engine::launch_solve_wg<Mdl>(m, b, &P, stream); }
+            // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form.
+            // With the folded blocks and the reduced rows in LDS a solve is shortest (config 3: 10.4 ms); with them in the workspace a CU
+            // holds one more workgroup (13.4 ms, and still below the wavefront form's 20.6): taken where it makes the batch resident.
+            auto resident = [&]() { return (long)b->batch <= 256L * P.per_cu; };
+            bool fits = plan(bl ? atoi(bl) : 1);
+            if (!bl && (!fits || (P.waves > 1 && !resident()))) fits = plan(-1);
+            if (fits && (force_wg || P.waves == 1 || resident())) { g_last_form = P.waves; return engine::launch_solve_wg<Mdl>(m, b, &P, stream); }
             if (force_wg) return -2;
         }
         g_last_form = 0;

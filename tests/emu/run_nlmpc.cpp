@@ -85,7 +85,7 @@ static int run(int argc, char **argv)
         int nsb = 0;
         for (int k = 0; k < M.nbnd; ++k) nsb += bidx[k] < nxs ? 1 : 0;
         const int waves = getenv("HIPEMU_WAVES") ? atoi(getenv("HIPEMU_WAVES")) : 0;
-        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
+        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, getenv("HIPEMU_BLOCKS") ? atoi(getenv("HIPEMU_BLOCKS")) : -1) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
         if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total);
     }
 #endif

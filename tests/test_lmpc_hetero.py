@@ -169,3 +169,54 @@ def test_a_bank_whose_constraint_structure_differs_from_controller_0_is_refused_
     with pytest.raises(Exception) as ei:
         LMPCHetero([_two_state_controller(0.3), _two_state_controller(0.0)], device=0, condense_on_host=on_host)
     assert "differs from controller 0" in str(ei.value) or "controller 1" in str(ei.value), str(ei.value)
+
+
+def _variant_oracle_chunk(job):
+    """worker: instances lo..hi of the heterogeneous bench batch, each on the C oracle of its own quadrotor_variant"""
+    lo, hi, ph, x0, u0, yref = job
+    from libmpc_amd.workloads import quadrotor_variant
+    from oracle.lmpc_oracle import default_params
+    cmd = np.zeros((hi - lo, 4)); cost = np.zeros(hi - lo); pol = np.zeros(hi - lo, dtype=bool); act = []
+    for t, k in enumerate(range(lo, hi)):
+        f = OracleFrontEnd(12, 4, 4, 12, ph, ph)
+        quadrotor_variant(k, ph, into=f)
+        f.o.params = default_params(maximum_iteration=250)
+        ref = f.o.solve_batch_constref(x0[t:t + 1], u0[t:t + 1], yref[t:t + 1], want_active=True)
+        cmd[t] = ref["cmd"][0]; cost[t] = ref["cost"][0]; pol[t] = ref["polished"][0] == 1
+        act.append((np.nonzero(ref["active_lower"][0][f.o.neq:])[0] + f.o.neq, np.nonzero(ref["active_upper"][0][f.o.neq:])[0] + f.o.neq))
+    return cmd, cost, pol, act
+
+
+def test_the_bench_batch_of_4096_distinct_controllers_matches_one_oracle_controller_per_instance():
+    """`bench.py --workload lmpc-hetero` on the batch it is quoted at: 4096 instances, instance k on controller quadrotor_variant(k)
+    (N = 20), every one against the C oracle configured as that variant (worker processes, one oracle controller per instance) --
+    commands to 1e-5, costs to 1e-7, active sets bit for bit wherever the oracle polished"""
+    import multiprocessing as mp
+    import os
+    import torch
+    from libmpc_amd import LMPCHetero
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_variant
+    B, ph = 4096, 20
+    x0, u0, yref = quadrotor_batch(B)
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    edges = np.linspace(0, B, 4 * workers + 1).astype(int)
+    jobs = [(int(a), int(b), ph, x0[a:b], u0[a:b], yref[a:b]) for a, b in zip(edges[:-1], edges[1:])]
+    with mp.get_context("fork").Pool(workers) as pool:            # (forked before the first GPU call of this test)
+        parts = pool.map(_variant_oracle_chunk, jobs)
+    ocmd = np.concatenate([p[0] for p in parts]); ocost = np.concatenate([p[1] for p in parts]); pol = np.concatenate([p[2] for p in parts])
+    oact = [a for p in parts for a in p[3]]
+    het = LMPCHetero([quadrotor_variant(k, ph, device=-1) for k in range(B)], device=0)
+    r = het.optimizeBatch(x0, u0, yref=yref, want_active=True); torch.cuda.synchronize()
+    cmd = r.cmd.cpu().numpy(); cost = r.cost.cpu().numpy(); st = r.status.cpu().numpy()
+    assert (st[pol] == 0).all()
+    err = np.abs(cmd - ocmd).max(axis=1) / np.maximum(np.abs(ocmd).max(axis=1), 1e-12)
+    cerr = np.abs(cost - ocost) / np.maximum(1.0, np.abs(ocost))
+    assert pol.sum() >= 0.95 * B, pol.sum()
+    assert err[pol].max() <= 1e-5, (err[pol].max(), int(np.argmax(err * pol)))
+    assert cerr[pol].max() <= 1e-7, cerr[pol].max()
+    if (~pol).any():
+        assert err[~pol].max() <= 5e-2
+    lo = bits_to_rows(r.active_lower.cpu().numpy(), het.m_ref); up = bits_to_rows(r.active_upper.cpu().numpy(), het.m_ref)
+    for b in np.nonzero(pol)[0]:
+        assert np.array_equal(lo[b], oact[b][0]) and np.array_equal(up[b], oact[b][1]), b
+    print("4096 distinct controllers: %d polished by the oracle, worst relative error of u* %.2e, of the cost %.2e" % (pol.sum(), err[pol].max(), cerr[pol].max()))

@@ -721,3 +721,19 @@ def test_lds_resident_blocks_agree_with_the_workspace_form(name, kw, hard, iters
     assert (a["status"] == 0).all()
     assert np.array_equal(a["iterations"], b["iterations"]) and np.array_equal(a["status"], b["status"])
     assert np.array_equal(a["cmd"], b["cmd"]) and np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["z"], b["z"])
+
+
+@pytest.mark.gpu
+def test_shape_sweep_never_trips_the_exec_guard():
+    """tools/nlmpc_stress.py in the wavefront form (the one that carries the guard): built-in and run-time compiled hook models over a range
+    of shapes; no instance may end with nlopt's FORCED_STOP code (-5), which that kernel reports only when a phase boundary found lanes missing from
+    EXEC (nlmpc_engine.hpp `exec_full`), and nothing may come back non-finite"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPCX_NLMPC_FORM="wave")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nlmpc_stress.py")], env=env, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "0 problem(s), 0 instance(s) with the FORCED_STOP code" in out.stdout
