@@ -962,12 +962,17 @@ struct WgSqp {
                 const bool isr = q == nzu;
                 const int bq = q / NU, jq = q - bq * NU;
                 double x[NX], t[NX], gacc = 0.0;
-                double fb[PF ? NX * NX : 1];
+                // (with the blocks in LDS the lane's right-hand side column travels with the prefetched block; with them in the workspace, where the
+                // variant lives on 170 registers, it is requested at the top of its own step and added after the products)
+                constexpr int FBW = FL ? NX + 1 : NX;
+                double fb[PF ? NX * FBW : 1];
                 auto fetch = [&](int i) {
+                    const bool drv = !isr && min(i, ch - 1) == bq;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) {
 #pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) fb[a * NX + bb] = F[(size_t)(i * NX + a) * FW + bb];
+                        for (int bb = 0; bb < NX; ++bb) fb[a * FBW + bb] = F[(size_t)(i * NX + a) * FW + bb];
+                        if constexpr (FL) fb[a * FBW + NX] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
                     }
                 };
                 // what state row i + 1 (held in x) is needed for; issued before the next step's products so that its LDS round trips and
@@ -1001,21 +1006,21 @@ struct WgSqp {
                 for (int i = 0; i < ph; ++i) {
                     if (i > 0) consume(i - 1);
                     if constexpr (PF) {
-                        // this step's block was requested a step ago; its right-hand side column (the lane's own: B e_q or c) is requested now and
-                        // added after the products, the next block behind it
-                        double fcur[NX * NX], rh[NX];
-                        const bool drv = !isr && min(i, ch - 1) == bq;
+                        double fcur[NX * FBW], rh[NX];
+                        if constexpr (!FL) {
+                            const bool drv = !isr && min(i, ch - 1) == bq;
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) rh[a] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+                            for (int a = 0; a < NX; ++a) rh[a] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
+                        }
 #pragma unroll
-                        for (int e = 0; e < NX * NX; ++e) fcur[e] = fb[e];
+                        for (int e = 0; e < NX * FBW; ++e) fcur[e] = fb[e];
                         if (i + 1 < ph) fetch(i + 1);
 #pragma unroll
                         for (int a = 0; a < NX; ++a) {
-                            double sacc = 0.0;
+                            double sacc = FL ? fcur[a * FBW + (FL ? NX : 0)] : 0.0;
 #pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * NX + bb], x[bb], sacc);
-                            t[a] = sacc + rh[a];
+                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * FBW + bb], x[bb], sacc);
+                            t[a] = FL ? sacc : sacc + rh[a];
                         }
                     } else {
                         const bool drives = !isr && min(i, ch - 1) == bq;

@@ -32,6 +32,7 @@ static int run(int argc, char **argv)
     const int hard = atoi(argv[5]), max_iter = atoi(argv[6]);
     const std::string form = argv[7];
     double lbu = -INFINITY, ubu = INFINITY, lbx0 = -INFINITY, ubx0 = INFINITY, suv = 1.0, ssv = 1.0;
+    int xs = 0;
     int warm = 0;
     std::vector<double> prm_override;
     for (int a = 8; a < argc; ++a) {
@@ -40,7 +41,7 @@ static int run(int argc, char **argv)
         const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
         if (k == "lbu") lbu = atof(v.c_str()); else if (k == "ubu") ubu = atof(v.c_str());
         else if (k == "lbx0") lbx0 = atof(v.c_str()); else if (k == "ubx0") ubx0 = atof(v.c_str());
-        else if (k == "warm") warm = atoi(v.c_str()); else if (k == "su") suv = atof(v.c_str()); else if (k == "ss") ssv = atof(v.c_str());
+        else if (k == "xs") xs = atoi(v.c_str()); else if (k == "warm") warm = atoi(v.c_str()); else if (k == "su") suv = atof(v.c_str()); else if (k == "ss") ssv = atof(v.c_str());
         else { fprintf(stderr, "unknown key %s\n", k.c_str()); return 2; }
     }
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
@@ -57,7 +58,7 @@ static int run(int argc, char **argv)
     engine::nlmpc_plan(M);
     const int nz = M.nz, nxs = ph * NX;
     std::vector<double> lb(nz, -INFINITY), ub(nz, INFINITY);
-    for (int i = 0; i < ph; ++i) { lb[i * NX] = lbx0; ub[i * NX] = ubx0; }
+    for (int i = xs; i < ph; ++i) { lb[i * NX] = lbx0; ub[i * NX] = ubx0; }      // (xs: the first state row that carries the bound)
     for (int k = 0; k < ch * NU; ++k) { lb[nxs + k] = lbu; ub[nxs + k] = ubu; }
     std::vector<int> bidx; std::vector<double> bsign, bval;
     for (int k = 0; k < nz - 1; ++k) {

@@ -35,5 +35,6 @@ for w in osc8 ugv osc6; do ( MPCX_NLMPC_FORM=wg MPCX_LIBRARY=$PWD/libmpc_amd/lib
 for w in osc8 ugv; do ( MPCX_NLMPC_FORM=wave MPCX_LIBRARY=$PWD/libmpc_amd/libmpcx_stats.so timeout 300 python tools/nlmpc_phases.py $w 1024 ) > $O/${T}_phases_wave_$w.txt 2>&1; grep -v amdgpu.ids $O/${T}_phases_wave_$w.txt | tail -9; done
 ( timeout 300 python tools/nlmpc_closed_loop.py; timeout 300 python tools/nlmpc_closed_loop.py 256 20 ) > $O/${T}_nlmpc_closed_loop.json 2>&1; tail -6 $O/${T}_nlmpc_closed_loop.json | cut -c1-300
 tools/nlmpc_forms.sh > $O/${T}_nlmpc_forms.txt 2>&1
+bash tools/gpu_occ.sh ugv > $O/${T}_nlmpc_occupancy.txt 2>&1
 tools/nlmpc_latency.sh > $O/${T}_nlmpc_latency.txt 2>&1
 tools/micro/latency > $O/${T}_micro_latency.txt 2>&1
