@@ -741,7 +741,9 @@ struct WgSqp {
     // a user row whose reduced entries come from one state row alone (no input enters it): the condensing sweep stores them
     static __device__ __forceinline__ bool sole_state_row(int k, unsigned long long mk, int mi, int ph)
     {
-        if (NX > 8 || __builtin_popcountll(mk) != 1) return false;     // (the sixteen-lane sweep of wide states adds throughout)
+        // (only where the reduced rows live in the workspace: there an add is a dependent trip to memory per entry; in LDS the plain form measured
+        // slower -- 324 k instead of 305 k cycles per iteration at config 3 -- and the sixteen-lane sweep of wide states adds throughout)
+        if (FL || NX > 8 || __builtin_popcountll(mk) != 1) return false;
         for (int i = 0; i < ph; ++i)
             if (k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i)) return false;
         return true;
@@ -983,12 +985,13 @@ struct WgSqp {
                         for (int a = 0; a < NX; ++a) gacc = fma(lam[i * NX + a], x[a], gacc);       // (lam still holds g_x)
                     }
                     for (int e = xrf[i]; e < xrf[i + 1]; ++e) {
-                        const int k = (xre[e] & 0x7fffffff) >> 12, sl = xre[e] & 0xfff;
+                        const int ent = xre[e];
+                        const int k = FL ? ent >> 12 : (ent & 0x7fffffff) >> 12, sl = ent & 0xfff;
                         double sacc = 0.0;
 #pragma unroll
                         for (int a = 0; a < NX; ++a) sacc = fma(jx[sl * NX + a], x[a], sacc);
                         if (isr) br[k] += sacc;
-                        else if (xre[e] < 0) art[q * ndld + dcol[k]] = sacc;
+                        else if (!FL && ent < 0) art[q * ndld + dcol[k]] = sacc;
                         else art[q * ndld + dcol[k]] += sacc;
                     }
                     for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {

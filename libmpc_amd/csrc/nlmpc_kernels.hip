@@ -8,27 +8,11 @@
 #include <cstring>
 
 #include "mpcx/nlmpc_engine.hpp"
-#include "mpcx/nlmpc_sqp_wg.hpp"
+#include "mpcx/nlmpc_sqp_wg.hpp"      // (for the plan: the kernels of that header are instantiated in nlmpc_wg_kernels.hip)
+
+#include "nlmpc_zoo.hpp"
 
 namespace mpcx {
-namespace {
-
-using namespace models;
-
-template <class F>
-int dispatch_model(int model_id, F &&fn)
-{
-    switch (model_id) {
-    case 1: return fn(VanDerPol{});
-    case 2: return fn(Ugv{});
-    case 3: return fn(Oscillators<6>{});
-    case 4: return fn(Oscillators<8>{});
-    case 5: return fn(VanDerPolTerminal{});
-    default: return -1;
-    }
-}
-
-}  // namespace
 
 int nlmpc_model_dims(int model_id, int *nx, int *nu, int *ny, int ph, int *nineq, int *nue)
 {
@@ -56,6 +40,10 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // The default follows that, and takes the workgroup form for a batch that it holds resident all at once (latency: each instance on its own
 // wavefronts); MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
 // which form the last launch of a built-in system took: 0 = nlmpc_sqp, 1 | 2 | 4 = nlmpc_sqp_wg with that many wavefronts per instance
+// (nlmpc_wg_kernels.hip)
+int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks);
+int nlmpc_wg_launch(const NlmpcDev *m, const NlmpcSolveDev *b, const engine::WgPlan *P, void *stream);
+
 static int g_last_form = -1;
 int nlmpc_last_form() { return g_last_form; }
 
@@ -68,7 +56,7 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
         if (!force_wave) {
             engine::WgPlan P;
             const char *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");   // (BLOCKS=1|0: folded blocks and reduced rows in LDS | workspace)
-            auto plan = [&](int blocks) { return engine::wg_plan<Mdl>(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P, blocks) == 0 && P.ws_total <= m->ws.total; };
+            auto plan = [&](int blocks) { return nlmpc_wg_plan(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P, blocks) == 0 && P.ws_total <= m->ws.total; };
             // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
             // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form.
             // With the folded blocks and the reduced rows in LDS a solve is shortest (config 3: 10.4 ms); with them in the workspace a CU
@@ -76,7 +64,7 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
             auto resident = [&]() { return (long)b->batch <= 256L * P.per_cu; };
             bool fits = plan(bl ? atoi(bl) : 1);
             if (!bl && (!fits || (P.waves > 1 && !resident()))) fits = plan(-1);
-            if (fits && (force_wg || P.waves == 1 || resident())) { g_last_form = P.waves; return engine::launch_solve_wg<Mdl>(m, b, &P, stream); }
+            if (fits && (force_wg || P.waves == 1 || resident())) { g_last_form = P.waves; return nlmpc_wg_launch(m, b, &P, stream); }
             if (force_wg) return -2;
         }
         g_last_form = 0;

@@ -3,7 +3,7 @@ inconsistent (solver status -1) -- the case Kraft's SLSQP handles with an augmen
 Runs on the CPU: the kernels' source through the emulator (tests/emu), the oracle's SLSQP beside it.  Van der Pol (ph = 10, ch = 5) with
 input bounds, a bound on the first state from stage `xs` on, random starts inside that bound; and Van der Pol with the terminal equality.
 Every instance the kernel ends with -1 is handed to the oracle: a hit is one that the oracle solves.
-Round 4: 13 + 1 settings x 16 starts, 130 instances ended with -1, the oracle fails on every one of them (SLSQP's modes 4 and 8: the problems
+Round 4 (profiles/r04_inconsistent_hunt.txt): 13 + 1 settings x 16 starts, 110 instances ended with -1, the oracle fails on every one of them (SLSQP's modes 4 and 8: the problems
 themselves are infeasible) -- no hit; the kernels report what NLOptimizer::run reports there.  Usage: python tools/nlmpc_inconsistent_hunt.py [trials]"""
 import json
 import os
