@@ -111,6 +111,43 @@ def test_config3_and_config5_golden_solutions_in_either_form(form, waves, monkey
         assert other <= allowed_other and compared >= n - allowed_other - 4, (key, compared, other)
 
 
+def test_workgroup_form_with_blocks_and_reduced_rows_in_the_workspace(monkeypatch):
+    """MPCX_NLMPC_BLOCKS=0: the variant of the workgroup form that keeps the folded dynamics blocks and the reduced rows in the per-instance
+    workspace (one more workgroup per CU at config 3; what the launcher takes for batches of 513 .. 768 UGV instances) against the variant
+    with both in LDS and against the golden solutions"""
+    from libmpc_amd.nlmpc import UGV
+    _set_form(monkeypatch, "wg", "4")
+    gold = _golden("ugv_ph30_ch30")
+    cases = gold["cases"][:32]
+    X0 = np.array([k["x0"] for k in cases]); U0 = np.array([k["u0"] for k in cases])
+    out = {}
+    for blocks in ("1", "0"):
+        monkeypatch.setenv("MPCX_NLMPC_BLOCKS", blocks)
+        out[blocks] = _solve(UGV, gold["ph"], gold["ch"], gold["Ts"], X0, U0, False, 150)
+    monkeypatch.delenv("MPCX_NLMPC_BLOCKS")
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a["status"], b["status"])
+    ok = a["status"] == 0
+    assert (np.abs(a["cmd"] - b["cmd"]) / np.maximum(1.0, np.abs(a["cmd"]).max(axis=1, keepdims=True)))[ok].max() <= 1e-5
+    compared = other = 0
+    for i, k in enumerate(cases):
+        if not (k["success"] or (k["slsqp_mode"] == 8 and k["eq_violation"] < 1e-8 and k["ineq_violation"] < 1e-6)):
+            continue
+        if np.allclose(b["cmd"][i], k["cmd"], rtol=1e-5, atol=1e-5):
+            compared += 1
+        else:
+            other += 1
+    assert other <= 3 and compared >= 25, (compared, other)
+    # the launcher's own choice at a batch between the two residencies: the workspace variant, four wavefronts per instance
+    monkeypatch.delenv("MPCX_NLMPC_FORM"); monkeypatch.delenv("MPCX_NLMPC_WAVES")
+    import ctypes as C
+    from libmpc_amd import _capi
+    rng = np.random.default_rng(5)
+    Xb = np.zeros((640, 4)); Xb[:, :2] = rng.uniform(-0.5, 0.5, size=(640, 2))
+    r = _solve(UGV, 30, 30, 0.1, Xb, np.zeros((640, 2)), False, 150)
+    assert int(_capi.lib().mpcx_nlmpc_debug_last_form()) == 4 and (r["status"] != 3).all()
+
+
 def test_the_two_forms_agree_with_each_other(monkeypatch):
     """same instances, both forms: statuses equal, commands within the solvers' own stopping tolerance, multipliers on the same rows"""
     from libmpc_amd.nlmpc import VANDERPOL, UGV, OSCILLATORS6
