@@ -8,7 +8,7 @@ txt = sys.stdin.read()
 for blk in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = blk.split()[0]
     try:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
+        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
     except OSError:
         pass
     name = re.sub(r"\(.*$", "", name)
