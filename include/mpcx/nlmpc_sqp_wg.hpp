@@ -62,7 +62,7 @@ typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
 constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
-enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
 // -DMPCX_NL_STATS (libmpcx_stats.so): shader-clock cycles of the sub-problem's parts in st[ST_QSTAT ..]: unconstrained minimiser, warm start (the kept
 // rows' Schur complement, its factor, the shedding rounds), and per dual step: scan, entering row, N_W v, solve, N_W' r, B^-1 w, the rest
 #ifdef MPCX_NL_STATS
@@ -365,13 +365,23 @@ __device__ __forceinline__ void chol_delete(double *Lp, double *invd, int n, int
         }
         nl_wave_sync();
     }
+    // (The entry of the next rotation is requested before this one's results are stored -- a row reads column r + 2 two rotations before
+    // its neighbour overwrites it, the wavefront runs in lockstep -- and 1 / sqrt comes from v_rsq_f64 and two Newton steps instead of the
+    // square root's and the division's expansions: the rotations are a serial chain, their latency is what a row that leaves costs.)
+    double y0n = (r0 >= j + 1 && r0 < n) ? Lp[s0 + j + 1] : 0.0, y1n = (r1 >= j + 1 && r1 < n) ? Lp[s1 + j + 1] : 0.0;
     for (int r = j; r <= n - 2; ++r) {
         const bool u0 = r0 >= r + 1 && r0 < n, u1 = r1 >= r + 1 && r1 < n;
-        const double y0 = u0 ? Lp[s0 + r + 1] : 0.0, y1 = u1 ? Lp[s1 + r + 1] : 0.0;
+        const double y0 = y0n, y1 = y1n;
+        y0n = (r0 >= r + 2 && r0 < n) ? Lp[s0 + r + 2] : 0.0; y1n = (r1 >= r + 2 && r1 < n) ? Lp[s1 + r + 2] : 0.0;
         const int pl = (r + 1) & 63;
         const double a = (r + 1) < 64 ? read_lane(carry0, pl) : read_lane(carry1, pl);
         const double b = (r + 1) < 64 ? read_lane(y0, pl) : read_lane(y1, pl);
-        const double rho = sqrt(a * a + b * b), ir = 1.0 / rho, c = a * ir, s = b * ir;
+        const double h2 = fma(a, a, b * b);
+        double ir = __builtin_amdgcn_rsq(h2);
+        ir = ir * fma(-0.5 * h2 * ir, ir, 1.5);
+        ir = ir * fma(-0.5 * h2 * ir, ir, 1.5);
+        if (!(h2 > 0.0)) ir = 0.0;                                 // (a dependent row: the factor's pivot test has the word)
+        const double c = a * ir, s = b * ir;
         const double n0 = c * carry0 + s * y0, n1 = c * carry1 + s * y1;
         carry0 = c * y0 - s * carry0; carry1 = c * y1 - s * carry1;
         if (u0) Lp[d0 + r] = n0;
@@ -708,21 +718,25 @@ struct WgSqp {
                 }
                 // Gauss-Jordan with partial pivoting.  The rows rotate by one per step, so that the pivot row is always register 0 and
                 // the loop body is the same for every step (no unrolling over the steps); after NX steps they are back in place.
+                // (Where a wavefront holds one tableau -- G == 1: the wide systems -- the pivot column's lane is the same for every lane: v_readlane,
+                // four cycles, instead of the LDS crossbar's round trip of a __shfl; 32 of them per pivot.)
+                auto bcast = [&](double x, int k) { if constexpr (G == 1) return read_lane(x, k); else return __shfl(x, base + k); };
+                auto bcast_i = [&](int x, int k) { if constexpr (G == 1) return __builtin_amdgcn_readlane(x, k); else return __shfl(x, base + k); };
 #pragma unroll 1
                 for (int k = 0; k < NX; ++k) {
                     int pr = 0;
                     double best = fabs(col[0]);
 #pragma unroll
                     for (int a = 1; a < NX; ++a) { const double av = fabs(col[a]); if (a < NX - k && av > best) { best = av; pr = a; } }
-                    pr = __shfl(pr, base + k);                           // the pivot column's choice
+                    pr = bcast_i(pr, k);                                 // the pivot column's choice
                     double cp = col[0];
 #pragma unroll
                     for (int a = 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[0]; }
-                    const double piv = __shfl(cp, base + k);
+                    const double piv = bcast(cp, k);
                     const double cs = cp / piv;
                     double nxt[NX];
 #pragma unroll
-                    for (int a = 1; a < NX; ++a) { const double ml = __shfl(col[a], base + k); nxt[a - 1] = fma(-ml, cs, col[a]); }
+                    for (int a = 1; a < NX; ++a) { const double ml = bcast(col[a], k); nxt[a - 1] = fma(-ml, cs, col[a]); }
                     nxt[NX - 1] = cs;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) col[a] = nxt[a];
@@ -1412,15 +1426,25 @@ struct WgSqp {
             for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
             T::sync();
             ws_solve(nw);
-            // every row with a negative multiplier leaves at once; equalities stay
-            auto sheds = [&](int t) { return tq[t] < 0.0 && !is_eq(wq[t]); };
-            int neg = -1;
-            for (int t = 0; t < nw; ++t) if (sheds(t)) neg = t;
-            if (neg < 0) break;
-            for (int t = nw - 1; t >= 0; --t) {
-                if (sheds(t)) { ws_drop(t, nw); --nw; }
+            // every row with a negative multiplier leaves at once; equalities stay.  One bit per row, by ballot (a working set holds at most
+            // 128 rows: two words) -- every thread walking the list itself was two dependent LDS reads per row and thread, twice a round
+            unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED);
+            for (int half = WAVES == 1 ? 0 : (tid >> 6); half < 2; half += WAVES == 1 ? 1 : WAVES) {
+                const int t = half * 64 + lane;
+                const bool sh = t < nw && tq[t] < 0.0 && !is_eq(wq[t]);
+                const unsigned long long bal = __ballot(sh);
+                if (lane == 0) shw[half] = bal;
             }
-            T::sync();                                           // (the next round overwrites tq)
+            T::sync();
+            unsigned long long m0 = shw[0], m1 = shw[1];
+            if (!(m0 | m1)) break;
+            while (m0 | m1) {                                    // from the last row down: the rows below a leaving one keep their numbers
+                int t;
+                if (m1) { const int bit = 63 - __builtin_clzll(m1); m1 &= ~(1ull << bit); t = 64 + bit; }
+                else { const int bit = 63 - __builtin_clzll(m0); m0 &= ~(1ull << bit); t = bit; }
+                ws_drop(t, nw); --nw;
+            }
+            T::sync();                                           // (the next round overwrites tq and the two words)
         }
         if (nw > 0) {
             ws_nt_mul(nw, P.o_tq, P.o_wv);

@@ -247,6 +247,8 @@ inline void *__builtin_amdgcn_kernarg_segment_ptr() { return const_cast<void *>(
 // the implicit arguments follow the explicit ones (here: one struct) at the next multiple of eight bytes
 inline void *__builtin_amdgcn_implicitarg_ptr() { return (char *)const_cast<void *>(hipemu::st().kernarg) + ((hipemu::st().kernarg_bytes + 7) & ~(size_t)7); }
 inline long long __builtin_readcyclecounter() { return 0; }
+// v_rsq_f64: about 2^-26 relative -- the emulation truncates to float precision so that the Newton steps after it have something to do
+inline double __builtin_amdgcn_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); }
 inline int __builtin_amdgcn_readlane(int v, int l) { return (int)(uint32_t)hipemu::exchange((uint32_t)v, l, "v_readlane"); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::exchange((uint32_t)v, 0, "v_readfirstlane"); }
 inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool)
