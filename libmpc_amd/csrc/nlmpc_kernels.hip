@@ -56,15 +56,19 @@ int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *
         if (!force_wave) {
             engine::WgPlan P;
             const char *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");   // (BLOCKS=1|0: folded blocks and reduced rows in LDS | workspace)
-            auto plan = [&](int blocks) { return nlmpc_wg_plan(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, P, blocks) == 0 && P.ws_total <= m->ws.total; };
+            auto plan = [&](engine::WgPlan &X, int blocks) { return nlmpc_wg_plan(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, X, blocks) == 0 && X.ws_total <= m->ws.total; };
             // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
             // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form.
-            // With the folded blocks and the reduced rows in LDS a solve is shortest (config 3: 10.4 ms); with them in the workspace a CU
-            // holds one more workgroup (13.4 ms, and still below the wavefront form's 20.6): taken where it makes the batch resident.
-            auto resident = [&]() { return (long)b->batch <= 256L * P.per_cu; };
-            bool fits = plan(bl ? atoi(bl) : 1);
-            if (!bl && (!fits || (P.waves > 1 && !resident()))) fits = plan(-1);
-            if (fits && (force_wg || P.waves == 1 || resident())) { g_last_form = P.waves; return nlmpc_wg_launch(m, b, &P, stream); }
+            // The plan with the most workgroups per CU first; where that keeps the folded blocks and the reduced rows in the workspace
+            // (config 3: three per CU, 12.0 ms a solve) and the batch is resident with them in LDS too (two per CU, 9.7 ms), that one.
+            // A problem that fills a CU's LDS alone (config 5) is still ahead at two rounds: 71 ms against 94 at 512 instances.
+            auto resident = [&](const engine::WgPlan &X, int rounds) { return (long)b->batch <= 256L * X.per_cu * rounds; };
+            bool fits = plan(P, bl ? atoi(bl) : -1);
+            if (!bl && fits && P.waves > 1 && !P.f_lds) {
+                engine::WgPlan Q;
+                if (plan(Q, 1) && Q.waves > 1 && resident(Q, 1)) P = Q;
+            }
+            if (fits && (force_wg || P.waves == 1 || resident(P, P.per_cu == 1 ? 2 : 1))) { g_last_form = P.waves; return nlmpc_wg_launch(m, b, &P, stream); }
             if (force_wg) return -2;
         }
         g_last_form = 0;

@@ -186,3 +186,10 @@ def test_default_form_is_the_measured_choice(monkeypatch):
     assert last() == 4
     _solve(UGV, 30, 30, 0.1, np.zeros((4096, 4)), np.zeros((4096, 2)), False, 2)
     assert last() == 0
+    # a problem that fills a CU's LDS alone (config 5) stays in the workgroup form up to two rounds of 256 (71 ms against 94 at 512 instances)
+    from libmpc_amd.nlmpc import OSCILLATORS8
+    X8 = np.zeros((512, 16)); X8[:, 0] = 1.0
+    _solve(OSCILLATORS8, 30, 15, 0.1, X8, np.zeros((512, 8)), True, 2)
+    assert last() == 4
+    _solve(OSCILLATORS8, 30, 15, 0.1, np.tile(X8, (2, 1)), np.zeros((1024, 8)), True, 2)
+    assert last() == 0
