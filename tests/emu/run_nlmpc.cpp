@@ -3,7 +3,8 @@
 //
 //   run_nlmpc <model> <ph> <ch> <Ts> <hard> <max_iter> <form> [key=value ...] < instances
 //     model: vanderpol | vanderpol_terminal | ugv | osc6 | osc8;  form: wave (nlmpc_sqp, one wavefront per instance) | wg (workgroup form)
-//     keys: lbu= ubu= (scalar input bounds on every block), lbx0= ubx0= (bounds on state component 0, every step),
+//     keys: lbu= ubu= (scalar input bounds on every block), lbx0= ubx0= (bounds on state component 0, every step; xs=<first state row
+//           that carries them>; HIPEMU_BLOCKS=1|0 in the environment: folded blocks and reduced rows of the workgroup form in LDS | workspace),
 //           warm=1 (second solve from the shifted solution), su=, ss= (uniform scalings)
 //   stdin: one instance per line: x0[nx] u0[nu]
 //   stdout: one JSON object per instance
