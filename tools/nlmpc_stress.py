@@ -47,7 +47,13 @@ for name, mid, nx, nu, ph, ch, hard in cases:
         x0 = rng.uniform(-0.3, 0.3, size=(B, nx))
         if name.startswith("osc"):
             x0[:, 0] += 1.0
-        r = c.optimizeBatch(torch.from_numpy(x0), torch.zeros(B, nu, dtype=torch.float64), sequences=True)
+        try:
+            r = c.optimizeBatch(torch.from_numpy(x0), torch.zeros(B, nu, dtype=torch.float64), sequences=True)
+        except Exception as e:                              # MPCX_NLMPC_FORM=wg forces the workgroup form: a shape its LDS plan does not take
+            if os.environ.get("MPCX_NLMPC_FORM") == "wg" and "launch failed (-2)" in str(e):     # (many state bounds: dense rows beyond 160 KB)
+                print("%-13s ph %2d ch %2d bounds %d: not taken by the workgroup form (the launcher's default falls back to nlmpc_sqp)" % (name, ph, ch, int(bounds)))
+                continue
+            raise
         torch.cuda.synchronize()
         st = r["status"].cpu().numpy(); cmd = r["cmd"].cpu().numpy()
         ok = st != 3
