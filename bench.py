@@ -609,6 +609,26 @@ def nlmpc_extra(local):
         res[key] = {"solves_per_s": B / (ms * 1e-3), "kernel_ms": ms, "kernel": "nlmpc_sqp_wg" if form > 0 else "nlmpc_sqp",
                     "wavefronts_per_instance": form if form > 0 else 1, "mean_iterations": float(it.mean()),
                     "solved_fraction": float(np.isin(st, (3, 4)).mean())}
+    # the receding-horizon loop a fleet controller runs (examples/ugv_ex.cpp's closed loop for 256 vehicles): every tick one batched
+    # solve from the shifted previous solution with the curvature estimate carried over, then one plant step; the first (cold) tick is not timed
+    c, x0, u0 = nl_make("ugv", 256, device=local)
+    x = torch.from_numpy(x0).to("cuda:%d" % local); u = torch.from_numpy(u0).to("cuda:%d" % local)
+    Ts, z, its, ticks = 0.1, None, 0.0, 12
+    for k in range(ticks + 1):
+        if k == 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter(); its = 0.0
+        r = c.optimizeBatch(x, u, z_warm=z, warm_curvature=z is not None)
+        u = r["cmd"]
+        x = torch.stack([x[:, 0] + Ts * x[:, 2] + 0.5 * Ts * Ts * u[:, 0], x[:, 1] + Ts * x[:, 3] + 0.5 * Ts * Ts * u[:, 1],
+                         x[:, 2] + Ts * u[:, 0], x[:, 3] + Ts * u[:, 1]], dim=1)
+        z = r["z"]
+        its += float(r["iterations"].float().mean())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res["config3_ugv_b256_closed_loop"] = {"ms_per_tick": dt / ticks * 1e3, "solves_per_s": 256 * ticks / dt, "mean_iterations": its / ticks,
+                                           "not_failed": float((r["status"] != 3).float().mean()), "ticks": ticks,
+                                           "note": "256 instances of config 3's synthetic batch in closed loop; warm start = shifted previous solution + carried curvature; "
+                                                   "host-synchronised wall time per tick, plant step included"}
     return res
 
 
