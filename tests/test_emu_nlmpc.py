@@ -74,3 +74,23 @@ def test_config3_golden_instances_through_the_interpreter(runner):
     for k, y in zip(cases, r):
         assert y["status"] == 0
         np.testing.assert_allclose(y["cmd"], k["cmd"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("env", [{"HIPEMU_BLOCKS": "0"}, {"HIPEMU_BLOCKS": "0", "HIPEMU_ORDER": "reverse"}])
+def test_config3_with_blocks_and_reduced_rows_in_the_workspace(runner, env):
+    """the variant of the workgroup form that keeps the folded blocks and the reduced rows in the per-instance workspace (three workgroups per CU
+    at config 3; its reduced rows are stored, not added, by the condensing sweep): golden instances, both thread orders"""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nlmpc_oracle_solutions.json")))["ugv_ph30_ch30"]
+    cases = gold["cases"][1:3]
+    inst = np.array([k["x0"] + k["u0"] for k in cases])
+    r = runner(["ugv", 30, 30, 0.1, 0, 150, "wg"], inst, env)
+    for k, y in zip(cases, r):
+        assert y["status"] == 0
+        np.testing.assert_allclose(y["cmd"], k["cmd"], rtol=1e-5, atol=1e-5)
+    # ... and with a bound on a state from the fourth state row on (rows of the bounds through the sweep as well)
+    a = runner(["ugv", 12, 4, 0.1, 0, 150, "wg", "lbx0=-0.6", "ubx0=0.9", "xs=3", "lbu=-3", "ubu=3"], inst, env)
+    b = runner(["ugv", 12, 4, 0.1, 0, 150, "wave", "lbx0=-0.6", "ubx0=0.9", "xs=3", "lbu=-3", "ubu=3"], inst)
+    for x, y in zip(a, b):
+        assert x["status"] == y["status"]
+        if x["status"] == 0:
+            np.testing.assert_allclose(x["cmd"], y["cmd"], rtol=1e-5, atol=1e-5)
