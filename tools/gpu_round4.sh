@@ -17,6 +17,8 @@ timeout 300 tools/profile.sh $T osc8_b256 --workload osc8 --batch 256 --steps 3 
 timeout 300 tools/profile.sh $T vanderpol_b4096 --workload vanderpol --steps 50 --warmup 5
 timeout 300 tools/profile.sh $T lmpchetero20_b4096 --workload lmpc-hetero --steps 30 --warmup 3
 timeout 600 tools/profile_sq.sh $T lmpc20_b4096 --steps 40 --warmup 5 --nlmpc-extra 0 > $O/${T}_sq_lmpc20.log 2>&1
+timeout 900 tools/profile_sq.sh $T ugv_b4096 --workload ugv --steps 2 --warmup 1 --nlmpc-extra 0 > $O/${T}_sq_ugv4096.log 2>&1
+timeout 900 tools/profile_sq.sh $T osc8_b1024 --workload osc8 --steps 2 --warmup 1 --nlmpc-extra 0 > $O/${T}_sq_osc81024.log 2>&1
 timeout 600 tools/profile_sq.sh $T ugv_b256 --workload ugv --batch 256 --steps 3 --warmup 1 > $O/${T}_sq_ugv256.log 2>&1
 timeout 600 tools/profile_sq.sh $T osc8_b256 --workload osc8 --batch 256 --steps 2 --warmup 1 > $O/${T}_sq_osc8256.log 2>&1
 timeout 600 tools/profile_sq.sh $T vanderpol_b4096 --workload vanderpol --steps 30 --warmup 3 > $O/${T}_sq_vdp.log 2>&1
