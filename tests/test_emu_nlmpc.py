@@ -94,3 +94,18 @@ def test_config3_with_blocks_and_reduced_rows_in_the_workspace(runner, env):
         assert x["status"] == y["status"]
         if x["status"] == 0:
             np.testing.assert_allclose(x["cmd"], y["cmd"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPEMU_ORDER": "reverse"}])
+def test_lds_blocks_next_to_a_two_level_factor_equal_the_workspace_form(runner, env):
+    """nlmpc_sqp<Model, true, true> (dynamics blocks and defects in LDS next to a two-level working-set factor): the combination that returned
+    wrong results in an experiment of round 3 and that the plan never selects.  The source is race-free: both thread
+    orders give the workspace form's results (on the GPU the probe build is bit-identical to it, profiles/r04_probe_blk_two_level.txt)"""
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nlmpc_oracle_solutions.json")))["ugv_ph30_ch30"]
+    cases = gold["cases"][1:3]
+    inst = np.array([k["x0"] + k["u0"] for k in cases])
+    a = runner(["ugv", 30, 30, 0.1, 0, 150, "wave"], inst)
+    b = runner(["ugv", 30, 30, 0.1, 0, 150, "wave-blk2"], inst, env)
+    for x, y in zip(a, b):
+        assert x["status"] == y["status"] == 0 and x["iterations"] == y["iterations"]
+        np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-9, atol=1e-12)
