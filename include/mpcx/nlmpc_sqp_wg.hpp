@@ -31,7 +31,7 @@ namespace engine {
 
 // ---- the plan: LDS and workspace layout of one instance (host-computed, a kernel argument) ------------------------------------------
 struct WgPlan {
-    int waves;                  // wavefronts per instance: 1, 2 or 4
+    int waves;                  // wavefronts per instance: 1, 2, 4 or (wide systems alone on their CU) 8
     int per_cu;                 // workgroups of this plan a CU's LDS holds
     int hard, nq;               // sub-problem variables: ch nu (+ slack when soft)
     int kw;                     // working-set capacity
@@ -43,7 +43,7 @@ struct WgPlan {
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
         o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F, o_prm, o_cd, o_yd,
-        o_bidx, o_bsign, o_bval, o_xrf, o_xre;
+        o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
@@ -62,7 +62,7 @@ typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
 constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
-enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
 // -DMPCX_NL_STATS (libmpcx_stats.so): shader-clock cycles of the sub-problem's parts in st[ST_QSTAT ..]: unconstrained minimiser, warm start (the kept
 // rows' Schur complement, its factor, the shedding rounds), and per dual step: scan, entering row, N_W v, solve, N_W' r, B^-1 w, the rest
 #ifdef MPCX_NL_STATS
@@ -72,6 +72,12 @@ enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3,
 #endif
 
 #define MPCX_WG_PHASE __device__ __attribute__((noinline))
+// -DMPCX_EMU_TRACE (the host interpreter of tests/emu only): a line per sub-problem on stderr
+#ifdef MPCX_EMU_TRACE
+#define MPCX_TRACE(...) do { if (threadIdx.x == 0 && blockIdx.x == 0) fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define MPCX_TRACE(...) do { } while (0)
+#endif
 
 __device__ __forceinline__ double *wg_lds()
 {
@@ -85,6 +91,8 @@ __device__ __forceinline__ WgArgsPtr wg_args()
     typedef const char __attribute__((address_space(4))) *cptr;
     return (WgArgsPtr)((cptr)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(WgArgs) + 7) & ~(size_t)7));
 }
+
+typedef double wg_v4d __attribute__((ext_vector_type(4)));      // the accumulator of v_mfma_f64_16x16x4_f64: element (lane >> 4) + 4 r, column lane & 15 in register r
 
 template <int CTRL> __device__ __forceinline__ double row_share(double v) { return dpp_d<CTRL>(v); }      // 0x150 + n: lane n of every row of 16
 
@@ -136,39 +144,58 @@ template <int WAVES> MPCX_WG_CALL double wg_red_max(double v, double *s)
         return r;
     }
 }
+// two sums with one barrier
+struct WgSum2 { double a, b; };
+template <int WAVES> MPCX_WG_CALL WgSum2 wg_red_sum2(double a, double b, double *s)
+{
+    a = wave_sum(a); b = wave_sum(b);
+    if constexpr (WAVES > 1) {
+        if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = a; s[8 + (threadIdx.x >> 6)] = b; }
+        __syncthreads();
+        a = s[0]; b = s[8];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) { a += s[i]; b += s[8 + i]; }
+    }
+    return WgSum2{a, b};
+}
 // largest value and the lowest index holding it
 struct WgArgmax { double v; int idx; };
 template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, double *s)
 {
     wave_argmax(v, idx);
     if constexpr (WAVES > 1) {
-        if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s[4 + (threadIdx.x >> 6)] = (double)idx; }
+        if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s[8 + (threadIdx.x >> 6)] = (double)idx; }
         __syncthreads();
-        v = s[0]; idx = (int)s[4];
+        v = s[0]; idx = (int)s[8];
 #pragma unroll
         for (int i = 1; i < WAVES; ++i) {
-            const double ov = s[i]; const int oi = (int)s[4 + i];
+            const double ov = s[i]; const int oi = (int)s[8 + i];
             if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
         }
     }
     return WgArgmax{v, idx};
 }
+// Slot sets: set 0 is everybody's (a phase that reduces ends with a barrier, so the next phase may start over at its first parity); the scan and
+// the entering row of the dual method, which follow each other with their results in registers, have a set each and no barrier behind them --
+// a set is written again only after every thread has passed a later barrier of the step.
+constexpr int kWgRedSets = 3;
 template <int WAVES> struct Red {
     double *buf;
     int par;
-    __device__ __forceinline__ explicit Red(double *b) : buf(b), par(0) {}
-    __device__ __forceinline__ double *slots() { double *s = buf + par * 8; par ^= 1; return s; }
+    __device__ __forceinline__ explicit Red(double *b, int set = 0) : buf(b + 32 * set), par(0) {}
+    __device__ __forceinline__ double *slots() { double *s = buf + par * 16; par ^= 1; return s; }
     __device__ __forceinline__ double sum(double v) { return wg_red_sum<WAVES>(v, slots()); }
     __device__ __forceinline__ double max(double v) { return wg_red_max<WAVES>(v, slots()); }
     __device__ __forceinline__ void argmax(double &v, int &idx) { const WgArgmax r = wg_red_argmax<WAVES>(v, idx, slots()); v = r.v; idx = r.idx; }
+    __device__ __forceinline__ void sum2(double &a, double &b) { const WgSum2 r = wg_red_sum2<WAVES>(a, b, slots()); a = r.a; b = r.b; }
 };
 
 // dst = scale * H src for the symmetric matrix H packed by rows of its lower triangle (row r at r (r + 1) / 2), all in LDS;
 // P lanes share a row: the row's own part (entries left of the diagonal, contiguous) and the column part below it (entry (c, r) at
 // c (c + 1) / 2 + r: the offset grows by c + 1 per step), four independent partial sums each.  Every thread of the workgroup calls it;
 // the caller synchronises.
-template <int P, int NT>
-__device__ __forceinline__ void hmul_rows(const double *hp, const double *src, double *dst, int n, double scale, int tid)
+template <int P, int NT, bool STEP = false>
+__device__ __forceinline__ void hmul_rows(const double *hp, const double *src, double *dst, int n, double scale, int tid, const double *extra = nullptr)
 {
     const int part = tid & (P - 1);
     for (int r0 = 0; r0 < n; r0 += NT / P) {
@@ -193,15 +220,18 @@ __device__ __forceinline__ void hmul_rows(const double *hp, const double *src, d
         }
         for (; c < n; c += P) { a1 = fma(hp[off], src[c], a1); off += P * c + P * (P + 1) / 2; }
         const double acc = group_sum<P>((a0 + a1) + (a2 + a3));
-        if (live && part == 0) dst[r] = scale * acc;
+        if (live && part == 0) {
+            if constexpr (STEP) dst[r] -= scale * ((extra ? extra[r] : 0.0) - acc);      // the dual step's move: x -= t (v - B^-1 w)
+            else dst[r] = scale * acc;
+        }
     }
 }
-template <int NT>
-__device__ __forceinline__ void hmul(const double *hp, const double *src, double *dst, int n, double scale, int tid)
+template <int NT, bool STEP = false>
+__device__ __forceinline__ void hmul(const double *hp, const double *src, double *dst, int n, double scale, int tid, const double *extra = nullptr)
 {
-    if (4 * n <= NT) hmul_rows<4, NT>(hp, src, dst, n, scale, tid);
-    else if (2 * n <= NT) hmul_rows<2, NT>(hp, src, dst, n, scale, tid);
-    else hmul_rows<1, NT>(hp, src, dst, n, scale, tid);
+    if (4 * n <= NT) hmul_rows<4, NT, STEP>(hp, src, dst, n, scale, tid, extra);
+    else if (2 * n <= NT) hmul_rows<2, NT, STEP>(hp, src, dst, n, scale, tid, extra);
+    else hmul_rows<1, NT, STEP>(hp, src, dst, n, scale, tid, extra);
 }
 __device__ __forceinline__ double hsym(const double *hp, int r, int c) { return r >= c ? hp[r * (r + 1) / 2 + c] : hp[c * (c + 1) / 2 + r]; }
 
@@ -505,11 +535,13 @@ struct WgSqp {
         T::sync();
         if (tid == 0) {                                       // prefix counts: Jacobian block slots and dense columns
             int ns = 0, ndc = 0;
+            int *drow = v.iat(P.o_drow);                        // the user row behind dense column dc
             for (int k = 0; k < m; ++k) {
                 jxoff[k] = ns;
                 unsigned long long mk = xmask[k];
                 const bool dense = mk != 0ull || !Mdl::XFREE_ROWS_SPARSE;
-                dcol[k] = dense ? ndc++ : -1;
+                dcol[k] = dense ? ndc : -1;
+                if (dense) drow[ndc++] = k;
                 while (mk) { const int i = (int)__builtin_ctzll(mk) + 1; mk &= mk - 1; slot[ns++] = (k << 8) | i; }
             }
             jxoff[m] = ns;
@@ -810,7 +842,7 @@ struct WgSqp {
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
-            if (dense) for (int q = sole_state_row(k, xmask[k], mi, ph) ? nzu : 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+            if (dense) for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
             int cnt = 0, ix[kNlSparse + 1];
             double ev[kNlSparse + 1];
             for (int u = 0; u <= kNlSparse; ++u) { ix[u] = 0; ev[u] = 0.0; }
@@ -967,94 +999,109 @@ struct WgSqp {
         double *gr = v.at(P.o_gr), *br = v.at(P.o_br);
         typename FP::type art = art_of(v);
         const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
+        (void)lam; (void)dcol; (void)sbf;
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         const int *bnd_idx = v.iat(P.o_bidx);
         const double *bnd_sign = v.at(P.o_bsign);
         typename FP::type F = FP::get(v);
         if constexpr (NX <= 8) {
-            constexpr bool PF = NX <= 4;                         // the next step's block is requested while this one's is used (registers for it: small states)
-            const int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
-            for (int q = tid; q <= nzu; q += NT) {
-                const bool isr = q == nzu;
-                const int bq = q / NU, jq = q - bq * NU;
-                double x[NX], t[NX], gacc = 0.0;
-                // (with the blocks in LDS the lane's right-hand side column travels with the prefetched block; with them in the workspace, where the
-                // variant lives on 170 registers, it is requested at the top of its own step and added after the products)
-                constexpr int FBW = FL ? NX + 1 : NX;
-                double fb[PF ? NX * FBW : 1];
-                auto fetch = [&](int i) {
-                    const bool drv = !isr && min(i, ch - 1) == bq;
+            // Row by row, backwards (the adjoint of the sweep): a dense row of the sub-problem is a covector w on the state rows it reads, and
+            //     l_top = w_top,   l_{s-1} = w_{s-1} + Abar_s' l_s,   entries of the row on input block b(s) += Bbar_s' l_s,   offset += cbar_s' l_s
+            // -- one lane per row, the multiplier l in its registers, every lane on the same step s (the block's entries are broadcast reads), the
+            // row's results filed as the sweep passes; nothing is looked up along the way (the forward form walked, per column and state row, the
+            // list of rows that read it: five dependent LDS reads per entry).  Wavefront 0 meanwhile runs the one chain of the reduced gradient
+            // (lam: g_x in, the chain's multipliers out -- as where no row reads a state), the others share the rows.
+            double *lamw = v.at(P.o_lam);
+            chain<true>(v, lamw, tid);
+            const int nd = P.nd, nd_user = P.nd_user, nq = v.nq;
+            const int *drow = v.iat(P.o_drow);
+            constexpr bool PF = NX <= 4;                         // the step's block in registers, requested in one batch (small states)
+            constexpr int RW = WAVES > 1 ? NT - 64 : 64;         // threads that share the rows
+            for (int dc = WAVES > 1 ? tid - 64 : tid; dc >= 0 && dc < nd; dc += RW) {
+                const bool user = dc < nd_user;
+                const int k = user ? drow[dc] : m + (dc - nd_user);
+                const unsigned long long mk = user ? xmask[k] : 0ull;
+                const int jo = user ? jxoff[k] : 0;
+                const int zi = user ? 0 : bnd_idx[dc - nd_user];
+                const int bs = user ? -1 : zi / NX, ba = user ? 0 : zi - (zi / NX) * NX;     // a bound: state row and entry
+                const double bsg = user ? 0.0 : bnd_sign[dc - nd_user];
+                const int top = user ? (mk ? 63 - __builtin_clzll(mk) : -1) : bs;           // the last state row the row reads
+                double l[NX], acc[NU], cst = 0.0, old[NU];
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) {
+                for (int a = 0; a < NX; ++a) l[a] = 0.0;
 #pragma unroll
-                        for (int bb = 0; bb < NX; ++bb) fb[a * FBW + bb] = F[(size_t)(i * NX + a) * FW + bb];
-                        if constexpr (FL) fb[a * FBW + NX] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
-                    }
+                for (int jq = 0; jq < NU; ++jq) acc[jq] = 0.0;
+                double fb[PF ? NX * FW : 1];
+                auto fetch = [&](int sI) {
+#pragma unroll
+                    for (int e = 0; e < NX * FW; ++e) fb[e] = F[(size_t)sI * NX * FW + e];
                 };
-                // what state row i + 1 (held in x) is needed for; issued before the next step's products so that its LDS round trips and
-                // theirs overlap: neither depends on the other
-                auto consume = [&](int i) {
-                    if (!isr) {
+                auto fetch_old = [&](int blk) {
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) gacc = fma(lam[i * NX + a], x[a], gacc);       // (lam still holds g_x)
-                    }
-                    for (int e = xrf[i]; e < xrf[i + 1]; ++e) {
-                        const int ent = xre[e];
-                        const int k = FL ? ent >> 12 : (ent & 0x7fffffff) >> 12, sl = ent & 0xfff;
-                        double sacc = 0.0;
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) sacc = fma(jx[sl * NX + a], x[a], sacc);
-                        if (isr) br[k] += sacc;
-                        else if (!FL && ent < 0) art[q * ndld + dcol[k]] = sacc;
-                        else art[q * ndld + dcol[k]] += sacc;
-                    }
-                    for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
-                        const int a = bnd_idx[kb] - i * NX;
-                        const double sg = bnd_sign[kb];
-                        double xa = 0.0;
-#pragma unroll
-                        for (int a2 = 0; a2 < NX; ++a2) if (a2 == a) xa = x[a2];
-                        if (isr) br[m + kb] += sg * xa; else art[q * ndld + dcol[m + kb]] = sg * xa;
-                    }
+                    for (int jq = 0; jq < NU; ++jq) old[jq] = art[(blk * NU + jq) * ndld + dc];
                 };
-#pragma unroll
-                for (int a = 0; a < NX; ++a) x[a] = 0.0;
-                if constexpr (PF) fetch(0);
-                for (int i = 0; i < ph; ++i) {
-                    if (i > 0) consume(i - 1);
-                    if constexpr (PF) {
-                        double fcur[NX * FBW], rh[NX];
-                        if constexpr (!FL) {
-                            const bool drv = !isr && min(i, ch - 1) == bq;
-#pragma unroll
-                            for (int a = 0; a < NX; ++a) rh[a] = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drv ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
-                        }
-#pragma unroll
-                        for (int e = 0; e < NX * FBW; ++e) fcur[e] = fb[e];
-                        if (i + 1 < ph) fetch(i + 1);
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double sacc = FL ? fcur[a * FBW + (FL ? NX : 0)] : 0.0;
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) sacc = fma(fcur[a * FBW + bb], x[bb], sacc);
-                            t[a] = FL ? sacc : sacc + rh[a];
-                        }
-                    } else {
-                        const bool drives = !isr && min(i, ch - 1) == bq;
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) {
-                            double sacc = isr ? F[(size_t)(i * NX + a) * FW + FW - 1] : (drives ? F[(size_t)(i * NX + a) * FW + NX + jq] : 0.0);
-#pragma unroll
-                            for (int bb = 0; bb < NX; ++bb) sacc = fma(F[(size_t)(i * NX + a) * FW + bb], x[bb], sacc);
-                            t[a] = sacc;
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) x[a] = t[a];
+                if (top >= 0) {
+                    if constexpr (PF) fetch(top);
+                    fetch_old(min(top, ch - 1));
                 }
-                consume(ph - 1);
-                if (!isr) gr[q] = gu[q] + gacc;
+                for (int sI = top; sI >= 0; --sI) {
+                    // w_s joins the multiplier
+                    if (user) {
+                        if ((mk >> sI) & 1ull) {
+                            const int sl = jo + __builtin_popcountll(mk & ((1ull << sI) - 1ull));
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) l[a] += jx[sl * NX + a];
+                        }
+                    } else if (sI == bs) {
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) if (a == ba) l[a] += bsg;
+                    }
+                    auto Fe = [&](int a, int c) -> double { if constexpr (PF) return fb[a * FW + c]; else return F[(size_t)(sI * NX + a) * FW + c]; };
+                    // inputs and offset
+#pragma unroll
+                    for (int jq = 0; jq < NU; ++jq) {
+                        double sacc = acc[jq];
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, NX + jq), l[a], sacc);
+                        acc[jq] = sacc;
+                    }
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) cst = fma(Fe(a, FW - 1), l[a], cst);
+                    if (sI <= ch - 1) {                            // the last step of this input block: file it, ask for the next block's entries
+                        const int blk = sI;
+#pragma unroll
+                        for (int jq = 0; jq < NU; ++jq) { art[(blk * NU + jq) * ndld + dc] = old[jq] + acc[jq]; acc[jq] = 0.0; }
+                        if (sI > 0) fetch_old(sI - 1);
+                    }
+                    // l_{s-1} = Abar_s' l_s (w_{s-1} joins at the top of the next step)
+                    if (sI > 0) {
+                        double ln[NX];
+#pragma unroll
+                        for (int b2 = 0; b2 < NX; ++b2) {
+                            double sacc = 0.0;
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, b2), l[a], sacc);
+                            ln[b2] = sacc;
+                        }
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) l[a] = ln[a];
+                        if constexpr (PF) fetch(sI - 1);         // (all of the block's entries in one batch of broadcast reads)
+                    }
+                }
+                if (top >= 0) br[k] += cst;
             }
+            T::sync();
+            // the reduced gradient from the chain's multipliers (lam = -l: Jx' lam = -g_x)
+            for (int q = tid; q < nzu; q += NT) {
+                const int bq = q / NU, jq = q - bq * NU;
+                double sacc = gu[q];
+                for (int i = bq; i < (bq == ch - 1 ? ph : bq + 1); ++i) {
+#pragma unroll
+                    for (int a = 0; a < NX; ++a) sacc = fma(-F[(size_t)(i * NX + a) * FW + NX + jq], lamw[i * NX + a], sacc);
+                }
+                gr[q] = sacc;
+            }
+            (void)nq; (void)mi;
         } else {
             static_assert(NX <= 16, "the workgroup form spreads a column over one DPP row");
             const int a = tid & 15, aa = min(a, NX - 1);
@@ -1214,8 +1261,25 @@ struct WgSqp {
         hmul<NT>(v.at(v.A->P.o_hinv), v.at(src_off), v.at(dst_off), v.nq, scale, threadIdx.x);
         T::sync();
     }
-    // the oriented normal n = sgn * (row k) of a sub-problem row into np and vv = B^-1 n
-    static MPCX_WG_CALL void normal_call(int k, double sgn)
+    // wv += art cd: the dense rows' part of N_W' rr (cd: their coefficients, scattered by the dual part of the step)
+    static MPCX_WG_CALL void art_mul_call()
+    {
+        const V v; const auto &P = v.A->P;
+        art_mul<true>(v, v.at(P.o_cd), v.at(P.o_wv), threadIdx.x);
+        T::sync();
+    }
+    // xq -= t (vv - B^-1 wv): the primal part of a dual step
+    // (with_v false: xq += t B^-1 wv -- the warm start's minimiser on the kept rows with t = -1)
+    static MPCX_WG_CALL void hmul_step_call(double t, bool with_v = true)
+    {
+        const V v; const auto &P = v.A->P;
+        hmul<NT, true>(v.at(P.o_hinv), v.at(P.o_wv), v.at(P.o_xq), v.nq, t, threadIdx.x, with_v ? v.at(P.o_vv) : nullptr);
+        T::sync();
+    }
+    // the oriented normal n = sgn * (row k) of a sub-problem row into np and vv = B^-1 n.  For the dual method (sums): returns n' B^-1 n and
+    // n'n, and leaves art' vv in yd -- the dense rows' part of N_W B^-1 n, for whoever gathers the working set's entries (with_t: there is a
+    // working set); no barrier behind the reduction (slot set 2).  For the warm start's row-by-row Schur complement: np and vv only.
+    static MPCX_WG_CALL WgSum2 normal_call(int k, double sgn, bool sums = true, bool with_t = false)
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
         const int tid = threadIdx.x, nq = v.nq, dc = v.iat(P.o_dcol)[k];
@@ -1240,6 +1304,13 @@ struct WgSqp {
             }
         }
         T::sync();
+        if (!sums) return WgSum2{0.0, 0.0};
+        double snn = 0, npn = 0;
+        for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
+        if (with_t && P.nd > 0) art_tmul(v, vv, v.at(P.o_yd), tid);
+        Red<WAVES> R(v.at(P.o_red), 2);
+        R.sum2(snn, npn);
+        return WgSum2{snn, npn};
     }
     // the most violated row outside the working set at xq (an equality is violated on either side); yd keeps art' xq
     static MPCX_WG_CALL WgArgmax scan_call()
@@ -1256,9 +1327,8 @@ struct WgSqp {
             if (k >= mi && k < m) s = fabs(s);
             if (flag[k] == 0 && s > vmax) { vmax = s; pidx = k; }
         }
-        Red<WAVES> R(v.at(P.o_red));
+        Red<WAVES> R(v.at(P.o_red), 1);
         R.argmax(vmax, pidx);
-        T::sync();
         return WgArgmax{vmax, pidx};
     }
 
@@ -1351,19 +1421,203 @@ struct WgSqp {
         if (mv2) { wq[tid + NT - 1] = kq2; sgq[tid + NT - 1] = sg2; uq[tid + NT - 1] = u2; }
         T::sync();
     }
-    // the entering row joins as row nw of the factor (from yv) and of the lists
-    static MPCX_WG_PHASE void ws_append(int nw, int pidx, double sgn, double up, double snn)
+    // The dual part of a step of the dual method, by wavefront 0 with the working set's vectors in its registers: t = N_W B^-1 n gathered
+    // (yd holds art' B^-1 n), rr = S^-1 t, N_W' rr set up for the primal part (sparse rows scattered into wv, the dense rows' coefficients
+    // into cd), the curvature along the step z'n = n'B^-1 n - |L^-1 t|^2 (what the factor's
+    // next diagonal is the square root of), the ratio test over the multipliers, the step length, the multipliers' update and -- on a full
+    // step -- the entering row's place in the factor and in the lists.  Results for everybody in st[R0 ..]: step length (1e300: none),
+    // z'n, what happens (0 no step: the row depends on the working set; 1 the row joins; 2 row st[R3] leaves first), that row.
+    static MPCX_WG_PHASE void ws_dual_step(int nw, int pidx, double sgn, double snn, double npn, double spv, double up)
     {
         const V v; const auto &P = v.A->P;
-        const int tid = threadIdx.x, lane = tid & 63;
-        double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *yv = v.at(P.o_yv);
+        const int tid = threadIdx.x, lane = tid & 63, mi = v.mi, m = v.m;
+        double *tq = v.at(P.o_tq), *uq = v.at(P.o_uq), *sgq = v.at(P.o_sgq), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         if (tid < 64) {
-            const Factor Fac{v.at(P.o_L), v.at(P.o_invd), nullptr, nullptr, v.kw, 0};
-            const double y0 = lane < nw ? yv[lane] : 0.0, y1 = lane + 64 < nw ? yv[lane + 64] : 0.0;
-            chol_append<false>(Fac, nw, y0, y1, snn, snn, lane);
+            const Sp sp(v);
+            double *Lp = v.at(P.o_L), *invd = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv);
+            const double *yd = v.at(P.o_yd), *vv = v.at(P.o_vv);
+            const int *dcol = v.iat(P.o_dcol);
+            const int nd = P.nd, nq = v.nq;
+            const bool h0 = lane < nw, h1 = lane + 64 < nw;
+            const int k0 = h0 ? wq[lane] : 0, k1 = h1 ? wq[lane + 64] : 0;
+            const int d0 = h0 ? dcol[k0] : -1, d1 = h1 ? dcol[k1] : -1;
+            const double s0 = h0 ? sgq[lane] : 0.0, s1 = h1 ? sgq[lane + 64] : 0.0;
+            // (requested before the substitutions, used after them)
+            const double u0 = h0 ? uq[lane] : 0.0, u1 = h1 ? uq[lane + 64] : 0.0;
+            // t = N_W v: a dense row's entry is in yd (the entering row's phase left art' v there), a sparse row's a few products
+            double t0 = !h0 ? 0.0 : s0 * (d0 >= 0 ? yd[d0] : sp.dot(k0, vv)), t1 = !h1 ? 0.0 : s1 * (d1 >= 0 ? yd[d1] : sp.dot(k1, vv));
+            double y0 = 0.0, y1 = 0.0;
+            // N_W' rr starts from zero: its sparse rows are scattered below, its dense rows' coefficients go to cd
+            for (int q = lane; q < nq; q += 64) wv[q] = 0.0;
+            for (int dc = lane; dc < nd; dc += 64) cd[dc] = 0.0;
+            if (nw > 0) {
+                if (v.kw <= 64) { tri_forward<false>(Lp, invd, nw, t0, t1, lane); y0 = t0; tri_backward<false>(Lp, invd, nw, t0, t1, lane); }
+                else { tri_forward<true>(Lp, invd, nw, t0, t1, lane); y0 = t0; y1 = t1; tri_backward<true>(Lp, invd, nw, t0, t1, lane); }
+            }
+            const double zn = snn - wave_sum((h0 ? y0 * y0 : 0.0) + (h1 ? y1 * y1 : 0.0));
+            // dual ratio test: the smallest ratio, lowest slot on ties (equalities never leave)
+            double tneg = -1e300; int tidx = 0x7fffffff;
+            if (h0 && t0 > 1e-14 && !(k0 >= mi && k0 < m)) { tneg = -(u0 / t0); tidx = lane; }
+            if (h1 && t1 > 1e-14 && !(k1 >= mi && k1 < m)) { const double tj = -(u1 / t1); if (tj > tneg) { tneg = tj; tidx = lane + 64; } }
+            wave_argmax(tneg, tidx);
+            const double tl = tneg > -1e300 ? -tneg : 1e300;
+            const bool can_move = zn > 1e-13 * fmax(1.0, npn);
+            const double t2 = can_move ? spv / zn : 1e300;
+            const double tt = fmin(tl, t2);
+            const int what = tt >= 1e300 ? 0 : (t2 <= tl ? 1 : 2);
+            if (what != 0) {
+                if (h0) uq[lane] = u0 - tt * t0;
+                if (h1) uq[lane + 64] = u1 - tt * t1;
+                if (can_move) {
+                    nl_wave_sync();                                  // (the zeros above are in place)
+                    auto scatter = [&](bool h, int k, int dc, double ml) {
+                        if (!h) return;
+                        if (dc >= 0) cd[dc] = ml;
+                        else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                    };
+                    scatter(h0, k0, d0, s0 * t0);
+                    scatter(h1, k1, d1, s1 * t1);
+                }
+            }
+            if (what == 1) {                                     // row nw of the factor: y and the square root of z'n (chol_append's guard)
+                const bool ok = zn > 1e-13 * snn;
+                const double dd = sqrt(ok ? zn : 1e-13 * snn + 1e-300);
+                const int ro = nw * (nw + 1) / 2;
+                if (h0) Lp[ro + lane] = y0;
+                if (h1) Lp[ro + lane + 64] = y1;
+                if (lane == 0) { Lp[ro + nw] = dd; invd[nw] = 1.0 / dd; uq[nw] = up + tt; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+            }
+            if (lane == 0) { st[ST_R0] = tt; st[ST_R1] = zn; st[ST_R2] = (double)what; st[ST_R3] = (double)tidx; }
         }
-        if (tid == 0) { uq[nw] = up; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+        T::sync();
+    }
+
+    // S = N_W B^-1 N_W' of the kept rows where some of them are dense (rows through the sensitivities: config 3), on the matrix pipe:
+    // the one GEMM-shaped product of the sub-problem (the reference's counterpart is the chain rule through the dense Jacobians,
+    // Constraints.hpp:455-482).  V = B^-1 N_W' is formed sixteen rows at a time -- a wavefront takes row blocks rb = wave, wave + WAVES, ..
+    // of B^-1 (v_mfma_f64_16x16x4_f64, B^-1 read through its packed triangle) and keeps its block of V in the accumulators; those
+    // registers ARE the B operands of the second product (register r of the accumulator holds rows 4 r .. 4 r + 3 of the block in the
+    // layout a k-step wants), so N_W[:, block] V[block, :] follows without V ever leaving the registers.  The wavefronts' partial sums meet
+    // in the factor's storage in a fixed order (wavefront 0 stores, 1 .. add in turn): the same bits on every run.  Up to 64 kept rows.
+    static constexpr int kSchurTiles = 4;
+    static MPCX_WG_PHASE void ws_schur_mfma(int nw)
+    {
+        const V v; const auto &P = v.A->P; const Sp sp(v);
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nq = v.nq, ndld = v.ndld, j = lane & 15, kq = lane >> 4;
+        const double *hinv = v.at(P.o_hinv), *sgq = v.at(P.o_sgq);
+        const int *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
+        double *Lp = v.at(P.o_L);
+        typename FP::type art = art_of(v);
+        const int nt = (nw + 15) >> 4, nkb = (nq + 15) >> 4;
+        // this lane's kept row in each tile of sixteen: where its entries are
+        int rk[kSchurTiles], rdc[kSchurTiles], rix[kSchurTiles], rcn[kSchurTiles];
+        double rsg[kSchurTiles], rv0[kSchurTiles];
+#pragma unroll
+        for (int ti = 0; ti < kSchurTiles; ++ti) {
+            const int t = 16 * ti + j;
+            const bool live = t < nw;
+            const int k = live ? wq[t] : 0;
+            rk[ti] = k; rdc[ti] = live ? dcol[k] : -1; rsg[ti] = live ? sgq[t] : 0.0;
+            rcn[ti] = (live && rdc[ti] < 0) ? sp.count(k) : 0;
+            rix[ti] = sp.index(k, 0); rv0[ti] = sp.value(k, 0);
+        }
+        // entry kk of the oriented normal of this lane's row in tile ti (zero beyond the row's or the matrix's end)
+        auto nrm = [&](int ti, int kk) -> double {
+            if (kk >= nq) return 0.0;
+            if (rdc[ti] >= 0) return rsg[ti] * art[kk * ndld + rdc[ti]];
+            double val = (rcn[ti] > 0 && rix[ti] == kk) ? rv0[ti] : 0.0;
+            for (int e = 1; e < rcn[ti]; ++e) if (sp.index(rk[ti], e) == kk) val += sp.value(rk[ti], e);
+            return rsg[ti] * val;
+        };
+        wg_v4d S[kSchurTiles * (kSchurTiles + 1) / 2];
+#pragma unroll
+        for (int e = 0; e < kSchurTiles * (kSchurTiles + 1) / 2; ++e) S[e] = wg_v4d{0.0, 0.0, 0.0, 0.0};
+        for (int rb = wave; rb < nkb; rb += WAVES) {
+            wg_v4d Vb[kSchurTiles];
+#pragma unroll
+            for (int ti = 0; ti < kSchurTiles; ++ti) Vb[ti] = wg_v4d{0.0, 0.0, 0.0, 0.0};
+            const int hr = 16 * rb + j;                          // this lane's row of B^-1
+            for (int k0 = 0; k0 < nq; k0 += 4) {
+                const int kk = k0 + kq;
+                const double a = (hr < nq && kk < nq) ? hsym(hinv, hr, kk) : 0.0;
+#pragma unroll
+                for (int ti = 0; ti < kSchurTiles; ++ti)
+                    if (ti < nt) Vb[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, nrm(ti, kk), Vb[ti], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < kSchurTiles; ++mi) {
+                if (mi >= nt) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double a = nrm(mi, 16 * rb + 4 * r + kq);
+#pragma unroll
+                    for (int ni = 0; ni <= mi; ++ni) S[mi * (mi + 1) / 2 + ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Vb[ni][r], S[mi * (mi + 1) / 2 + ni], 0, 0, 0);
+                }
+            }
+        }
+        for (int turn = 0; turn < (WAVES < nkb ? WAVES : nkb); ++turn) {
+            if (wave == turn) {
+#pragma unroll
+                for (int mi = 0; mi < kSchurTiles; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni <= mi; ++ni) {
+                        if (mi >= nt) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * mi + kq + 4 * r, col = 16 * ni + j;
+                            if (row < nw && col <= row) {
+                                const int e = row * (row + 1) / 2 + col;
+                                const double x = S[mi * (mi + 1) / 2 + ni][r];
+                                Lp[e] = turn == 0 ? x : Lp[e] + x;
+                            }
+                        }
+                    }
+                }
+            }
+            T::sync();
+        }
+    }
+
+    // One round of the warm start, by wavefront 0: the multipliers of the kept rows at the minimiser on them, u = S^-1 (N_W x0 + b) with
+    // yd = art' x0 (x0 = -B^-1 gr does not change while rows are shed); the rows whose multiplier is negative as two 64-bit words in
+    // st[ST_SHED] (equalities stay).  When none is: u is filed as the multipliers, and N_W' u is set up for the minimiser (sparse rows
+    // scattered into wv, dense coefficients in cd), as in a dual step.
+    static MPCX_WG_PHASE void ws_shed_round(int nw)
+    {
+        const V v; const auto &P = v.A->P;
+        const int tid = threadIdx.x, lane = tid & 63, mi = v.mi, m = v.m;
+        if (tid < 64) {
+            const Sp sp(v);
+            double *Lp = v.at(P.o_L), *invd = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv), *uq = v.at(P.o_uq), *st = v.at(P.o_st);
+            const double *yd = v.at(P.o_yd), *xq = v.at(P.o_xq), *br = v.at(P.o_br), *sgq = v.at(P.o_sgq);
+            const int *dcol = v.iat(P.o_dcol), *wq = v.iat(P.o_wq);
+            const int nd = P.nd, nq = v.nq;
+            const bool h0 = lane < nw, h1 = lane + 64 < nw;
+            const int k0 = h0 ? wq[lane] : 0, k1 = h1 ? wq[lane + 64] : 0;
+            const int d0 = h0 ? dcol[k0] : -1, d1 = h1 ? dcol[k1] : -1;
+            const double s0 = h0 ? sgq[lane] : 0.0, s1 = h1 ? sgq[lane + 64] : 0.0;
+            double t0 = !h0 ? 0.0 : s0 * ((d0 >= 0 ? yd[d0] : sp.dot(k0, xq)) + br[k0]), t1 = !h1 ? 0.0 : s1 * ((d1 >= 0 ? yd[d1] : sp.dot(k1, xq)) + br[k1]);
+            if (v.kw <= 64) { tri_forward<false>(Lp, invd, nw, t0, t1, lane); tri_backward<false>(Lp, invd, nw, t0, t1, lane); }
+            else { tri_forward<true>(Lp, invd, nw, t0, t1, lane); tri_backward<true>(Lp, invd, nw, t0, t1, lane); }
+            const unsigned long long b0 = __ballot(h0 && t0 < 0.0 && !(k0 >= mi && k0 < m)), b1 = __ballot(h1 && t1 < 0.0 && !(k1 >= mi && k1 < m));
+            if (!(b0 | b1)) {
+                if (h0) uq[lane] = t0;
+                if (h1) uq[lane + 64] = t1;
+                for (int q = lane; q < nq; q += 64) wv[q] = 0.0;
+                for (int dc = lane; dc < nd; dc += 64) cd[dc] = 0.0;
+                nl_wave_sync();
+                auto scatter = [&](bool h, int k, int dc, double ml) {
+                    if (!h) return;
+                    if (dc >= 0) cd[dc] = ml;
+                    else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                };
+                scatter(h0, k0, d0, s0 * t0);
+                scatter(h1, k1, d1, s1 * t1);
+            }
+            if (lane == 0) { unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED); shw[0] = b0; shw[1] = b1; }
+        }
         T::sync();
     }
 
@@ -1402,15 +1656,19 @@ struct WgSqp {
                         s = fma(sp.value(ka, ja) * sp.value(kb, jb), hsym(hinv, sp.index(ka, ja), sp.index(kb, jb)), s);
                 Lp[e] = sgq[a] * sgq[b2] * s;
             }
+        } else if (nw <= 16 * kSchurTiles) {
+            ws_schur_mfma(nw);
         } else {
             for (int b2 = 0; b2 < nw; ++b2) {
-                normal_call(wq[b2], sgq[b2]);
+                normal_call(wq[b2], sgq[b2], false);
                 ws_n_mul(b2 + 1, P.o_vv, P.o_L + b2 * (b2 + 1) / 2);        // row b2 of S: entries 0 .. b2
             }
         }
         T::sync();
         MPCX_QLAP(1);
-        {
+        if (nw <= 32) {                                          // a small set: one wavefront, no workgroup barriers
+            if (tid < 64) { const bool ok = chol_inplace(Lp, invd, nw, lane); if (lane == 0) st[ST_R4] = ok ? 1.0 : 0.0; }
+        } else {
             const bool ok = chol_inplace_wg<WAVES>(Lp, invd, v.at(P.o_red), nw, tid);
             if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0;
         }
@@ -1421,21 +1679,11 @@ struct WgSqp {
             T::sync();
             return 0;
         }
+        if (P.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
         while (nw > 0) {
-            ws_n_mul(nw, P.o_xq, P.o_tq);
-            for (int t = tid; t < nw; t += NT) tq[t] += sgq[t] * br[wq[t]];
-            T::sync();
-            ws_solve(nw);
-            // every row with a negative multiplier leaves at once; equalities stay.  One bit per row, by ballot (a working set holds at most
-            // 128 rows: two words) -- every thread walking the list itself was two dependent LDS reads per row and thread, twice a round
-            unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED);
-            for (int half = WAVES == 1 ? 0 : (tid >> 6); half < 2; half += WAVES == 1 ? 1 : WAVES) {
-                const int t = half * 64 + lane;
-                const bool sh = t < nw && tq[t] < 0.0 && !is_eq(wq[t]);
-                const unsigned long long bal = __ballot(sh);
-                if (lane == 0) shw[half] = bal;
-            }
-            T::sync();
+            ws_shed_round(nw);
+            // every row with a negative multiplier leaves at once; equalities stay
+            const unsigned long long *shw = reinterpret_cast<const unsigned long long *>(st + ST_SHED);
             unsigned long long m0 = shw[0], m1 = shw[1];
             if (!(m0 | m1)) break;
             while (m0 | m1) {                                    // from the last row down: the rows below a leaving one keep their numbers
@@ -1443,16 +1691,13 @@ struct WgSqp {
                 if (m1) { const int bit = 63 - __builtin_clzll(m1); m1 &= ~(1ull << bit); t = 64 + bit; }
                 else { const int bit = 63 - __builtin_clzll(m0); m0 &= ~(1ull << bit); t = bit; }
                 ws_drop(t, nw); --nw;
+                if (tid == 0) st[ST_NSHED] += 1.0;
             }
-            T::sync();                                           // (the next round overwrites tq and the two words)
         }
         if (nw > 0) {
-            ws_nt_mul(nw, P.o_tq, P.o_wv);
-            for (int t = tid; t < nw; t += NT) uq[t] = tq[t];
-            hmul_call(P.o_wv, P.o_zd, 1.0);
-            for (int q = tid; q < nq; q += NT) xq[q] -= zd[q];
+            if (P.nd > 0) art_mul_call();
+            hmul_step_call(-1.0, false);                        // x = x0 - B^-1 N_W' u
         }
-        T::sync();
         MPCX_QLAP(3);
         return nw;
     }
@@ -1483,6 +1728,7 @@ struct WgSqp {
         T::sync();
         MPCX_QLAP(0);
         int nw = nw_keep > 0 ? ws_warm(nw_keep) : 0;
+        MPCX_TRACE("qp: kept %d of %d;", nw, nw_keep);
 #ifdef MPCX_NL_STATS
         qt_ = __builtin_readcyclecounter();
 #endif
@@ -1506,72 +1752,45 @@ struct WgSqp {
                 const int dc = dcol[pidx];
                 sgn = br[pidx] + (dc >= 0 ? W.yd[dc] : sp.dot(pidx, xq)) < 0.0 ? -1.0 : 1.0;
             }
-            normal_call(pidx, sgn);
+            const WgSum2 nn = normal_call(pidx, sgn, true, nw > 0);
             MPCX_QLAP(5);
-            double snn = 0, npn = 0;
-            for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
-            snn = R.sum(snn); npn = R.sum(npn);
+            const double snn = nn.a, npn = nn.b;
             double up = 0.0, spv_ = vmax;
             bool added = false;
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
-                // t = N_W v (the new column of S), rr = S^-1 t, zd = B^-1 (n - N_W' rr)
-                if (nw > 0) {
-                    MPCX_QLAP(10);
-                    ws_n_mul(nw, P.o_vv, P.o_tq);
-                    MPCX_QLAP(6);
-                    ws_solve(nw);
-                    MPCX_QLAP(7);
-                    ws_nt_mul(nw, P.o_tq, P.o_wv);
-                    MPCX_QLAP(8);
-                    hmul_call(P.o_wv, P.o_zd, 1.0);
-                    MPCX_QLAP(9);
-                    for (int q = tid; q < nq; q += NT) zd[q] = vv[q] - zd[q];
-                } else {
-                    for (int q = tid; q < nq; q += NT) zd[q] = vv[q];
-                }
-                T::sync();
-                double zn = 0;
-                for (int q = tid; q < nq; q += NT) zn += zd[q] * np_[q];
-                zn = R.sum(zn);
-                // dual ratio test: the smallest ratio, lowest slot on ties
-                double t1 = 1e300; int kdrop = -1;
-                {
-                    double tneg = -1e300; int tidx = 0x7fffffff;
-                    for (int t = tid; t < nw; t += NT) {
-                        const double rr = tq[t];
-                        if (rr > 1e-14 && !is_eq(wq[t])) { const double tj = uq[t] / rr; if (-tj > tneg) { tneg = -tj; tidx = t; } }
-                    }
-                    R.argmax(tneg, tidx);
-                    if (tneg > -1e300) { t1 = -tneg; kdrop = tidx; }
-                }
+                // t = N_W v (the new column of S); wavefront 0: rr = S^-1 t, the step length, the multipliers; then x -= t B^-1 (n - N_W' rr)
+                ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
+                MPCX_QLAP(7);
+                const double tt = st[ST_R0], zn = st[ST_R1];
+                const int what = (int)st[ST_R2], kdrop = (int)st[ST_R3];
                 const bool can_move = zn > 1e-13 * fmax(1.0, npn);
-                const double t2 = can_move ? spv_ / zn : 1e300;
-                const double tt = fmin(t1, t2);
-                if (tt >= 1e300) {
+                if (what == 0) {
                     // no step: the row is a combination of working rows.  Violated by round-off only (a copy of an active row): set it
                     // aside; violated for real: the linearised constraints are inconsistent.
                     if (spv_ <= 1e-7 && !p_is_eq) { if (tid == 0) flag[pidx] = 2; T::sync(); added = true; break; }
                     fail = -1; break;
                 }
                 if (can_move) {
-                    for (int q = tid; q < nq; q += NT) xq[q] -= tt * zd[q];
+                    if (nw > 0) {
+                        if (P.nd > 0) art_mul_call();
+                        MPCX_QLAP(8);
+                        hmul_step_call(tt);
+                        MPCX_QLAP(9);
+                    } else {
+                        for (int q = tid; q < nq; q += NT) xq[q] -= tt * vv[q];
+                        T::sync();
+                    }
                     spv_ -= tt * zn;
                 }
-                for (int t = tid; t < nw; t += NT) uq[t] -= tt * tq[t];
                 up += tt;
-                T::sync();
-                if (t2 <= t1) {                                          // full step: the row joins the working set
-                    ws_append(nw, pidx, sgn, up, snn);
-                    ++nw; added = true;
-                } else {                                                 // a multiplier hit zero: that row leaves, try again
-                    ws_drop(kdrop, nw);
-                    --nw;
-                }
+                if (what == 1) { ++nw; added = true; }                  // full step: the row has joined the working set
+                else { ws_drop(kdrop, nw); --nw; }                       // a multiplier hit zero: that row leaves, try again
             }
             if (!fail && !added) fail = -1;
             MPCX_QLAP(10);
         }
         if (!fail && !done) fail = -1;
+        MPCX_TRACE(" %d dual steps, %d rows at the end, fail %d\n", nsteps, nw, fail);
         if (tid == 0) { st[ST_R5] += (double)nsteps; st[ST_R5 + 1] = fmax(st[ST_R5 + 1], (double)nw); }
         if (fail) { T::sync(); return fail; }
         for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
@@ -1745,7 +1964,7 @@ struct WgSqp {
             dUs[k] = sc.by_su(p[q], j);
         }
         T::sync();
-        constexpr int GS = NT / kNlTrials;                       // lanes per trial point: 8, 16 or 32
+        constexpr int GS = NT / kNlTrials;                       // lanes per trial point: 8, 16, 32 or 64
         const int grp = tid / GS, part = tid % GS;
         double a_step = -1.0;
         for (int round = 0; round < 5 && a_step < 0.0; ++round) {
@@ -1755,7 +1974,8 @@ struct WgSqp {
             double mer = (part == 0 ? cst : 0.0) + nu_pen * vio;
             if constexpr (GS == 8) mer = group_sum<8>(mer);
             else if constexpr (GS == 16) mer = group_sum<16>(mer);
-            else { mer = group_sum<16>(mer); mer += __shfl_xor(mer, 16); }
+            else if constexpr (GS == 32) { mer = group_sum<16>(mer); mer += __shfl_xor(mer, 16); }
+            else mer = wave_sum(mer);
             if (part == 0) st[ST_ACC + grp] = mer <= phi0 + 1e-4 * al * dphi ? 1.0 : 0.0;
             T::sync();
             for (int g = kNlTrials - 1; g >= 0; --g) if (st[ST_ACC + g] != 0.0) a_step = ldexp(1.0, -(g + 8 * round));
@@ -1870,6 +2090,10 @@ struct WgSqp {
 // A problem of several wavefronts whose blocks and reduced rows live in the workspace (FL = false) is built for three workgroups per CU
 // (170 registers): its LDS block is a third of a CU's, and the third workgroup is what pays for the global fetches.
 template <class Mdl, int WAVES, bool FL = true> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : (WAVES == 4 && !FL && Mdl::NX <= 4) ? 3 : 2;
+// Eight wavefronts per instance: for a system whose LDS block fills a CU alone (config 5: 153 KB).  Four wavefronts would leave every SIMD with
+// one -- nothing to issue while a dependent operation is in flight; eight put two on each, at the same 256 registers, and the phases that are
+// loops over steps, perturbations or matrix rows (evaluation, line search, products with B^-1) take half the rounds.  Instantiated for wide states only.
+template <class Mdl> constexpr bool kWgEightWaves = Mdl::NX >= 8;
 // one workgroup = one instance
 template <class Mdl, int WAVES, bool FL>
 __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void nlmpc_sqp_wg(const WgArgs A)
@@ -1885,7 +2109,12 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
     const double *st = sm + P.o_st;
     // shader-clock cycles per phase (tools/nlmpc_phases.py): evaluate (cost, dynamics, constraints), condense, BFGS, sub-problem, step, merit, line search, update
     long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
+#ifdef MPCX_EMU_TRACE
+    auto lap = [&](int k) { const long long now = hipemu::st().n_block_syncs; cyc[k] += now - tstamp; tstamp = now; };    // (the interpreter: barriers per phase)
+    tstamp = hipemu::st().n_block_syncs;
+#else
     auto lap = [&](int k) { const long long now = __builtin_readcyclecounter(); cyc[k] += now - tstamp; tstamp = now; };
+#endif
     K::start();
     lap(9);
     const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
@@ -1963,10 +2192,14 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         ++it;
     }
     K::finish(code, it);
+    MPCX_TRACE("barriers per iteration (%d iterations): cost %.1f dyn %.1f con %.1f condense %.1f bfgs %.1f qp %.1f step %.1f merit %.1f ls %.1f update+start %.1f\n", it,
+               (double)cyc[0] / NT / it, (double)cyc[1] / NT / it, (double)cyc[2] / NT / it, (double)cyc[3] / NT / it, (double)cyc[4] / NT / it, (double)cyc[5] / NT / it,
+               (double)cyc[6] / NT / it, (double)cyc[7] / NT / it, (double)cyc[8] / NT / it, (double)cyc[9] / NT / it);
     if (tid == 0) {
         double *scal = S.ws + (size_t)b * M.ws.total + P.w_scal;
         scal[1] = st[ST_R5];
         scal[12] = st[ST_R5 + 1];                                // the largest working set of the solve
+        scal[13] = st[ST_NSHED];
 #ifdef MPCX_NL_STATS
         for (int k = 0; k < 12; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
 #endif
@@ -2007,12 +2240,12 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     auto imax = [](int a, int b) { return a > b ? a : b; };
     const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
     int waves = waves_wanted;
-    if (waves != 0 && waves != 1 && waves != 2 && waves != 4) return -2;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && !(waves == 8 && kWgEightWaves<Mdl>)) return -2;
     auto layout = [&](int kw, int f_lds) {
         int o = kWgCtxDoubles;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         P.kw = kw; P.f_lds = f_lds;
-        P.o_red = take(16); P.o_st = take(ST_TOTAL);
+        P.o_red = take(32 * kWgRedSets); P.o_st = take(ST_TOTAL);
         P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr); P.o_p = take(nr);
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
@@ -2022,7 +2255,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
-        P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2);
+        P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2); P.o_drow = take((P.nd_user + 1) / 2);
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;
         P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
@@ -2047,7 +2280,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
             for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
                 if (blocks_wanted >= 0 && f_lds != (blocks_wanted ? 1 : 0)) continue;
                 // the registers of the variant (kWgWavesPerSimd) bound the workgroups per CU as well
-                const int by_regs = 4 * (P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
+                const int by_regs = 4 * (P.waves == 8 ? 2 : P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
                 if (per_cu > by_regs) continue;
                 if (layout(kw_full, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
                 if (per_cu == 1) continue;                      // (alone on the CU the factor keeps its full capacity)
@@ -2064,6 +2297,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.waves = 1;
         place();
         if (!placed || P.per_cu < 8) { P.waves = nz >= 96 ? 4 : 2; place(); }
+        if (kWgEightWaves<Mdl> && placed && P.waves == 4 && P.per_cu == 1) { P.waves = 8; place(); }     // alone on its CU: two wavefronts per SIMD
     } else {
         P.waves = waves;
         place();
@@ -2082,6 +2316,9 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         // the instances keep the stride of the controller's workspace (NlmpcWsLayout), the statistics block its place in it
         P.w_scal = m.ws.scal;
         if (P.ws_total > m.ws.scal || m.ws.scal + 16 > m.ws.total) return -2;
+#ifdef MPCX_NL_STATS
+        if (m.ws.scal + 28 > m.ws.total) return -2;            // (the statistics build files the sub-problem's cycle counts behind the block)
+#endif
     }
     return 0;
 }
@@ -2105,6 +2342,9 @@ int launch_solve_wg(const NlmpcDev *m, const NlmpcSolveDev *b, const WgPlan *P, 
         hipLaunchKernelGGL(kern, dim3(b->batch), dim3(P->waves * 64), lds, s, A);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     };
+    if constexpr (kWgEightWaves<Mdl>) {
+        if (P->waves == 8) return P->f_lds ? go(nlmpc_sqp_wg<Mdl, 8, true>) : go(nlmpc_sqp_wg<Mdl, 8, false>);
+    }
     if (P->f_lds) {
         if (P->waves == 4) return go(nlmpc_sqp_wg<Mdl, 4, true>);
         if (P->waves == 2) return go(nlmpc_sqp_wg<Mdl, 2, true>);

@@ -263,6 +263,25 @@ inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool)
     return (int)(uint32_t)hipemu::exchange((uint32_t)src, from, "DPP");
 }
 inline unsigned long long __ballot(int p) { return hipemu::ballot(p != 0); }
+// v_mfma_f64_16x16x4_f64: D = C + A B with A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15] one double per lane, C / D
+// four per lane: row (lane >> 4) + 4 r, column lane & 15 in element r.  (clang's ext_vector_type spelled for g++.)
+#define ext_vector_type(N) vector_size(8 * (N))
+typedef double hipemu_v4d __attribute__((vector_size(32)));
+inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_v4d c, int, int, int)
+{
+    const int lane = hipemu::tid() % hipemu::kWave, col = lane & 15, g = lane >> 4;
+    uint64_t ab, bb; memcpy(&ab, &a, 8); memcpy(&bb, &b, 8);
+    double bk[4];
+    for (int k = 0; k < 4; ++k) { const uint64_t x = hipemu::exchange(bb, 16 * k + col, "v_mfma (B)"); memcpy(&bk[k], &x, 8); }
+    hipemu_v4d d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = g + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) { const uint64_t x = hipemu::exchange(ab, 16 * k + row, "v_mfma (A)"); double ak; memcpy(&ak, &x, 8); acc = std::fma(ak, bk[k], acc); }
+        d[r] = acc;
+    }
+    return d;
+}
 template <class T> inline T __shfl(T v, int src)
 {
     static_assert(sizeof(T) <= 8, "");

@@ -135,7 +135,8 @@ static int run(int argc, char **argv)
             for (int j = 0; j < NU; ++j) printf("%s%.17g", j ? ", " : "", cmd[b * NU + j]);
             printf("], \"z\": [");
             for (int k = 0; k < nz; ++k) printf("%s%.17g", k ? ", " : "", zout[(size_t)b * nz + k]);
-            printf("], \"max_nw\": %g, \"mu\": [", ws[(size_t)b * ws_total + M.ws.scal + 12]);
+            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"mu\": [", ws[(size_t)b * ws_total + M.ws.scal + 12], ws[(size_t)b * ws_total + M.ws.scal + 1],
+                   ws[(size_t)b * ws_total + M.ws.scal + 13]);
             for (int k = 0; k < mt; ++k) printf("%s%.17g", k ? ", " : "", mu[(size_t)b * mt + k]);
             printf("]}\n");
         }
