@@ -467,9 +467,13 @@ int mpcx_lmpc_debug_set_cycle_buffer(mpcx_lmpc_t h, void *dev_ptr);
 int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_con);
 /* which kernel the last solve of a built-in system went through: 0 = nlmpc_sqp (one wavefront per instance, the reduced problem in a
  * per-instance HBM workspace), 1 | 2 | 4 = nlmpc_sqp_wg (one workgroup of that many wavefronts per instance, the reduced problem in LDS);
- * -1 = none yet.  The library chooses per launch (small systems and batches it holds resident at once: the workgroup form);
- * MPCX_NLMPC_FORM=wg|wave and MPCX_NLMPC_WAVES=1|2|4 in the environment force a form (measurements, tests/test_nlmpc_forms.py). */
+ * -1 = none yet.  This one: the last launch of the process.  MPCX_NLMPC_FORM=wg|wave, MPCX_NLMPC_WAVES=1|2|4|8 and MPCX_NLMPC_BLOCKS=1|0 in
+ * the environment force a form for the handles created afterwards (measurements, tests/test_nlmpc_forms.py). */
 int mpcx_nlmpc_debug_last_form(void);
+/* the same for the last solve of this handle (the form is a property of the controller: chosen when its bounds are set, from the plan of the
+ * workgroup form, the same for every batch size -- a shard of a batch takes the kernel the whole batch would; the overrides are read when
+ * the handle is created) */
+int mpcx_nlmpc_last_form(mpcx_nlmpc_t h);
 /* one instance's slice of the SQP workspace copied to the host, with the offsets of its arrays (NlmpcWsLayout) */
 int mpcx_nlmpc_debug_get_ws(mpcx_nlmpc_t h, int instance, double *out, int cap, int *layout, int nlayout);
 /* user hooks given as source: the translation unit the run-time compiler is fed / a compile-only check (> 0: it builds, the size of the

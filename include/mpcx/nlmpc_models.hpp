@@ -12,6 +12,12 @@
 //   cost(X, U, e, ph, params)   ObjFunHandle: X(i, j), U(i, j) are rows i = 0..ph of the (ph+1) x n matrices the
 //                               reference passes (row 0 = x0, U row ph = copy of row ph-1), e the slack
 //   ineq(k, X, U, e, ph, p)     component k of IConFunHandle's output vector, g_k <= 0
+//   COST_STAGEWISE, stage(i, X, U, ph, p)
+//                               optional: the cost is a sum over the rows i = 0..ph of X and U (plus a term in the slack alone) and stage(i)
+//                               is row i's share.  A finite difference of the cost in an entry of row i is then the difference of that
+//                               row's share -- the same quotient as (f(x + d e) - f(x)) / d of Objective.hpp:198-265 with the rows that
+//                               cancel left out (ph (nx + nu) evaluations of one row instead of the whole horizon, and without the
+//                               cancellation of two sums of ph rows); cost() itself stays the value that is reported and searched on
 //   neq_user(ph), eq(k, X, U, ph, p)
 //                               EConFunHandle: component k of the user equalities h_k = 0 (defaults: none, NoUserEq)
 //   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK, INEQ_U_ROWS_DISJOINT
@@ -68,6 +74,9 @@ struct NoUserEq {
     __host__ __device__ static bool eq_reads_x(int, int) { return true; }       // dense unless the model says otherwise
     __host__ __device__ static bool eq_reads_u(int, int) { return true; }
     static constexpr bool INEQ_U_ROWS_DISJOINT = false;                 // true: ineq_rows_of_u(i) and ineq_rows_of_u(i') share no row for i != i'
+    static constexpr bool COST_STAGEWISE = false;                       // true: stage(i, X, U, ph, p) is row i's share of the cost (see the header)
+    template <class XA, class UA>
+    __device__ static double stage(int, const XA &, const UA &, int, const double *) { return 0.0; }
     static constexpr bool XFREE_ROWS_SPARSE = false;                    // true: a user row that reads no state has at most kNlSparse non-zero entries in the
                                                                         // move-blocked inputs (+ slack); the workgroup form then keeps it as an (index, value) list
 };
@@ -95,6 +104,12 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
 #pragma unroll 8
         for (int i = 0; i <= ph; ++i) su += U(i, 0) * U(i, 0);
         return sx + su;
+    }
+    static constexpr bool COST_STAGEWISE = true;
+    template <class XA, class UA>
+    __device__ static double stage(int i, const XA &X, const UA &U, int, const double *)
+    {
+        return (X(i, 0) * X(i, 0) + X(i, 1) * X(i, 1)) + U(i, 0) * U(i, 0);
     }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *) { return U(k, 0) - 0.5; }
@@ -145,6 +160,13 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
         }
         return s + 1e-5 * e * e;
     }
+    static constexpr bool COST_STAGEWISE = true;
+    template <class XA, class UA>
+    __device__ static double stage(int i, const XA &X, const UA &U, int, const double *p)
+    {
+        const double a = X(i, 2) - p[0], b = X(i, 3) - p[1];
+        return 1e3 * (a * a + b * b) + 1e-2 * (U(i, 0) * U(i, 0) + U(i, 1) * U(i, 1));
+    }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &X, const UA &, double, int, const double *p)
     {
@@ -169,9 +191,12 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     __device__ static void f(double *dx, const double *x, const double *u, const double *p)
     {
         const double mu = p[0], k = p[1];
+        // (unrolled: with run-time subscripts the callers' copies of x and dx would live in scratch memory, a trip to HBM per element)
+#pragma unroll
         for (int i = 0; i < N; ++i) {
             dx[2 * i] = x[2 * i + 1];
             double a = mu * (1 - x[2 * i] * x[2 * i]) * x[2 * i + 1] - x[2 * i] + u[i];
+#pragma unroll
             for (int j = 0; j < N; ++j)
                 if (i != j) a += k * (x[2 * j] - x[2 * i]);
             dx[2 * i + 1] = a;
@@ -187,6 +212,17 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
         for (int j = 0; j < NU; ++j)
 #pragma unroll 8
             for (int i = 0; i <= ph; ++i) su += U(i, j) * U(i, j);
+        return sx + su;
+    }
+    static constexpr bool COST_STAGEWISE = true;
+    template <class XA, class UA>
+    __device__ static double stage(int i, const XA &X, const UA &U, int, const double *)
+    {
+        double sx = 0, su = 0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) sx += X(i, j) * X(i, j);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) su += U(i, j) * U(i, j);
         return sx + su;
     }
     template <class XA, class UA>

@@ -39,10 +39,11 @@ struct WgPlan {
     int nsx;                    // (user row, state row) pairs with a non-zero Jacobian block
     int needs_phi;              // some sub-problem row reads a state
     int f_lds;                  // the folded dynamics blocks live in LDS
+    int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
     int lds_total;              // doubles
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
-        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_yv, o_xq, o_np, o_vv, o_zd, o_wv, o_F, o_prm, o_cd, o_yd,
+        o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_xq, o_np, o_vv, o_wv, o_F, o_prm, o_cd, o_yd,
         o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
@@ -62,7 +63,13 @@ typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
 constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
-enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_ACC = 16, ST_QSTAT = 32, ST_TOTAL = 48 };
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_OVER = 15 /* the working set outgrew its capacity */, ST_ACC = 16, ST_QSTAT = 32,
+#ifdef MPCX_NL_STATS
+       ST_TOTAL = 48
+#else
+       ST_TOTAL = 32
+#endif
+};
 // -DMPCX_NL_STATS (libmpcx_stats.so): shader-clock cycles of the sub-problem's parts in st[ST_QSTAT ..]: unconstrained minimiser, warm start (the kept
 // rows' Schur complement, its factor, the shedding rounds), and per dual step: scan, entering row, N_W v, solve, N_W' r, B^-1 w, the rest
 #ifdef MPCX_NL_STATS
@@ -158,6 +165,26 @@ template <int WAVES> MPCX_WG_CALL WgSum2 wg_red_sum2(double a, double b, double 
     }
     return WgSum2{a, b};
 }
+// four reductions with one barrier; bit i of maxmask: value i is a maximum, otherwise a sum.  Takes both parities of a slot set: the
+// caller puts a barrier before its next reduction.
+struct WgRed4 { double a, b, c, d; };
+template <int WAVES> MPCX_WG_CALL WgRed4 wg_red_mix4(double a, double b, double c, double d, int maxmask, double *s)
+{
+    a = (maxmask & 1) ? wave_max(a) : wave_sum(a); b = (maxmask & 2) ? wave_max(b) : wave_sum(b);
+    c = (maxmask & 4) ? wave_max(c) : wave_sum(c); d = (maxmask & 8) ? wave_max(d) : wave_sum(d);
+    if constexpr (WAVES > 1) {
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s[w] = a; s[8 + w] = b; s[16 + w] = c; s[24 + w] = d; }
+        __syncthreads();
+        a = s[0]; b = s[8]; c = s[16]; d = s[24];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) {
+            a = (maxmask & 1) ? fmax(a, s[i]) : a + s[i]; b = (maxmask & 2) ? fmax(b, s[8 + i]) : b + s[8 + i];
+            c = (maxmask & 4) ? fmax(c, s[16 + i]) : c + s[16 + i]; d = (maxmask & 8) ? fmax(d, s[24 + i]) : d + s[24 + i];
+        }
+    }
+    return WgRed4{a, b, c, d};
+}
 // largest value and the lowest index holding it
 struct WgArgmax { double v; int idx; };
 template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, double *s)
@@ -178,15 +205,16 @@ template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, doub
 // Slot sets: set 0 is everybody's (a phase that reduces ends with a barrier, so the next phase may start over at its first parity); the scan and
 // the entering row of the dual method, which follow each other with their results in registers, have a set each and no barrier behind them --
 // a set is written again only after every thread has passed a later barrier of the step.
-constexpr int kWgRedSets = 3;
+constexpr int kWgRedDoubles = 64;     // set 0: two parities of sixteen; sets 1 and 2: one reduction per use, sixteen each
 template <int WAVES> struct Red {
     double *buf;
     int par;
-    __device__ __forceinline__ explicit Red(double *b, int set = 0) : buf(b + 32 * set), par(0) {}
+    __device__ __forceinline__ explicit Red(double *b, int set = 0) : buf(b + (set == 0 ? 0 : 16 + 16 * set)), par(0) {}
     __device__ __forceinline__ double *slots() { double *s = buf + par * 16; par ^= 1; return s; }
     __device__ __forceinline__ double sum(double v) { return wg_red_sum<WAVES>(v, slots()); }
     __device__ __forceinline__ double max(double v) { return wg_red_max<WAVES>(v, slots()); }
     __device__ __forceinline__ void argmax(double &v, int &idx) { const WgArgmax r = wg_red_argmax<WAVES>(v, idx, slots()); v = r.v; idx = r.idx; }
+    __device__ __forceinline__ WgRed4 mix4(double a, double b, double c, double d, int maxmask) { par = 0; return wg_red_mix4<WAVES>(a, b, c, d, maxmask, buf); }
     __device__ __forceinline__ void sum2(double &a, double &b) { const WgSum2 r = wg_red_sum2<WAVES>(a, b, slots()); a = r.a; b = r.b; }
 };
 
@@ -421,6 +449,15 @@ __device__ __forceinline__ void chol_delete(double *Lp, double *invd, int n, int
     nl_wave_sync();
 }
 
+// Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
+// block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
+// for the smallest systems at one wavefront per instance, whose 4 KB blocks let sixteen instances share a CU, and for the four-wavefront
+// variant of a small-state system that keeps its blocks and reduced rows in the workspace: its LDS block is a quarter of a CU's (config 3:
+// 40 KB), and four workgroups per CU deliver more than three at 168 registers did (63 k against 56 k solves/s).
+template <class Mdl, int WAVES, bool FL> struct kWgWavesPerSimdOf {
+    static constexpr int value = (WAVES == 1 && Mdl::NX <= 2) ? 4 : (WAVES == 4 && !FL && Mdl::NX <= 4) ? 4 : 2;
+};
+
 // ---- the kernel's phases ----------------------------------------------------------------------------------------------------------------
 template <class Mdl, int WAVES, bool FL>
 struct WgSqp {
@@ -607,6 +644,17 @@ struct WgSqp {
                 const Pert Xp{Xs, NX, isx ? i + 1 : -1, -1, isx ? j : -1, isx ? dx : 0.0};       // no chain rule for the state scaling (Objective.hpp:107-144)
                 const Pert Up{Us, NU, isu ? i : -1, (isu && i == ph - 1) ? ph : -1, isu ? j : -1, isu ? du : 0.0};   // the last row moves with its copy
                 const double ee = idx == nall - 2 ? e + de : (idx == nall - 1 ? e - de : e);
+                if constexpr (Mdl::COST_STAGEWISE) {
+                    // the rows of the horizon that do not see the perturbation cancel in f(x + d e) - f(x): only the one that does is evaluated
+                    if (isx || isu) {
+                        const int r = isx ? i + 1 : i;
+                        double fpl = Mdl::stage(r, Xp, Up, ph, prm), f0l = Mdl::stage(r, X0, U0, ph, prm);
+                        if (isu && i == ph - 1) { fpl += Mdl::stage(ph, Xp, Up, ph, prm); f0l += Mdl::stage(ph, X0, U0, ph, prm); }
+                        const double gk = (fpl - f0l) / (isx ? dx : du);
+                        if (isx) { lam[kk] = gk; gxg[kk] = gk; } else Jm[kk] = gk;
+                        continue;
+                    }
+                }
                 const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
                 if (isx) { const double gk = (fp - f0) / dx; lam[kk] = gk; gxg[kk] = gk; }
                 else if (isu) Jm[kk] = (fp - f0) / du;
@@ -762,8 +810,12 @@ struct WgSqp {
                     for (int a = 1; a < NX; ++a) { const double av = fabs(col[a]); if (a < NX - k && av > best) { best = av; pr = a; } }
                     pr = bcast_i(pr, k);                                 // the pivot column's choice
                     double cp = col[0];
+                    // (one tableau per wavefront: the choice is the same in every lane -- a scalar branch around the exchange, which a system whose
+                    // E is close to -I, h small, never takes)
+                    if (G != 1 || pr != 0) {
 #pragma unroll
-                    for (int a = 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[0]; }
+                        for (int a = 1; a < NX; ++a) if (a == pr) { cp = col[a]; col[a] = col[0]; }
+                    }
                     const double piv = bcast(cp, k);
                     const double cs = cp / piv;
                     double nxt[NX];
@@ -845,15 +897,22 @@ struct WgSqp {
             if (dense) for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
             int cnt = 0, ix[kNlSparse + 1];
             double ev[kNlSparse + 1];
+#pragma unroll
             for (int u = 0; u <= kNlSparse; ++u) { ix[u] = 0; ev[u] = 0.0; }
             auto put = [&](int q, double val) {
                 if (q >= nq) return;
                 if (dense) { art[q * ndld + dc] += val; return; }
                 if (val == 0.0) return;                          // the finite differences leave exact zeros outside the structure
+                // (every subscript a constant after unrolling: the two little arrays stay in registers -- through run-time subscripts they
+                // lived in scratch memory, a trip to HBM per look)
+                bool found = false;
+#pragma unroll
                 for (int u = 0; u < kNlSparse + 1; ++u) {
-                    if (u < cnt && ix[u] == q) { ev[u] += val; return; }
+                    if (!found && u < cnt && ix[u] == q) { ev[u] += val; found = true; }
                 }
-                if (cnt <= kNlSparse) { for (int u = 0; u <= kNlSparse; ++u) if (u == cnt) { ix[u] = q; ev[u] = val; } }
+                if (found) return;
+#pragma unroll
+                for (int u = 0; u <= kNlSparse; ++u) if (u == cnt) { ix[u] = q; ev[u] = val; }
                 ++cnt;
             };
             for (int i = 0; i < ph; ++i) {
@@ -881,6 +940,7 @@ struct WgSqp {
                 if (cnt > kNlSparse) st[ST_ERR] = 1.0;           // the model's promise (XFREE_ROWS_SPARSE) does not hold
                 const int cn = min(cnt, kNlSparse);
                 s1v[k] = ev[0]; s1m[k] = (cn << 16) | ix[0];
+#pragma unroll
                 for (int u = 0; u < kNlSparse; ++u) { spv[k * kNlSparse + u] = ev[u]; spi[k * kNlSparse + u] = ix[u]; }
             } else {
                 s1v[k] = 0.0; s1m[k] = kSpDense;
@@ -932,29 +992,38 @@ struct WgSqp {
         typename FP::type F = FP::get(v);
         const int a = tid & (NXP - 1), aa = min(a, NX - 1);
         const bool alive = a < NX, writes = alive && tid < NXP;
-        double fn[NX];
-        auto fetch = [&](int blk) {                             // this lane's row of block blk (its column, backward)
+        // forward: step i uses block i (from i = 1 on; v_0 = 0); backward: step i uses block i + 1 (up to i = ph - 2; l_ph = 0).
+        // The blocks of the next D steps are in flight while one is used: one step ahead hides an LDS access, four a trip to the workspace
+        // (where the blocks of a wide system live: a step's arithmetic is a few hundred cycles, the trip a thousand and more).
+        constexpr int D = FL ? 1 : 4;
+        double fq[D][NX], rq[D];
+        auto blk_of = [&](int step) { return BACKWARD ? ph - step : step; };            // (step >= 1)
+        auto row_of = [&](int step) { return BACKWARD ? ph - 1 - step : step; };
+        auto fetch = [&](int d, int step) {                     // this lane's row of the step's block (its column, backward) and right-hand side
+            const int blk = blk_of(step);
 #pragma unroll
-            for (int bb = 0; bb < NX; ++bb) fn[bb] = !alive ? 0.0 : (BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb]);
+            for (int bb = 0; bb < NX; ++bb)
+                fq[d][bb] = (!alive || step == 0) ? 0.0 : (BACKWARD ? F[(size_t)(blk * NX + bb) * FW + aa] : F[(size_t)(blk * NX + aa) * FW + bb]);
+            rq[d] = alive ? io[row_of(step) * NX + aa] : 0.0;
         };
-        // forward: step i uses block i (from i = 1 on; v_0 = 0); backward: step i uses block i + 1 (up to i = ph - 2; l_ph = 0)
 #pragma unroll
-        for (int bb = 0; bb < NX; ++bb) fn[bb] = 0.0;
+        for (int d = 0; d < D; ++d) if (d < ph) fetch(d, d);
         double x = 0.0;
-        double rh = alive ? io[(BACKWARD ? ph - 1 : 0) * NX + aa] : 0.0;
-        for (int step = 0; step < ph; ++step) {
-            const int i = BACKWARD ? ph - 1 - step : step;
-            double fc[NX];
+        for (int step0 = 0; step0 < ph; step0 += D) {
 #pragma unroll
-            for (int bb = 0; bb < NX; ++bb) fc[bb] = fn[bb];
-            const double rc = rh;
-            if (step + 1 < ph) {
-                fetch(BACKWARD ? i : i + 1);
-                rh = alive ? io[(BACKWARD ? i - 1 : i + 1) * NX + aa] : 0.0;
+            for (int d = 0; d < D; ++d) {
+                const int step = step0 + d;
+                if (step < ph) {
+                    double fc[NX];
+#pragma unroll
+                    for (int bb = 0; bb < NX; ++bb) fc[bb] = fq[d][bb];
+                    const double rc = rq[d];
+                    if (step + D < ph) fetch(d, step + D);
+                    const double s = ChainDot<0>::run(fc, x, 0.0);       // (zero on the first step: fc = 0)
+                    x = alive ? (BACKWARD ? s - rc : s + rc) : 0.0;
+                    if (writes) io[row_of(step) * NX + aa] = x;
+                }
             }
-            const double s = ChainDot<0>::run(fc, x, 0.0);       // (zero on the first step: fc = 0)
-            x = alive ? (BACKWARD ? s - rc : s + rc) : 0.0;
-            if (writes) io[i * NX + aa] = x;
         }
         nl_wave_sync();
     }
@@ -1040,53 +1109,53 @@ struct WgSqp {
 #pragma unroll
                     for (int jq = 0; jq < NU; ++jq) old[jq] = art[(blk * NU + jq) * ndld + dc];
                 };
-                if (top >= 0) {
-                    if constexpr (PF) fetch(top);
-                    fetch_old(min(top, ch - 1));
-                }
-                for (int sI = top; sI >= 0; --sI) {
-                    // w_s joins the multiplier
-                    if (user) {
-                        if ((mk >> sI) & 1ull) {
-                            const int sl = jo + __builtin_popcountll(mk & ((1ull << sI) - 1ull));
+                // (every lane walks the whole horizon, idle above its own top: the same step everywhere, so that the block's entries are one broadcast)
+                if constexpr (PF) fetch(ph - 1);
+                if (top >= 0) fetch_old(min(top, ch - 1));
+                for (int sI = ph - 1; sI >= 0; --sI) {
+                    if (sI <= top) {
+                        // w_s joins the multiplier
+                        if (user) {
+                            if ((mk >> sI) & 1ull) {
+                                const int sl = jo + __builtin_popcountll(mk & ((1ull << sI) - 1ull));
 #pragma unroll
-                            for (int a = 0; a < NX; ++a) l[a] += jx[sl * NX + a];
+                                for (int a = 0; a < NX; ++a) l[a] += jx[sl * NX + a];
+                            }
+                        } else if (sI == bs) {
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) if (a == ba) l[a] += bsg;
                         }
-                    } else if (sI == bs) {
+                        auto Fe = [&](int a, int c) -> double { if constexpr (PF) return fb[a * FW + c]; else return F[(size_t)(sI * NX + a) * FW + c]; };
+                        // inputs and offset
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) if (a == ba) l[a] += bsg;
-                    }
-                    auto Fe = [&](int a, int c) -> double { if constexpr (PF) return fb[a * FW + c]; else return F[(size_t)(sI * NX + a) * FW + c]; };
-                    // inputs and offset
+                        for (int jq = 0; jq < NU; ++jq) {
+                            double sacc = acc[jq];
 #pragma unroll
-                    for (int jq = 0; jq < NU; ++jq) {
-                        double sacc = acc[jq];
-#pragma unroll
-                        for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, NX + jq), l[a], sacc);
-                        acc[jq] = sacc;
-                    }
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) cst = fma(Fe(a, FW - 1), l[a], cst);
-                    if (sI <= ch - 1) {                            // the last step of this input block: file it, ask for the next block's entries
-                        const int blk = sI;
-#pragma unroll
-                        for (int jq = 0; jq < NU; ++jq) { art[(blk * NU + jq) * ndld + dc] = old[jq] + acc[jq]; acc[jq] = 0.0; }
-                        if (sI > 0) fetch_old(sI - 1);
-                    }
-                    // l_{s-1} = Abar_s' l_s (w_{s-1} joins at the top of the next step)
-                    if (sI > 0) {
-                        double ln[NX];
-#pragma unroll
-                        for (int b2 = 0; b2 < NX; ++b2) {
-                            double sacc = 0.0;
-#pragma unroll
-                            for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, b2), l[a], sacc);
-                            ln[b2] = sacc;
+                            for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, NX + jq), l[a], sacc);
+                            acc[jq] = sacc;
                         }
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) l[a] = ln[a];
-                        if constexpr (PF) fetch(sI - 1);         // (all of the block's entries in one batch of broadcast reads)
+                        for (int a = 0; a < NX; ++a) cst = fma(Fe(a, FW - 1), l[a], cst);
+                        if (sI <= ch - 1) {                        // the last step of this input block: file it, ask for the next block's entries
+#pragma unroll
+                            for (int jq = 0; jq < NU; ++jq) { art[(sI * NU + jq) * ndld + dc] = old[jq] + acc[jq]; acc[jq] = 0.0; }
+                            if (sI > 0) fetch_old(sI - 1);
+                        }
+                        // l_{s-1} = Abar_s' l_s (w_{s-1} joins at the top of the next step)
+                        if (sI > 0) {
+                            double ln[NX];
+#pragma unroll
+                            for (int b2 = 0; b2 < NX; ++b2) {
+                                double sacc = 0.0;
+#pragma unroll
+                                for (int a = 0; a < NX; ++a) sacc = fma(Fe(a, b2), l[a], sacc);
+                                ln[b2] = sacc;
+                            }
+#pragma unroll
+                            for (int a = 0; a < NX; ++a) l[a] = ln[a];
+                        }
                     }
+                    if constexpr (PF) { if (sI > 0) fetch(sI - 1); }     // (all of the next block's entries in one batch of broadcast reads)
                 }
                 if (top >= 0) br[k] += cst;
             }
@@ -1352,7 +1421,7 @@ struct WgSqp {
             v0[q] = y; v1[q] = Bs;
             sBs += sv[q] * Bs; sy += sv[q] * y;
         }
-        sBs = R.sum(sBs); sy = R.sum(sy);
+        R.sum2(sBs, sy);
         if (sy < 0.2 * sBs) {
             const double th = 0.8 * sBs / (sBs - sy);
             for (int q = tid; q < nq; q += NT) v0[q] = th * v0[q] + (1 - th) * v1[q];
@@ -1376,31 +1445,6 @@ struct WgSqp {
     }
 
     // ------------------------------------------------------------------------------------------------------------------------------
-    // tq <- S^-1 tq over the working set with its factor (wavefront 0); y = L^-1 tq is left in yv: the factor's next row if the entering
-    // row joins
-    static MPCX_WG_PHASE void ws_solve(int nw)
-    {
-        const V v; const auto &P = v.A->P;
-        const int tid = threadIdx.x, lane = tid & 63;
-        double *tq = v.at(P.o_tq), *yv = v.at(P.o_yv);
-        if (tid < 64) {
-            const double *Lp = v.at(P.o_L), *invd = v.at(P.o_invd);
-            double t0 = lane < nw ? tq[lane] : 0.0, t1 = lane + 64 < nw ? tq[lane + 64] : 0.0;
-            if (v.kw <= 64) {
-                tri_forward<false>(Lp, invd, nw, t0, t1, lane);
-                if (lane < nw) yv[lane] = t0;
-                tri_backward<false>(Lp, invd, nw, t0, t1, lane);
-            } else {
-                tri_forward<true>(Lp, invd, nw, t0, t1, lane);
-                if (lane < nw) yv[lane] = t0;
-                if (lane + 64 < nw) yv[lane + 64] = t1;
-                tri_backward<true>(Lp, invd, nw, t0, t1, lane);
-            }
-            if (lane < nw) tq[lane] = t0;
-            if (lane + 64 < nw) tq[lane + 64] = t1;
-        }
-        T::sync();
-    }
     // row t leaves the working set of nw rows: the factor is down-dated, the lists close up
     static MPCX_WG_PHASE void ws_drop(int kdrop, int nw)
     {
@@ -1500,7 +1544,7 @@ struct WgSqp {
     // registers ARE the B operands of the second product (register r of the accumulator holds rows 4 r .. 4 r + 3 of the block in the
     // layout a k-step wants), so N_W[:, block] V[block, :] follows without V ever leaving the registers.  The wavefronts' partial sums meet
     // in the factor's storage in a fixed order (wavefront 0 stores, 1 .. add in turn): the same bits on every run.  Up to 64 kept rows.
-    static constexpr int kSchurTiles = 4;
+    static constexpr int kSchurTiles = kWgWavesPerSimdOf<Mdl, WAVES, FL>::value >= 3 ? 2 : 4;    // (the accumulators of ten tiles do not fit a 128-register budget)
     static MPCX_WG_PHASE void ws_schur_mfma(int nw)
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
@@ -1632,7 +1676,7 @@ struct WgSqp {
         const Sp sp(v);
         const Ws W(v);
         double *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq), *invd = v.at(P.o_invd),
-               *Lp = v.at(P.o_L), *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
+               *Lp = v.at(P.o_L), *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         const int *dcol = v.iat(P.o_dcol);
         Red<WAVES> R(v.at(P.o_red));
@@ -1713,7 +1757,7 @@ struct WgSqp {
         const Ws W(v);
         double *gr = v.at(P.o_gr), *hinv = v.at(P.o_hinv), *br = v.at(P.o_br), *mu = v.at(P.o_mu), *p = v.at(P.o_p),
                *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *tq = v.at(P.o_tq),
-               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *zd = v.at(P.o_zd), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
+               *xq = v.at(P.o_xq), *np_ = v.at(P.o_np), *vv = v.at(P.o_vv), *wv = v.at(P.o_wv), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         const int *dcol = v.iat(P.o_dcol);
         Red<WAVES> R(v.at(P.o_red));
@@ -1744,7 +1788,7 @@ struct WgSqp {
             const int pidx = worst.idx;
             if (mt == 0 || vmax <= 1e-12) { done = true; break; }        // primal feasible: optimal
             ++nsteps;
-            if (nw >= KW) { fail = -3; break; }                          // working set full
+            if (nw >= KW) { fail = -3; if (tid == 0) st[ST_OVER] = 1.0; break; }      // working set full
             // an equality enters oriented so that it reads "n'p + b <= 0, violated"; it is never shed afterwards
             const bool p_is_eq = is_eq(pidx);
             double sgn = 1.0;
@@ -1796,7 +1840,7 @@ struct WgSqp {
         for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
         T::sync();
         for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
-        for (int q = tid; q < nr; q += NT) p[q] = q < nq ? xq[q] : 0.0;
+        if (tid == 0 && nq < nr) xq[nq] = 0.0;                  // (p is xq: without a slack variable its last entry stays zero)
         T::sync();
         MPCX_QLAP(10);
         return nw;
@@ -1830,8 +1874,8 @@ struct WgSqp {
         for (int q = tid; q < nr; q += NT) { dmax = fmax(dmax, fabs(p[q])); gd += gu[q] * p[q]; }
         for (int k = tid; k < nz; k += NT) zmax = fmax(zmax, fabs(z[k]));
         for (int k = mi + tid; k < m; k += NT) cmax = fmax(cmax, fabs(gin[k]));       // user equalities count as defects
-        dmax = R.max(dmax); cmax = R.max(cmax); gd = R.sum(gd); zmax = R.max(zmax);
-        if (tid == 0) { st[ST_R0] = dmax; st[ST_R1] = cmax; st[ST_R2] = gd; st[ST_R3] = zmax; }
+        const WgRed4 r4 = R.mix4(dmax, cmax, gd, zmax, 0xB);
+        if (tid == 0) { st[ST_R0] = r4.a; st[ST_R1] = r4.b; st[ST_R2] = r4.c; st[ST_R3] = r4.d; }
         T::sync();
     }
 
@@ -1886,12 +1930,11 @@ struct WgSqp {
             lam_max = tid == 0 ? st[ST_LAMDYN] : 0.0;
         }
         for (int t = tid; t < nw; t += NT) lam_max = fmax(lam_max, fabs(uq[t]));
-        lam_max = R.max(lam_max);
         double viol = 0;
         for (int k = tid; k < nxs; k += NT) viol += fabs(c[k]);
         for (int k = tid; k < m; k += NT) viol += k < mi ? fmax(gin[k], 0.0) : fabs(gin[k]);
-        viol = R.sum(viol);
-        if (tid == 0) { st[ST_R0] = lam_max; st[ST_R1] = viol; }
+        const WgRed4 r4 = R.mix4(lam_max, viol, 0.0, 0.0, 0x1);
+        if (tid == 0) { st[ST_R0] = r4.a; st[ST_R1] = r4.b; }
         T::sync();
     }
 
@@ -2001,8 +2044,8 @@ struct WgSqp {
             z[k] = zn;
             s1 += fabs(dk); z1 += fabs(zn); smax = fmax(smax, fabs(dk));
         }
-        s1 = R.sum(s1); z1 = R.sum(z1); smax = R.max(smax);
-        if (tid == 0) { st[ST_R0] = s1; st[ST_R1] = z1; st[ST_R2] = smax; }
+        const WgRed4 r4 = R.mix4(s1, z1, smax, 0.0, 0x4);
+        if (tid == 0) { st[ST_R0] = r4.a; st[ST_R1] = r4.b; st[ST_R2] = r4.c; }
         T::sync();
     }
 
@@ -2084,12 +2127,7 @@ struct WgSqp {
     }
 };
 
-// Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
-// block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
-// for the smallest systems at one wavefront per instance, whose 4 KB blocks let sixteen instances share a CU.
-// A problem of several wavefronts whose blocks and reduced rows live in the workspace (FL = false) is built for three workgroups per CU
-// (170 registers): its LDS block is a third of a CU's, and the third workgroup is what pays for the global fetches.
-template <class Mdl, int WAVES, bool FL = true> constexpr int kWgWavesPerSimd = (WAVES == 1 && Mdl::NX <= 2) ? 4 : (WAVES == 4 && !FL && Mdl::NX <= 4) ? 3 : 2;
+template <class Mdl, int WAVES, bool FL = true> constexpr int kWgWavesPerSimd = kWgWavesPerSimdOf<Mdl, WAVES, FL>::value;
 // Eight wavefronts per instance: for a system whose LDS block fills a CU alone (config 5: 153 KB).  Four wavefronts would leave every SIMD with
 // one -- nothing to issue while a dependent operation is in flight; eight put two on each, at the same 256 registers, and the phases that are
 // loops over steps, perturbations or matrix rows (evaluation, line search, products with B^-1) take half the rounds.  Instantiated for wide states only.
@@ -2108,6 +2146,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
     double *sm = wg_lds();
     const double *st = sm + P.o_st;
     // shader-clock cycles per phase (tools/nlmpc_phases.py): evaluate (cost, dynamics, constraints), condense, BFGS, sub-problem, step, merit, line search, update
+    if (P.only_overflowed && S.ws[(size_t)b * M.ws.total + P.w_scal + 14] != 1.0) return;      // (uniform over the workgroup, before any barrier)
     long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
 #ifdef MPCX_EMU_TRACE
     auto lap = [&](int k) { const long long now = hipemu::st().n_block_syncs; cyc[k] += now - tstamp; tstamp = now; };    // (the interpreter: barriers per phase)
@@ -2200,6 +2239,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         scal[1] = st[ST_R5];
         scal[12] = st[ST_R5 + 1];                                // the largest working set of the solve
         scal[13] = st[ST_NSHED];
+        scal[14] = st[ST_OVER];                                  // 1: a pass with the full capacity has to take this instance again
 #ifdef MPCX_NL_STATS
         for (int k = 0; k < 12; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
 #endif
@@ -2213,7 +2253,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 // the LDS / workspace plan of the workgroup form for controller m (dimensions, bounds) and the hard / soft flag; 0, or -2 if the
 // shape does not fit (the caller falls back to nlmpc_sqp)
 template <class Mdl>
-inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1)
+inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1, bool cut_ok = true, int lds_per_cu = 160 * 1024)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
@@ -2245,14 +2285,15 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         int o = kWgCtxDoubles;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         P.kw = kw; P.f_lds = f_lds;
-        P.o_red = take(32 * kWgRedSets); P.o_st = take(ST_TOTAL);
-        P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr); P.o_p = take(nr);
+        P.o_red = take(kWgRedDoubles); P.o_st = take(ST_TOTAL);
+        P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr);
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
         P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
         P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = f_lds ? take(nr * P.ndld) : 0;
-        P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw); P.o_yv = take(kw);
-        P.o_xq = take(nr); P.o_np = take(nr); P.o_vv = take(nr); P.o_zd = take(nr); P.o_wv = take(nr);
+        P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw);
+        P.o_xq = take(nr); P.o_p = P.o_xq;        // (the sub-problem's iterate is the step when it ends)
+        P.o_np = take(nr); P.o_vv = take(nr); P.o_wv = take(nr);
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
         P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2); P.o_drow = take((P.nd_user + 1) / 2);
@@ -2269,21 +2310,22 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     // How many workgroups a CU holds is decided by the LDS block (160 KB per CU): with one wavefront per SIMD nothing hides the latency of
     // a dependent LDS access, a second or third workgroup does.  The plan therefore takes the smallest budget (most workgroups per CU, up to
     // the 32 wavefronts a CU runs) that holds the whole problem; where only the factor of the largest possible working set stands in the
-    // way of one more workgroup per CU, its capacity is cut -- not below 48 rows: a working set that outgrows it ends the solve with
-    // nlopt's OUT_OF_MEMORY code (status ERROR), as one beyond kNlMaxWorking always did.
-    const int kw_floor = imin(kw_full, 48);
+    // way of one more workgroup per CU, its capacity is cut -- not below 46 rows.  An instance whose working set outgrows the cut capacity is marked
+    // (scal[14]) and taken again by a second launch planned with cut_ok = false (WgPlan::only_overflowed: every other workgroup of that launch
+    // returns at once); only one beyond kNlMaxWorking ends with nlopt's OUT_OF_MEMORY code (status ERROR), as it always did.
+    const int kw_floor = imin(kw_full, 46);
     bool placed = false;
     auto place = [&]() {
         placed = false;
         for (int per_cu = imin(16, 32 / P.waves); per_cu >= 1 && !placed; --per_cu) {
-            const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)15;
+            const size_t budget = (size_t)(lds_per_cu / per_cu) & ~(size_t)15;
             for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
                 if (blocks_wanted >= 0 && f_lds != (blocks_wanted ? 1 : 0)) continue;
                 // the registers of the variant (kWgWavesPerSimd) bound the workgroups per CU as well
                 const int by_regs = 4 * (P.waves == 8 ? 2 : P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
                 if (per_cu > by_regs) continue;
                 if (layout(kw_full, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
-                if (per_cu == 1) continue;                      // (alone on the CU the factor keeps its full capacity)
+                if (per_cu == 1 || !cut_ok) continue;           // (alone on the CU the factor keeps its full capacity)
                 int kw = kw_full;
                 while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
                 if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
@@ -2332,7 +2374,8 @@ int launch_solve_wg(const NlmpcDev *m, const NlmpcSolveDev *b, const WgPlan *P, 
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
-        if (getenv("MPCX_DEBUG_OCCUPANCY")) {
+        static const bool show = getenv("MPCX_DEBUG_OCCUPANCY") != nullptr;      // (read once)
+        if (show) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, P->waves * 64, lds);
             fprintf(stderr, "nlmpc_sqp_wg: %d workgroups of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; blocks in LDS %d\n",

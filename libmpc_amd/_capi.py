@@ -72,7 +72,7 @@ EXPORTS = [
     # profiling and testing aids (declared in include/mpcx.h under that heading)
     "mpcx_lmpc_debug_time_kernels", "mpcx_lmpc_debug_get", "mpcx_lmpc_debug_setup_counts", "mpcx_lmpc_debug_use_fused",
     "mpcx_lmpc_debug_force_generic", "mpcx_lmpc_debug_set_rounds", "mpcx_lmpc_debug_set_cycle_buffer",
-    "mpcx_nlmpc_debug_set_tolerances", "mpcx_nlmpc_debug_last_form", "mpcx_nlmpc_debug_get_ws", "mpcx_nlmpc_debug_generated_source", "mpcx_nlmpc_debug_compile_source",
+    "mpcx_nlmpc_debug_set_tolerances", "mpcx_nlmpc_debug_last_form", "mpcx_nlmpc_last_form", "mpcx_nlmpc_debug_get_ws", "mpcx_nlmpc_debug_generated_source", "mpcx_nlmpc_debug_compile_source",
 ]
 
 

@@ -16,6 +16,11 @@ void nlmpc_plan_host(NlmpcDev &m);
 int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream);
 int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream);
 int nlmpc_last_form();
+// the launcher's per-handle state for the built-in systems (nlmpc_kernels.hip): overrides read once, the device's limits, the cached plans
+void *nlmpc_zoo_new();
+void nlmpc_zoo_free(void *z);
+int nlmpc_zoo_last_form(void *z);
+long nlmpc_zoo_layout_signature(void *z, const NlmpcDev *m, int hard);
 // run-time compiled hooks (nlmpc_jit.cpp)
 void nlmpc_jit_release(void *jit);
 }
@@ -28,6 +33,8 @@ struct mpcx_nlmpc {
     mpcx::nlmpc_launch_solve_fn launch_solve = mpcx::nlmpc_launch_solve;
     void *launch_ctx = nullptr;
     void *jit = nullptr;                 // run-time compiled module (nlmpc_jit.cpp), released with the handle
+    void *zoo = nullptr;                 // built-in systems: the launcher's state (form, plans), = launch_ctx
+    long curv_sig = -1;                  // layout signature of the solve that left its curvature estimate in the workspace
     double *params_d = nullptr;
     int n_params = 0;                   // parameters of the built-in system (0: none, or a hook model)
     double *scale_d = nullptr;           // input scaling [nu] | state scaling [nx] (Mapping.hpp:71-86), ones by default
@@ -82,8 +89,10 @@ struct mpcx_nlmpc {
         }
         if (!ok) return MPCX_E_DEVICE;
         dev.zlb = d; dev.zub = d + nz; dev.bnd_val = dval; dev.bnd_sign = dsign; dev.bnd_idx = didx;
+        const int nbs_before = dev.nbnd_state;
         dev.nbnd_state = 0;
         for (int k : idx) dev.nbnd_state += k < dev.ph * dev.nx ? 1 : 0;
+        if (dev.nbnd_state != nbs_before) solved_batch = 0;      // (the workgroup form's layout depends on it: no carried curvature across the change)
         if (nb != dev.nbnd) {                       // the workspace layout depends on the number of rows
             dev.nbnd = nb;
             mpcx::nlmpc_plan_host(dev);
@@ -121,6 +130,7 @@ static int finish_create(mpcx_nlmpc *h, mpcx_nlmpc_t *out)
         mpcx_nlmpc_destroy(h);
         return capi_fail(MPCX_E_DEVICE, "could not upload the scalings");
     }
+    if (h->launch_solve == mpcx::nlmpc_launch_solve && !h->launch_ctx) { h->zoo = mpcx::nlmpc_zoo_new(); h->launch_ctx = h->zoo; }
     *out = h;
     return MPCX_OK;
 }
@@ -202,6 +212,7 @@ int mpcx_nlmpc_destroy(mpcx_nlmpc_t h)
     if (h->scale_d) (void)hipFree(h->scale_d);
     if (h->hook_ws) (void)hipFree(h->hook_ws);
     if (h->jit) mpcx::nlmpc_jit_release(h->jit);
+    if (h->zoo) mpcx::nlmpc_zoo_free(h->zoo);
     if (h->ws) (void)hipFree(h->ws);
     if (h->bnd_block) (void)hipFree(h->bnd_block);
     delete h;
@@ -321,7 +332,9 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
         if (h->n_params <= 0) return capi_fail(MPCX_E_INVALID, "this model has no parameters to give per instance");
         s.params_b = b->params; s.nparams = h->n_params;
     }
-    s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch) ? 1 : 0;
+    // carried curvature: only from a solve of the same batch that left it in the layout the next launch will read (form, wavefronts, offsets)
+    const long sig = h->zoo ? mpcx::nlmpc_zoo_layout_signature(h->zoo, &h->dev, s.hard) : 0;
+    s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch && sig >= 0 && sig == h->curv_sig) ? 1 : 0;
     h->solved_batch = b->batch;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
     s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input; s.seq_output = b->seq_output;
@@ -334,7 +347,8 @@ int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stre
     const int rc = prepare_solve(h, b, s);
     if (rc != MPCX_OK) return rc > 0 ? MPCX_OK : rc;
     const int lr = h->launch_solve(h->launch_ctx, &h->dev, &s, stream);
-    if (lr != 0) return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")");
+    if (lr != 0) { h->solved_batch = 0; return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")"); }
+    h->curv_sig = h->zoo ? mpcx::nlmpc_zoo_layout_signature(h->zoo, &h->dev, s.hard) : 0;
     return MPCX_OK;
 }
 
@@ -428,6 +442,8 @@ extern "C" int mpcx_discretize_batch(int device, int nx, int nu, int batch, cons
 // Which kernel the last solve of a built-in system went through (bench.py names it): 0 = nlmpc_sqp (one wavefront per instance),
 // 1 | 2 | 4 = nlmpc_sqp_wg with that many wavefronts per instance, -1 = none yet
 extern "C" int mpcx_nlmpc_debug_last_form(void) { return mpcx::nlmpc_last_form(); }
+// ... and the last solve of THIS handle (the one above is the last launch of the process, whoever made it)
+extern "C" int mpcx_nlmpc_last_form(mpcx_nlmpc_t h) { return (h && h->zoo) ? mpcx::nlmpc_zoo_last_form(h->zoo) : (h ? 0 : -1); }
 
 // Experiment knob (not part of include/mpcx.h): the step / defect thresholds of the solver's own convergence test
 extern "C" int mpcx_nlmpc_debug_set_tolerances(mpcx_nlmpc_t h, double tol_step, double tol_con)

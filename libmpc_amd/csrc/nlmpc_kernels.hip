@@ -4,6 +4,7 @@
 // translation unit (mpcx/nlmpc_hooks.hpp) or in a run-time compiled module (nlmpc_jit.cpp).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -33,45 +34,96 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // Two forms of the SQP for the built-in systems (mpcx_nlmpc_solve_batch):
 //   * nlmpc_sqp_wg (mpcx/nlmpc_sqp_wg.hpp): one workgroup per instance, the reduced problem in LDS, no streaming of a workspace through HBM;
 //   * nlmpc_sqp (mpcx/nlmpc_engine.hpp): one wavefront per instance, the reduced problem in a per-instance HBM workspace.
-// Which one is faster is a matter of how many instances a CU holds at once -- both are bound by the issue latency of dependent
-// instructions at one or two wavefronts per SIMD (tools/micro/latency.hip): the LDS-resident form holds 160 KB /
-// (its LDS block) instances per CU, the workspace form eight.  Measured on MI355X (profiles/r04_nlmpc_forms.txt): the workgroup form wins
-// where an instance needs one wavefront and a few KB of LDS (config 1), the wavefront form where the LDS block is tens of KB (configs 3, 5).
-// The default follows that, and takes the workgroup form for a batch that it holds resident all at once (latency: each instance on its own
-// wavefronts); MPCX_NLMPC_FORM=wg|wave forces one, MPCX_NLMPC_WAVES=1|2|4 the wavefronts per instance of the workgroup form.
-// which form the last launch of a built-in system took: 0 = nlmpc_sqp, 1 | 2 | 4 = nlmpc_sqp_wg with that many wavefronts per instance
-// (nlmpc_wg_kernels.hip)
-int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks);
+// Both are bound by the issue latency of dependent instructions; what a CU delivers is (instances resident) / (latency of one), the first set
+// by the LDS block of the workgroup form.  The choice is a property of the CONTROLLER, not of the batch handed to one
+// call: it is made once per handle and bound set (NlmpcZoo below) from the plan alone, so that a shard of a batch takes the kernel the
+// whole batch would (the only thing a batch changes is where the folded blocks live -- LDS when the batch is resident with them there -- and
+// that changes no arithmetic).  MPCX_NLMPC_FORM=wg|wave, MPCX_NLMPC_WAVES=1|2|4|8 and MPCX_NLMPC_BLOCKS=1|0 override; they are read when
+// the handle is created, never on the solve path.
+int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu);
 int nlmpc_wg_launch(const NlmpcDev *m, const NlmpcSolveDev *b, const engine::WgPlan *P, void *stream);
 
-static int g_last_form = -1;
-int nlmpc_last_form() { return g_last_form; }
+static std::atomic<int> g_last_form{-1};
+int nlmpc_last_form() { return g_last_form.load(std::memory_order_relaxed); }
 
-int nlmpc_launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
+// per-handle state of the launcher: the overrides, the device's limits, the plans of the current (hard / soft, bounds) shape
+struct NlmpcZoo {
+    int env_form = -1, env_waves = 0, env_blocks = -1;          // -1 / 0: not set
+    int lds_per_cu = 160 * 1024, cus = 256;
+    int last_form = -1;
+    // cache key and plans: throughput plan (most workgroups per CU; blocks where it puts them), the plan with the blocks in LDS, and the
+    // plans of the second pass (full working-set capacity) for either
+    int k_hard = -1, k_nbnd = -1, k_nbnd_state = -1, k_ws_total = -1;
+    bool fits = false, has_lds = false, has_full = false, has_lds_full = false;
+    engine::WgPlan P{}, Q{}, Pfull{}, Qfull{};
+};
+
+void *nlmpc_zoo_new()
+{
+    NlmpcZoo *z = new NlmpcZoo;
+    const char *form = getenv("MPCX_NLMPC_FORM"), *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");
+    if (form) z->env_form = !strcmp(form, "wave") ? 0 : (!strcmp(form, "wg") ? 1 : -1);
+    if (wv) z->env_waves = atoi(wv);
+    if (bl) z->env_blocks = atoi(bl) ? 1 : 0;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) z->lds_per_cu = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) z->cus = v;
+    }
+    return z;
+}
+void nlmpc_zoo_free(void *z) { delete static_cast<NlmpcZoo *>(z); }
+int nlmpc_zoo_last_form(void *z) { return z ? static_cast<NlmpcZoo *>(z)->last_form : -1; }
+// a signature of the layout the last solve left its curvature estimate in (form, wavefronts, where the packed matrix lies): carried curvature
+// is only valid for the same one
+long nlmpc_zoo_layout_signature(void *zp, const NlmpcDev *m, int hard)
+{
+    NlmpcZoo *z = static_cast<NlmpcZoo *>(zp);
+    if (!z || z->last_form < 0) return -1;
+    if (z->last_form == 0) return 0;
+    return 1 + z->P.w_hinv * 16L + z->P.waves + 1000003L * (z->k_nbnd_state + 1) + (hard ? 7 : 0);
+}
+
+int nlmpc_launch_solve(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
     return dispatch_model(m->model_id, [&](auto mdl) {
         using Mdl = decltype(mdl);
-        const char *form = getenv("MPCX_NLMPC_FORM");
-        const bool force_wave = form && !strcmp(form, "wave"), force_wg = form && !strcmp(form, "wg");
-        if (!force_wave) {
-            engine::WgPlan P;
-            const char *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");   // (BLOCKS=1|0: folded blocks and reduced rows in LDS | workspace)
-            auto plan = [&](engine::WgPlan &X, int blocks) { return nlmpc_wg_plan(*m, b->hard, wv ? atoi(wv) : 0, m->nbnd_state, X, blocks) == 0 && X.ws_total <= m->ws.total; };
-            // throughput: one wavefront per instance and a CU full of instances; latency: a batch that is resident all at once in the
-            // workgroup form (every instance on its own four wavefronts) finishes in half the time of the same batch in the wavefront form.
-            // The plan with the most workgroups per CU first; where that keeps the folded blocks and the reduced rows in the workspace
-            // (config 3: three per CU, 12.0 ms a solve) and the batch is resident with them in LDS too (two per CU, 9.7 ms), that one.
-            // A problem that fills a CU's LDS alone (config 5) is still ahead at two rounds: 71 ms against 94 at 512 instances.
-            auto resident = [&](const engine::WgPlan &X, int rounds) { return (long)b->batch <= 256L * X.per_cu * rounds; };
-            bool fits = plan(P, bl ? atoi(bl) : -1);
-            if (!bl && fits && P.waves > 1 && !P.f_lds) {
-                engine::WgPlan Q;
-                if (plan(Q, 1) && Q.waves > 1 && resident(Q, 1)) P = Q;
+        NlmpcZoo local;
+        NlmpcZoo *z = ctx ? static_cast<NlmpcZoo *>(ctx) : &local;
+        if (z->env_form != 0) {
+            if (z->k_hard != b->hard || z->k_nbnd != m->nbnd || z->k_nbnd_state != m->nbnd_state || z->k_ws_total != m->ws.total) {
+                auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok) {
+                    return nlmpc_wg_plan(*m, b->hard, z->env_waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu) == 0 && X.ws_total <= m->ws.total;
+                };
+                z->k_hard = b->hard; z->k_nbnd = m->nbnd; z->k_nbnd_state = m->nbnd_state; z->k_ws_total = m->ws.total;
+                z->fits = plan(z->P, z->env_blocks, true);
+                z->has_lds = z->fits && z->env_blocks < 0 && z->P.waves > 1 && !z->P.f_lds && plan(z->Q, 1, true) && z->Q.waves > 1;
+                z->has_full = z->fits && plan(z->Pfull, z->P.f_lds, false) && z->Pfull.kw > z->P.kw && z->Pfull.waves == z->P.waves;
+                z->has_lds_full = z->has_lds && plan(z->Qfull, 1, false) && z->Qfull.kw > z->Q.kw && z->Qfull.waves == z->Q.waves;
+                if (z->fits && z->Pfull.kw <= z->P.kw) z->has_full = false;
             }
-            if (fits && (force_wg || P.waves == 1 || resident(P, P.per_cu == 1 ? 2 : 1))) { g_last_form = P.waves; return nlmpc_wg_launch(m, b, &P, stream); }
-            if (force_wg) return -2;
+            if (z->fits) {
+                // the blocks in LDS where the whole batch is resident with them there (the latency form: config 3 at up to two instances per CU)
+                const bool lds_plan = z->has_lds && (long)b->batch <= (long)z->cus * z->Q.per_cu;
+                const engine::WgPlan &X = lds_plan ? z->Q : z->P;
+                int rc = nlmpc_wg_launch(m, b, &X, stream);
+                if (rc == 0) {
+                    // working sets that outgrew a capacity the plan had cut: those instances again, with the full one
+                    const bool again = lds_plan ? z->has_lds_full : z->has_full;
+                    if (again) {
+                        engine::WgPlan Y = lds_plan ? z->Qfull : z->Pfull;
+                        Y.only_overflowed = 1;
+                        NlmpcSolveDev b2 = *b;
+                        b2.keep_curvature = 0;                  // (the first pass left its own estimate where this layout does not look)
+                        rc = nlmpc_wg_launch(m, &b2, &Y, stream);
+                    }
+                    if (rc == 0) { z->last_form = X.waves; g_last_form.store(X.waves, std::memory_order_relaxed); return 0; }
+                }
+                if (z->env_form == 1) return rc;                // forced: report
+                // otherwise (an attribute or launch error on this device): the wavefront form still runs
+            } else if (z->env_form == 1) return -2;
         }
-        g_last_form = 0;
+        z->last_form = 0; g_last_form.store(0, std::memory_order_relaxed);
         return engine::launch_solve<Mdl>(nullptr, m, b, stream);
     });
 }
