@@ -439,6 +439,10 @@ int mpcx_lmpc_hetero_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b,
 int mpcx_lmpc_hetero_time_solve_batch(mpcx_lmpc_hetero_t f, const mpcx_lmpc_batch *b, const int32_t *model_index, void *stream,
                                       int repeats, float *ms_mean);
 
+/* Sharding: this handle solves contiguous shards of a batch of `total` instances -- the kernel form is chosen for
+ * the whole batch's size, so that a shard's results are bit for bit the rows of the unsharded solve (0 = every call is a whole batch). */
+int mpcx_lmpc_set_total_batch(mpcx_lmpc_t h, int total);
+
 /* ---- profiling and testing aids ------------------------------------------------------------------------------------
  * Not part of the reference-facing surface, but part of the exported ABI: bench.py's roofline block, tools/ and tests/ call
  * them, so they are declared (and kept) here.  "debug" in a name = may change between versions.                        */

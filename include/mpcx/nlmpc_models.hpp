@@ -17,7 +17,8 @@
 //                               is row i's share.  A finite difference of the cost in an entry of row i is then the difference of that
 //                               row's share -- the same quotient as (f(x + d e) - f(x)) / d of Objective.hpp:198-265 with the rows that
 //                               cancel left out (ph (nx + nu) evaluations of one row instead of the whole horizon, and without the
-//                               cancellation of two sums of ph rows); cost() itself stays the value that is reported and searched on
+//                               cancellation of two sums of ph rows); slack_cost(e, p) is the term in the slack alone.  The workgroup form
+//                               also sums the rows' shares over its lanes for the cost itself (another order of the same additions)
 //   neq_user(ph), eq(k, X, U, ph, p)
 //                               EConFunHandle: component k of the user equalities h_k = 0 (defaults: none, NoUserEq)
 //   ineq_reads_x/u(k, i), ineq_rows_of_x/u(i, first, count), INEQ_USES_SLACK, INEQ_U_ROWS_DISJOINT
@@ -77,6 +78,7 @@ struct NoUserEq {
     static constexpr bool COST_STAGEWISE = false;                       // true: stage(i, X, U, ph, p) is row i's share of the cost (see the header)
     template <class XA, class UA>
     __device__ static double stage(int, const XA &, const UA &, int, const double *) { return 0.0; }
+    __device__ static double slack_cost(double, const double *) { return 0.0; }      // the cost's term in the slack variable alone
     static constexpr bool XFREE_ROWS_SPARSE = false;                    // true: a user row that reads no state has at most kNlSparse non-zero entries in the
                                                                         // move-blocked inputs (+ slack); the workgroup form then keeps it as an (index, value) list
 };
@@ -167,6 +169,7 @@ struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero
         const double a = X(i, 2) - p[0], b = X(i, 3) - p[1];
         return 1e3 * (a * a + b * b) + 1e-2 * (U(i, 0) * U(i, 0) + U(i, 1) * U(i, 1));
     }
+    __device__ static double slack_cost(double e, const double *) { return 1e-5 * e * e; }
     template <class XA, class UA>
     __device__ static double ineq(int k, const XA &X, const UA &, double, int, const double *p)
     {

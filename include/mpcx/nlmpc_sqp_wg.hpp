@@ -631,7 +631,15 @@ struct WgSqp {
         auto Xa = [&](int j) { const double a = fabs(Xs[(j % (ph + 1)) * NX + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
         auto Ua = [&](int j) { const double a = fabs(Us[(j % (ph + 1)) * NU + j / (ph + 1)]); return a > 1.0 ? a : 1.0; };
         const Pert X0{Xs, NX, -1, -1, -1, 0.0}, U0{Us, NU, -1, -1, -1, 0.0};
-        const double f0 = Mdl::cost(X0, U0, e, ph, prm);
+        double f0;
+        if constexpr (Mdl::COST_STAGEWISE) {                    // the rows' shares over the lanes (every lane on the whole horizon: the longest part of this phase)
+            double part = 0.0;
+            for (int i = tid; i <= ph; i += NT) part += Mdl::stage(i, X0, U0, ph, prm);
+            Red<WAVES> R(v.at(P.o_red));
+            f0 = R.sum(part) + Mdl::slack_cost(e, prm);
+        } else {
+            f0 = Mdl::cost(X0, U0, e, ph, prm);
+        }
         if (tid == 0) st[ST_COST] = f0;
         if (!values_only) {
             const int nxv = ph * NX, nuv = ph * NU, nall = nxv + nuv + 2;
@@ -655,7 +663,7 @@ struct WgSqp {
                         continue;
                     }
                 }
-                const double fp = Mdl::cost(Xp, Up, ee, ph, prm);
+                const double fp = Mdl::COST_STAGEWISE ? f0 - Mdl::slack_cost(e, prm) + Mdl::slack_cost(ee, prm) : Mdl::cost(Xp, Up, ee, ph, prm);
                 if (isx) { const double gk = (fp - f0) / dx; lam[kk] = gk; gxg[kk] = gk; }
                 else if (isu) Jm[kk] = (fp - f0) / du;
                 else st[idx == nall - 2 ? ST_FP : ST_FM] = fp;
@@ -1827,6 +1835,14 @@ struct WgSqp {
                     spv_ -= tt * zn;
                 }
                 up += tt;
+#ifdef MPCX_EMU_TRACE
+                if (what == 1 && tid == 0 && blockIdx.x == 0) {
+                    double r = 0.0;
+                    for (int q = 0; q < nq; ++q) r += np_[q] * xq[q];
+                    r += sgn * br[pidx];
+                    if (fabs(r) > 1e-11) fprintf(stderr, "  [row %d joined with residual %.3e (violation before %.3e, nw %d, zn %.3e snn %.3e)]\n", pidx, r, vmax, nw, zn, snn);
+                }
+#endif
                 if (what == 1) { ++nw; added = true; }                  // full step: the row has joined the working set
                 else { ws_drop(kdrop, nw); --nw; }                       // a multiplier hit zero: that row leaves, try again
             }
@@ -1954,12 +1970,22 @@ struct WgSqp {
         for (int k = part; k < m - mi; k += stride) vio += fabs(Mdl::eq(k, XL, UL, ph, prm));
         return vio;
     }
-    static __device__ __attribute__((noinline)) double ls_cost(double al)
+    // (this lane's share of the trial point's cost: all of it on lane 0 of the group, or -- a cost that is a sum over the horizon's rows -- the
+    // rows part, part + stride, ..)
+    static __device__ __attribute__((noinline)) double ls_cost(double al, int part, int stride)
     {
         const V v; const auto &P = v.A->P;
         const double *z = v.at(P.o_z), *p = v.at(P.o_p);
         const Lin XL{v.at(P.o_Xs), v.at(P.o_dXs), NX, al}, UL{v.at(P.o_Us), v.at(P.o_dUs), NU, al};
-        return Mdl::cost(XL, UL, z[v.nz - 1] + al * p[v.nzu], v.ph, v.at(P.o_prm));
+        const double et = z[v.nz - 1] + al * p[v.nzu];
+        if constexpr (Mdl::COST_STAGEWISE) {
+            double s = part == 0 ? Mdl::slack_cost(et, v.at(P.o_prm)) : 0.0;
+            for (int i = part; i <= v.ph; i += stride) s += Mdl::stage(i, XL, UL, v.ph, v.at(P.o_prm));
+            return s;
+        } else {
+            const double c = Mdl::cost(XL, UL, et, v.ph, v.at(P.o_prm));     // (every lane evaluates it: no divergence around the call)
+            return part == 0 ? c : 0.0;
+        }
     }
     static __device__ __attribute__((noinline)) double ls_defects(double al, int part, int stride)
     {
@@ -2012,9 +2038,9 @@ struct WgSqp {
         double a_step = -1.0;
         for (int round = 0; round < 5 && a_step < 0.0; ++round) {
             const double al = ldexp(1.0, -(grp + 8 * round));
-            const double cst = ls_cost(al);                      // (every lane evaluates it: no divergence around the call)
+            const double cst = ls_cost(al, part, GS);
             const double vio = ls_user_rows(al, part, GS) + ls_defects(al, part, GS);
-            double mer = (part == 0 ? cst : 0.0) + nu_pen * vio;
+            double mer = cst + nu_pen * vio;
             if constexpr (GS == 8) mer = group_sum<8>(mer);
             else if constexpr (GS == 16) mer = group_sum<16>(mer);
             else if constexpr (GS == 32) { mer = group_sum<16>(mer); mer += __shfl_xor(mer, 16); }

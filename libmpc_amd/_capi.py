@@ -70,7 +70,7 @@ EXPORTS = [
     "mpcx_lmpc_hetero_create", "mpcx_lmpc_hetero_destroy", "mpcx_lmpc_hetero_get_info", "mpcx_lmpc_hetero_solve_batch",
     "mpcx_lmpc_hetero_time_solve_batch", "mpcx_lmpc_hetero_create_ex", "mpcx_lmpc_hetero_debug_get",
     # profiling and testing aids (declared in include/mpcx.h under that heading)
-    "mpcx_lmpc_debug_time_kernels", "mpcx_lmpc_debug_get", "mpcx_lmpc_debug_setup_counts", "mpcx_lmpc_debug_use_fused",
+    "mpcx_lmpc_set_total_batch", "mpcx_lmpc_debug_time_kernels", "mpcx_lmpc_debug_get", "mpcx_lmpc_debug_setup_counts", "mpcx_lmpc_debug_use_fused",
     "mpcx_lmpc_debug_force_generic", "mpcx_lmpc_debug_set_rounds", "mpcx_lmpc_debug_set_cycle_buffer",
     "mpcx_nlmpc_debug_set_tolerances", "mpcx_nlmpc_debug_last_form", "mpcx_nlmpc_last_form", "mpcx_nlmpc_debug_get_ws", "mpcx_nlmpc_debug_generated_source", "mpcx_nlmpc_debug_compile_source",
 ]

@@ -56,6 +56,7 @@ struct mpcx_lmpc {
     // only on request), 0 = always two kernels, 1 = the fused form wherever the dimensions allow, 2 = the group form (mpcx_lmpc_debug_use_fused)
     int use_fused = -1;
     int group_max = 4096;               // automatic mode: batches up to this size take lmpc_solve_group (assemble + solve in one workgroup)
+    int total_batch = 0;                // mpcx_lmpc_set_total_batch: this handle solves shards of a batch of that size (0: every call is a whole batch)
     // staging of mpcx_lmpc_solve_host (kept between calls) and the active sets it carries from one call to the next
     double *stage_d = nullptr; int32_t *stage_i = nullptr; uint32_t *stage_act = nullptr;
     size_t stage_cap = 0;               // instances
@@ -648,7 +649,7 @@ int mpcx_lmpc_solve_batch(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *stream)
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && (b->batch > h->total_batch ? b->batch : h->total_batch) <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
     else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     int lr = mpcx::lmpc_launch(h->dev, h->dev_d, B, h->ws, stream, 7, fast);
     if (lr == -2) return fail(MPCX_E_UNSUPPORTED, "problem dimensions exceed the kernel's LDS budget");
@@ -1055,7 +1056,7 @@ int mpcx_lmpc_debug_time_kernels(mpcx_lmpc_t h, const mpcx_lmpc_batch *b, void *
         if (b->yref_mode == MPCX_REF_SHARED) fast = 0;
         else if (b->yref_mode == MPCX_REF_PER_INSTANCE) fast = 1;
     }
-    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && b->batch <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
+    if (fast >= 0 && h->dev.group_ok && (h->use_fused == 2 || (h->use_fused < 0 && (b->batch > h->total_batch ? b->batch : h->total_batch) <= h->group_max))) { B.fused = fast + 3; B.done = h->done; }
     else if (fast >= 0 && h->dev.fused_ok && !B.dbg_cycles && h->use_fused == 1) { B.fused = fast + 1; B.pcounter = h->pcounter; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
@@ -1103,6 +1104,17 @@ int mpcx_lmpc_debug_use_fused(mpcx_lmpc_t h, int on)
     CHECK_H(h);
     h->use_fused = on < 0 ? -1 : (on > 2 ? 2 : on);      // 2: lmpc_solve_group (assemble + solve in one workgroup of sixteen wavefronts)
     h->dirty = true;
+    return MPCX_OK;
+}
+
+/* Sharding: this handle is given contiguous shards of a batch of `total` instances (one rank of N).  The kernel form is chosen for the
+ * whole batch's size, so that a shard's results are, bit for bit, the rows of the unsharded solve also where the two sizes lie on either
+ * side of the threshold between the in-workgroup form and the two-kernel form (0: every call is a whole batch, the default). */
+int mpcx_lmpc_set_total_batch(mpcx_lmpc_t h, int total)
+{
+    CHECK_H(h);
+    if (total < 0) return fail(MPCX_E_INVALID, "negative batch");
+    h->total_batch = total;
     return MPCX_OK;
 }
 

@@ -92,15 +92,15 @@ int nlmpc_launch_solve(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, voi
         NlmpcZoo *z = ctx ? static_cast<NlmpcZoo *>(ctx) : &local;
         if (z->env_form != 0) {
             if (z->k_hard != b->hard || z->k_nbnd != m->nbnd || z->k_nbnd_state != m->nbnd_state || z->k_ws_total != m->ws.total) {
-                auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok) {
-                    return nlmpc_wg_plan(*m, b->hard, z->env_waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu) == 0 && X.ws_total <= m->ws.total;
+                auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok, int waves = -1) {
+                    return nlmpc_wg_plan(*m, b->hard, waves < 0 ? z->env_waves : waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu) == 0 && X.ws_total <= m->ws.total;
                 };
                 z->k_hard = b->hard; z->k_nbnd = m->nbnd; z->k_nbnd_state = m->nbnd_state; z->k_ws_total = m->ws.total;
                 z->fits = plan(z->P, z->env_blocks, true);
                 z->has_lds = z->fits && z->env_blocks < 0 && z->P.waves > 1 && !z->P.f_lds && plan(z->Q, 1, true) && z->Q.waves > 1;
-                z->has_full = z->fits && plan(z->Pfull, z->P.f_lds, false) && z->Pfull.kw > z->P.kw && z->Pfull.waves == z->P.waves;
-                z->has_lds_full = z->has_lds && plan(z->Qfull, 1, false) && z->Qfull.kw > z->Q.kw && z->Qfull.waves == z->Q.waves;
-                if (z->fits && z->Pfull.kw <= z->P.kw) z->has_full = false;
+                // (the second pass: the same wavefronts per instance -- the same arithmetic -- with the working set's full capacity)
+                z->has_full = z->fits && plan(z->Pfull, z->P.f_lds, false, z->P.waves) && z->Pfull.kw > z->P.kw;
+                z->has_lds_full = z->has_lds && plan(z->Qfull, 1, false, z->Q.waves) && z->Qfull.kw > z->Q.kw;
             }
             if (z->fits) {
                 // the blocks in LDS where the whole batch is resident with them there (the latency form: config 3 at up to two instances per CU)

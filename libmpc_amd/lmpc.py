@@ -290,6 +290,12 @@ class LMPC:
         check(f(self._h, name.encode(), _p(out), n))
         return out
 
+    def setTotalBatch(self, total):
+        """sharding: this controller is given contiguous shards of a batch of `total` instances (one rank of N); the kernel form is then chosen
+        for the whole batch's size and a shard's results are bit for bit the rows of the unsharded solve (0: every call is a whole batch)"""
+        check(self._lib.mpcx_lmpc_set_total_batch(self._h, int(total)))
+        return True
+
     def debug_force_generic(self, on=True):
         """testing aid: route every batch through the generic (roll-out) assemble kernel"""
         check(self._lib.mpcx_lmpc_debug_force_generic(self._h, int(bool(on))))

@@ -395,6 +395,30 @@ def test_shards_equal_rows_of_the_unsharded_solve():
             assert torch.equal(part.active_lower, whole.active_lower[sl]) and torch.equal(part.active_upper, whole.active_upper[sl])
 
 
+def test_shards_across_the_form_threshold_equal_rows_of_the_unsharded_solve():
+    """The library picks the kernel form by batch size (one workgroup per sixteen instances up to 4096 instances, assemble + solve as two
+    kernels beyond).  A rank that is given a shard tells its handle the size of the whole batch (setTotalBatch, mpcx_lmpc_set_total_batch):
+    the shard then takes the form the whole batch would, and its results are bit for bit the rows of the unsharded solve -- 2 x 4096 against
+    8192 here, the two sizes on either side of the threshold.  Without the hint the two forms agree to 1e-9, not in every bit."""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    Bs, R = 4096, 2
+    x0, u0, yref = quadrotor_batch(Bs * R)
+    c = quadrotor_lmpc(20, device=0)
+    whole = c.optimizeBatch(x0, u0, yref=yref, want_active=True); torch.cuda.synchronize()
+    shard = quadrotor_lmpc(20, device=0)
+    assert shard.setTotalBatch(Bs * R)
+    for rk in range(R):
+        sl = slice(rk * Bs, (rk + 1) * Bs)
+        part = shard.optimizeBatch(x0[sl], u0[sl], yref=yref[sl], want_active=True); torch.cuda.synchronize()
+        assert torch.equal(part.cmd, whole.cmd[sl]) and torch.equal(part.cost, whole.cost[sl]) and torch.equal(part.status, whole.status[sl])
+        assert torch.equal(part.active_lower, whole.active_lower[sl]) and torch.equal(part.active_upper, whole.active_upper[sl])
+    plain = quadrotor_lmpc(20, device=0)                       # no hint: the in-workgroup form
+    part = plain.optimizeBatch(x0[:Bs], u0[:Bs], yref=yref[:Bs]); torch.cuda.synchronize()
+    ok = (part.status == 0) & (whole.status[:Bs] == 0)
+    assert ((part.cmd - whole.cmd[:Bs]).abs().max(dim=1).values[ok] <= 1e-9 * whole.cmd[:Bs].abs().max(dim=1).values[ok].clamp(min=1.0)).all()
+
+
 def test_warm_start_carries_the_working_set():
     """f1: the previous tick's active set seeds the working set (LOptimizer.hpp:268-281 carries x, y): same results,
     an unchanged active set verifies in one round, a plant step needs fewer rounds than a cold start."""

@@ -1,7 +1,7 @@
 """The two forms of the NLMPC solve kernel -- nlmpc_sqp_wg (one workgroup per instance, the reduced problem in LDS) and nlmpc_sqp (one
 wavefront per instance, the reduced problem in an HBM workspace) -- pinned to the same oracle answers: whichever the library picks by
 default for a shape (csrc/nlmpc_kernels.hip), both reach the oracle's optimum within north_star's 1e-5, report the same statuses and agree
-with each other.  The forms are chosen per launch through MPCX_NLMPC_FORM / MPCX_NLMPC_WAVES.
+with each other.  The forms are forced through MPCX_NLMPC_FORM / MPCX_NLMPC_WAVES, read when a handle is created.
 """
 import json
 import os
@@ -171,25 +171,51 @@ def test_the_two_forms_agree_with_each_other(monkeypatch):
         assert np.array_equal(a["multipliers"][ok] > 1e-9, b["multipliers"][ok] > 1e-9)
 
 
-def test_default_form_is_the_measured_choice(monkeypatch):
-    """csrc/nlmpc_kernels.hip: the workgroup form where an instance takes one wavefront (config 1: a CU full of instances) and for a batch it
-    holds resident all at once (latency: every instance on its own four wavefronts), the wavefront form for large batches of the larger
-    systems (throughput); mpcx_nlmpc_debug_last_form says which one ran"""
+def test_the_form_is_a_property_of_the_controller(monkeypatch):
+    """csrc/nlmpc_kernels.hip: the kernel form is chosen per handle from the plan of the workgroup form -- one wavefront per instance where
+    a CU holds many of them (config 1), four for config 3, eight for a system that fills a CU's LDS alone (config 5) -- and is the SAME for
+    every batch size of that handle (a shard takes the kernel the whole batch would); mpcx_nlmpc_last_form(handle) says which one ran"""
+    import torch
     from libmpc_amd import _capi
-    from libmpc_amd.nlmpc import VANDERPOL, UGV
-    monkeypatch.delenv("MPCX_NLMPC_FORM", raising=False)
-    monkeypatch.delenv("MPCX_NLMPC_WAVES", raising=False)
-    last = _capi.lib().mpcx_nlmpc_debug_last_form
-    _solve(VANDERPOL, 10, 5, 0.1, np.tile([[0.0, 1.0]], (4096, 1)), np.zeros((4096, 1)), True, 50)
-    assert last() == 1
-    _solve(UGV, 30, 30, 0.1, np.zeros((8, 4)), np.zeros((8, 2)), False, 5)
-    assert last() == 4
-    _solve(UGV, 30, 30, 0.1, np.zeros((4096, 4)), np.zeros((4096, 2)), False, 2)
-    assert last() == 0
-    # a problem that fills a CU's LDS alone (config 5) stays in the workgroup form up to two rounds of 256 (71 ms against 94 at 512 instances)
-    from libmpc_amd.nlmpc import OSCILLATORS8
-    X8 = np.zeros((512, 16)); X8[:, 0] = 1.0
-    _solve(OSCILLATORS8, 30, 15, 0.1, X8, np.zeros((512, 8)), True, 2)
-    assert last() == 4
-    _solve(OSCILLATORS8, 30, 15, 0.1, np.tile(X8, (2, 1)), np.zeros((1024, 8)), True, 2)
-    assert last() == 0
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV, OSCILLATORS8
+    for k in ("MPCX_NLMPC_FORM", "MPCX_NLMPC_WAVES", "MPCX_NLMPC_BLOCKS"):
+        monkeypatch.delenv(k, raising=False)
+    lib = _capi.lib()
+
+    def forms(model, ph, ch, nx, nu, hard, batches):
+        c = NLMPC(model, ph, ch, 0.1)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=2, hard_constraints=int(hard)))
+        assert int(lib.mpcx_nlmpc_last_form(c._h)) == -1
+        got = []
+        for B in batches:
+            X0 = np.zeros((B, nx)); X0[:, 0] = 1.0
+            c.optimizeBatch(torch.from_numpy(X0), torch.zeros(B, nu, dtype=torch.float64)); torch.cuda.synchronize()
+            got.append(int(lib.mpcx_nlmpc_last_form(c._h)))
+        return got
+
+    assert forms(VANDERPOL, 10, 5, 2, 1, True, [16, 4096]) == [1, 1]
+    assert forms(UGV, 30, 30, 4, 2, False, [8, 512, 4096]) == [4, 4, 4]
+    assert forms(OSCILLATORS8, 30, 15, 16, 8, True, [64, 1024]) == [8, 8]
+    # the override is read when the handle is created, never on the solve path
+    monkeypatch.setenv("MPCX_NLMPC_FORM", "wave")
+    c = NLMPC(UGV, 12, 4, 0.1)
+    monkeypatch.delenv("MPCX_NLMPC_FORM")
+    c.optimizeBatch(torch.zeros(4, 4, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64)); torch.cuda.synchronize()
+    assert int(lib.mpcx_nlmpc_last_form(c._h)) == 0
+
+
+def test_working_sets_beyond_a_cut_capacity_are_solved_by_the_second_pass(monkeypatch):
+    """where the plan cuts the working set's capacity for one more workgroup per CU (six oscillators: 53 of 61 rows with the blocks in LDS), an
+    instance that outgrows it is marked and taken again by a launch planned with the full capacity: same statuses and optimum as the
+    wavefront form, which never cuts"""
+    from libmpc_amd.nlmpc import OSCILLATORS6
+    rng = np.random.default_rng(0)
+    B = 256
+    X0 = rng.uniform(-0.1, 0.1, size=(B, 12)); X0[:, 0] += 1.0
+    out = {}
+    for form in ("wg", "wave"):
+        _set_form(monkeypatch, form, None)
+        out[form] = _solve(OSCILLATORS6, 20, 10, 0.1, X0, np.zeros((B, 6)), True, 200)
+    a, b = out["wg"], out["wave"]
+    assert (b["status"] == 0).all() and np.array_equal(a["status"], b["status"]), (a["solver_status"][a["status"] != 0], np.nonzero(a["status"] != 0)[0])
+    assert (np.abs(a["cmd"] - b["cmd"]) / np.maximum(1.0, np.abs(b["cmd"]).max(axis=1, keepdims=True))).max() <= 1e-5
