@@ -39,12 +39,13 @@ struct WgPlan {
     int nsx;                    // (user row, state row) pairs with a non-zero Jacobian block
     int needs_phi;              // some sub-problem row reads a state
     int f_lds;                  // the folded dynamics blocks live in LDS
+    int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor
     int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
     int lds_total;              // doubles
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
         o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_xq, o_np, o_vv, o_wv, o_F, o_prm, o_cd, o_yd,
-        o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow;
+        o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow, o_mbuf;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
@@ -206,6 +207,26 @@ template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, doub
 // the entering row of the dual method, which follow each other with their results in registers, have a set each and no barrier behind them --
 // a set is written again only after every thread has passed a later barrier of the step.
 constexpr int kWgRedDoubles = 64;     // set 0: two parities of sixteen; sets 1 and 2: one reduction per use, sixteen each
+// a sum and an argmax with one barrier (the dual ratio test next to the curvature along the step)
+struct WgSumArgmax { double sum, v; int idx; };
+template <int WAVES> MPCX_WG_CALL WgSumArgmax wg_red_sum_argmax(double a, double v, int idx, double *s)
+{
+    a = wave_sum(a);
+    wave_argmax(v, idx);
+    if constexpr (WAVES > 1) {
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s[w] = a; s[8 + w] = v; s[16 + w] = (double)idx; }
+        __syncthreads();
+        a = s[0]; v = s[8]; idx = (int)s[16];
+#pragma unroll
+        for (int i = 1; i < WAVES; ++i) {
+            a += s[i];
+            const double ov = s[8 + i]; const int oi = (int)s[16 + i];
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+    }
+    return WgSumArgmax{a, v, idx};
+}
 template <int WAVES> struct Red {
     double *buf;
     int par;
@@ -923,8 +944,13 @@ struct WgSqp {
                 for (int u = 0; u <= kNlSparse; ++u) if (u == cnt) { ix[u] = q; ev[u] = val; }
                 ++cnt;
             };
-            for (int i = 0; i < ph; ++i) {
-                if (!(k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i))) continue;
+            // (the input rows this constraint reads as a bit mask first, then a walk over its set bits: the lanes' first rows are handled
+            // together, then their second ones -- a loop over all rows with a test inside ran the body once per DISTINCT row of a wavefront)
+            unsigned long long um = 0;
+            for (int i = 0; i < ph; ++i) if (k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i)) um |= 1ull << i;
+            while (um) {
+                const int i = (int)__builtin_ctzll(um);
+                um &= um - 1;
                 for (int j = 0; j < NU; ++j) {
                     double val;
                     if (k < mi) {
@@ -1673,6 +1699,184 @@ struct WgSqp {
         T::sync();
     }
 
+    // ---- the working set's Schur complement kept as its INVERSE M = S^-1 (WgPlan::minv: large working sets) ----------------------------------
+    // With the Cholesky factor every use of S is a pair of substitutions and every row that leaves a chain of rotations -- serial in the
+    // number of working rows, on one wavefront, while the others wait (config 5: 50 to 90 rows, thirteen dual steps and thirteen rows shed
+    // per iteration: half of the sub-problem's time).  With the inverse, S^-1 t is one symmetric product over the whole workgroup, a row
+    // that joins is the bordering formula  M <- [M + r r'/d, -r/d; -r'/d, 1/d]  (r = M t, d = n'B^-1 n - t'r), a row that leaves the
+    // rank-one correction  M <- M - m_j m_j'/M_jj  with the last row moved into its place: element-wise updates, no chain.  The price
+    // is conditioning (errors grow with cond(S), not its root); the inverse is formed afresh at every warm start (a symmetric
+    // Gauss-Jordan sweep of S, which also tells a dependent row by its pivot), so that an error lives for one sub-problem.
+    // Packed like the factor (row r at r (r + 1) / 2), in the factor's storage.  P lanes share a row in the element-wise passes.
+    template <class FN> static __device__ __forceinline__ void tri_rows(double *Mp, int n, int tid, FN fn)
+    {
+        constexpr int PL = 4;
+        for (int r0 = 0; r0 < n; r0 += NT / PL) {
+            const int r = r0 + tid / PL;
+            if (r < n) for (int c = tid % PL; c <= r; c += PL) fn(r, c, Mp[r * (r + 1) / 2 + c]);
+        }
+    }
+    // M <- S^-1 in place (S packed in Mp); false: a pivot vanished (dependent rows)
+    static MPCX_WG_PHASE int ws_invert_m(int n)
+    {
+        const V v; const auto &P = v.A->P;
+        const int tid = threadIdx.x;
+        double *Mp = v.at(P.o_L), *buf = v.at(P.o_mbuf);
+        double dmax = 0.0;
+        for (int r = tid; r < n; r += NT) dmax = fmax(dmax, Mp[r * (r + 1) / 2 + r]);
+        Red<WAVES> R(v.at(P.o_red));
+        dmax = R.max(dmax);
+        T::sync();
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {                       // the sweep operator on pivot k: afterwards Mp = -(S^-1) on the swept part
+            for (int t = tid; t < n; t += NT) buf[t] = hsym(Mp, t, k);
+            const double d = Mp[k * (k + 1) / 2 + k];
+            T::sync();
+            ok = d > 1e-13 * dmax;
+            const double id = 1.0 / d;
+            tri_rows(Mp, n, tid, [&](int r, int c, double &a) {
+                if (r == k) a = c == k ? -id : buf[c] * id;
+                else if (c == k) a = buf[r] * id;
+                else a = fma(-buf[r] * id, buf[c], a);
+            });
+            T::sync();
+        }
+        if (!ok) return 0;
+        tri_rows(Mp, n, tid, [&](int, int, double &a) { a = -a; });
+        T::sync();
+        return 1;
+    }
+    // row j leaves: M <- M - m_j m_j' / M_jj on the others, the last row takes slot j (in M and in the lists)
+    static MPCX_WG_PHASE void ws_drop_m(int j, int nw)
+    {
+        const V v; const auto &P = v.A->P;
+        const int tid = threadIdx.x, last = nw - 1;
+        double *Mp = v.at(P.o_L), *buf = v.at(P.o_mbuf), *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        for (int t = tid; t < nw; t += NT) buf[t] = hsym(Mp, t, j);
+        T::sync();
+        const double id = 1.0 / buf[j];
+        tri_rows(Mp, nw, tid, [&](int r, int c, double &a) { if (r != j && c != j) a = fma(-buf[r] * id, buf[c], a); });
+        T::sync();
+        if (j != last) {
+            // the last row (its entries with the others, its diagonal) into row / column j
+            for (int t = tid; t < last; t += NT) buf[t] = Mp[last * (last + 1) / 2 + t];
+            const double dl = Mp[last * (last + 1) / 2 + last];
+            T::sync();
+            for (int t = tid; t < last; t += NT) {
+                if (t < j) Mp[j * (j + 1) / 2 + t] = buf[t];
+                else if (t > j) Mp[t * (t + 1) / 2 + j] = buf[t];
+                else Mp[j * (j + 1) / 2 + j] = dl;
+            }
+        }
+        if (tid == 0) {
+            flag[wq[j]] = 0;
+            if (j != last) { wq[j] = wq[last]; sgq[j] = sgq[last]; uq[j] = uq[last]; }
+        }
+        T::sync();
+    }
+    // one round of the warm start with the inverse: u = M (N_W x0 + b); the rows with a negative multiplier in st[ST_SHED]; when there is none,
+    // u filed and N_W' u set up for the minimiser (as ws_shed_round)
+    static MPCX_WG_PHASE void ws_shed_round_m(int nw)
+    {
+        const V v; const auto &P = v.A->P; const Sp sp(v);
+        const int tid = threadIdx.x, lane = tid & 63, mi = v.mi, m = v.m, nq = v.nq, nd = P.nd;
+        double *Mp = v.at(P.o_L), *tq = v.at(P.o_tq), *rq = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv), *uq = v.at(P.o_uq), *st = v.at(P.o_st);
+        const double *yd = v.at(P.o_yd), *xq = v.at(P.o_xq), *br = v.at(P.o_br), *sgq = v.at(P.o_sgq);
+        const int *dcol = v.iat(P.o_dcol), *wq = v.iat(P.o_wq);
+        for (int t = tid; t < nw; t += NT) {
+            const int k = wq[t], dc = dcol[k];
+            tq[t] = sgq[t] * ((dc >= 0 ? yd[dc] : sp.dot(k, xq)) + br[k]);
+        }
+        for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
+        for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
+        T::sync();
+        hmul<NT>(Mp, tq, rq, nw, 1.0, tid);
+        T::sync();
+        unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED);
+        if (tid < 64) {
+            const bool h0 = lane < nw, h1 = lane + 64 < nw;
+            const int k0 = h0 ? wq[lane] : 0, k1 = h1 ? wq[lane + 64] : 0;
+            const double u0 = h0 ? rq[lane] : 0.0, u1 = h1 ? rq[lane + 64] : 0.0;
+            // ONE row leaves per round here, the one with the most negative multiplier: with the inverse a round costs a product and a rank-one
+            // correction, a dual step ten times that -- and of the rows that all have a negative multiplier on the full kept set most turn
+            // positive again once the worst has left (config 5: 387 rows shed and 478 dual steps per solve this way, 639 and 673 when every
+            // negative row leaves at once)
+            double vneg = 0.0; int tsel = 0x7fffffff;
+            if (h0 && u0 < 0.0 && !(k0 >= mi && k0 < m)) { vneg = -u0; tsel = lane; }
+            if (h1 && u1 < 0.0 && !(k1 >= mi && k1 < m) && -u1 > vneg) { vneg = -u1; tsel = lane + 64; }
+            wave_argmax(vneg, tsel);
+            if (lane == 0) { shw[0] = tsel < 64 ? 1ull << tsel : 0ull; shw[1] = (tsel >= 64 && tsel < 128) ? 1ull << (tsel - 64) : 0ull; }
+        }
+        T::sync();
+        if (!(shw[0] | shw[1])) {
+            for (int t = tid; t < nw; t += NT) {
+                const int k = wq[t], dc = dcol[k];
+                const double u = rq[t], ml = sgq[t] * u;
+                uq[t] = u;
+                if (dc >= 0) cd[dc] = ml;
+                else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+            }
+            T::sync();
+        }
+    }
+    // the dual part of a step with the inverse (see ws_dual_step for what it delivers in st[R0 ..]): t = N_W B^-1 n gathered, r = M t by the whole
+    // workgroup, z'n = n'B^-1 n - t'r and the ratio test in one reduction, then the multipliers, N_W' r for the primal part and -- on a full
+    // step -- the bordering of M and the lists
+    static MPCX_WG_PHASE void ws_dual_step_m(int nw, int pidx, double sgn, double snn, double npn, double spv, double up)
+    {
+        const V v; const auto &P = v.A->P; const Sp sp(v);
+        const int tid = threadIdx.x, mi = v.mi, m = v.m, nq = v.nq, nd = P.nd;
+        double *Mp = v.at(P.o_L), *tq = v.at(P.o_tq), *rq = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv), *uq = v.at(P.o_uq),
+               *sgq = v.at(P.o_sgq), *st = v.at(P.o_st);
+        const double *yd = v.at(P.o_yd), *vv = v.at(P.o_vv);
+        const int *dcol = v.iat(P.o_dcol);
+        int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+        for (int t = tid; t < nw; t += NT) {
+            const int k = wq[t], dc = dcol[k];
+            tq[t] = sgq[t] * (dc >= 0 ? yd[dc] : sp.dot(k, vv));
+        }
+        for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
+        for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
+        T::sync();
+        if (nw > 0) { hmul<NT>(Mp, tq, rq, nw, 1.0, tid); T::sync(); }
+        double tr = 0.0, tneg = -1e300; int tidx = 0x7fffffff;
+        for (int t = tid; t < nw; t += NT) {
+            const double r = rq[t];
+            tr = fma(tq[t], r, tr);
+            const int k = wq[t];
+            if (r > 1e-14 && !(k >= mi && k < m)) { const double tj = -(uq[t] / r); if (tj > tneg) { tneg = tj; tidx = t; } }
+        }
+        const WgSumArgmax red = wg_red_sum_argmax<WAVES>(tr, tneg, tidx, v.at(P.o_red));
+        const double zn = snn - red.sum;
+        const double tl = red.v > -1e300 ? -red.v : 1e300;
+        const bool can_move = zn > 1e-13 * fmax(1.0, npn);
+        const double t2 = can_move ? spv / zn : 1e300;
+        const double tt = fmin(tl, t2);
+        const int what = tt >= 1e300 ? 0 : (t2 <= tl ? 1 : 2);
+        if (what != 0) {
+            for (int t = tid; t < nw; t += NT) {
+                const double r = rq[t];
+                uq[t] -= tt * r;
+                if (can_move) {
+                    const int k = wq[t], dc = dcol[k];
+                    const double ml = sgq[t] * r;
+                    if (dc >= 0) cd[dc] = ml;
+                    else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                }
+            }
+            if (what == 1) {                                     // M <- [M + r r'/d, -r/d; -r'/d, 1/d] with d = z'n (guarded as the factor's pivot is)
+                const double d = zn > 1e-13 * snn ? zn : 1e-13 * snn + 1e-300, id = 1.0 / d;
+                tri_rows(Mp, nw, tid, [&](int r, int c, double &a) { a = fma(rq[r] * id, rq[c], a); });
+                const int ro = nw * (nw + 1) / 2;
+                for (int t = tid; t < nw; t += NT) Mp[ro + t] = -rq[t] * id;
+                if (tid == 0) { Mp[ro + nw] = id; uq[nw] = up + tt; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
+            }
+        }
+        if (tid == 0) { st[ST_R0] = tt; st[ST_R1] = zn; st[ST_R2] = (double)what; st[ST_R3] = (double)red.idx; }
+        T::sync();
+    }
+
     // warm start of the sub-problem: the rows active in the previous one (wq, sgq) as long as their multipliers stay non-negative -- the
     // minimiser on that set with u >= 0 is a valid state of the dual method.  xq holds -B^-1 gr on entry, the minimiser on the kept set
     // on return; returns the number of rows kept.
@@ -1718,7 +1922,11 @@ struct WgSqp {
         }
         T::sync();
         MPCX_QLAP(1);
-        if (nw <= 32) {                                          // a small set: one wavefront, no workgroup barriers
+        const bool minv = P.minv != 0;
+        if (minv) {
+            const int ok = ws_invert_m(nw);
+            if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0;
+        } else if (nw <= 32) {                                   // a small set: one wavefront, no workgroup barriers
             if (tid < 64) { const bool ok = chol_inplace(Lp, invd, nw, lane); if (lane == 0) st[ST_R4] = ok ? 1.0 : 0.0; }
         } else {
             const bool ok = chol_inplace_wg<WAVES>(Lp, invd, v.at(P.o_red), nw, tid);
@@ -1733,7 +1941,7 @@ struct WgSqp {
         }
         if (P.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
         while (nw > 0) {
-            ws_shed_round(nw);
+            if (minv) ws_shed_round_m(nw); else ws_shed_round(nw);
             // every row with a negative multiplier leaves at once; equalities stay
             const unsigned long long *shw = reinterpret_cast<const unsigned long long *>(st + ST_SHED);
             unsigned long long m0 = shw[0], m1 = shw[1];
@@ -1742,7 +1950,8 @@ struct WgSqp {
                 int t;
                 if (m1) { const int bit = 63 - __builtin_clzll(m1); m1 &= ~(1ull << bit); t = 64 + bit; }
                 else { const int bit = 63 - __builtin_clzll(m0); m0 &= ~(1ull << bit); t = bit; }
-                ws_drop(t, nw); --nw;
+                if (minv) ws_drop_m(t, nw); else ws_drop(t, nw);
+                --nw;
                 if (tid == 0) st[ST_NSHED] += 1.0;
             }
         }
@@ -1811,7 +2020,7 @@ struct WgSqp {
             bool added = false;
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S); wavefront 0: rr = S^-1 t, the step length, the multipliers; then x -= t B^-1 (n - N_W' rr)
-                ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
+                if (P.minv) ws_dual_step_m(nw, pidx, sgn, snn, npn, spv_, up); else ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
                 MPCX_QLAP(7);
                 const double tt = st[ST_R0], zn = st[ST_R1];
                 const int what = (int)st[ST_R2], kdrop = (int)st[ST_R3];
@@ -1844,7 +2053,7 @@ struct WgSqp {
                 }
 #endif
                 if (what == 1) { ++nw; added = true; }                  // full step: the row has joined the working set
-                else { ws_drop(kdrop, nw); --nw; }                       // a multiplier hit zero: that row leaves, try again
+                else { if (P.minv) ws_drop_m(kdrop, nw); else ws_drop(kdrop, nw); --nw; }       // a multiplier hit zero: that row leaves, try again
             }
             if (!fail && !added) fail = -1;
             MPCX_QLAP(10);
@@ -2305,6 +2514,10 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     auto imin = [](int a, int b) { return a < b ? a : b; };
     auto imax = [](int a, int b) { return a > b ? a : b; };
     const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
+    // working sets of more than 64 rows: the Schur complement's inverse instead of its factor (see ws_invert_m); MPCX_NLMPC_MINV=0|1 overrides
+    // (measurements; read once)
+    static const int minv_env = [] { const char *e = getenv("MPCX_NLMPC_MINV"); return e ? atoi(e) : -1; }();
+    P.minv = minv_env >= 0 ? (minv_env ? 1 : 0) : (kw_full > 64 ? 1 : 0);
     int waves = waves_wanted;
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && !(waves == 8 && kWgEightWaves<Mdl>)) return -2;
     auto layout = [&](int kw, int f_lds) {
@@ -2323,6 +2536,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_prm = take(Mdl::NPARAMS); P.o_cd = take(P.ndld); P.o_yd = take(P.ndld);
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
         P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2); P.o_drow = take((P.nd_user + 1) / 2);
+        P.o_mbuf = P.minv ? take(kw) : 0;
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;
         P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
