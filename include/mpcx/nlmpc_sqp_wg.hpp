@@ -833,11 +833,20 @@ struct WgSqp {
                 auto bcast_i = [&](int x, int k) { if constexpr (G == 1) return __builtin_amdgcn_readlane(x, k); else return __shfl(x, base + k); };
 #pragma unroll 1
                 for (int k = 0; k < NX; ++k) {
+                    // threshold pivoting: the row in place (register 0: the diagonal) stays the pivot while it is within a factor ten of the
+                    // column's largest entry -- the rule for E = -I + h df/dx -- and only otherwise the search for the largest runs (where a
+                    // wavefront holds one tableau both decisions are scalar branches)
                     int pr = 0;
-                    double best = fabs(col[0]);
+                    double best = fabs(col[0]), mx = best;
 #pragma unroll
-                    for (int a = 1; a < NX; ++a) { const double av = fabs(col[a]); if (a < NX - k && av > best) { best = av; pr = a; } }
-                    pr = bcast_i(pr, k);                                 // the pivot column's choice
+                    for (int a = 1; a < NX; ++a) mx = fmax(mx, a < NX - k ? fabs(col[a]) : 0.0);
+                    const int search = bcast_i(best < 0.1 * mx ? 1 : 0, k);
+                    if (G != 1 || search) {
+#pragma unroll
+                        for (int a = 1; a < NX; ++a) { const double av = fabs(col[a]); if (a < NX - k && av > best) { best = av; pr = a; } }
+                        if (!search) pr = 0;
+                        pr = bcast_i(pr, k);                             // the pivot column's choice
+                    }
                     double cp = col[0];
                     // (one tableau per wavefront: the choice is the same in every lane -- a scalar branch around the exchange, which a system whose
                     // E is close to -I, h small, never takes)
@@ -1708,12 +1717,21 @@ struct WgSqp {
     // is conditioning (errors grow with cond(S), not its root); the inverse is formed afresh at every warm start (a symmetric
     // Gauss-Jordan sweep of S, which also tells a dependent row by its pivot), so that an error lives for one sub-problem.
     // Packed like the factor (row r at r (r + 1) / 2), in the factor's storage.  P lanes share a row in the element-wise passes.
+    // (an element-wise pass over the packed triangle: rows r and n - 1 - r together have n + 1 elements, so a group of lanes per PAIR of rows
+    // gives every thread the same share -- by single rows the last ones are n times the first)
     template <class FN> static __device__ __forceinline__ void tri_rows(double *Mp, int n, int tid, FN fn)
     {
-        constexpr int PL = 4;
-        for (int r0 = 0; r0 < n; r0 += NT / PL) {
-            const int r = r0 + tid / PL;
-            if (r < n) for (int c = tid % PL; c <= r; c += PL) fn(r, c, Mp[r * (r + 1) / 2 + c]);
+        const int np = (n + 1) >> 1;
+        const int PL = np > 0 && NT / np > 0 ? NT / np : 1, groups = NT / PL, g = tid / PL, l = tid - g * PL;
+        for (int p0 = 0; p0 < np; p0 += groups) {
+            const int p = p0 + g;
+            if (p < np && g < groups) {
+                const int ra = p, rb = n - 1 - p, len = ra == rb ? ra + 1 : n + 1;
+                for (int j = l; j < len; j += PL) {
+                    if (j <= ra) fn(ra, j, Mp[ra * (ra + 1) / 2 + j]);
+                    else fn(rb, j - ra - 1, Mp[rb * (rb + 1) / 2 + (j - ra - 1)]);
+                }
+            }
         }
     }
     // M <- S^-1 in place (S packed in Mp); false: a pivot vanished (dependent rows)
@@ -2517,7 +2535,10 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     // working sets of more than 64 rows: the Schur complement's inverse instead of its factor (see ws_invert_m); MPCX_NLMPC_MINV=0|1 overrides
     // (measurements; read once)
     static const int minv_env = [] { const char *e = getenv("MPCX_NLMPC_MINV"); return e ? atoi(e) : -1; }();
-    P.minv = minv_env >= 0 ? (minv_env ? 1 : 0) : (kw_full > 64 ? 1 : 0);
+    // (only where every row is one of the short lists -- bounds, constraints on single inputs: S is then all but a principal block of B^-1 and as
+    // well conditioned; with dense rows through the sensitivities -- config 3's obstacle rows, two of them nearly parallel at a time -- the
+    // inverse lost 3 instances of 4096 that the factor solves)
+    P.minv = minv_env >= 0 ? (minv_env ? 1 : 0) : ((kw_full > 64 && P.nd == 0) ? 1 : 0);
     int waves = waves_wanted;
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && !(waves == 8 && kWgEightWaves<Mdl>)) return -2;
     auto layout = [&](int kw, int f_lds) {
@@ -2559,16 +2580,18 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         placed = false;
         for (int per_cu = imin(16, 32 / P.waves); per_cu >= 1 && !placed; --per_cu) {
             const size_t budget = (size_t)(lds_per_cu / per_cu) & ~(size_t)15;
-            for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
-                if (blocks_wanted >= 0 && f_lds != (blocks_wanted ? 1 : 0)) continue;
-                // the registers of the variant (kWgWavesPerSimd) bound the workgroups per CU as well
-                const int by_regs = 4 * (P.waves == 8 ? 2 : P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
-                if (per_cu > by_regs) continue;
-                if (layout(kw_full, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
-                if (per_cu == 1 || !cut_ok) continue;           // (alone on the CU the factor keeps its full capacity)
-                int kw = kw_full;
-                while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
-                if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; break; }
+            // at this many workgroups per CU: the full capacity first (blocks in LDS, then in the workspace), a cut one only if neither fits
+            for (int cut = 0; cut <= 1 && !placed; ++cut) {
+                if (cut && (per_cu == 1 || !cut_ok)) continue;  // (alone on the CU the factor keeps its full capacity)
+                for (int f_lds = 1; f_lds >= 0 && !placed; --f_lds) {
+                    if (blocks_wanted >= 0 && f_lds != (blocks_wanted ? 1 : 0)) continue;
+                    // the registers of the variant (kWgWavesPerSimd) bound the workgroups per CU as well
+                    const int by_regs = 4 * (P.waves == 8 ? 2 : P.waves == 4 ? (f_lds ? kWgWavesPerSimd<Mdl, 4, true> : kWgWavesPerSimd<Mdl, 4, false>) : P.waves == 2 ? kWgWavesPerSimd<Mdl, 2> : kWgWavesPerSimd<Mdl, 1>) / P.waves;
+                    if (per_cu > by_regs) continue;
+                    int kw = kw_full;
+                    if (cut) while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
+                    if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; }
+                }
             }
         }
     };
