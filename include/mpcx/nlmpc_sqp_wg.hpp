@@ -781,7 +781,7 @@ struct WgSqp {
                     const double *xr = Xs + ii * NX, *ur = Us + ii * NU;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) col[a] = 0.0;
-#pragma unroll 1
+#pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
                         const bool at_next = pass == 1 || kind == 0;
                         double xp[NX], up[NU], o1[NX], o2[NX];
@@ -812,16 +812,28 @@ struct WgSqp {
 #pragma unroll
                         for (int a = 0; a < NX; ++a) col[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) * i2d);
                     }
+                    if (!M.scaled) {
+                        // (no scalings -- the rule: the five kinds of column by selects, the same arithmetic; as branches on the lane's kind the
+                        // sixteen entries were eighty little blocks under exec masks)
+                        const double dg = kind == 0 ? -1.0 : 1.0;
 #pragma unroll
-                    for (int a = 0; a < NX; ++a) {
-                        const double da = col[a];
-                        double cv;
-                        if (kind == 0) cv = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
-                        else if (kind == 1) cv = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
-                        else if (kind == 2) cv = sc.by_su(h * sc.over_ss(da, a), vv);
-                        else if (kind == 3) cv = sc.over_ss(xr[a] + (h * da) - xr[NX + a], a);
-                        else cv = a == vv ? 1.0 : 0.0;
-                        col[a] = cv;
+                        for (int a = 0; a < NX; ++a) {
+                            const double hd = h * col[a], x0a = xr[a], x1a = xr[NX + a];
+                            const double unit = a == vv ? dg : 0.0;
+                            col[a] = kind <= 1 ? unit + hd : (kind == 2 ? hd : (kind == 3 ? x0a + hd - x1a : unit));
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) {
+                            const double da = col[a];
+                            double cv;
+                            if (kind == 0) cv = (a == vv ? -1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
+                            else if (kind == 1) cv = (a == vv ? 1.0 : 0.0) + h * sc.over_ss(sc.by_ss(da, vv), a);
+                            else if (kind == 2) cv = sc.by_su(h * sc.over_ss(da, a), vv);
+                            else if (kind == 3) cv = sc.over_ss(xr[a] + (h * da) - xr[NX + a], a);
+                            else cv = a == vv ? 1.0 : 0.0;
+                            col[a] = cv;
+                        }
                     }
                     if (live && kind == 3) for (int a = 0; a < NX; ++a) c[i * NX + a] = col[a];
                 }
@@ -831,7 +843,7 @@ struct WgSqp {
                 // four cycles, instead of the LDS crossbar's round trip of a __shfl; 32 of them per pivot.)
                 auto bcast = [&](double x, int k) { if constexpr (G == 1) return read_lane(x, k); else return __shfl(x, base + k); };
                 auto bcast_i = [&](int x, int k) { if constexpr (G == 1) return __builtin_amdgcn_readlane(x, k); else return __shfl(x, base + k); };
-#pragma unroll 1
+#pragma unroll
                 for (int k = 0; k < NX; ++k) {
                     // threshold pivoting: the row in place (register 0: the diagonal) stays the pivot while it is within a factor ten of the
                     // column's largest entry -- the rule for E = -I + h df/dx -- and only otherwise the search for the largest runs (where a
