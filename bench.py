@@ -581,9 +581,14 @@ def nl_flops(c, name, it, nact):
         step = sweep
         qp = 2.0 * nq * nq + nact * (2.0 * nq * nact + 2.0 * nact * nact)              # B^-1 g; per step: z = v - V rr, two substitutions
     else:
-        cond = (nzu + 1) * sweep + einv
-        red = 2.0 * nxs * nzu + 2.0 * c.nineq * nzu
-        step = 2.0 * nxs * nzu
+        # rows of the sub-problem read states (config 3): the kernel condenses row by row, backwards (nlmpc_sqp_wg.hpp, condense_phi): one
+        # adjoint sweep per dense row over the steps below the state row it reads (half the horizon on average: l <- Abar' l, Bbar' l and
+        # cbar' l per step), one full chain for the reduced gradient and its inputs' part, the state step one more chain with the inputs
+        # applied -- counted as that, not as the products with a stored Phi (61 column sweeps + two nz x nzu products) of rounds 1 to 4
+        row = 0.5 * ph * (2.0 * nx * nx + 2.0 * nx * nu + 2.0 * nx)
+        cond = c.nineq * row + sweep + einv
+        red = 2.0 * nx * nzu
+        step = sweep + 2.0 * nxs * nu
         qp = 2.0 * nq * nq + nact * (2.0 * nq * nq + 4.0 * nq * nact)
     bfgs = 8.0 * nq * nq
     ls = 8 * (f_cost + f_f * ph * (1 + ct) + f_ineq * c.nineq)
@@ -605,7 +610,7 @@ def nlmpc_extra(local):
         ms = c.time_launches(b, steps, stream.cuda_stream)
         torch.cuda.synchronize()
         st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy()
-        form = int(c._lib.mpcx_nlmpc_debug_last_form())
+        form = int(c._lib.mpcx_nlmpc_last_form(c._h))
         res[key] = {"solves_per_s": B / (ms * 1e-3), "kernel_ms": ms, "kernel": "nlmpc_sqp_wg" if form > 0 else "nlmpc_sqp",
                     "wavefronts_per_instance": form if form > 0 else 1, "mean_iterations": float(it.mean()),
                     "solved_fraction": float(np.isin(st, (3, 4)).mean())}
@@ -656,7 +661,7 @@ def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, bar
     flops = nl_flops(c, name, it, nact)
     bytes_alg = float(B) * 8.0 * (c.nx + c.nu + c.nu + 1 + 2)
     ach = flops / (kern_ms * 1e-3) / 1e12
-    form = int(c._lib.mpcx_nlmpc_debug_last_form())
+    form = int(c._lib.mpcx_nlmpc_last_form(c._h))
     dom = "nlmpc_sqp_wg" if form > 0 else "nlmpc_sqp"
     traffic, traffic_src, traffic_note = _traffic(dom, "%s_b%d" % (name, B))
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,

@@ -37,6 +37,7 @@ struct WgPlan {
     int kw;                     // working-set capacity
     int nd, ndld, nd_user, nsb; // dense sub-problem rows (columns of art): user rows that read a state (or promise no sparsity), then bounds on states
     int nsx;                    // (user row, state row) pairs with a non-zero Jacobian block
+    int art_total;              // doubles of the dense rows' storage (every row as long as the last input block it can depend on: wg_row_len)
     int needs_phi;              // some sub-problem row reads a state
     int f_lds;                  // the folded dynamics blocks live in LDS
     int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor
@@ -45,7 +46,7 @@ struct WgPlan {
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
         o_slot, o_sbf, o_jx, o_art, o_wq, o_sgq, o_uq, o_tq, o_invd, o_xq, o_np, o_vv, o_wv, o_F, o_prm, o_cd, o_yd,
-        o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow, o_mbuf;
+        o_bidx, o_bsign, o_bval, o_xrf, o_xre, o_drow, o_mbuf, o_aoff, o_alen;
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
@@ -470,6 +471,25 @@ __device__ __forceinline__ void chol_delete(double *Lp, double *invd, int n, int
     nl_wave_sync();
 }
 
+// The dense rows of the sub-problem are stored row by row, each as long as it can be non-zero: a row that reads states up to x_{s+1} depends on
+// the input blocks 0 .. min(s, ch - 1) only -- on average half of the nq columns at config 3 (art: 15 KB instead of 30).  Returns the length of
+// user row k in bits 0 .. 15 and bit 30 if nothing but the sweep writes it (no input read directly, no slack entry: the sweep then stores
+// its entries instead of adding them to zeros).  Wide states (nx > 8: the forward sweep) keep whole rows.
+template <class Mdl> __host__ __device__ inline int wg_row_len(int k, int ph, int ch, int nq, int nzu, int mi)
+{
+    constexpr int NU = Mdl::NU;
+    if (Mdl::NX > 8) return nq;
+    int top = -1, ublk = -1;
+    for (int i = 1; i <= ph; ++i) if (k < mi ? Mdl::ineq_reads_x(k, i) : Mdl::eq_reads_x(k - mi, i)) top = i - 1;
+    for (int i = 0; i < ph; ++i) if (k < mi ? Mdl::ineq_reads_u(k, i) : Mdl::eq_reads_u(k - mi, i)) ublk = i < ch - 1 ? i : ch - 1;
+    if (Mdl::INEQ_USES_SLACK && k < mi && nq > nzu) return nq;
+    const int lx = top >= 0 ? ((top < ch - 1 ? top : ch - 1) + 1) * NU : 0, lu = (ublk + 1) * NU;
+    const int len = lx > lu ? lx : lu;
+    return len | (ublk < 0 ? 1 << 30 : 0);
+}
+// (a bound on a state: the whole input part -- the host's plan does not see which state it bounds -- written by the sweep alone)
+__host__ __device__ inline int wg_bound_row_len(int nzu) { return nzu | (1 << 30); }
+
 // Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
 // block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
 // for the smallest systems at one wavefront per instance, whose 4 KB blocks let sixteen instances share a CU, and for the four-wavefront
@@ -617,6 +637,16 @@ struct WgSqp {
         }
         // bounds: those on states come first in the table (ascending index) and are dense rows after the user's
         for (int kb = tid; kb < nbnd; kb += NT) dcol[m + kb] = bnd_idx[kb] < nxs ? nd_user + kb : -1;
+        T::sync();
+        {
+            // where the dense rows lie (wg_row_len): lengths by every thread, offsets by one
+            int *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen);
+            const int *drow = v.iat(P.o_drow);
+            for (int dc = tid; dc < P.nd; dc += NT)
+                alen[dc] = dc < nd_user ? wg_row_len<Mdl>(drow[dc], ph, ch, P.nq, nzu, mi) : (NX > 8 ? P.nq : wg_bound_row_len(nzu));
+            T::sync();
+            if (tid == 0) { int o = 0; for (int dc = 0; dc < P.nd; ++dc) { aoff[dc] = o; o += alen[dc] & 0xffff; } aoff[P.nd] = o; }
+        }
         for (int i = tid; i <= ph; i += NT) {                 // first state bound of state row i + 1 (z entries i NX ..)
             int f = 0;
             while (f < nsb && bnd_idx[f] < i * NX) ++f;
@@ -912,7 +942,7 @@ struct WgSqp {
         double *st = v.at(P.o_st), *gin = v.at(P.o_gin), *jx = v.at(P.o_jx), *br = v.at(P.o_br), *s1v = v.at(P.o_s1v);
         typename FP::type art = art_of(v);
         int *s1m = v.iat(P.o_s1m);
-        const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot);
+        const int *dcol = v.iat(P.o_dcol), *slot = v.iat(P.o_slot), *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen);
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         const int *bnd_idx = v.iat(P.o_bidx);
         const double *bnd_sign = v.at(P.o_bsign), *bnd_val = v.at(P.o_bval);
@@ -944,14 +974,15 @@ struct WgSqp {
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
-            if (dense) for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+            const int ro = dense ? aoff[dc] : 0, rl = dense ? alen[dc] : 0;
+            if (dense && !(rl >> 30)) for (int q = 0; q < (rl & 0xffff); ++q) art[ro + q] = 0.0;      // (a row only the sweep writes is stored by it)
             int cnt = 0, ix[kNlSparse + 1];
             double ev[kNlSparse + 1];
 #pragma unroll
             for (int u = 0; u <= kNlSparse; ++u) { ix[u] = 0; ev[u] = 0.0; }
             auto put = [&](int q, double val) {
                 if (q >= nq) return;
-                if (dense) { art[q * ndld + dc] += val; return; }
+                if (dense) { art[ro + q] += val; return; }
                 if (val == 0.0) return;                          // the finite differences leave exact zeros outside the structure
                 // (every subscript a constant after unrolling: the two little arrays stay in registers -- through run-time subscripts they
                 // lived in scratch memory, a trip to HBM per look)
@@ -1009,7 +1040,7 @@ struct WgSqp {
             if (zi < nxs) {
                 const int dc = dcol[k];
                 s1v[k] = 0.0; s1m[k] = kSpDense;
-                for (int q = 0; q < nq; ++q) art[q * ndld + dc] = 0.0;
+                if constexpr (NX > 8) { const int ro = aoff[dc]; for (int q = 0; q < nq; ++q) art[ro + q] = 0.0; }     // (the forward sweep adds; the row-wise one stores)
             } else {
                 s1v[k] = sg; s1m[k] = (1 << 16) | (zi - nxs);
                 spv[k * kNlSparse] = sg; spi[k * kNlSparse] = zi - nxs;
@@ -1122,8 +1153,8 @@ struct WgSqp {
         const double *lam = v.at(P.o_lam), *gu = v.at(P.o_gu), *jx = v.at(P.o_jx);
         double *gr = v.at(P.o_gr), *br = v.at(P.o_br);
         typename FP::type art = art_of(v);
-        const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf);
-        (void)lam; (void)dcol; (void)sbf;
+        const int *dcol = v.iat(P.o_dcol), *jxoff = v.iat(P.o_jxoff), *sbf = v.iat(P.o_sbf), *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen);
+        (void)lam; (void)dcol; (void)sbf; (void)alen;
         const unsigned long long *xmask = reinterpret_cast<const unsigned long long *>(v.at(P.o_xmask));
         const int *bnd_idx = v.iat(P.o_bidx);
         const double *bnd_sign = v.at(P.o_bsign);
@@ -1160,9 +1191,11 @@ struct WgSqp {
 #pragma unroll
                     for (int e = 0; e < NX * FW; ++e) fb[e] = F[(size_t)sI * NX * FW + e];
                 };
+                const int ro = aoff[dc];
+                const bool stores = (alen[dc] >> 30) != 0;      // nothing else writes this row: its entries are stored, not added
                 auto fetch_old = [&](int blk) {
 #pragma unroll
-                    for (int jq = 0; jq < NU; ++jq) old[jq] = art[(blk * NU + jq) * ndld + dc];
+                    for (int jq = 0; jq < NU; ++jq) old[jq] = stores ? 0.0 : art[ro + blk * NU + jq];
                 };
                 // (every lane walks the whole horizon, idle above its own top: the same step everywhere, so that the block's entries are one broadcast)
                 if constexpr (PF) fetch(ph - 1);
@@ -1193,7 +1226,7 @@ struct WgSqp {
                         for (int a = 0; a < NX; ++a) cst = fma(Fe(a, FW - 1), l[a], cst);
                         if (sI <= ch - 1) {                        // the last step of this input block: file it, ask for the next block's entries
 #pragma unroll
-                            for (int jq = 0; jq < NU; ++jq) { art[(sI * NU + jq) * ndld + dc] = old[jq] + acc[jq]; acc[jq] = 0.0; }
+                            for (int jq = 0; jq < NU; ++jq) { art[ro + sI * NU + jq] = old[jq] + acc[jq]; acc[jq] = 0.0; }
                             if (sI > 0) fetch_old(sI - 1);
                         }
                         // l_{s-1} = Abar_s' l_s (w_{s-1} joins at the top of the next step)
@@ -1244,7 +1277,7 @@ struct WgSqp {
                     auto row = [&](int k) {
                         const int sl = jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << i) - 1ull));
                         const double s = group_sum<16>(alive ? jx[sl * NX + aa] * x : 0.0);
-                        if (qlive && a == 0) { if (isr) br[k] += s; else art[q * ndld + dcol[k]] += s; }
+                        if (qlive && a == 0) { if (isr) br[k] += s; else art[aoff[dcol[k]] + q] += s; }
                     };
                     int first, count;
                     Mdl::ineq_rows_of_x(i + 1, first, count);
@@ -1253,7 +1286,7 @@ struct WgSqp {
                     for (int kb = sbf[i]; kb < sbf[i + 1]; ++kb) {
                         if (qlive && bnd_idx[kb] - i * NX == a) {
                             const double sg = bnd_sign[kb];
-                            if (isr) br[m + kb] += sg * x; else art[q * ndld + dcol[m + kb]] = sg * x;
+                            if (isr) br[m + kb] += sg * x; else art[aoff[dcol[m + kb]] + q] = sg * x;
                         }
                     }
                 }
@@ -1291,43 +1324,41 @@ struct WgSqp {
         T::sync();
     }
 
-    // The dense rows of the sub-problem are the columns of art [nq x nd] (row q contiguous).  Products with the whole matrix replace
-    // loops over the working set: their cost does not depend on how many rows are active, the loads are contiguous and independent.
-    // yd[dc] = (column dc of art)' x for every dense column (four lanes share a column).  Every thread calls; the caller synchronises.
+    // The dense rows of the sub-problem, row by row (wg_row_len).  yd[dc] = (row dc)' x for every dense row: sixteen lanes share a row (its
+    // entries are contiguous: one 128-byte line per group and pass).  Every thread calls; the caller synchronises.
     static __device__ __forceinline__ void art_tmul(const V &v, const double *x, double *yd, int tid)
     {
         const auto &P = v.A->P;
-        const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const int nd = P.nd, l = tid & 15;
+        const int *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen);
         typename FP::type art = art_of(v);
-        for (int d0 = 0; d0 < nd; d0 += NT / 4) {
-            const int dc = d0 + (tid >> 2);
+        for (int d0 = 0; d0 < nd; d0 += NT / 16) {
+            const int dc = d0 + (tid >> 4);
             const bool live = dc < nd;
-            typename FP::type col = art + (live ? dc : 0);
+            const int ro = live ? aoff[dc] : 0, len = live ? alen[dc] & 0xffff : 0;
             double a0 = 0.0, a1 = 0.0;
-            int q = part;
-            for (; q + 4 < nq; q += 8) { a0 = fma(col[q * ndld], x[q], a0); a1 = fma(col[(q + 4) * ndld], x[q + 4], a1); }
-            for (; q < nq; q += 4) a0 = fma(col[q * ndld], x[q], a0);
-            const double acc = group_sum<4>(a0 + a1);
-            if (live && part == 0) yd[dc] = acc;
+            int q = l;
+            for (; q + 16 < len; q += 32) { a0 = fma(art[ro + q], x[q], a0); a1 = fma(art[ro + q + 16], x[q + 16], a1); }
+            for (; q < len; q += 16) a0 = fma(art[ro + q], x[q], a0);
+            const double acc = group_sum<16>(a0 + a1);
+            if (live && l == 0) yd[dc] = acc;
         }
     }
-    // out[q] (+)= sum_dc art[q][dc] cd[dc] (four lanes share a row)
-    template <bool ACCUMULATE>
-    static __device__ __forceinline__ void art_mul(const V &v, const double *cd, double *out, int tid)
+    // out[q] += sum over the dense rows of the working set of cd[row] * (row)[q]: a loop over the WORKING rows (a dozen, not all sixty: the
+    // product with the whole matrix read every row to multiply most of them by zero), a lane per entry.  Every thread calls; the caller synchronises.
+    static __device__ __forceinline__ void art_ws_mul(const V &v, int nw, const double *cd, double *out, int tid)
     {
         const auto &P = v.A->P;
-        const int nd = P.nd, nq = v.nq, ndld = v.ndld, part = tid & 3;
+        const int nq = v.nq;
+        const int *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen), *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
         typename FP::type art = art_of(v);
-        for (int q0 = 0; q0 < nq; q0 += NT / 4) {
-            const int q = q0 + (tid >> 2);
-            const bool live = q < nq;
-            typename FP::type row = art + (live ? q : 0) * ndld;
-            double a0 = 0.0, a1 = 0.0;
-            int dc = part;
-            for (; dc + 4 < nd; dc += 8) { a0 = fma(row[dc], cd[dc], a0); a1 = fma(row[dc + 4], cd[dc + 4], a1); }
-            for (; dc < nd; dc += 4) a0 = fma(row[dc], cd[dc], a0);
-            const double acc = group_sum<4>(a0 + a1);
-            if (live && part == 0) out[q] = ACCUMULATE ? out[q] + acc : acc;
+        for (int q = tid; q < nq; q += NT) {
+            double acc = 0.0;
+            for (int t = 0; t < nw; ++t) {
+                const int dc = dcol[wq[t]];
+                if (dc >= 0 && q < (alen[dc] & 0xffff)) acc = fma(art[aoff[dc] + q], cd[dc], acc);
+            }
+            out[q] += acc;
         }
     }
     // the working set as it stands in LDS: row numbers, orientations, and where the rows' entries are (derived once per phase,
@@ -1362,7 +1393,7 @@ struct WgSqp {
             }
         }
         T::sync();
-        if (W.nd > 0) { art_mul<true>(v, W.cd, out, tid); T::sync(); }
+        if (W.nd > 0) { art_ws_mul(v, nw, W.cd, out, tid); T::sync(); }
     }
     // out[t] = (oriented normal of working row t)' x for t < nw
     static MPCX_WG_CALL void ws_n_mul(int nw, int x_off, int out_off)
@@ -1386,10 +1417,10 @@ struct WgSqp {
         T::sync();
     }
     // wv += art cd: the dense rows' part of N_W' rr (cd: their coefficients, scattered by the dual part of the step)
-    static MPCX_WG_CALL void art_mul_call()
+    static MPCX_WG_CALL void art_mul_call(int nw)
     {
         const V v; const auto &P = v.A->P;
-        art_mul<true>(v, v.at(P.o_cd), v.at(P.o_wv), threadIdx.x);
+        art_ws_mul(v, nw, v.at(P.o_cd), v.at(P.o_wv), threadIdx.x);
         T::sync();
     }
     // xq -= t (vv - B^-1 wv): the primal part of a dual step
@@ -1411,7 +1442,8 @@ struct WgSqp {
         typename FP::type art = art_of(v);
         double *np_ = v.at(P.o_np), *vv = v.at(P.o_vv);
         if (dc >= 0) {
-            for (int q = tid; q < nq; q += NT) np_[q] = sgn * art[q * v.ndld + dc];
+            const int ro = v.iat(P.o_aoff)[dc], rl = v.iat(P.o_alen)[dc] & 0xffff;
+            for (int q = tid; q < nq; q += NT) np_[q] = q < rl ? sgn * art[ro + q] : 0.0;
             T::sync();
             hmul<NT>(hinv, np_, vv, nq, 1.0, tid);
         } else {
@@ -1611,7 +1643,8 @@ struct WgSqp {
         typename FP::type art = art_of(v);
         const int nt = (nw + 15) >> 4, nkb = (nq + 15) >> 4;
         // this lane's kept row in each tile of sixteen: where its entries are
-        int rk[kSchurTiles], rdc[kSchurTiles], rix[kSchurTiles], rcn[kSchurTiles];
+        int rk[kSchurTiles], rdc[kSchurTiles], rix[kSchurTiles], rcn[kSchurTiles], rro[kSchurTiles], rrl[kSchurTiles];
+        const int *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen);
         double rsg[kSchurTiles], rv0[kSchurTiles];
 #pragma unroll
         for (int ti = 0; ti < kSchurTiles; ++ti) {
@@ -1619,13 +1652,14 @@ struct WgSqp {
             const bool live = t < nw;
             const int k = live ? wq[t] : 0;
             rk[ti] = k; rdc[ti] = live ? dcol[k] : -1; rsg[ti] = live ? sgq[t] : 0.0;
+            rro[ti] = rdc[ti] >= 0 ? aoff[rdc[ti]] : 0; rrl[ti] = rdc[ti] >= 0 ? alen[rdc[ti]] & 0xffff : 0;
             rcn[ti] = (live && rdc[ti] < 0) ? sp.count(k) : 0;
             rix[ti] = sp.index(k, 0); rv0[ti] = sp.value(k, 0);
         }
         // entry kk of the oriented normal of this lane's row in tile ti (zero beyond the row's or the matrix's end)
         auto nrm = [&](int ti, int kk) -> double {
             if (kk >= nq) return 0.0;
-            if (rdc[ti] >= 0) return rsg[ti] * art[kk * ndld + rdc[ti]];
+            if (rdc[ti] >= 0) return kk < rrl[ti] ? rsg[ti] * art[rro[ti] + kk] : 0.0;
             double val = (rcn[ti] > 0 && rix[ti] == kk) ? rv0[ti] : 0.0;
             for (int e = 1; e < rcn[ti]; ++e) if (sp.index(rk[ti], e) == kk) val += sp.value(rk[ti], e);
             return rsg[ti] * val;
@@ -1986,7 +2020,7 @@ struct WgSqp {
             }
         }
         if (nw > 0) {
-            if (P.nd > 0) art_mul_call();
+            if (P.nd > 0) art_mul_call(nw);
             hmul_step_call(-1.0, false);                        // x = x0 - B^-1 N_W' u
         }
         MPCX_QLAP(3);
@@ -2063,7 +2097,7 @@ struct WgSqp {
                 }
                 if (can_move) {
                     if (nw > 0) {
-                        if (P.nd > 0) art_mul_call();
+                        if (P.nd > 0) art_mul_call(nw);
                         MPCX_QLAP(8);
                         hmul_step_call(tt);
                         MPCX_QLAP(9);
@@ -2539,6 +2573,16 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     const int nsb = state_bounds;                          // finite bounds on states: the first rows of the bound table
     if (nsx >= 4096) return -2;
     P.nsx = nsx; P.nd_user = ndu; P.nsb = nsb; P.nd = ndu + nsb; P.ndld = (P.nd + 1) | 1;
+    {
+        int tot = 0;
+        for (int k = 0; k < mu_; ++k) {
+            bool dense = !Mdl::XFREE_ROWS_SPARSE;
+            for (int i = 1; i <= ph && !dense; ++i) dense = k < mi ? Mdl::ineq_reads_x(k, i) : Mdl::eq_reads_x(k - mi, i);
+            if (dense) tot += wg_row_len<Mdl>(k, ph, m.ch, P.nq, m.nzu, mi) & 0xffff;
+        }
+        tot += nsb * (NX > 8 ? P.nq : (wg_bound_row_len(m.nzu) & 0xffff));
+        P.art_total = tot;
+    }
     P.needs_phi = (reads_x || nsb > 0) ? 1 : 0;
     // a working set holds linearly independent rows: never more than there are rows or sub-problem variables
     auto imin = [](int a, int b) { return a < b ? a : b; };
@@ -2562,7 +2606,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
         P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
         P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
-        P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = f_lds ? take(nr * P.ndld) : 0;
+        P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = f_lds ? take(P.art_total) : 0;
         P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw);
         P.o_xq = take(nr); P.o_p = P.o_xq;        // (the sub-problem's iterate is the step when it ends)
         P.o_np = take(nr); P.o_vv = take(nr); P.o_wv = take(nr);
@@ -2570,6 +2614,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_bidx = take((m.nbnd + 1) / 2); P.o_bsign = take(m.nbnd); P.o_bval = take(m.nbnd);
         P.o_xrf = take((ph + 3) / 2); P.o_xre = take((nsx + 1) / 2); P.o_drow = take((P.nd_user + 1) / 2);
         P.o_mbuf = P.minv ? take(kw) : 0;
+        P.o_aoff = take((P.nd + 2) / 2); P.o_alen = take((P.nd + 1) / 2);
         P.o_F = f_lds ? take(ph * NX * FW) : 0;
         const int ov = o;
         P.o_Xs = take((ph + 1) * NX); P.o_Us = take((ph + 1) * NU); P.o_dXs = take((ph + 1) * NX); P.o_dUs = take((ph + 1) * NU);
@@ -2624,7 +2669,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         P.w_F = take(P.f_lds ? 0 : ph * NX * FW);
-        P.w_art = take(P.f_lds ? 0 : nr * P.ndld);
+        P.w_art = take(P.f_lds ? 0 : P.art_total);
         P.w_einv = take(Mdl::CONTINUOUS ? ph * NX * NX : 0);
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);
