@@ -487,8 +487,8 @@ template <class Mdl> __host__ __device__ inline int wg_row_len(int k, int ph, in
     const int len = lx > lu ? lx : lu;
     return len | (ublk < 0 ? 1 << 30 : 0);
 }
-// (a bound on a state: the whole input part -- the host's plan does not see which state it bounds -- written by the sweep alone)
-__host__ __device__ inline int wg_bound_row_len(int nzu) { return nzu | (1 << 30); }
+// (a bound on a state: the whole input part -- the host's plan does not see which state it bounds; zeroed at evaluation, the sweep adds)
+__host__ __device__ inline int wg_bound_row_len(int nzu) { return nzu; }
 
 // Register budget (inherited by every phase): two wavefronts per SIMD -- no phase of any built-in system spills at 256 registers, and the LDS
 // block of a problem that takes several wavefronts leaves room for two or three workgroups per CU at most; four per SIMD (128 registers)
@@ -1040,7 +1040,7 @@ struct WgSqp {
             if (zi < nxs) {
                 const int dc = dcol[k];
                 s1v[k] = 0.0; s1m[k] = kSpDense;
-                if constexpr (NX > 8) { const int ro = aoff[dc]; for (int q = 0; q < nq; ++q) art[ro + q] = 0.0; }     // (the forward sweep adds; the row-wise one stores)
+                { const int ro = aoff[dc], rl = alen[dc] & 0xffff; for (int q = 0; q < rl; ++q) art[ro + q] = 0.0; }
             } else {
                 s1v[k] = sg; s1m[k] = (1 << 16) | (zi - nxs);
                 spv[k * kNlSparse] = sg; spi[k * kNlSparse] = zi - nxs;

@@ -91,7 +91,9 @@ static int run(int argc, char **argv)
         if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total);
     }
 #endif
-    std::vector<double> ws((size_t)B * ws_total, 0.0), cmd(B * NU), cost(B), zout((size_t)B * nz), sx((size_t)B * (ph + 1) * NX), su_((size_t)B * (ph + 1) * NU),
+    // (workspace and LDS start as NaNs: a kernel that reads what it has not written shows it -- the interpreter's memory would otherwise be zeros)
+    std::fill(engine::smem, engine::smem + 40960, std::nan(""));
+    std::vector<double> ws((size_t)B * ws_total, std::nan("")), cmd(B * NU), cost(B), zout((size_t)B * nz), sx((size_t)B * (ph + 1) * NX), su_((size_t)B * (ph + 1) * NU),
         sy((size_t)B * (ph + 1) * (Mdl::NY > 0 ? Mdl::NY : 1)), mu((size_t)B * (mt > 0 ? mt : 1));
     std::vector<int> status(B), sstat(B), feas(B), iters(B);
     NlmpcSolveDev S{};
@@ -135,8 +137,8 @@ static int run(int argc, char **argv)
             for (int j = 0; j < NU; ++j) printf("%s%.17g", j ? ", " : "", cmd[b * NU + j]);
             printf("], \"z\": [");
             for (int k = 0; k < nz; ++k) printf("%s%.17g", k ? ", " : "", zout[(size_t)b * nz + k]);
-            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"mu\": [", ws[(size_t)b * ws_total + M.ws.scal + 12], ws[(size_t)b * ws_total + M.ws.scal + 1],
-                   ws[(size_t)b * ws_total + M.ws.scal + 13]);
+            auto stat = [&](int k) { const double x = ws[(size_t)b * ws_total + M.ws.scal + k]; return std::isfinite(x) ? x : -1.0; };       // (the one-wavefront form files fewer)
+            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"mu\": [", stat(12), stat(1), stat(13));
             for (int k = 0; k < mt; ++k) printf("%s%.17g", k ? ", " : "", mu[(size_t)b * mt + k]);
             printf("]}\n");
         }
