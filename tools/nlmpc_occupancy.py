@@ -24,6 +24,6 @@ for k in ks:
     check(c._lib.mpcx_nlmpc_solve_batch(c._h, C.byref(b), s)); torch.cuda.synchronize()
     ms = c.time_launches(b, 2, s); torch.cuda.synchronize()
     it = out["iterations"].cpu().numpy()
-    form = int(c._lib.mpcx_nlmpc_debug_last_form())
+    form = int(c._lib.mpcx_nlmpc_last_form(c._h))
     print(f"{name} k={k:2d} per CU (batch {B:5d}) form {form}: {ms:8.3f} ms, {it[0]} iterations, {k / ms:7.4f} instances per ms and CU, "
           f"{B / ms:8.1f} solves/ms", flush=True)

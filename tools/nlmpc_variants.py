@@ -32,7 +32,7 @@ for spec in (sys.argv[1:] or DEFAULT):
         ms = c.time_launches(b, reps)
         torch.cuda.synchronize()
         st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy()
-        got = int(c._lib.mpcx_nlmpc_debug_last_form())
+        got = int(c._lib.mpcx_nlmpc_last_form(c._h))
         print("%-28s form %d  %9.3f ms  %10.1f solves/s  iterations %.1f (max %d)  solved %.5f" %
               (spec, got, ms, B / ms * 1e3, it.mean(), it.max(), float((st > 0).mean())), flush=True)
     except Exception as e:  # a variant the plan refuses

@@ -12,6 +12,18 @@ def main(db_path, out_path=None):
     for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         short = name.replace("mpcx::(anonymous namespace)::", "").replace("mpcx::", "")
         lines.append("%-72s %8d %14.3f %12.3f %7.2f%%" % (short[:72], calls, total, avg, pct))
+    # launches of one kernel that do different work (nlmpc_sqp_wg: the solve, then the second pass over the instances whose working set outgrew
+    # a cut capacity -- normally none, a few microseconds): the longest launches on their own
+    try:
+        rows = list(cur.execute("select name, count(*), avg(end - start) / 1e3, max(end - start) / 1e3 from kernels group by name"))
+        for name, n, avg, mx in rows:
+            if n > 1 and mx > 4.0 * avg:
+                big = [d for (d,) in cur.execute("select (end - start) / 1e3 from kernels where name = ? and (end - start) / 1e3 > ?", (name, 0.25 * mx))]
+                short = name.replace("mpcx::(anonymous namespace)::", "").replace("mpcx::", "")
+                lines.append("  %s: %d of the %d launches are longer than a quarter of the longest: their average %.3f us (the others: the second pass)"
+                             % (short[:72], len(big), n, sum(big) / len(big)))
+    except sqlite3.Error:
+        pass
     lines.append("")
     lines.append("per-kernel launch geometry / resources (first dispatch of each):")
     seen = set()
