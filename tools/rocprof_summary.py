@@ -15,9 +15,9 @@ def main(db_path, out_path=None):
     # launches of one kernel that do different work (nlmpc_sqp_wg: the solve, then the second pass over the instances whose working set outgrew
     # a cut capacity -- normally none, a few microseconds): the longest launches on their own
     try:
-        rows = list(cur.execute("select name, count(*), avg(end - start) / 1e3, max(end - start) / 1e3 from kernels group by name"))
-        for name, n, avg, mx in rows:
-            if n > 1 and mx > 4.0 * avg:
+        rows = list(cur.execute("select name, count(*), min(end - start) / 1e3, max(end - start) / 1e3 from kernels group by name"))
+        for name, n, mn, mx in rows:
+            if n > 1 and mn < 0.05 * mx:
                 big = [d for (d,) in cur.execute("select (end - start) / 1e3 from kernels where name = ? and (end - start) / 1e3 > ?", (name, 0.25 * mx))]
                 short = name.replace("mpcx::(anonymous namespace)::", "").replace("mpcx::", "")
                 lines.append("  %s: %d of the %d launches are longer than a quarter of the longest: their average %.3f us (the others: the second pass)"
