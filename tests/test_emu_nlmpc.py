@@ -109,3 +109,38 @@ def test_lds_blocks_next_to_a_two_level_factor_equal_the_workspace_form(runner, 
     for x, y in zip(a, b):
         assert x["status"] == y["status"] == 0 and x["iterations"] == y["iterations"]
         np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPEMU_ORDER": "reverse"}])
+def test_inverse_of_the_schur_complement_equals_the_factor_form(runner, env):
+    """WgPlan::minv (round 5): the working set's Schur complement kept as its inverse -- product, bordering and rank-one correction over the
+    workgroup, one row shed per warm-start round -- against the Cholesky form of the same kernel on the six-oscillator network (working
+    sets of 20 to 50 input bounds), in both thread orders: same statuses, the same optimum to the solver's own tolerance"""
+    rng = np.random.default_rng(5)
+    X0 = rng.uniform(-0.1, 0.1, size=(2, 12)); X0[:, 0] += 1.0
+    inst = np.hstack([X0, np.zeros((2, 6))])
+    a = runner(["osc6", 20, 10, 0.1, 1, 200, "wg"], inst, {"MPCX_NLMPC_MINV": "0"})
+    e = dict(env); e["MPCX_NLMPC_MINV"] = "1"
+    b = runner(["osc6", 20, 10, 0.1, 1, 200, "wg"], inst, e)
+    for x, y in zip(a, b):
+        assert x["status"] == y["status"] == 0
+        np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-5, atol=1e-6)
+        assert abs(x["cost"] - y["cost"]) <= 1e-9 * max(1.0, abs(x["cost"]))
+        assert y["dual_steps"] <= x["dual_steps"]            # (shedding one row at a time keeps more of the kept set)
+
+
+def test_eight_wavefronts_per_instance_and_the_mfma_schur_complement(runner):
+    """the eight-wavefront variant (systems alone on a CU) on a small oscillator problem, and config 3's first golden instance with the
+    dense rows' Schur complement on v_mfma_f64_16x16x4 (the interpreter models the instruction lane for lane)"""
+    rng = np.random.default_rng(7)
+    X0 = rng.uniform(-0.1, 0.1, size=(1, 12)); X0[:, 0] += 1.0
+    inst = np.hstack([X0, np.zeros((1, 6))])
+    a = runner(["osc6", 12, 6, 0.1, 1, 200, "wg"], inst, {"HIPEMU_WAVES": "4"})
+    b = runner(["osc6", 12, 6, 0.1, 1, 200, "wg"], inst, {"HIPEMU_WAVES": "8"})
+    assert a[0]["status"] == b[0]["status"] == 0
+    np.testing.assert_allclose(b[0]["cmd"], a[0]["cmd"], rtol=1e-5, atol=1e-6)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nlmpc_oracle_solutions.json")))["ugv_ph30_ch30"]
+    k = gold["cases"][1]
+    y = runner(["ugv", 30, 30, 0.1, 0, 150, "wg"], np.array([k["x0"] + k["u0"]]), {"HIPEMU_BLOCKS": "1"})[0]
+    assert y["status"] == 0 and y["max_nw"] >= 2              # a kept set with dense rows went through ws_schur_mfma
+    np.testing.assert_allclose(y["cmd"], k["cmd"], rtol=1e-5, atol=1e-5)
