@@ -1896,6 +1896,9 @@ struct WgSqp {
         const double *yd = v.at(P.o_yd), *vv = v.at(P.o_vv);
         const int *dcol = v.iat(P.o_dcol);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+#ifdef MPCX_NL_STATS
+        long long qt_ = __builtin_readcyclecounter();
+#endif
         for (int t = tid; t < nw; t += NT) {
             const int k = wq[t], dc = dcol[k];
             tq[t] = sgq[t] * (dc >= 0 ? yd[dc] : sp.dot(k, vv));
@@ -1903,21 +1906,31 @@ struct WgSqp {
         for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
         for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
         T::sync();
+        MPCX_QLAP(11);
         if (nw > 0) { hmul<NT>(Mp, tq, rq, nw, 1.0, tid); T::sync(); }
-        double tr = 0.0, tneg = -1e300; int tidx = 0x7fffffff;
-        for (int t = tid; t < nw; t += NT) {
-            const double r = rq[t];
-            tr = fma(tq[t], r, tr);
-            const int k = wq[t];
-            if (r > 1e-14 && !(k >= mi && k < m)) { const double tj = -(uq[t] / r); if (tj > tneg) { tneg = tj; tidx = t; } }
+        MPCX_QLAP(12);
+        // z'n = n'B^-1 n - t'r and the dual ratio test: by wavefront 0 alone, the working set's vectors two entries a lane (a reduction over
+        // the whole workgroup walked eight wavefronts through two wave reductions for the sake of the first two: 4.2 k cycles a step)
+        if (tid < 64) {
+            const int lane = tid;
+            const bool h0 = lane < nw, h1 = lane + 64 < nw;
+            const double r0 = h0 ? rq[lane] : 0.0, r1 = h1 ? rq[lane + 64] : 0.0;
+            const double tr = wave_sum((h0 ? tq[lane] * r0 : 0.0) + (h1 ? tq[lane + 64] * r1 : 0.0));
+            double tneg = -1e300; int tidx = 0x7fffffff;
+            if (h0 && r0 > 1e-14) { const int k0 = wq[lane]; if (!(k0 >= mi && k0 < m)) { tneg = -(uq[lane] / r0); tidx = lane; } }
+            if (h1 && r1 > 1e-14) { const int k1 = wq[lane + 64]; if (!(k1 >= mi && k1 < m)) { const double tj = -(uq[lane + 64] / r1); if (tj > tneg) { tneg = tj; tidx = lane + 64; } } }
+            wave_argmax(tneg, tidx);
+            const double zn_ = snn - tr;
+            const double tl_ = tneg > -1e300 ? -tneg : 1e300;
+            const double t2_ = zn_ > 1e-13 * fmax(1.0, npn) ? spv / zn_ : 1e300;
+            const double tt_ = fmin(tl_, t2_);
+            if (lane == 0) { st[ST_R0] = tt_; st[ST_R1] = zn_; st[ST_R2] = tt_ >= 1e300 ? 0.0 : (t2_ <= tl_ ? 1.0 : 2.0); st[ST_R3] = (double)tidx; }
         }
-        const WgSumArgmax red = wg_red_sum_argmax<WAVES>(tr, tneg, tidx, v.at(P.o_red));
-        const double zn = snn - red.sum;
-        const double tl = red.v > -1e300 ? -red.v : 1e300;
+        T::sync();
+        MPCX_QLAP(13);
+        const double tt = st[ST_R0], zn = st[ST_R1];
+        const int what = (int)st[ST_R2];
         const bool can_move = zn > 1e-13 * fmax(1.0, npn);
-        const double t2 = can_move ? spv / zn : 1e300;
-        const double tt = fmin(tl, t2);
-        const int what = tt >= 1e300 ? 0 : (t2 <= tl ? 1 : 2);
         if (what != 0) {
             for (int t = tid; t < nw; t += NT) {
                 const double r = rq[t];
@@ -1937,8 +1950,8 @@ struct WgSqp {
                 if (tid == 0) { Mp[ro + nw] = id; uq[nw] = up + tt; wq[nw] = pidx; sgq[nw] = sgn; flag[pidx] = 1; }
             }
         }
-        if (tid == 0) { st[ST_R0] = tt; st[ST_R1] = zn; st[ST_R2] = (double)what; st[ST_R3] = (double)red.idx; }
         T::sync();
+        MPCX_QLAP(14);
     }
 
     // warm start of the sub-problem: the rows active in the previous one (wq, sgq) as long as their multipliers stay non-negative -- the
@@ -2540,7 +2553,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         scal[13] = st[ST_NSHED];
         scal[14] = st[ST_OVER];                                  // 1: a pass with the full capacity has to take this instance again
 #ifdef MPCX_NL_STATS
-        for (int k = 0; k < 12; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
+        for (int k = 0; k < 16; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
 #endif
         for (int k = 0; k < 10; ++k) scal[2 + k] = (double)cyc[k];
     }
@@ -2679,7 +2692,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.w_scal = m.ws.scal;
         if (P.ws_total > m.ws.scal || m.ws.scal + 16 > m.ws.total) return -2;
 #ifdef MPCX_NL_STATS
-        if (m.ws.scal + 28 > m.ws.total) return -2;            // (the statistics build files the sub-problem's cycle counts behind the block)
+        if (m.ws.scal + 32 > m.ws.total) return -2;            // (the statistics build files the sub-problem's cycle counts behind the block)
 #endif
     }
     return 0;
