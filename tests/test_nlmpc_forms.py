@@ -205,17 +205,30 @@ def test_the_form_is_a_property_of_the_controller(monkeypatch):
 
 
 def test_working_sets_beyond_a_cut_capacity_are_solved_by_the_second_pass(monkeypatch):
-    """where the plan cuts the working set's capacity for one more workgroup per CU (six oscillators: 53 of 61 rows with the blocks in LDS), an
-    instance that outgrows it is marked and taken again by a launch planned with the full capacity: same statuses and optimum as the
-    wavefront form, which never cuts"""
-    from libmpc_amd.nlmpc import OSCILLATORS6
+    """where the plan cuts the working set's capacity for one more workgroup per CU (six oscillators with the blocks forced into LDS: 53 of 61
+    rows), an instance that outgrows it is marked and taken again by a launch planned with the full capacity: same statuses and optimum as the
+    wavefront form, which never cuts -- and some instances of this batch do outgrow 53 rows"""
+    import torch
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, OSCILLATORS6
     rng = np.random.default_rng(0)
-    B = 256
+    B = 1024
     X0 = rng.uniform(-0.1, 0.1, size=(B, 12)); X0[:, 0] += 1.0
     out = {}
     for form in ("wg", "wave"):
         _set_form(monkeypatch, form, None)
-        out[form] = _solve(OSCILLATORS6, 20, 10, 0.1, X0, np.zeros((B, 6)), True, 200)
+        if form == "wg":
+            monkeypatch.setenv("MPCX_NLMPC_BLOCKS", "1")
+        else:
+            monkeypatch.delenv("MPCX_NLMPC_BLOCKS", raising=False)
+        c = NLMPC(OSCILLATORS6, 20, 10, 0.1)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+        r = c.optimizeBatch(torch.from_numpy(X0), torch.zeros(B, 6, dtype=torch.float64)); torch.cuda.synchronize()
+        out[form] = {k: v.cpu().numpy() for k, v in r.items() if k != "_keep"}
+        if form == "wg":
+            # the largest working set of each solve is filed in the workspace's statistics block (slot 12)
+            biggest = max(c.debug_workspace(i)["scal"][12] for i in range(0, B, 8))
+            assert biggest > 53, biggest
+    monkeypatch.delenv("MPCX_NLMPC_BLOCKS", raising=False)
     a, b = out["wg"], out["wave"]
     assert (b["status"] == 0).all() and np.array_equal(a["status"], b["status"]), (a["solver_status"][a["status"] != 0], np.nonzero(a["status"] != 0)[0])
     assert (np.abs(a["cmd"] - b["cmd"]) / np.maximum(1.0, np.abs(b["cmd"]).max(axis=1, keepdims=True))).max() <= 1e-5
