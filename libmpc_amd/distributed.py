@@ -164,3 +164,47 @@ class OverlappedGather:
     def finish(self):
         if self.cuda:
             self.gather_stream.synchronize()
+
+
+class GraphedOverlap:
+    """`OverlappedGather` without its host calls: {solve of step k on the capture stream || all-gather of step k-1 on a second stream}
+    captured once per buffer parity as ONE HIP graph (fork at the graph's root, join at its end) and replayed with one launch per step.
+    The eager form orders the two streams with five host calls per step (two waits, two records, a second-stream launch), which at a 50 us
+    step is what the loop then waits for; a graph launch is one.  RCCL (>= 2.9) collectives can be captured; so can the solve (it is what
+    `mpcx_lmpc_graph_create` captures).  After graph k: `cmd[k % 2]` holds step k's controls, `all[(k - 1) % 2]` the gathered controls of
+    step k - 1; `flush()` gathers the last step's.  One instance per (controller, pair of batch descriptors): the descriptors' pointers are
+    baked into the graphs, what they point to may change between launches."""
+
+    def __init__(self, og: OverlappedGather, launch, warmup: int = 2):
+        assert og.cuda and og.gather is not None
+        self.og, self.launch = og, launch
+        dev = og.cmd[0].device
+        # eager rounds first: allocations, function attributes, RCCL's lazy set-up must not happen inside a capture
+        for k in range(2 * warmup):
+            og.step(k, launch)
+        og.finish()
+        torch.cuda.synchronize(dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graphs = []
+        for i in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                cur = torch.cuda.current_stream(dev)
+                og.gather_stream.wait_stream(cur)                  # fork at the root: nothing of this step is enqueued yet
+                launch(i, cur)                                     # solve of step k -> cmd[i]
+                og.gather.allgather(og.cmd[1 - i], out=og.all[1 - i], stream=og.gather_stream.cuda_stream)      # step k-1's controls
+                cur.wait_stream(og.gather_stream)                  # join
+            self.graphs.append(g)
+        self.k = 0
+
+    def step(self):
+        with torch.cuda.stream(self.stream):
+            self.graphs[self.k % 2].replay()
+        self.k += 1
+
+    def flush(self):
+        """the all-gather of the last step (its graph has not been launched), in series on the graphs' stream"""
+        i = (self.k - 1) % 2
+        self.og.gather.allgather(self.og.cmd[i], out=self.og.all[i], stream=self.stream.cuda_stream)
+        self.stream.synchronize()
+        return self.og.all[i]

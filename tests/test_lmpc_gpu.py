@@ -534,3 +534,33 @@ def test_a_step_replayed_as_a_hip_graph_gives_the_plain_launch_s_results():
     assert torch.equal(res.cmd, plain2.cmd) and torch.equal(res.cost, plain2.cost)
     assert not torch.equal(plain.cmd, plain2.cmd)
     c.destroy_graph(g)
+
+
+def test_overlapped_gather_as_one_hip_graph_per_parity_gathers_every_step():
+    """libmpc_amd.distributed.GraphedOverlap: {solve of step k || RCCL all-gather of step k-1} captured as one HIP graph per buffer parity
+    (one rank here: the collective gathers the block onto itself).  Inputs change between launches (the descriptors' pointers are baked in,
+    what they point to is not): after every launch the gathered controls of the previous step are that step's results, and the last step's
+    arrive with flush()."""
+    import torch
+    from libmpc_amd.distributed import ControlGather, GraphedOverlap, OverlappedGather
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    B = 256
+    c = quadrotor_lmpc(20, device=0)
+    x0, u0, yref = quadrotor_batch(B)
+    b0, r0, keep0 = c.make_batch(x0, u0, yref=yref)
+    b1, r1, keep1 = c.make_batch(x0, u0, yref=yref)
+    pair, res = [b0, b1], [r0, r1]
+    g = ControlGather(0, 0, 1)
+    og = OverlappedGather(B, 4, torch.device("cuda:0"), gather=g, solve_stream=torch.cuda.current_stream(0))
+    og.cmd = [r0.cmd, r1.cmd]
+    go = GraphedOverlap(og, lambda i, s: c.launch(pair[i], s))
+    ref = c.optimizeBatch(x0, u0, yref=yref).cmd.clone(); torch.cuda.synchronize()
+    prev = None
+    for k in range(5):
+        go.step(); go.stream.synchronize()
+        i = (go.k - 1) % 2
+        assert torch.equal(res[i].cmd, ref)                     # the same inputs every step: the same controls
+        if prev is not None:
+            assert torch.equal(og.all[prev], ref)               # the previous step's controls were gathered by this graph
+        prev = i
+    assert torch.equal(go.flush(), ref)
