@@ -1344,6 +1344,26 @@ struct WgSqp {
             if (live && l == 0) yd[dc] = acc;
         }
     }
+    // yd[dc] = (row dc)' x for the dense rows of the WORKING set only (what t = N_W B^-1 n and the warm start's multipliers need: a dozen rows of
+    // sixty -- the scan is the one product that needs them all).  Sixteen lanes a row; every thread calls; the caller synchronises.
+    static __device__ __forceinline__ void art_ws_tmul(const V &v, int nw, const double *x, double *yd, int tid)
+    {
+        const auto &P = v.A->P;
+        const int l = tid & 15;
+        const int *aoff = v.iat(P.o_aoff), *alen = v.iat(P.o_alen), *wq = v.iat(P.o_wq), *dcol = v.iat(P.o_dcol);
+        typename FP::type art = art_of(v);
+        for (int t0 = 0; t0 < nw; t0 += NT / 16) {
+            const int t = t0 + (tid >> 4);
+            const int dc = t < nw ? dcol[wq[t]] : -1;
+            const int ro = dc >= 0 ? aoff[dc] : 0, len = dc >= 0 ? alen[dc] & 0xffff : 0;
+            double a0 = 0.0, a1 = 0.0;
+            int q = l;
+            for (; q + 16 < len; q += 32) { a0 = fma(art[ro + q], x[q], a0); a1 = fma(art[ro + q + 16], x[q + 16], a1); }
+            for (; q < len; q += 16) a0 = fma(art[ro + q], x[q], a0);
+            const double acc = group_sum<16>(a0 + a1);
+            if (dc >= 0 && l == 0) yd[dc] = acc;
+        }
+    }
     // out[q] += sum over the dense rows of the working set of cd[row] * (row)[q]: a loop over the WORKING rows (a dozen, not all sixty: the
     // product with the whole matrix read every row to multiply most of them by zero), a lane per entry.  Every thread calls; the caller synchronises.
     static __device__ __forceinline__ void art_ws_mul(const V &v, int nw, const double *cd, double *out, int tid)
@@ -1354,9 +1374,19 @@ struct WgSqp {
         typename FP::type art = art_of(v);
         for (int q = tid; q < nq; q += NT) {
             double acc = 0.0;
-            for (int t = 0; t < nw; ++t) {
-                const int dc = dcol[wq[t]];
-                if (dc >= 0 && q < (alen[dc] & 0xffff)) acc = fma(art[aoff[dc] + q], cd[dc], acc);
+            // four rows at a time: their look-ups (row -> dense index -> offset, length, coefficient) and their entries are requested together --
+            // one row at a time every step was four dependent trips to LDS and one to the rows
+            for (int t0 = 0; t0 < nw; t0 += 4) {
+                int dc[4], ro[4], rl[4];
+                double cf[4], av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dc[u] = t0 + u < nw ? dcol[wq[t0 + u]] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int d = dc[u] >= 0 ? dc[u] : 0; ro[u] = aoff[d]; rl[u] = dc[u] >= 0 ? alen[d] & 0xffff : 0; cf[u] = cd[d]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = q < rl[u] ? art[ro[u] + q] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fma(av[u], cf[u], acc);
             }
             out[q] += acc;
         }
@@ -1432,9 +1462,9 @@ struct WgSqp {
         T::sync();
     }
     // the oriented normal n = sgn * (row k) of a sub-problem row into np and vv = B^-1 n.  For the dual method (sums): returns n' B^-1 n and
-    // n'n, and leaves art' vv in yd -- the dense rows' part of N_W B^-1 n, for whoever gathers the working set's entries (with_t: there is a
-    // working set); no barrier behind the reduction (slot set 2).  For the warm start's row-by-row Schur complement: np and vv only.
-    static MPCX_WG_CALL WgSum2 normal_call(int k, double sgn, bool sums = true, bool with_t = false)
+    // n'n, and leaves (row)' vv of the nw_t working rows' dense ones in yd -- the dense rows' part of N_W B^-1 n, for whoever gathers the
+    // working set's entries; no barrier behind the reduction (slot set 2).  For the warm start's row-by-row Schur complement: np and vv only.
+    static MPCX_WG_CALL WgSum2 normal_call(int k, double sgn, bool sums = true, int nw_t = 0)
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
         const int tid = threadIdx.x, nq = v.nq, dc = v.iat(P.o_dcol)[k];
@@ -1463,7 +1493,7 @@ struct WgSqp {
         if (!sums) return WgSum2{0.0, 0.0};
         double snn = 0, npn = 0;
         for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
-        if (with_t && P.nd > 0) art_tmul(v, vv, v.at(P.o_yd), tid);
+        if (nw_t > 0 && P.nd > 0) art_ws_tmul(v, nw_t, vv, v.at(P.o_yd), tid);
         Red<WAVES> R(v.at(P.o_red), 2);
         R.sum2(snn, npn);
         return WgSum2{snn, npn};
@@ -2016,7 +2046,7 @@ struct WgSqp {
             T::sync();
             return 0;
         }
-        if (P.nd > 0) { art_tmul(v, xq, W.yd, tid); T::sync(); }
+        if (P.nd > 0) { art_ws_tmul(v, nw, xq, W.yd, tid); T::sync(); }       // (the kept rows' products with x0: fixed while rows are shed)
         while (nw > 0) {
             if (minv) ws_shed_round_m(nw); else ws_shed_round(nw);
             // every row with a negative multiplier leaves at once; equalities stay
@@ -2090,7 +2120,7 @@ struct WgSqp {
                 const int dc = dcol[pidx];
                 sgn = br[pidx] + (dc >= 0 ? W.yd[dc] : sp.dot(pidx, xq)) < 0.0 ? -1.0 : 1.0;
             }
-            const WgSum2 nn = normal_call(pidx, sgn, true, nw > 0);
+            const WgSum2 nn = normal_call(pidx, sgn, true, nw);
             MPCX_QLAP(5);
             const double snn = nn.a, npn = nn.b;
             double up = 0.0, spv_ = vmax;
