@@ -96,11 +96,12 @@ int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, d
                 int which = 7, int fast_variant = -1);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
 int lmpc_fast_slice(const LmpcDev &m);          // needs wsld, kin, nx
+size_t lmpc_group_lds_bytes(const LmpcDev &m);  // LDS block of lmpc_solve_group (0: no group form for the variant); needs fast_slice, kin, nz16, nu
 // implemented in lmpc_fast.hip: the lean polish kernel (b.fused: the fused / persistent forms) on `stream`
 int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream);
 // implemented in lmpc_hetero.hip: the O(n^3) arrays of `count` model structs (device array) computed in place, one workgroup each;
 // -2: the dimensions do not fit the kernel's LDS plan (the bank then condenses on the host)
-size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out);
+size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out, size_t *big_out = nullptr);
 int lmpc_condense_launch(LmpcDev *models_d, const LmpcDev &m0, int count, void *stream);
 
 }  // namespace mpcx

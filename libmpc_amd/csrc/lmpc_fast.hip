@@ -845,10 +845,15 @@ __global__ __launch_bounds__(kPersistWaves * 64) void lmpc_solve_persistent(cons
 // of its instance.  Phase 2: wavefront w solves instance w from its slice (solve_fast, SRC = 2).  No workspace record, no second
 // launch: the only HBM traffic of a solve is its inputs and outputs.  One workgroup per CU; at the benchmark batch the launch is
 // one workgroup deep.  A workgroup moves on when its slowest instance is done, so long batches use the two-kernel path instead.
-constexpr int kGroupWaves = 16;
+// Round 5: the two-chunk variant too (CPZ = CPG = 2: up to 256 condensed variables -- config 4's N = 50).  Its slices are 10.9 KB, so a workgroup
+// holds EIGHT instances on eight wavefronts (eight of the sixteen MFMA columns carry an instance, the others repeat the last one and store
+// nothing); such a controller's cost comes from its definition, one product with H per instance inside solve_fast (SRC = 2 is a fused form).
+template <int CPZ> constexpr int kGroupWavesOf = CPZ == 1 ? 16 : 8;
 constexpr int kGroupKU = 20;              // MFMA k-steps whose A operands are in flight together (the whole of N = 20's second product)
-__global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase, const int variant)
+template <int CPZ, int CPG>
+__global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase, const int variant)
 {
+    constexpr int kGroupWaves = kGroupWavesOf<CPZ>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const LmpcDev &M = *Mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
     const int nx = M.nx, nu = M.nu, ny = M.ny;
     const int kin4 = M.kin >> 2, nz4 = M.nz16 >> 2;
     const int ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
-    constexpr int ZP = 128, GPD = 128;
+    constexpr int ZP = 128 * CPZ, GPD = 128 * CPG;
     double *lwuw = smem;
     double *slices = lwuw + 2 * ZP;
     double *Bv = slices + (size_t)kGroupWaves * M.fast_slice;      // [kin4][64]   vin as MFMA B operands
@@ -865,22 +870,23 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + kGroupWaves * 16);   // [16]
     const int outld = 8 + ((nu + 1) & ~1);
     double *outs = c0s + kGroupWaves * 16 + 16;                             // [16][8 + nu]: results of the sixteen instances
-    fast_load_box<1>(M, lwuw);
+    fast_load_box<CPZ>(M, lwuw);
     double *mine = slices + (size_t)wave * M.fast_slice;
     const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
-    // the slice of instance j (this lane's MFMA column)
-    double *sj = slices + (size_t)j * M.fast_slice;
+    // the slice of instance j (this lane's MFMA column; a column beyond the workgroup's instances computes a copy and stores nothing)
+    const bool jlive = j < kGroupWaves;
+    double *sj = slices + (size_t)(jlive ? j : 0) * M.fast_slice;
     double *t0j = sj, *gt0j = sj + ZP, *lgj = gt0j + GPD, *ugj = lgj + GPD, *fj = ugj + GPD;
 
     {
-        const int b0 = blockIdx.x * 16;             // one batch of sixteen per workgroup, no loop (see lmpc_solve)
-        const int bj = b0 + j;
+        const int b0 = blockIdx.x * kGroupWaves;    // one batch of sixteen (eight) per workgroup, no loop (see lmpc_solve)
+        const int bj = b0 + (jlive ? j : kGroupWaves - 1);
         const int bc = bj < Bt.batch ? bj : Bt.batch - 1;
         // profiling aid: when the wavefront started its batch, when the first product was done, when the records were complete
         auto gstamp = [&](int k) { if (Bt.dbg_cycles && lane == 0 && b0 + wave < Bt.batch) Bt.dbg_cycles[(size_t)(b0 + wave) * 8 + k] = (long long)__builtin_readcyclecounter(); };
         gstamp(4);
-        fast_init_pads<1, 1>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
+        fast_init_pads<CPZ, CPG>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
         // vin operands: k-step kb holds rows 4kb + kq of instance j
         for (int kb = wave; kb < kin4; kb += kGroupWaves) {
             const int k = 4 * kb + kq;
@@ -916,13 +922,13 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
                 for (int r = 0; r < 4; ++r) {
                     Bf[(4 * t + r) * 64 + lane] = acc[r];
                     const int row = 16 * t + 4 * r + kq;
-                    if (row < ldz) fj[row] = acc[r];
+                    if (jlive && row < ldz) fj[row] = acc[r];
                 }
             } else if (t < ts) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * (t - tg) + 4 * r + kq;
-                    if (row < ldg) { lgj[row] = GP(lg0)[row] - acc[r]; ugj[row] = GP(ug0)[row] - acc[r]; }
+                    if (jlive && row < ldg) { lgj[row] = GP(lg0)[row] - acc[r]; ugj[row] = GP(ug0)[row] - acc[r]; }
                 }
             } else if (t < tq) {
 #pragma unroll
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
                 }
             }
         }
-        if (badl) atomicOr(&bad[j], 1u);
+        if (badl && jlive) atomicOr(&bad[j], 1u);
         // this wavefront's share of the cost constant of instance j (no atomics: the sum must not depend on arrival order)
         c0p += __shfl_xor(c0p, 16, 64);
         c0p += __shfl_xor(c0p, 32, 64);
@@ -963,11 +969,12 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
+                if (!jlive) continue;
                 if (row < ldz) t0j[row] = acc[r];
                 else if (row < ldy) gt0j[row - ldz] = acc[r];
             }
         }
-        if (threadIdx.x < 16) {
+        if (threadIdx.x < kGroupWaves) {
             double *tl = slices + (size_t)threadIdx.x * M.fast_slice + 2 * ZP + 3 * GPD;
             double c0 = 0.0;
             for (int w = 0; w < kGroupWaves; ++w) c0 += c0s[w * 16 + threadIdx.x];
@@ -977,12 +984,12 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
         __syncthreads();
         const int b = b0 + wave;
         gstamp(6);
-        if (b < Bt.batch) solve_fast<1, 1, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld);
+        if (b < Bt.batch) solve_fast<CPZ, CPG, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld);
         __syncthreads();
         // the sixteen instances' results, written by neighbouring lanes: one transaction per array and workgroup instead of sixteen
         {
             const int t = threadIdx.x;
-            if (t < 16 && b0 + t < Bt.batch) {
+            if (t < kGroupWaves && b0 + t < Bt.batch) {
                 const double *o = outs + t * outld;
                 const int bb = b0 + t;
                 const bool done = o[7] == 2.0;
@@ -997,13 +1004,17 @@ __global__ __launch_bounds__(kGroupWaves * 64) void lmpc_solve_group(const LmpcD
                     if (Bt.active_count) glw(Bt.active_count)[bb] = (int)o[6];
                 }
             }
-            for (int e = t; e < 16 * nu; e += blockDim.x) {
+            for (int e = t; e < kGroupWaves * nu; e += blockDim.x) {
                 const int ti = e / nu, jj = e - ti * nu;
                 if (b0 + ti < Bt.batch && outs[ti * outld + 7] == 2.0) glw(Bt.cmd)[(size_t)(b0 + ti) * nu + jj] = outs[ti * outld + 8 + jj];
             }
         }
     }
 }
+
+}  // namespace
+size_t lmpc_group_lds_bytes(const LmpcDev &m);
+namespace {
 
 template <int CPZ, int CPG>
 int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
@@ -1031,18 +1042,21 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
     int blocks = (b.batch + kWavesPerBlock - 1) / kWavesPerBlock;      // one wavefront per instance: the grid covers the batch
     if (blocks < 1) blocks = 1;
     const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
-    if (fused && b.fused >= 3) {
-        // assemble + solve in one workgroup of sixteen wavefronts (one per CU)
-        const size_t ldsg = ((size_t)2 * 128 + (size_t)kGroupWaves * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + kGroupWaves * 16 + 16 + 16 * (8 + ((m.nu + 1) & ~1))) * sizeof(double);
-        if (ldsg > 160 * 1024) return -2;
-        static std::atomic<int> gconf[64];
-        if (!gconf[devid].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
-            gconf[devid].store(1, std::memory_order_release);
+    if constexpr (CPZ <= 2 && CPZ == CPG) {
+        if (b.fused >= 3) {
+            // assemble + solve in one workgroup of sixteen (two-chunk variant: eight) wavefronts, one per CU
+            constexpr int NW = kGroupWavesOf<CPZ>;
+            const size_t ldsg = lmpc_group_lds_bytes(m);
+            if (ldsg == 0 || ldsg > 160 * 1024) return -2;
+            static std::atomic<int> gconf[64];
+            if (!gconf[devid].load(std::memory_order_acquire)) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group<CPZ, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+                gconf[devid].store(1, std::memory_order_release);
+            }
+            const int wgs = (b.batch + NW - 1) / NW;
+            hipLaunchKernelGGL((lmpc_solve_group<CPZ, CPG>), dim3(wgs), dim3(NW * 64), ldsg, stream, m_dev, b, ws, b.fused - 3);
+            return hipGetLastError() == hipSuccess ? 0 : -3;
         }
-        const int wgs = (b.batch + 15) / 16;
-        hipLaunchKernelGGL(lmpc_solve_group, dim3(wgs), dim3(kGroupWaves * 64), ldsg, stream, m_dev, b, ws, b.fused - 3);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     // persistent form: the composed map, the box bounds and kPersistWaves slices must fit one CU's LDS, and the batch must be worth
     // the prologue of every workgroup (the composed map: 87 KB at N = 20)
@@ -1074,6 +1088,16 @@ int lmpc_fast_slice(const LmpcDev &m)
     int n = (fixed + scratch + 1) / 2 * 2;
     while (n % 16 != 2) n += 2;                                 // slices 2 doubles apart modulo the 32 LDS banks x 4 bytes
     return n;
+}
+
+// LDS block of lmpc_solve_group for this controller (0: no group form for its variant): two box-bound vectors, a slice per instance, the staged
+// MFMA operands, the cost constants and flags, the result records
+size_t lmpc_group_lds_bytes(const LmpcDev &m)
+{
+    const int cp = lmpc_kernel_variant(m.ldz, m.ldg);
+    if (cp != 1 && cp != 2) return 0;
+    const int nw = cp == 1 ? 16 : 8;
+    return ((size_t)2 * 128 * cp + (size_t)nw * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + (size_t)nw * 16 + 16 + (size_t)nw * (8 + ((m.nu + 1) & ~1))) * sizeof(double);
 }
 
 int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)

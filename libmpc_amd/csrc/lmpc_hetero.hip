@@ -74,8 +74,7 @@ __device__ void tri_inverse_lds(const double *L, double *Q, const int n, const i
 {
     for (int e = threadIdx.x; e < n * ld; e += blockDim.x) Q[e] = 0.0;
     __syncthreads();
-    const int jj = threadIdx.x;
-    if (jj < n) {
+    for (int jj = threadIdx.x; jj < n; jj += blockDim.x) {
         Q[jj * ld + jj] = 1.0 / L[jj * ld + jj];
         for (int i = jj + 1; i < n; ++i) {
             double s = 0.0;
@@ -87,7 +86,12 @@ __device__ void tri_inverse_lds(const double *L, double *Q, const int n, const i
 }
 
 // LDS plan (doubles): P [NP x ld] | Q [NQ x ld] | Sx [2][nx x ld] | CS [nyr x ld] | small vectors
-__global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev *models, const int count, const int NP, const int NQ)
+// BIG (more than 96 condensed variables -- config 4's shape, N = 50: P and Q alone are 2 x 340 KB): P and Q live in a scratch block of the
+// workgroup in global memory (L2-resident; the same code walks them through flat addresses), the Hessian's tiles are added to P step by
+// step instead of being carried in registers; everything else as below.  A set-up step: it is bound by the latency of the factorisations'
+// dependent passes, not by bytes -- and still two orders of magnitude ahead of condensing K controllers on the host's cores.
+template <bool BIG>
+__global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev *models, const int count, const int NP, const int NQ, double *scratch, const size_t scratch_stride)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int flag, cstat;
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
         __syncthreads();
         const int nx = M.nx, nu = M.nu, ny = M.ny, ph = M.ph, nz = M.nz, mg = M.mg, ldz = M.ldz, ldg = M.ldg, ldy = M.ldy;
         const int ld = NP + 1;
-        double *P = smem, *Q = P + (size_t)NP * ld, *Sx0 = Q + (size_t)NQ * ld, *Sx1 = Sx0 + (size_t)nx * ld, *CS = Sx1 + (size_t)nx * ld;
+        double *P = BIG ? scratch + (size_t)blockIdx.x * scratch_stride : smem, *Q = P + (size_t)NP * ld;
+        double *Sx0 = BIG ? smem : Q + (size_t)NQ * ld, *Sx1 = Sx0 + (size_t)nx * ld, *CS = Sx1 + (size_t)nx * ld;
         double *wv = CS + (size_t)(ny > 1 ? ny : 1) * ld;                      // ny: the step's output weights
         double *rb = wv + ((ny + 3) & ~3) + 4, *rg = rb + NP;                  // rho_b [NP], rho_g [NQ]
         const gdp gA = gl(M.A), gB = gl(M.B), gC = gl(M.C), gWy = gl(M.Wy), gWu = gl(M.Wu), gWdu = gl(M.Wdu), gsX = gl(M.sX), gsU = gl(M.sU);
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) hacc[s] = v4d{0.0, 0.0, 0.0, 0.0};
         for (int e = t; e < nx * ld; e += blockDim.x) Sx0[e] = 0.0;
+        if constexpr (BIG) for (int e = t; e < NP * ld; e += blockDim.x) P[e] = 0.0;
         __syncthreads();
         double *Sp = Sx0, *Sn = Sx1;
         for (int i = 1; i <= ph; ++i) {
@@ -168,14 +174,27 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
                             const double bv = a < ny ? CS[a * ld + 16 * tn + j] : 0.0;
                             acc = mfma4(av, bv, acc);
                         }
+                        if constexpr (BIG) {
+                            // (a tile belongs to one wavefront, an element of it to one lane: no two threads add to the same place)
 #pragma unroll
-                        for (int u = 0; u < MAXS; ++u) if (u == s) hacc[u] += acc;
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * tm + 4 * r + kq, col = 16 * tn + j;
+                                if (row < nz && col < nz && row <= col) P[row * ld + col] += acc[r];
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < MAXS; ++u) if (u == s) hacc[u] += acc;
+                        }
                         ++s;
                     }
             }
             __syncthreads();
             double *tmp = Sp; Sp = Sn; Sn = tmp;
         }
+        if constexpr (BIG) {
+            // the lower triangle from the upper one
+            for (int e = t; e < nz * nz; e += blockDim.x) { const int row = e / nz, col = e - row * nz; if (row < col) P[col * ld + row] = P[row * ld + col]; }
+        } else {
         // the accumulated tiles to LDS (both triangles)
         for (int e = t; e < NP * ld; e += blockDim.x) P[e] = 0.0;
         __syncthreads();
@@ -195,6 +214,7 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
                         if (row < nz && col < nz && row <= col) { P[row * ld + col] = acc[r]; P[col * ld + row] = acc[r]; }
                     }
                 }
+        }
         }
         __syncthreads();
         // weights on the inputs and on their increments (LmpcController::condense)
@@ -335,34 +355,52 @@ __global__ __launch_bounds__(kCondWaves * 64) void lmpc_condense_models(LmpcDev 
 
 }  // namespace
 
-// LDS the condensing kernel needs for these dimensions (bytes); > 160 KB: the bank condenses on the host instead
-size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out)
+// LDS the condensing kernel needs for these dimensions (bytes); > 160 KB: the bank condenses on the host instead.  More than 96 condensed
+// variables (the register-held Hessian tiles: at most 21 upper-triangle tiles over four wavefronts) or P and Q beyond the LDS: the BIG form,
+// P and Q in a scratch block per workgroup (big_out: its doubles, 0 for the LDS form).
+size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out, size_t *big_out)
 {
     const int NP = (m.nz + 15) / 16 * 16, MP = (m.mg + 15) / 16 * 16, NQ = NP > MP ? NP : MP, ld = NP + 1;
     if (NP_out) *NP_out = NP;
     if (NQ_out) *NQ_out = NQ;
-    if (NP > 96) return (size_t)1 << 30;                    // hacc: at most 21 upper-triangle tiles over four wavefronts
-    const size_t dbl = (size_t)NP * ld + (size_t)NQ * ld + 2 * (size_t)m.nx * ld + (size_t)(m.ny > 1 ? m.ny : 1) * ld + ((m.ny + 3) & ~3) + 4 + NP + NQ + 8;
-    return dbl * sizeof(double);
+    const size_t rest = 2 * (size_t)m.nx * ld + (size_t)(m.ny > 1 ? m.ny : 1) * ld + ((m.ny + 3) & ~3) + 4 + NP + NQ + 8;
+    const size_t pq = (size_t)NP * ld + (size_t)NQ * ld;
+    const bool big = NP > 96 || (pq + rest) * sizeof(double) > 160 * 1024 - 64;
+    if (big_out) *big_out = big ? pq : 0;
+    return ((big ? 0 : pq) + rest) * sizeof(double);
 }
 
 int lmpc_condense_launch(LmpcDev *models_d, const LmpcDev &m0, int count, void *stream)
 {
     int NP = 0, NQ = 0;
-    const size_t lds = lmpc_condense_lds(m0, &NP, &NQ);
+    size_t big = 0;
+    const size_t lds = lmpc_condense_lds(m0, &NP, &NQ, &big);
     if (lds > 160 * 1024 - 64) return -2;
-    static std::atomic<size_t> conf[64];
+    static std::atomic<size_t> conf[2][64];
     int devid = 0;
     (void)hipGetDevice(&devid);
     devid &= 63;
-    if (lds > conf[devid].load(std::memory_order_acquire)) {
+    const void *fn = big ? reinterpret_cast<const void *>(lmpc_condense_models<true>) : reinterpret_cast<const void *>(lmpc_condense_models<false>);
+    if (lds > conf[big ? 1 : 0][devid].load(std::memory_order_acquire)) {
         // (the kernel also has four bytes of static LDS: ask for what is needed, not for the whole CU)
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_condense_models), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
-        conf[devid].store(lds, std::memory_order_release);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+        conf[big ? 1 : 0][devid].store(lds, std::memory_order_release);
     }
-    int blocks = count < 1024 ? count : 1024;
-    hipLaunchKernelGGL(lmpc_condense_models, dim3(blocks), dim3(kCondWaves * 64), lds, reinterpret_cast<hipStream_t>(stream), models_d, count, NP, NQ);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!big) {
+        const int blocks = count < 1024 ? count : 1024;
+        hipLaunchKernelGGL(lmpc_condense_models<false>, dim3(blocks), dim3(kCondWaves * 64), lds, s, models_d, count, NP, NQ, nullptr, 0);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    // the BIG form: a scratch block per workgroup, two workgroups per CU's worth of them; released when the kernel has finished
+    const int blocks = count < 512 ? count : 512;
+    double *scratch = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&scratch), (size_t)blocks * big * sizeof(double)) != hipSuccess) return -4;
+    hipLaunchKernelGGL(lmpc_condense_models<true>, dim3(blocks), dim3(kCondWaves * 64), lds, s, models_d, count, NP, NQ, scratch, big);
+    const bool ok = hipGetLastError() == hipSuccess;
+    const hipError_t es = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    return ok && es == hipSuccess ? 0 : -3;
 }
 
 }  // namespace mpcx

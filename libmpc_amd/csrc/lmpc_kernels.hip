@@ -1497,7 +1497,8 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
     const int cap = 256 * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    const bool fused = b.fused != 0 && CPZ == 1 && CPG == 1;
+    // (one-kernel forms: the fused / persistent mat-vec forms serve the one-chunk variant, the in-workgroup form -- b.fused >= 3 -- the two-chunk one too)
+    const bool fused = b.fused != 0 && ((CPZ == 1 && CPG == 1) || (b.fused >= 3 && CPZ == 2 && CPG == 2));
     if ((which & 1) && !fused) {
         if (fast >= 0) {
             const size_t lds1 = ((size_t)(m.kin / 4 + m.nz16 / 4) * 64 + 64 + 32) * sizeof(double);

@@ -172,8 +172,11 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
     // assemble + solve in one workgroup (lmpc_solve_group): the one-chunk variant, cost from the multipliers
     // lmpc_solve_group's LDS block: two box-bound vectors, sixteen per-instance slices, the staged operands, the result records -- one CU's worth at most
     // (otherwise the two-kernel path, which handled such a controller before the group form existed, takes it)
-    const size_t ldsg = ((size_t)2 * 128 + (size_t)16 * D.fast_slice + (size_t)(D.kin / 4 + D.nz16 / 4) * 64 + 16 * 16 + 16 + 16 * (8 + ((D.nu + 1) & ~1))) * sizeof(double);
-    D.group_ok = (h->use_fused != 0 && mpcx::lmpc_kernel_variant(o.ldz, o.ldg) == 1 && !D.cost_direct && ldsg <= 160 * 1024) ? 1 : 0;
+    // Round 5: the two-chunk variant as well (config 4's N = 50: eight instances per workgroup, the cost from its definition inside the solve);
+    // there it is taken on request only (mpcx_lmpc_debug_use_fused(h, 2)): measured no faster than the two-kernel path
+    const size_t ldsg = mpcx::lmpc_group_lds_bytes(D);
+    const int cpv = mpcx::lmpc_kernel_variant(o.ldz, o.ldg);
+    D.group_ok = (h->use_fused != 0 && ldsg > 0 && ldsg <= 160 * 1024 && ((cpv == 1 && !D.cost_direct) || (cpv == 2 && h->use_fused == 2))) ? 1 : 0;
     D.slo = U.up(o.slo, rc); D.shi = U.up(o.shi, rc);
 }
 

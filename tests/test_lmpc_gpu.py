@@ -297,28 +297,35 @@ def test_config2_whole_batch_against_oracle():
 
 
 def test_full_size_properties_config4_shard():
-    """BASELINE config 4's per-GPU shard (N=50, B=32768): every instance solved and feasible, inputs inside their box,
-    bit-identical across launches (costs come from the batched MFMA kernel here), the first 2048 instances against the oracle"""
+    """BASELINE config 4's per-GPU shard (N=50, B=32768), on both forms -- the default (assemble, solve and cost kernels with the record in
+    the workspace) and the in-workgroup form on request (lmpc_solve_group<2, 2>: eight instances per workgroup, two-chunk MFMA assemble,
+    the solve and the cost from LDS; debug_use_fused(2)): every instance solved and feasible, inputs inside their box, bit-identical
+    across launches, the first 2048 instances against the oracle; the two forms within 1e-9 of each other"""
     import torch
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
-    c = quadrotor_lmpc(50, device=0)
-    B = 32768
-    x0, u0, yref = quadrotor_batch(B)
-    a = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
-    b = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
-    assert torch.equal(a.cmd, b.cmd) and torch.equal(a.cost, b.cost)
-    assert (a.status == 0).all() and (a.is_feasible == 1).all()
-    u = a.cmd.cpu().numpy()
-    assert u.min() >= 9.6 - 10.5916 - 1e-7 and u.max() <= 13 - 10.5916 + 1e-7
-    # the first 2048 instances against the oracle (thread pool), active sets included
     from helpers import assert_matches_oracle, oracle_batch_parallel
-    n = 2048
+    B, n = 32768, 2048
+    x0, u0, yref = quadrotor_batch(B)
     ref = oracle_batch_parallel(50, x0[:n], u0[:n], yref[:n], want_active=True)
     oq = quadrotor_oracle(50)
-    r = c.optimizeBatch(x0[:n], u0[:n], yref=yref[:n], want_active=True); torch.cuda.synchronize()
-    assert torch.equal(r.cmd, a.cmd[:n])                  # a prefix of the batch solved alone: the same bits
-    unpolished = assert_matches_oracle(r, ref, oq.neq, oq.ncon)
-    assert unpolished <= n // 20, unpolished
+    cmds = {}
+    for mode in (None, 2):
+        c = quadrotor_lmpc(50, device=0)
+        c.debug_use_fused(mode)
+        a = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+        b = c.optimizeBatch(x0, u0, yref=yref); torch.cuda.synchronize()
+        assert torch.equal(a.cmd, b.cmd) and torch.equal(a.cost, b.cost)
+        assert (a.status == 0).all() and (a.is_feasible == 1).all()
+        u = a.cmd.cpu().numpy()
+        assert u.min() >= 9.6 - 10.5916 - 1e-7 and u.max() <= 13 - 10.5916 + 1e-7
+        # the first 2048 instances against the oracle (thread pool), active sets included
+        r = c.optimizeBatch(x0[:n], u0[:n], yref=yref[:n], want_active=True); torch.cuda.synchronize()
+        assert torch.equal(r.cmd, a.cmd[:n])                  # a prefix of the batch solved alone: the same bits
+        unpolished = assert_matches_oracle(r, ref, oq.neq, oq.ncon)
+        assert unpolished <= n // 20, unpolished
+        cmds[mode] = (a.cmd.clone(), a.cost.clone())
+    assert (cmds[None][0] - cmds[2][0]).abs().max().item() <= 1e-9
+    assert ((cmds[None][1] - cmds[2][1]).abs() / cmds[None][1].abs().clamp(min=1.0)).max().item() <= 1e-9
 
 
 def test_admm_fallback_is_reached_and_lands_on_the_oracle():

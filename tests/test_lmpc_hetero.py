@@ -105,16 +105,17 @@ def test_structure_mismatch_is_refused():
         LMPCHetero([a, b], device=0)
 
 
-@pytest.mark.parametrize("family", ["quadrotor", "random"])
+@pytest.mark.parametrize("family", ["quadrotor", "random", "quadrotor50"])
 def test_device_condensing_matches_the_host_set_up(family):
     """the bank's O(n^3) arrays -- Hessian, constraint rows, dual Hessian, ADMM matrix -- computed by lmpc_condense_models (MFMA)
     against LmpcController::condense on the host, array by array, and the solves of the two banks against each other"""
     import torch
     from libmpc_amd import LMPC, LMPCHetero, LParameters
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_variant
-    if family == "quadrotor":
-        K = 24
-        ctrls = [quadrotor_variant(k, 20, device=-1) for k in range(K)]
+    if family in ("quadrotor", "quadrotor50"):
+        # (N = 50, config 4's shape: 200 condensed variables -- P and Q of the kernel in a scratch block per workgroup, not in LDS)
+        K = 24 if family == "quadrotor" else 10
+        ctrls = [quadrotor_variant(k, 20 if family == "quadrotor" else 50, device=-1) for k in range(K)]
         x0, u0, yref = quadrotor_batch(K)
     else:
         K = 24
@@ -130,7 +131,9 @@ def test_device_condensing_matches_the_host_set_up(family):
     dev = LMPCHetero(ctrls, device=0)
     assert host.debug_get(0, "flags")[1] == 0.0 and dev.debug_get(0, "flags")[1] == 1.0
     for k in (0, 1, K // 2, K - 1):
-        for name, tol in (("H", 1e-12), ("Gr", 1e-12), ("Gc", 1e-12), ("Y", 1e-9), ("rho_b", 1e-9), ("rho_g", 1e-9), ("Kinv", 1e-8)):
+        # (the inverses are as good as the Hessian's conditioning lets them be: two orders looser at 200 variables than at 80)
+        loose = 100.0 if family == "quadrotor50" else 1.0
+        for name, tol in (("H", 1e-12), ("Gr", 1e-12), ("Gc", 1e-12), ("Y", 1e-9 * loose), ("rho_b", 1e-9 * loose), ("rho_g", 1e-9 * loose), ("Kinv", 1e-8 * loose)):
             a, b = host.debug_get(k, name), dev.debug_get(k, name)
             scale = max(np.abs(a).max(), 1e-300)
             assert np.abs(a - b).max() <= tol * scale, (k, name, np.abs(a - b).max() / scale)
@@ -138,9 +141,22 @@ def test_device_condensing_matches_the_host_set_up(family):
     ra = host.optimizeBatch(x0, u0, yref=yref, want_active=True); rb = dev.optimizeBatch(x0, u0, yref=yref, want_active=True)
     torch.cuda.synchronize()
     assert torch.equal(ra.status, rb.status)
-    np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(ra.cmd.cpu().numpy(), rb.cmd.cpu().numpy(), rtol=1e-8 * loose, atol=1e-10 * loose)
+    np.testing.assert_allclose(ra.cost.cpu().numpy(), rb.cost.cpu().numpy(), rtol=1e-8 * loose, atol=1e-8 * loose)
     assert torch.equal(ra.active_lower, rb.active_lower) and torch.equal(ra.active_upper, rb.active_upper)
+    if family == "quadrotor50":
+        # ... and the bank against one oracle controller per instance (the N = 50 bank: device condensing in its scratch-block form)
+        from oracle.lmpc_oracle import default_params
+        assert (rb.status == 0).all()
+        for k in range(K):
+            f = OracleFrontEnd(12, 4, 4, 12, 50, 50)
+            quadrotor_variant(k, 50, into=f)
+            f.o.params = default_params(maximum_iteration=250)
+            ref = f.o.solve_batch_constref(x0[k:k + 1], u0[k:k + 1], yref[k:k + 1])
+            if ref["status"][0] == 0 and ref["polished"][0] == 1:
+                np.testing.assert_allclose(rb.cmd.cpu().numpy()[k], ref["cmd"][0], rtol=1e-5, atol=1e-7)
+        print("N = 50 bank of %d controllers: the condensing kernel %.2f ms, the bank's set-up %.1f ms (on the host's cores: %.1f ms)"
+              % (K, dev.debug_get(0, "flags")[2], dev.debug_get(0, "flags")[3], host.debug_get(0, "flags")[3]))
 
 
 def _two_state_controller(b1, hessian_weight=1.0):
