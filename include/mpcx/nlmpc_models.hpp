@@ -81,6 +81,8 @@ struct NoUserEq {
     __device__ static double slack_cost(double, const double *) { return 0.0; }      // the cost's term in the slack variable alone
     static constexpr bool XFREE_ROWS_SPARSE = false;                    // true: a user row that reads no state has at most kNlSparse non-zero entries in the
                                                                         // move-blocked inputs (+ slack); the workgroup form then keeps it as an (index, value) list
+    static constexpr bool XFREE_ROWS_AFFINE = false;                    // true: those rows are affine in the inputs -- the same Jacobian at every iterate (the workgroup
+                                                                        // form then carries the inverse of the working set's Schur complement from one sub-problem to the next)
 };
 
 // ---- model zoo ----------------------------------------------------------------------------------
@@ -119,6 +121,7 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
     static constexpr bool INEQ_USES_SLACK = false;
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     static constexpr bool XFREE_ROWS_SPARSE = true;
+    static constexpr bool XFREE_ROWS_AFFINE = true;                     // u <= 0.5
     __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
     __host__ __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
     __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
@@ -233,6 +236,7 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     static constexpr bool INEQ_USES_SLACK = false;
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     static constexpr bool XFREE_ROWS_SPARSE = true;
+    static constexpr bool XFREE_ROWS_AFFINE = true;                     // u_j <= 0.5
     __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
     __host__ __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
     __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }

@@ -42,6 +42,7 @@ struct WgPlan {
     int f_lds;                  // the folded dynamics blocks live in LDS
     int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor
     int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
+    int carry_m;                // (minv, every row a short list with constant entries) the inverse is carried from one sub-problem to the next: w_msave
     int lds_total;              // doubles
     // LDS offsets (doubles)
     int o_red, o_st, o_z, o_c, o_gin, o_gu, o_gr, o_p, o_glold, o_sv, o_hinv, o_mu, o_flag, o_br, o_s1v, o_s1m, o_dcol, o_xmask, o_jxoff,
@@ -50,7 +51,7 @@ struct WgPlan {
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
-    int w_scal, w_F, w_art, w_einv, w_gx, w_hinv, w_sp;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
+    int w_scal, w_F, w_art, w_einv, w_gx, w_hinv, w_sp, w_msave;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
     int ws_total;
 };
 
@@ -65,7 +66,9 @@ typedef const WgArgs __attribute__((address_space(4))) *WgArgsPtr;
 constexpr int kWgCtxDoubles = 0;
 
 // slots of the scalar block st[] through which the phases hand results to the loop
-enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_OVER = 15 /* the working set outgrew its capacity */, ST_ACC = 16, ST_QSTAT = 32,
+enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_OVER = 15 /* the working set outgrew its capacity */, ST_ACC = 16,
+       ST_CARRY = 24 /* the saved inverse: 0 none, 1 valid for the current B^-1, 2 valid up to the BFGS update in ST_BFRHO / ST_BFCC */, ST_BFRHO, ST_BFCC, ST_CARRYN /* sub-problems since the inverse was formed afresh */, ST_NCARRY /* warm starts that took the carried inverse, whole solve */, ST_CONSET /* eval_con has filed the rows once */,
+       ST_QSTAT = 32,
 #ifdef MPCX_NL_STATS
        ST_TOTAL = 48
 #else
@@ -971,9 +974,13 @@ struct WgSqp {
         // the input part, one lane per user row: into the row's column of art (dense rows) or its (index, value) list
         gwp spv = (gwp)(v.w + P.w_sp);
         int *spi = reinterpret_cast<int *>(v.w + P.w_sp + (size_t)mt * kNlSparse);
+        // (Mdl::XFREE_ROWS_AFFINE: a short-list row's entries are the same at every iterate -- differenced once, at the first; what central
+        // differences make of a constant afterwards is that constant with nine good digits, a different ninth each time)
+        const bool frozen = Mdl::XFREE_ROWS_AFFINE && st[ST_CONSET] != 0.0;
         for (int k = tid; k < m; k += NT) {
             const int dc = dcol[k];
             const bool dense = dc >= 0;
+            if (frozen && !dense) { br[k] = gin[k]; continue; }
             const int ro = dense ? aoff[dc] : 0, rl = dense ? alen[dc] : 0;
             if (dense && !(rl >> 30)) for (int q = 0; q < (rl & 0xffff); ++q) art[ro + q] = 0.0;      // (a row only the sweep writes is stored by it)
             int cnt = 0, ix[kNlSparse + 1];
@@ -1048,6 +1055,7 @@ struct WgSqp {
             }
         }
         T::sync();
+        if (tid == 0) st[ST_CONSET] = 1.0;                       // (read at the top of the next call: barriers in between)
     }
 
     // ------------------------------------------------------------------------------------------------------------------------------
@@ -1527,7 +1535,7 @@ struct WgSqp {
         const int nq = v.nq;
         const Sp sp(v);
         const Ws W(v);
-        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq);
+        double *gr = v.at(P.o_gr), *glold = v.at(P.o_glold), *sv = v.at(P.o_sv), *hinv = v.at(P.o_hinv), *uq = v.at(P.o_uq), *st = v.at(P.o_st);
         double *v0 = v.at(P.o_xq), *v1 = v.at(P.o_np), *v2 = v.at(P.o_vv);
         Red<WAVES> R(v.at(P.o_red));
         double sBs = 0, sy = 0;
@@ -1557,6 +1565,9 @@ struct WgSqp {
                 tri_index(e, r, c);
                 hinv[e] += -rho * (sv[r] * v2[c] + v2[r] * sv[c]) + cc * sv[r] * sv[c];
             }
+            // (the change of B^-1 is [s v2] [cc, -rho; -rho, 0] [s v2]': what a carried inverse of the Schur complement needs -- ws_warm; sv and
+            // v2 stay where they are until then)
+            if (tid == 0 && st[ST_CARRY] == 1.0) { st[ST_CARRY] = 2.0; st[ST_BFRHO] = rho; st[ST_BFCC] = cc; }
         }
         T::sync();
     }
@@ -2004,6 +2015,66 @@ struct WgSqp {
 #ifdef MPCX_NL_STATS
         long long qt_ = __builtin_readcyclecounter();
 #endif
+        const bool minv = P.minv != 0;
+        // The inverse carried over from the previous sub-problem (WgPlan::carry_m: every row a short list with constant entries, so N_W has
+        // not changed; the kept rows are that sub-problem's final working set, in its order).  B^-1 has changed by the BFGS update
+        // [s v2] C [s v2]', C = [cc, -rho; -rho, 0], so S by U C U' with U = N_W [s v2], and by Woodbury
+        //     M <- M - W (C^-1 + U'W)^-1 W',   W = M U,   C^-1 = [0, -1/rho; -1/rho, -cc/rho^2]:
+        // two products with M and one element-wise pass instead of the sweep's n pivots (config 5: 88 k cycles per iteration for 60 to 80
+        // rows).  Errors would add up along the iterations: after eight carried sub-problems, or when the 2 x 2 system is near singular, the
+        // inverse is formed afresh.
+        bool have_m = false;
+        if (P.carry_m && minv && st[ST_CARRY] >= 1.0 && st[ST_CARRYN] < 8.0) {
+            const bool upd = st[ST_CARRY] == 2.0;
+            const double rho = st[ST_BFRHO], cc = st[ST_BFCC];
+            const double *keep = v.w + P.w_msave, *sv = v.at(P.o_sv);
+            double *u0 = tq, *u1 = np_, *w0 = invd, *w1 = wv;
+            for (int e = tid; e < nw * (nw + 1) / 2; e += NT) Lp[e] = keep[e];
+            if (upd)
+                for (int t = tid; t < nw; t += NT) { const int k = wq[t]; u0[t] = sgq[t] * sp.dot(k, sv); u1[t] = sgq[t] * sp.dot(k, vv); }
+            T::sync();
+            have_m = true;
+            if (upd) {
+                hmul<NT>(Lp, u0, w0, nw, 1.0, tid);
+                hmul<NT>(Lp, u1, w1, nw, 1.0, tid);
+                T::sync();
+                double g00 = 0.0, g01 = 0.0, g11 = 0.0, gsc = 0.0;
+                for (int t = tid; t < nw; t += NT) { g00 += u0[t] * w0[t]; g01 += u0[t] * w1[t]; g11 += u1[t] * w1[t]; }
+                const WgRed4 g = R.mix4(g00, g01, g11, gsc, 0);
+                g00 = g.a; g01 = g.b - 1.0 / rho; g11 = g.c - cc / (rho * rho);
+                const double det = g00 * g11 - g01 * g01, big = fmax(fabs(g00 * g11), g01 * g01);
+                T::sync();
+                if (fabs(det) > 1e-10 * big && big > 0.0) {
+                    const double i00 = g11 / det, i01 = -g01 / det, i11 = g00 / det;
+                    tri_rows(Lp, nw, tid, [&](int r, int c, double &a) {
+                        a -= i00 * w0[r] * w0[c] + i01 * (w0[r] * w1[c] + w1[r] * w0[c]) + i11 * w1[r] * w1[c];
+                    });
+                } else have_m = false;
+                T::sync();
+            }
+#ifdef HIPEMU_CHECK_CARRY
+            // (tests/emu, -DHIPEMU_CHECK_CARRY: the carried inverse against the Schur complement formed afresh)
+            if (tid == 0 && have_m) {
+                double worst = 0.0;
+                for (int a = 0; a < nw; ++a)
+                    for (int b2 = 0; b2 < nw; ++b2) {
+                        double acc = a == b2 ? -1.0 : 0.0;
+                        for (int c = 0; c < nw; ++c) {
+                            const int ka = wq[a], kc = wq[c];
+                            double sac = 0.0;
+                            for (int ja = 0; ja < sp.count(ka); ++ja)
+                                for (int jc = 0; jc < sp.count(kc); ++jc) sac = fma(sp.value(ka, ja) * sp.value(kc, jc), hsym(hinv, sp.index(ka, ja), sp.index(kc, jc)), sac);
+                            acc += sgq[a] * sgq[c] * sac * hsym(Lp, c, b2);
+                        }
+                        worst = fmax(worst, fabs(acc));
+                    }
+                fprintf(stderr, "carry check: nw %d upd %d carried %g  |S M - I| = %.3e\n", nw, (int)upd, st[ST_CARRYN], worst);
+            }
+#endif
+            if (tid == 0) { if (have_m) { st[ST_CARRYN] += 1.0; st[ST_NCARRY] += 1.0; st[ST_R4] = 1.0; } }
+        }
+        if (have_m) { T::sync(); }
+        else {
         // S = N B^-1 N' of the kept rows, straight into the factor's storage
         int anyd = 0;
         for (int t = tid; t < nw; t += NT) anyd |= dcol[wq[t]] >= 0 ? 1 : 0;
@@ -2029,7 +2100,7 @@ struct WgSqp {
         }
         T::sync();
         MPCX_QLAP(1);
-        const bool minv = P.minv != 0;
+        if (tid == 0) st[ST_CARRYN] = 0.0;                      // (behind a barrier: everybody has read it)
         if (minv) {
             const int ok = ws_invert_m(nw);
             if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0;
@@ -2040,6 +2111,7 @@ struct WgSqp {
             if (tid == 0) st[ST_R4] = ok ? 1.0 : 0.0;
         }
         T::sync();
+        }
         MPCX_QLAP(2);
         if (st[ST_R4] == 0.0) {                                  // dependent rows: start cold
             for (int t = tid; t < nw; t += NT) flag[wq[t]] = 0;
@@ -2173,6 +2245,14 @@ struct WgSqp {
         T::sync();
         for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
         if (tid == 0 && nq < nr) xq[nq] = 0.0;                  // (p is xq: without a slack variable its last entry stays zero)
+        if (P.carry_m) {
+            // the inverse of this working set's Schur complement is the next sub-problem's, up to the rank-two change of B^-1 in between
+            // (the factor's storage is an overlay: the evaluation phases write over it)
+            double *keep = v.w + P.w_msave;
+            const double *Mp = v.at(P.o_L);
+            for (int e = tid; e < nw * (nw + 1) / 2; e += NT) keep[e] = Mp[e];
+            if (tid == 0) st[ST_CARRY] = nw > 0 ? 1.0 : 0.0;
+        }
         T::sync();
         MPCX_QLAP(10);
         return nw;
@@ -2413,6 +2493,7 @@ struct WgSqp {
         double *hinv = v.at(P.o_hinv);
         const int nr = v.nr;
         for (int e = threadIdx.x; e < nr * (nr + 1) / 2; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
+        if (threadIdx.x == 0) v.at(P.o_st)[ST_CARRY] = 0.0;       // (a saved inverse of the Schur complement belongs to the estimate that is gone)
         T::sync();
     }
     static MPCX_WG_PHASE void take_last_step()
@@ -2582,6 +2663,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         scal[12] = st[ST_R5 + 1];                                // the largest working set of the solve
         scal[13] = st[ST_NSHED];
         scal[14] = st[ST_OVER];                                  // 1: a pass with the full capacity has to take this instance again
+        scal[15] = st[ST_NCARRY];
 #ifdef MPCX_NL_STATS
         for (int k = 0; k < 16; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
 #endif
@@ -2717,6 +2799,11 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);
         P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
+        // the carried inverse (see ws_warm): where no row's entries change between sub-problems -- bounds on inputs, user rows affine in the inputs (Mdl::XFREE_ROWS_AFFINE) --
+        // and the controller's workspace has the room; MPCX_NLMPC_CARRY=0 switches it off (measurements; read once)
+        static const int carry_env = [] { const char *e = getenv("MPCX_NLMPC_CARRY"); return e ? atoi(e) : 1; }();
+        P.carry_m = 0; P.w_msave = 0;
+        if (carry_env && P.minv && P.nd == 0 && (mu_ == 0 || Mdl::XFREE_ROWS_AFFINE) && o + P.kw * (P.kw + 1) / 2 + 2 <= m.ws.scal) { P.carry_m = 1; P.w_msave = take(P.kw * (P.kw + 1) / 2); }
         P.ws_total = o;
         // the instances keep the stride of the controller's workspace (NlmpcWsLayout), the statistics block its place in it
         P.w_scal = m.ws.scal;

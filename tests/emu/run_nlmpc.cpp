@@ -88,7 +88,7 @@ static int run(int argc, char **argv)
         for (int k = 0; k < M.nbnd; ++k) nsb += bidx[k] < nxs ? 1 : 0;
         const int waves = getenv("HIPEMU_WAVES") ? atoi(getenv("HIPEMU_WAVES")) : 0;
         if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, getenv("HIPEMU_BLOCKS") ? atoi(getenv("HIPEMU_BLOCKS")) : -1) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
-        if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total);
+        if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles, inverse form %d carried %d (plan %d of %d doubles)\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total, P.minv, P.carry_m, P.ws_total, M.ws.scal);
     }
 #endif
     // (workspace and LDS start as NaNs: a kernel that reads what it has not written shows it -- the interpreter's memory would otherwise be zeros)
@@ -138,7 +138,7 @@ static int run(int argc, char **argv)
             printf("], \"z\": [");
             for (int k = 0; k < nz; ++k) printf("%s%.17g", k ? ", " : "", zout[(size_t)b * nz + k]);
             auto stat = [&](int k) { const double x = ws[(size_t)b * ws_total + M.ws.scal + k]; return std::isfinite(x) ? x : -1.0; };       // (the one-wavefront form files fewer)
-            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"mu\": [", stat(12), stat(1), stat(13));
+            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"carried\": %g, \"mu\": [", stat(12), stat(1), stat(13), stat(15));
             for (int k = 0; k < mt; ++k) printf("%s%.17g", k ? ", " : "", mu[(size_t)b * mt + k]);
             printf("]}\n");
         }

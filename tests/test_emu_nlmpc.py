@@ -144,3 +144,34 @@ def test_eight_wavefronts_per_instance_and_the_mfma_schur_complement(runner):
     y = runner(["ugv", 30, 30, 0.1, 0, 150, "wg"], np.array([k["x0"] + k["u0"]]), {"HIPEMU_BLOCKS": "1"})[0]
     assert y["status"] == 0 and y["max_nw"] >= 2              # a kept set with dense rows went through ws_schur_mfma
     np.testing.assert_allclose(y["cmd"], k["cmd"], rtol=1e-5, atol=1e-5)
+
+
+def test_carried_inverse_stays_the_inverse(tmp_path_factory):
+    """WgPlan::carry_m (round 5): where every row of the sub-problem has the same entries at every iterate (bounds on inputs, user rows affine in
+    the inputs -- Mdl::XFREE_ROWS_AFFINE, their entries differenced once), the inverse of the working set's Schur complement is carried from one
+    sub-problem to the next through the rank-two change of B^-1 (Woodbury) instead of being formed by n sweeps.  A build with
+    -DHIPEMU_CHECK_CARRY forms S afresh at every carried warm start and reports |S M - I|; the solve must be the one without carrying."""
+    if not shutil.which("g++"):
+        pytest.skip("g++ not installed")
+    exe = str(tmp_path_factory.mktemp("emuchk") / "run_chk")
+    subprocess.run(["g++", "-O1", "-std=c++20", "-DHIPEMU_WITH_WG", "-DHIPEMU_CHECK_CARRY", "-I" + EMU, "-I" + os.path.join(ROOT, "include"), "-fpermissive", "-w",
+                    "-o", exe, os.path.join(EMU, "run_nlmpc.cpp"), os.path.join(EMU, "hipemu_switch.S")], check=True)
+    rng = np.random.default_rng(5)
+    X0 = rng.uniform(-0.1, 0.1, size=(1, 12)); X0[:, 0] += 1.0
+    inp = " ".join(repr(float(x)) for x in np.hstack([X0, np.zeros((1, 6))])[0]) + "\n"
+    out = {}
+    for carry, order in (("0", "forward"), ("1", "forward"), ("1", "reverse")):
+        e = dict(os.environ); e.update({"MPCX_NLMPC_MINV": "1", "MPCX_NLMPC_CARRY": carry, "HIPEMU_ORDER": order})
+        r = subprocess.run([exe, "osc6", "20", "10", "0.1", "1", "200", "wg"], input=inp, capture_output=True, text=True, env=e, timeout=900)
+        assert r.returncode == 0, r.stderr[:2000]
+        errs = [float(l.split("=")[-1]) for l in r.stderr.splitlines() if l.startswith("carry check")]
+        out[(carry, order)] = (json.loads(r.stdout.splitlines()[0]), errs)
+    plain, _ = out[("0", "forward")]
+    assert plain["carried"] == 0
+    for key in (("1", "forward"), ("1", "reverse")):
+        y, errs = out[key]
+        assert y["carried"] >= 20 and len(errs) == y["carried"] and max(errs) <= 1e-11, (y["carried"], max(errs))
+        assert y["status"] == plain["status"] == 0 and y["iterations"] == plain["iterations"] and y["dual_steps"] == plain["dual_steps"]
+        assert abs(y["cost"] - plain["cost"]) <= 1e-12 * max(1.0, abs(plain["cost"]))
+        np.testing.assert_allclose(y["cmd"], plain["cmd"], rtol=1e-6, atol=1e-7)
+    assert out[("1", "forward")][0]["cmd"] == out[("1", "reverse")][0]["cmd"]           # (no exchange through LDS without its barrier)
