@@ -1502,6 +1502,14 @@ struct WgSqp {
         double snn = 0, npn = 0;
         for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
         if (nw_t > 0 && P.nd > 0) art_ws_tmul(v, nw_t, vv, v.at(P.o_yd), tid);
+        if (P.minv && P.nd == 0) {
+            // (the inverse form, every row a short list: t = N_W B^-1 n and the zeros N_W' r starts from, under the reduction's barrier --
+            // what ws_dual_step_m would otherwise spend a phase on)
+            const Ws W(v);
+            double *tq = v.at(P.o_tq), *wv = v.at(P.o_wv);
+            for (int t = tid; t < nw_t; t += NT) tq[t] = W.sgq[t] * sp.dot(W.wq[t], vv);
+            for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
+        }
         Red<WAVES> R(v.at(P.o_red), 2);
         R.sum2(snn, npn);
         return WgSum2{snn, npn};
@@ -1851,53 +1859,57 @@ struct WgSqp {
         T::sync();
         return 1;
     }
-    // row j leaves: M <- M - m_j m_j' / M_jj on the others, the last row takes slot j (in M and in the lists)
+    // row j leaves: M <- M - m_j m_j' / M_jj on the others, the last row takes slot j (in M and in the lists).  The vector rq = M t of the
+    // warm start (the multipliers on the kept set, t fixed while rows are shed) follows: without row j it is rq_i - M_ij rq_j / M_jj -- the
+    // next round needs no product (in the dual method's loop rq is recomputed anyway).
     static MPCX_WG_PHASE void ws_drop_m(int j, int nw)
     {
         const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x, last = nw - 1;
-        double *Mp = v.at(P.o_L), *buf = v.at(P.o_mbuf), *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq);
+        double *Mp = v.at(P.o_L), *buf = v.at(P.o_mbuf), *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq), *rq = v.at(P.o_invd);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
         for (int t = tid; t < nw; t += NT) buf[t] = hsym(Mp, t, j);
+        const double uj = rq[j];
         T::sync();
         const double id = 1.0 / buf[j];
-        tri_rows(Mp, nw, tid, [&](int r, int c, double &a) { if (r != j && c != j) a = fma(-buf[r] * id, buf[c], a); });
+        for (int t = tid; t < nw; t += NT) if (t != j) rq[t] = fma(-buf[t] * id, uj, rq[t]);
+        // (the last row's entries go to row / column j as they are corrected: nobody reads or writes those places in this pass)
+        tri_rows(Mp, nw, tid, [&](int r, int c, double &a) {
+            if (r == j || c == j) return;
+            const double x = fma(-buf[r] * id, buf[c], a);
+            if (r == last && j != last) {
+                if (c == last) Mp[j * (j + 1) / 2 + j] = x;
+                else if (c < j) Mp[j * (j + 1) / 2 + c] = x;
+                else Mp[c * (c + 1) / 2 + j] = x;
+            } else a = x;
+        });
         T::sync();
-        if (j != last) {
-            // the last row (its entries with the others, its diagonal) into row / column j
-            for (int t = tid; t < last; t += NT) buf[t] = Mp[last * (last + 1) / 2 + t];
-            const double dl = Mp[last * (last + 1) / 2 + last];
-            T::sync();
-            for (int t = tid; t < last; t += NT) {
-                if (t < j) Mp[j * (j + 1) / 2 + t] = buf[t];
-                else if (t > j) Mp[t * (t + 1) / 2 + j] = buf[t];
-                else Mp[j * (j + 1) / 2 + j] = dl;
-            }
-        }
         if (tid == 0) {
             flag[wq[j]] = 0;
-            if (j != last) { wq[j] = wq[last]; sgq[j] = sgq[last]; uq[j] = uq[last]; }
+            if (j != last) { wq[j] = wq[last]; sgq[j] = sgq[last]; uq[j] = uq[last]; rq[j] = rq[last]; }
         }
         T::sync();
     }
-    // one round of the warm start with the inverse: u = M (N_W x0 + b); the rows with a negative multiplier in st[ST_SHED]; when there is none,
-    // u filed and N_W' u set up for the minimiser (as ws_shed_round)
-    static MPCX_WG_PHASE void ws_shed_round_m(int nw)
+    // one round of the warm start with the inverse: u = M (N_W x0 + b) (product: the first round; afterwards ws_drop_m keeps u current); the
+    // rows with a negative multiplier in st[ST_SHED]; when there is none, u filed and N_W' u set up for the minimiser (as ws_shed_round)
+    static MPCX_WG_PHASE void ws_shed_round_m(int nw, bool product)
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
         const int tid = threadIdx.x, lane = tid & 63, mi = v.mi, m = v.m, nq = v.nq, nd = P.nd;
         double *Mp = v.at(P.o_L), *tq = v.at(P.o_tq), *rq = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv), *uq = v.at(P.o_uq), *st = v.at(P.o_st);
         const double *yd = v.at(P.o_yd), *xq = v.at(P.o_xq), *br = v.at(P.o_br), *sgq = v.at(P.o_sgq);
         const int *dcol = v.iat(P.o_dcol), *wq = v.iat(P.o_wq);
-        for (int t = tid; t < nw; t += NT) {
-            const int k = wq[t], dc = dcol[k];
-            tq[t] = sgq[t] * ((dc >= 0 ? yd[dc] : sp.dot(k, xq)) + br[k]);
-        }
         for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
         for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
-        T::sync();
-        hmul<NT>(Mp, tq, rq, nw, 1.0, tid);
-        T::sync();
+        if (product) {
+            for (int t = tid; t < nw; t += NT) {
+                const int k = wq[t], dc = dcol[k];
+                tq[t] = sgq[t] * ((dc >= 0 ? yd[dc] : sp.dot(k, xq)) + br[k]);
+            }
+            T::sync();
+            hmul<NT>(Mp, tq, rq, nw, 1.0, tid);
+            T::sync();
+        }
         unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED);
         if (tid < 64) {
             const bool h0 = lane < nw, h1 = lane + 64 < nw;
@@ -1928,7 +1940,8 @@ struct WgSqp {
     // the dual part of a step with the inverse (see ws_dual_step for what it delivers in st[R0 ..]): t = N_W B^-1 n gathered, r = M t by the whole
     // workgroup, z'n = n'B^-1 n - t'r and the ratio test in one reduction, then the multipliers, N_W' r for the primal part and -- on a full
     // step -- the bordering of M and the lists
-    static MPCX_WG_PHASE void ws_dual_step_m(int nw, int pidx, double sgn, double snn, double npn, double spv, double up)
+    // (gathered: normal_call has left t in tq and the zeros in wv -- the first attempt of a row where every row is a short list)
+    static MPCX_WG_PHASE void ws_dual_step_m(int nw, int pidx, double sgn, double snn, double npn, double spv, double up, bool gathered)
     {
         const V v; const auto &P = v.A->P; const Sp sp(v);
         const int tid = threadIdx.x, mi = v.mi, m = v.m, nq = v.nq, nd = P.nd;
@@ -1940,18 +1953,21 @@ struct WgSqp {
 #ifdef MPCX_NL_STATS
         long long qt_ = __builtin_readcyclecounter();
 #endif
-        for (int t = tid; t < nw; t += NT) {
-            const int k = wq[t], dc = dcol[k];
-            tq[t] = sgq[t] * (dc >= 0 ? yd[dc] : sp.dot(k, vv));
+        if (!gathered) {
+            for (int t = tid; t < nw; t += NT) {
+                const int k = wq[t], dc = dcol[k];
+                tq[t] = sgq[t] * (dc >= 0 ? yd[dc] : sp.dot(k, vv));
+            }
+            for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
+            for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
+            T::sync();
         }
-        for (int q = tid; q < nq; q += NT) wv[q] = 0.0;
-        for (int dc = tid; dc < nd; dc += NT) cd[dc] = 0.0;
-        T::sync();
         MPCX_QLAP(11);
         if (nw > 0) { hmul<NT>(Mp, tq, rq, nw, 1.0, tid); T::sync(); }
         MPCX_QLAP(12);
         // z'n = n'B^-1 n - t'r and the dual ratio test: by wavefront 0 alone, the working set's vectors two entries a lane (a reduction over
-        // the whole workgroup walked eight wavefronts through two wave reductions for the sake of the first two: 4.2 k cycles a step)
+        // the whole workgroup walked eight wavefronts through two wave reductions for the sake of the first two: 4.2 k cycles a step; the
+        // test in the product's epilogue with one sum-and-argmax reduction over the workgroup: 24 k -> 40 k cycles per iteration at config 5)
         if (tid < 64) {
             const int lane = tid;
             const bool h0 = lane < nw, h1 = lane + 64 < nw;
@@ -2021,10 +2037,10 @@ struct WgSqp {
         // [s v2] C [s v2]', C = [cc, -rho; -rho, 0], so S by U C U' with U = N_W [s v2], and by Woodbury
         //     M <- M - W (C^-1 + U'W)^-1 W',   W = M U,   C^-1 = [0, -1/rho; -1/rho, -cc/rho^2]:
         // two products with M and one element-wise pass instead of the sweep's n pivots (config 5: 88 k cycles per iteration for 60 to 80
-        // rows).  Errors would add up along the iterations: after eight carried sub-problems, or when the 2 x 2 system is near singular, the
+        // rows).  Errors would add up along the iterations: after sixteen carried sub-problems, or when the 2 x 2 system is near singular, the
         // inverse is formed afresh.
         bool have_m = false;
-        if (P.carry_m && minv && st[ST_CARRY] >= 1.0 && st[ST_CARRYN] < 8.0) {
+        if (P.carry_m && minv && st[ST_CARRY] >= 1.0 && st[ST_CARRYN] < 16.0) {
             const bool upd = st[ST_CARRY] == 2.0;
             const double rho = st[ST_BFRHO], cc = st[ST_BFCC];
             const double *keep = v.w + P.w_msave, *sv = v.at(P.o_sv);
@@ -2119,8 +2135,10 @@ struct WgSqp {
             return 0;
         }
         if (P.nd > 0) { art_ws_tmul(v, nw, xq, W.yd, tid); T::sync(); }       // (the kept rows' products with x0: fixed while rows are shed)
+        bool first_round = true;
         while (nw > 0) {
-            if (minv) ws_shed_round_m(nw); else ws_shed_round(nw);
+            if (minv) ws_shed_round_m(nw, first_round); else ws_shed_round(nw);
+            first_round = false;
             // every row with a negative multiplier leaves at once; equalities stay
             const unsigned long long *shw = reinterpret_cast<const unsigned long long *>(st + ST_SHED);
             unsigned long long m0 = shw[0], m1 = shw[1];
@@ -2199,7 +2217,7 @@ struct WgSqp {
             bool added = false;
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S); wavefront 0: rr = S^-1 t, the step length, the multipliers; then x -= t B^-1 (n - N_W' rr)
-                if (P.minv) ws_dual_step_m(nw, pidx, sgn, snn, npn, spv_, up); else ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
+                if (P.minv) ws_dual_step_m(nw, pidx, sgn, snn, npn, spv_, up, inner == 0 && P.nd == 0); else ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
                 MPCX_QLAP(7);
                 const double tt = st[ST_R0], zn = st[ST_R1];
                 const int what = (int)st[ST_R2], kdrop = (int)st[ST_R3];
