@@ -1613,6 +1613,9 @@ struct WgSqp {
         const int tid = threadIdx.x, lane = tid & 63, mi = v.mi, m = v.m;
         double *tq = v.at(P.o_tq), *uq = v.at(P.o_uq), *sgq = v.at(P.o_sgq), *st = v.at(P.o_st);
         int *wq = v.iat(P.o_wq), *flag = v.iat(P.o_flag);
+#ifdef MPCX_NL_STATS
+        long long qt_ = __builtin_readcyclecounter();          // (the parts of this phase: st[ST_QSTAT + 11 ..], as the inverse form's)
+#endif
         if (tid < 64) {
             const Sp sp(v);
             double *Lp = v.at(P.o_L), *invd = v.at(P.o_invd), *cd = v.at(P.o_cd), *wv = v.at(P.o_wv);
@@ -1631,10 +1634,12 @@ struct WgSqp {
             // N_W' rr starts from zero: its sparse rows are scattered below, its dense rows' coefficients go to cd
             for (int q = lane; q < nq; q += 64) wv[q] = 0.0;
             for (int dc = lane; dc < nd; dc += 64) cd[dc] = 0.0;
+            MPCX_QLAP(11);
             if (nw > 0) {
                 if (v.kw <= 64) { tri_forward<false>(Lp, invd, nw, t0, t1, lane); y0 = t0; tri_backward<false>(Lp, invd, nw, t0, t1, lane); }
                 else { tri_forward<true>(Lp, invd, nw, t0, t1, lane); y0 = t0; y1 = t1; tri_backward<true>(Lp, invd, nw, t0, t1, lane); }
             }
+            MPCX_QLAP(12);
             const double zn = snn - wave_sum((h0 ? y0 * y0 : 0.0) + (h1 ? y1 * y1 : 0.0));
             // dual ratio test: the smallest ratio, lowest slot on ties (equalities never leave)
             double tneg = -1e300; int tidx = 0x7fffffff;
@@ -1646,6 +1651,7 @@ struct WgSqp {
             const double t2 = can_move ? spv / zn : 1e300;
             const double tt = fmin(tl, t2);
             const int what = tt >= 1e300 ? 0 : (t2 <= tl ? 1 : 2);
+            MPCX_QLAP(13);
             if (what != 0) {
                 if (h0) uq[lane] = u0 - tt * t0;
                 if (h1) uq[lane + 64] = u1 - tt * t1;
@@ -1671,6 +1677,7 @@ struct WgSqp {
             if (lane == 0) { st[ST_R0] = tt; st[ST_R1] = zn; st[ST_R2] = (double)what; st[ST_R3] = (double)tidx; }
         }
         T::sync();
+        MPCX_QLAP(14);
     }
 
     // S = N_W B^-1 N_W' of the kept rows where some of them are dense (rows through the sensitivities: config 3), on the matrix pipe:

@@ -39,8 +39,8 @@ if wg and "stats" in os.environ.get("MPCX_LIBRARY", ""):
     raw /= len(range(0, B, max(1, B // 16)))
     qn = ["x0 = -B^-1 gr", "warm: Schur complement", "warm: factor", "warm: shedding rounds + minimiser", "scan", "entering row (n, B^-1 n)", "N_W v", "solve", "N_W' r", "B^-1 w", "rest of the step"]
     print("sub-problem, cycles per SQP iteration: " + "; ".join("%s %.0f" % (n, v) for n, v in zip(qn, raw)))
-    if raw[11:15].any():     # the inverse form's dual part, its four stretches (they are counted inside "solve" above too)
-        print("   dual part (inverse form): gather + zero %.0f; M t %.0f; z'n and ratio test %.0f; multipliers, scatter, bordering %.0f" % tuple(raw[11:15]))
+    if raw[11:15].any():     # the dual part of a step, its four stretches (they are counted inside "solve" above too)
+        print("   dual part: gather + zero %.0f; S^-1 t (the inverse's product / the factor's two substitutions) %.0f; z'n and ratio test %.0f; multipliers, scatter, the row's place %.0f" % tuple(raw[11:15]))
 if wg:
     print("dual steps per SQP iteration: %.2f" % (dual / len(range(0, B, max(1, B // 16)))))
 print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
