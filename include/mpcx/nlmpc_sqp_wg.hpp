@@ -2738,13 +2738,14 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     auto imin = [](int a, int b) { return a < b ? a : b; };
     auto imax = [](int a, int b) { return a > b ? a : b; };
     const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
-    // working sets of more than 64 rows: the Schur complement's inverse instead of its factor (see ws_invert_m); MPCX_NLMPC_MINV=0|1 overrides
-    // (measurements; read once)
+    // working sets that can hold more than 32 rows: the Schur complement's inverse instead of its factor (see ws_invert_m; since the inverse is
+    // carried between sub-problems it pays from there on -- six oscillators, 61 rows: 79 k -> 90 k solves/s; below, the factor's one-wavefront
+    // substitutions are the shorter way); MPCX_NLMPC_MINV=0|1 overrides (measurements; read once)
     static const int minv_env = [] { const char *e = getenv("MPCX_NLMPC_MINV"); return e ? atoi(e) : -1; }();
     // (only where every row is one of the short lists -- bounds, constraints on single inputs: S is then all but a principal block of B^-1 and as
     // well conditioned; with dense rows through the sensitivities -- config 3's obstacle rows, two of them nearly parallel at a time -- the
     // inverse lost 3 instances of 4096 that the factor solves)
-    P.minv = minv_env >= 0 ? (minv_env ? 1 : 0) : ((kw_full > 64 && P.nd == 0) ? 1 : 0);
+    P.minv = minv_env >= 0 ? (minv_env ? 1 : 0) : ((P.nd == 0 && (kw_full > 64 || (kw_full > 32 && (mu_ == 0 || Mdl::XFREE_ROWS_AFFINE)))) ? 1 : 0);      // (33 .. 64: where the inverse can be carried)
     int waves = waves_wanted;
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && !(waves == 8 && kWgEightWaves<Mdl>)) return -2;
     auto layout = [&](int kw, int f_lds) {
