@@ -362,7 +362,9 @@ typedef struct mpcx_nlmpc_batch {
     double *cmd;               /* [B x nu] */
     double *cost;              /* [B] */
     int32_t *status, *solver_status, *is_feasible, *iterations;   /* [B] each */
-    double *z;                 /* [B x nz] the optimal decision vectors (next call's z_warm)       */
+    double *z;                 /* [B x nz] the optimal decision vectors (next call's z_warm; may be the
+                                  same buffer as this call's z_warm: an instance reads its start
+                                  before its result is written)                                     */
     double *seq_state;         /* [B x (ph+1) x nx] row-major, row 0 = x0                           */
     double *seq_input;         /* [B x (ph+1) x nu]                                                 */
     double *seq_output;        /* [B x (ph+1) x ny] Model::getOutput (Model.hpp:72-96)                */

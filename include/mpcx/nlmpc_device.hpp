@@ -108,6 +108,15 @@ inline int nlmpc_waves_per_block(const NlmpcDev &m)
 // How the library launches the two kernels of a controller.  Zoo models: thunks inside libmpcx.so.  User hooks compiled
 // in the user's translation unit (mpcx/nlmpc_hooks.hpp): thunks instantiated there and registered through
 // mpcx_nlmpc_create_custom (include/mpcx.h).  Both return 0, -2 (LDS budget) or -3 (launch error).
+// Where a solve leaves the inverse BFGS matrix for a receding-horizon successor (NlmpcSolveDev::keep_curvature): the fields that decide it,
+// compared one by one (form: 0 nlmpc_sqp, 1 nlmpc_sqp_wg, < 0 nowhere)
+struct NlmpcCurvLayout {
+    int form, waves, f_lds, w_hinv, hard, nbnd_state, nr;
+    bool operator==(const NlmpcCurvLayout &o) const
+    {
+        return form >= 0 && form == o.form && waves == o.waves && f_lds == o.f_lds && w_hinv == o.w_hinv && hard == o.hard && nbnd_state == o.nbnd_state && nr == o.nr;
+    }
+};
 typedef int (*nlmpc_launch_eval_fn)(void *ctx, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream);
 typedef int (*nlmpc_launch_solve_fn)(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream);
 

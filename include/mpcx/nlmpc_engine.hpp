@@ -1919,7 +1919,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             cmax = wave_max(cmax);
             if (dmax <= S.tol_step * fmax(1.0, zmax) && cmax <= S.tol_con) {
                 // converged: take this last (tiny) step too -- it carries the final correction of the active constraints
-                for (int k = lane; k < nz; k += 64) z[k] += d[k];
+                // (bounds on the decision vector are kept exactly, as nlopt's SLSQP keeps them: its iterates are clamped to [lb, ub])
+                for (int k = lane; k < nz; k += 64) { const double zn = z[k] + d[k]; z[k] = M.nbnd > 0 ? fmin(fmax(zn, M.zlb[k]), M.zub[k]) : zn; }
                 nl_wave_sync();
                 code = 4; ++it;
                 final_eval = true;
@@ -2054,7 +2055,8 @@ __device__ __forceinline__ void sqp_body(const NlmpcDev &M, const NlmpcSolveDev 
             step_l1 = 0; z_l1 = 0; step_max = 0;
             for (int k = lane; k < nz; k += 64) {
                 const double dk = a_step * d[k];
-                z[k] += dk;
+                const double zn = z[k] + dk;
+                z[k] = M.nbnd > 0 ? fmin(fmax(zn, M.zlb[k]), M.zub[k]) : zn;
                 step_l1 += fabs(dk); z_l1 += fabs(z[k]); step_max = fmax(step_max, fabs(dk));
             }
             step_l1 = wave_sum(step_l1); z_l1 = wave_sum(z_l1); step_max = wave_max(step_max);

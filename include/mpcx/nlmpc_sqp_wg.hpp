@@ -40,7 +40,9 @@ struct WgPlan {
     int art_total;              // doubles of the dense rows' storage (every row as long as the last input block it can depend on: wg_row_len)
     int needs_phi;              // some sub-problem row reads a state
     int f_lds;                  // the folded dynamics blocks live in LDS
-    int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor
+    int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor --
+                                // per instance and per attempt: an instance that fails in the inverse form is solved again, from the start, in the factor form (ST_MINV)
+    int cut;                    // the working set's capacity was cut below what the problem can need: a second launch (only_overflowed) takes the instances that outgrow it
     int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
     int carry_m;                // (minv, every row a short list with constant entries) the inverse is carried from one sub-problem to the next: w_msave
     int lds_total;              // doubles
@@ -68,11 +70,13 @@ constexpr int kWgCtxDoubles = 0;
 // slots of the scalar block st[] through which the phases hand results to the loop
 enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3, ST_R4, ST_R5, ST_SHED = 12 /* two 64-bit words */, ST_NSHED = 14 /* rows shed at warm starts, whole solve */, ST_OVER = 15 /* the working set outgrew its capacity */, ST_ACC = 16,
        ST_CARRY = 24 /* the saved inverse: 0 none, 1 valid for the current B^-1, 2 valid up to the BFGS update in ST_BFRHO / ST_BFCC */, ST_BFRHO, ST_BFCC, ST_CARRYN /* sub-problems since the inverse was formed afresh */, ST_NCARRY /* warm starts that took the carried inverse, whole solve */, ST_CONSET /* eval_con has filed the rows once */,
-       ST_QSTAT = 32,
+       ST_MINV = 30 /* the sub-problems keep the Schur complement's inverse (WgPlan::minv, the first attempt, until one of them fails its check) */,
+       ST_QNW /* rows in the working set when the last sub-problem ended, failed or not */, ST_SWITCHED /* 1: this attempt has left the inverse form */,
+       ST_QSTAT = 40,
 #ifdef MPCX_NL_STATS
-       ST_TOTAL = 48
+       ST_TOTAL = 56
 #else
-       ST_TOTAL = 32
+       ST_TOTAL = 40
 #endif
 };
 // -DMPCX_NL_STATS (libmpcx_stats.so): shader-clock cycles of the sub-problem's parts in st[ST_QSTAT ..]: unconstrained minimiser, warm start (the kept
@@ -84,6 +88,10 @@ enum { ST_COST = 0, ST_FP, ST_FM, ST_ERR, ST_LAMDYN, ST_R0, ST_R1, ST_R2, ST_R3,
 #endif
 
 #define MPCX_WG_PHASE __device__ __attribute__((noinline))
+// a probe point of the host interpreter's tests (tests/emu/wg_probes.hpp defines it before this header is read); nothing in the product
+#ifndef MPCX_WG_PROBE_CARRY
+#define MPCX_WG_PROBE_CARRY(...) do { } while (0)
+#endif
 // -DMPCX_EMU_TRACE (the host interpreter of tests/emu only): a line per sub-problem on stderr
 #ifdef MPCX_EMU_TRACE
 #define MPCX_TRACE(...) do { if (threadIdx.x == 0 && blockIdx.x == 0) fprintf(stderr, __VA_ARGS__); } while (0)
@@ -556,7 +564,8 @@ struct WgSqp {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // start: initial guess (NLOptimizer.hpp:431-510), inverse Hessian estimate, structure tables
-    static MPCX_WG_PHASE void start()
+    // (attempt 1: the same instance again after the inverse form failed -- everything as at the first, the factor form)
+    static MPCX_WG_PHASE void start(int attempt)
     {
         const V v; const auto &M = v.A->M; const auto &S = v.A->S; const auto &P = v.A->P;
         const int tid = threadIdx.x;
@@ -599,7 +608,7 @@ struct WgSqp {
             for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
         }
         for (int k = tid; k < mt; k += NT) { mu[k] = 0.0; flag[k] = 0; }
-        for (int k = tid; k < ST_TOTAL; k += NT) st[k] = 0.0;
+        for (int k = tid; k < ST_TOTAL; k += NT) st[k] = (k == ST_MINV && P.minv && attempt == 0) ? 1.0 : 0.0;
         T::sync();
         // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
         for (int k = tid; k < nz; k += NT) {
@@ -1502,7 +1511,7 @@ struct WgSqp {
         double snn = 0, npn = 0;
         for (int q = tid; q < nq; q += NT) { snn += np_[q] * vv[q]; npn += np_[q] * np_[q]; }
         if (nw_t > 0 && P.nd > 0) art_ws_tmul(v, nw_t, vv, v.at(P.o_yd), tid);
-        if (P.minv && P.nd == 0) {
+        if (P.minv && P.nd == 0 && v.at(P.o_st)[ST_MINV] != 0.0) {
             // (the inverse form, every row a short list: t = N_W B^-1 n and the zeros N_W' r starts from, under the reduction's barrier --
             // what ws_dual_step_m would otherwise spend a phase on)
             const Ws W(v);
@@ -2038,7 +2047,7 @@ struct WgSqp {
 #ifdef MPCX_NL_STATS
         long long qt_ = __builtin_readcyclecounter();
 #endif
-        const bool minv = P.minv != 0;
+        const bool minv = st[ST_MINV] != 0.0;
         // The inverse carried over from the previous sub-problem (WgPlan::carry_m: every row a short list with constant entries, so N_W has
         // not changed; the kept rows are that sub-problem's final working set, in its order).  B^-1 has changed by the BFGS update
         // [s v2] C [s v2]', C = [cc, -rho; -rho, 0], so S by U C U' with U = N_W [s v2], and by Woodbury
@@ -2075,25 +2084,7 @@ struct WgSqp {
                 } else have_m = false;
                 T::sync();
             }
-#ifdef HIPEMU_CHECK_CARRY
-            // (tests/emu, -DHIPEMU_CHECK_CARRY: the carried inverse against the Schur complement formed afresh)
-            if (tid == 0 && have_m) {
-                double worst = 0.0;
-                for (int a = 0; a < nw; ++a)
-                    for (int b2 = 0; b2 < nw; ++b2) {
-                        double acc = a == b2 ? -1.0 : 0.0;
-                        for (int c = 0; c < nw; ++c) {
-                            const int ka = wq[a], kc = wq[c];
-                            double sac = 0.0;
-                            for (int ja = 0; ja < sp.count(ka); ++ja)
-                                for (int jc = 0; jc < sp.count(kc); ++jc) sac = fma(sp.value(ka, ja) * sp.value(kc, jc), hsym(hinv, sp.index(ka, ja), sp.index(kc, jc)), sac);
-                            acc += sgq[a] * sgq[c] * sac * hsym(Lp, c, b2);
-                        }
-                        worst = fmax(worst, fabs(acc));
-                    }
-                fprintf(stderr, "carry check: nw %d upd %d carried %g  |S M - I| = %.3e\n", nw, (int)upd, st[ST_CARRYN], worst);
-            }
-#endif
+            MPCX_WG_PROBE_CARRY(have_m, nw, wq, sgq, sp, hinv, Lp, upd, st[ST_CARRYN]);
             if (tid == 0) { if (have_m) { st[ST_CARRYN] += 1.0; st[ST_NCARRY] += 1.0; st[ST_R4] = 1.0; } }
         }
         if (have_m) { T::sync(); }
@@ -2187,6 +2178,7 @@ struct WgSqp {
 #ifdef MPCX_NL_STATS
         long long qt_ = __builtin_readcyclecounter();
 #endif
+        const bool minv = st[ST_MINV] != 0.0;                   // (constant over a solve attempt: set by start)
         for (int k = tid; k < mt; k += NT) flag[k] = 0;
         hmul_call(P.o_gr, P.o_xq, -1.0);                        // the unconstrained minimiser x = -B^-1 gr
         for (int t = tid; t < nw_keep; t += NT) flag[wq[t]] = 1;
@@ -2224,7 +2216,7 @@ struct WgSqp {
             bool added = false;
             for (int inner = 0; inner <= KW + 1 && !added && !fail; ++inner) {
                 // t = N_W v (the new column of S); wavefront 0: rr = S^-1 t, the step length, the multipliers; then x -= t B^-1 (n - N_W' rr)
-                if (P.minv) ws_dual_step_m(nw, pidx, sgn, snn, npn, spv_, up, inner == 0 && P.nd == 0); else ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
+                if (minv) ws_dual_step_m(nw, pidx, sgn, snn, npn, spv_, up, inner == 0 && P.nd == 0); else ws_dual_step(nw, pidx, sgn, snn, npn, spv_, up);
                 MPCX_QLAP(7);
                 const double tt = st[ST_R0], zn = st[ST_R1];
                 const int what = (int)st[ST_R2], kdrop = (int)st[ST_R3];
@@ -2257,20 +2249,34 @@ struct WgSqp {
                 }
 #endif
                 if (what == 1) { ++nw; added = true; }                  // full step: the row has joined the working set
-                else { if (P.minv) ws_drop_m(kdrop, nw); else ws_drop(kdrop, nw); --nw; }       // a multiplier hit zero: that row leaves, try again
+                else { if (minv) ws_drop_m(kdrop, nw); else ws_drop(kdrop, nw); --nw; }       // a multiplier hit zero: that row leaves, try again
             }
             if (!fail && !added) fail = -1;
             MPCX_QLAP(10);
         }
         if (!fail && !done) fail = -1;
+        if (!fail && minv && nw > 0) {
+            // The inverse form is trusted only as far as it can be checked.  Whatever r = M t was, the steps keep B x + g + N_W' u = 0 (x and u move
+            // together) and u >= 0, and the scan has found every row outside the working set satisfied: x is the sub-problem's solution exactly when
+            // the WORKING rows hold with equality -- which they do as far as M is S^-1 (a step keeps them at zero through t - S r = 0).  Their
+            // residuals at x measure the inverse's error; beyond 1e-9 the sub-problem counts as failed (-5) and the attempt loop takes the
+            // instance again with the factor.  (Found with tight input bounds on six oscillators: 2 of 256 instances "converged" at points
+            // whose cost was 2e-4 and 5e-4 above the optimum, status SUCCESS.)
+            ws_n_mul(nw, P.o_xq, P.o_tq);
+            double rmax = 0.0;
+            for (int t = tid; t < nw; t += NT) rmax = fmax(rmax, fabs(tq[t] + sgq[t] * br[wq[t]]));
+            rmax = R.max(rmax);
+            T::sync();
+            if (rmax > 1e-9) fail = -5;
+        }
         MPCX_TRACE(" %d dual steps, %d rows at the end, fail %d\n", nsteps, nw, fail);
-        if (tid == 0) { st[ST_R5] += (double)nsteps; st[ST_R5 + 1] = fmax(st[ST_R5 + 1], (double)nw); }
+        if (tid == 0) { st[ST_R5] += (double)nsteps; st[ST_R5 + 1] = fmax(st[ST_R5 + 1], (double)nw); st[ST_QNW] = (double)nw; }
         if (fail) { T::sync(); return fail; }
         for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
         T::sync();
         for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
         if (tid == 0 && nq < nr) xq[nq] = 0.0;                  // (p is xq: without a slack variable its last entry stays zero)
-        if (P.carry_m) {
+        if (P.carry_m && minv) {
             // the inverse of this working set's Schur complement is the next sub-problem's, up to the rank-two change of B^-1 in between
             // (the factor's storage is an overlay: the evaluation phases write over it)
             double *keep = v.w + P.w_msave;
@@ -2478,16 +2484,20 @@ struct WgSqp {
     // z += a d; s = a p for the next BFGS update; the step's norms for nlopt's stopping rules: st[R0..R2] = |step|_1, |z|_1, max |step|
     static MPCX_WG_PHASE void update(double a_step)
     {
-        const V v; const auto &P = v.A->P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int tid = threadIdx.x;
         const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p), *sv = v.at(P.o_sv), *st = v.at(P.o_st);
         Red<WAVES> R(v.at(P.o_red));
         double s1 = 0, z1 = 0, smax = 0;
+        const bool bounded = M.nbnd > 0;
         for (int q = tid; q < nr; q += NT) sv[q] = a_step * p[q];
         for (int k = tid; k < nxs + nr; k += NT) {
             const double dk = a_step * (k < nxs ? dx[k] : p[k - nxs]);
-            const double zn = z[k] + dk;
+            double zn = z[k] + dk;
+            // (bounds on the decision vector are kept exactly, as nlopt's SLSQP keeps them -- its iterates are clamped to [lb, ub]; the
+            // sub-problem's bound rows hold to round-off of the step, 1e-8 after a few partial steps)
+            if (bounded) zn = fmin(fmax(zn, M.zlb[k]), M.zub[k]);
             z[k] = zn;
             s1 += fabs(dk); z1 += fabs(zn); smax = fmax(smax, fabs(dk));
         }
@@ -2512,6 +2522,15 @@ struct WgSqp {
         return vmax;
     }
 
+    // from here on the sub-problems of this attempt keep the working set's factor (see the kernel's loop)
+    static MPCX_WG_PHASE void leave_inverse()
+    {
+        const V v;
+        double *st = v.at(v.A->P.o_st);
+        T::sync();                                               // (everybody has read the flags the failed sub-problem left)
+        if (threadIdx.x == 0) { st[ST_MINV] = 0.0; st[ST_SWITCHED] = 1.0; st[ST_CARRY] = 0.0; st[ST_OVER] = 0.0; }
+        T::sync();
+    }
     static MPCX_WG_PHASE void reset_hessian()
     {
         const V v; const auto &P = v.A->P;
@@ -2523,10 +2542,15 @@ struct WgSqp {
     }
     static MPCX_WG_PHASE void take_last_step()
     {
-        const V v; const auto &P = v.A->P;
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
         const int nxs = v.nxs, nr = v.nr;
         double *z = v.at(P.o_z), *dx = v.at(P.o_dx), *p = v.at(P.o_p);
-        for (int k = threadIdx.x; k < nxs + nr; k += NT) z[k] += k < nxs ? dx[k] : p[k - nxs];
+        const bool bounded = M.nbnd > 0;
+        for (int k = threadIdx.x; k < nxs + nr; k += NT) {
+            double zn = z[k] + (k < nxs ? dx[k] : p[k - nxs]);
+            if (bounded) zn = fmin(fmax(zn, M.zlb[k]), M.zub[k]);      // (as in update)
+            z[k] = zn;
+        }
         T::sync();
     }
 
@@ -2548,7 +2572,10 @@ struct WgSqp {
         const bool failed = code < 0;
         double *o_cmd = S.cmd, *o_z = S.z_out, *o_mu = S.mu_out, *o_sx = S.seq_state, *o_su = S.seq_input, *o_sy = S.seq_output;
         if (o_cmd) for (int j = tid; j < NU; j += NT) o_cmd[(size_t)b * NU + j] = failed ? u0[j] : Us[j];
-        if (o_z) for (int k = tid; k < nz; k += NT) o_z[(size_t)b * nz + k] = z[k];
+        // (an instance that outgrew a cut capacity is taken again by the second launch, from the same z_warm and curvature estimate: neither is
+        // overwritten here -- z_out may be the caller's z_warm, the estimate's place is the same in both plans)
+        const bool again = P.cut && st[ST_OVER] != 0.0;
+        if (o_z && !again) for (int k = tid; k < nz; k += NT) o_z[(size_t)b * nz + k] = z[k];
         if (o_mu) for (int k = tid; k < mt; k += NT) o_mu[(size_t)b * mt + k] = mu[k];
         if (o_sx) for (int k = tid; k < (ph + 1) * NX; k += NT) o_sx[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
         if (o_su) for (int k = tid; k < (ph + 1) * NU; k += NT) o_su[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
@@ -2561,7 +2588,7 @@ struct WgSqp {
             }
         // the curvature estimate stays in the workspace for a receding-horizon successor (keep_curvature)
         gwp hs = (gwp)(v.w + P.w_hinv);
-        for (int e = tid; e < nr * (nr + 1) / 2; e += NT) hs[e] = hinv[e];
+        if (!again) for (int e = tid; e < nr * (nr + 1) / 2; e += NT) hs[e] = hinv[e];
         double *scal = v.w + P.w_scal;
         if (tid == 0) {
             if (S.cost) S.cost[b] = failed ? __builtin_huge_val() : st[ST_COST];
@@ -2594,7 +2621,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
     double *sm = wg_lds();
     const double *st = sm + P.o_st;
     // shader-clock cycles per phase (tools/nlmpc_phases.py): evaluate (cost, dynamics, constraints), condense, BFGS, sub-problem, step, merit, line search, update
-    if (P.only_overflowed && S.ws[(size_t)b * M.ws.total + P.w_scal + 14] != 1.0) return;      // (uniform over the workgroup, before any barrier)
+    if (P.only_overflowed && !((int)S.ws[(size_t)b * M.ws.total + P.w_scal + 14] & 1)) return;      // (uniform over the workgroup, before any barrier)
     long long cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = __builtin_readcyclecounter();
 #ifdef MPCX_EMU_TRACE
     auto lap = [&](int k) { const long long now = hipemu::st().n_block_syncs; cyc[k] += now - tstamp; tstamp = now; };    // (the interpreter: barriers per phase)
@@ -2602,12 +2629,20 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 #else
     auto lap = [&](int k) { const long long now = __builtin_readcyclecounter(); cyc[k] += now - tstamp; tstamp = now; };
 #endif
-    K::start();
-    lap(9);
     const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
+    int it = 0, code = 5, attempt = 0;                   // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
+    // An instance is attempted in the plan's form.  With the Schur complement kept as its inverse (errors of the inverse grow with the condition
+    // number of S, the factor's with its root: working sets that fill the sub-problem's variables under tight bounds) every sub-problem's solution
+    // is checked, and the first that fails is solved again with the factor, as are all that follow.  An instance that began with the inverse and
+    // still FAILS is solved once more from the start with the factor alone -- the result is then, bit for bit, what a plan without the inverse
+    // form delivers for it.
+    for (;; ++attempt) {
+    K::start(attempt);
+    lap(9);
     double nu_pen = 0.0, a_prev = 0.0, f_prev = 0, step_l1 = 0, z_l1 = 0, step_max = 0;
     bool have_old = false, stepped = false, final_eval = false;
-    int resets = 0, nw_keep = 0, it = 0, code = 5;       // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
+    int resets = 0, nw_keep = 0;
+    it = 0; code = 5;
     for (;;) {
         K::eval_cost(final_eval ? 1 : 0);
         lap(0);
@@ -2635,7 +2670,15 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         lap(3);
         if (have_old) K::bfgs(a_prev, nw_keep);
         lap(4);
-        const int nw = K::qp(nw_keep);
+        int nw = K::qp(nw_keep);
+        if (nw < 0 && st[ST_MINV] != 0.0 && st[ST_ERR] == 0.0) {
+            // a sub-problem that fails with the inverse (its check of the working rows, or the dual method itself) is solved again with the factor --
+            // from the set it ended with where that set is what the check rejected (a good guess of the active set: the warm start sheds what does
+            // not belong), cold otherwise -- and the instance stays with the factor from here on
+            const int keep = nw == -5 ? (int)st[ST_QNW] : 0;
+            K::leave_inverse();
+            nw = K::qp(keep);
+        }
         lap(5);
         if (nw < 0) { code = nw; break; }
         nw_keep = nw;
@@ -2660,6 +2703,9 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         const double a_step = K::linesearch(nu_pen, phi0, dphi);
         lap(8);
         if (a_step < 0.0) {                                  // no decrease left within 2^-40: the iteration has stalled
+            // (every sub-problem solution of the inverse form has passed its check, so the stall is the iteration's own; the instance goes on with
+            // the factor all the same -- what is left of it is the hard part)
+            if (st[ST_MINV] != 0.0) K::leave_inverse();
             if (cmax <= fmax(S.tol_con, 1e-8) && dmax <= 1e-3 * fmax(1.0, zmax)) { code = 4; break; }
             if (resets >= 5) { code = -4; break; }
             // far from a solution: the curvature estimate has gone bad -- forget it and try a steepest-descent-like step
@@ -2678,6 +2724,9 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         a_prev = a_step; have_old = true; stepped = true;
         ++it;
     }
+    if (!(code < 0 && attempt == 0 && P.minv && st[ST_ERR] == 0.0)) break;
+    T::sync();                                               // (everybody has read the attempt's scalars before start() clears them)
+    }
     K::finish(code, it);
     MPCX_TRACE("barriers per iteration (%d iterations): cost %.1f dyn %.1f con %.1f condense %.1f bfgs %.1f qp %.1f step %.1f merit %.1f ls %.1f update+start %.1f\n", it,
                (double)cyc[0] / NT / it, (double)cyc[1] / NT / it, (double)cyc[2] / NT / it, (double)cyc[3] / NT / it, (double)cyc[4] / NT / it, (double)cyc[5] / NT / it,
@@ -2687,7 +2736,8 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         scal[1] = st[ST_R5];
         scal[12] = st[ST_R5 + 1];                                // the largest working set of the solve
         scal[13] = st[ST_NSHED];
-        scal[14] = st[ST_OVER];                                  // 1: a pass with the full capacity has to take this instance again
+        // bit 0: a pass with the full capacity has to take this instance again; bit 1: solved again from the start with the factor; bit 2: left the inverse form on the way
+        scal[14] = st[ST_OVER] + 2.0 * (double)attempt + 4.0 * st[ST_SWITCHED];
         scal[15] = st[ST_NCARRY];
 #ifdef MPCX_NL_STATS
         for (int k = 0; k < 16; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
@@ -2701,8 +2751,10 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 #if !defined(__HIPCC_RTC__)
 // the LDS / workspace plan of the workgroup form for controller m (dimensions, bounds) and the hard / soft flag; 0, or -2 if the
 // shape does not fit (the caller falls back to nlmpc_sqp)
+// (minv_wanted / carry_wanted: -1 the plan's own choice, 0 | 1 forced -- the launcher's MPCX_NLMPC_MINV / MPCX_NLMPC_CARRY, read when the handle is created)
 template <class Mdl>
-inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1, bool cut_ok = true, int lds_per_cu = 160 * 1024)
+inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1, bool cut_ok = true, int lds_per_cu = 160 * 1024,
+                   int minv_wanted = -1, int carry_wanted = -1)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
@@ -2740,8 +2792,8 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     const int kw_full = imin(kNlMaxWorking, imax(2, imin(mt, P.nq) + 1));
     // working sets that can hold more than 32 rows: the Schur complement's inverse instead of its factor (see ws_invert_m; since the inverse is
     // carried between sub-problems it pays from there on -- six oscillators, 61 rows: 79 k -> 90 k solves/s; below, the factor's one-wavefront
-    // substitutions are the shorter way); MPCX_NLMPC_MINV=0|1 overrides (measurements; read once)
-    static const int minv_env = [] { const char *e = getenv("MPCX_NLMPC_MINV"); return e ? atoi(e) : -1; }();
+    // substitutions are the shorter way).  An instance the inverse form fails is solved again with the factor (the kernel's attempt loop).
+    const int minv_env = minv_wanted;
     // (only where every row is one of the short lists -- bounds, constraints on single inputs: S is then all but a principal block of B^-1 and as
     // well conditioned; with dense rows through the sensitivities -- config 3's obstacle rows, two of them nearly parallel at a time -- the
     // inverse lost 3 instances of 4096 that the factor solves)
@@ -2798,7 +2850,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
                     if (per_cu > by_regs) continue;
                     int kw = kw_full;
                     if (cut) while (kw > kw_floor && layout(kw, f_lds) > budget) --kw;
-                    if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; }
+                    if (layout(kw, f_lds) <= budget) { placed = true; P.per_cu = per_cu; P.cut = kw < kw_full ? 1 : 0; }
                 }
             }
         }
@@ -2826,8 +2878,8 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.w_hinv = take(nr * (nr + 1) / 2);
         P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
         // the carried inverse (see ws_warm): where no row's entries change between sub-problems -- bounds on inputs, user rows affine in the inputs (Mdl::XFREE_ROWS_AFFINE) --
-        // and the controller's workspace has the room; MPCX_NLMPC_CARRY=0 switches it off (measurements; read once)
-        static const int carry_env = [] { const char *e = getenv("MPCX_NLMPC_CARRY"); return e ? atoi(e) : 1; }();
+        // and the controller's workspace has the room
+        const int carry_env = carry_wanted < 0 ? 1 : carry_wanted;
         P.carry_m = 0; P.w_msave = 0;
         if (carry_env && P.minv && P.nd == 0 && (mu_ == 0 || Mdl::XFREE_ROWS_AFFINE) && o + P.kw * (P.kw + 1) / 2 + 2 <= m.ws.scal) { P.carry_m = 1; P.w_msave = take(P.kw * (P.kw + 1) / 2); }
         P.ws_total = o;

@@ -20,7 +20,8 @@ int nlmpc_last_form();
 void *nlmpc_zoo_new();
 void nlmpc_zoo_free(void *z);
 int nlmpc_zoo_last_form(void *z);
-long nlmpc_zoo_layout_signature(void *z, const NlmpcDev *m, int hard);
+void nlmpc_zoo_next_layout(void *z, const NlmpcDev *m, int hard, int batch, NlmpcCurvLayout *out);
+void nlmpc_zoo_last_layout(void *z, NlmpcCurvLayout *out);
 // run-time compiled hooks (nlmpc_jit.cpp)
 void nlmpc_jit_release(void *jit);
 }
@@ -34,7 +35,7 @@ struct mpcx_nlmpc {
     void *launch_ctx = nullptr;
     void *jit = nullptr;                 // run-time compiled module (nlmpc_jit.cpp), released with the handle
     void *zoo = nullptr;                 // built-in systems: the launcher's state (form, plans), = launch_ctx
-    long curv_sig = -1;                  // layout signature of the solve that left its curvature estimate in the workspace
+    mpcx::NlmpcCurvLayout curv{-1, 0, 0, 0, 0, 0, 0};      // where the last solve left its curvature estimate in the workspace (form < 0: nowhere)
     double *params_d = nullptr;
     int n_params = 0;                   // parameters of the built-in system (0: none, or a hook model)
     double *scale_d = nullptr;           // input scaling [nu] | state scaling [nx] (Mapping.hpp:71-86), ones by default
@@ -332,13 +333,23 @@ static int prepare_solve(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, mpcx::NlmpcS
         if (h->n_params <= 0) return capi_fail(MPCX_E_INVALID, "this model has no parameters to give per instance");
         s.params_b = b->params; s.nparams = h->n_params;
     }
+    // (z_warm may be the same buffer as z: an instance reads its start before it writes its result, and one that a second launch takes again
+    // -- a working set that outgrew a cut capacity -- has neither its start nor its curvature estimate overwritten by the first: WgSqp::finish)
     // carried curvature: only from a solve of the same batch that left it in the layout the next launch will read (form, wavefronts, offsets)
-    const long sig = h->zoo ? mpcx::nlmpc_zoo_layout_signature(h->zoo, &h->dev, s.hard) : 0;
-    s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch && sig >= 0 && sig == h->curv_sig) ? 1 : 0;
+    mpcx::NlmpcCurvLayout next{0, 0, 0, h->dev.ws.hinv, s.hard, h->dev.nbnd_state, h->dev.nr};      // (hook models: always nlmpc_sqp)
+    if (h->zoo) mpcx::nlmpc_zoo_next_layout(h->zoo, &h->dev, s.hard, b->batch, &next);
+    s.keep_curvature = (b->warm_curvature && b->z_warm && h->solved_batch == b->batch && next == h->curv) ? 1 : 0;
     h->solved_batch = b->batch;
     s.cmd = b->cmd; s.cost = b->cost; s.z_out = b->z; s.status = b->status; s.solver_status = b->solver_status;
     s.is_feasible = b->is_feasible; s.iterations = b->iterations; s.seq_state = b->seq_state; s.seq_input = b->seq_input; s.seq_output = b->seq_output;
     return MPCX_OK;
+}
+
+// after a launch: where this solve's curvature estimate lies
+static void note_curvature(mpcx_nlmpc_t h, const mpcx::NlmpcSolveDev &s)
+{
+    h->curv = mpcx::NlmpcCurvLayout{0, 0, 0, h->dev.ws.hinv, s.hard, h->dev.nbnd_state, h->dev.nr};
+    if (h->zoo) mpcx::nlmpc_zoo_last_layout(h->zoo, &h->curv);
 }
 
 int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stream)
@@ -347,8 +358,8 @@ int mpcx_nlmpc_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void *stre
     const int rc = prepare_solve(h, b, s);
     if (rc != MPCX_OK) return rc > 0 ? MPCX_OK : rc;
     const int lr = h->launch_solve(h->launch_ctx, &h->dev, &s, stream);
-    if (lr != 0) { h->solved_batch = 0; return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")"); }
-    h->curv_sig = h->zoo ? mpcx::nlmpc_zoo_layout_signature(h->zoo, &h->dev, s.hard) : 0;
+    if (lr != 0) { h->solved_batch = 0; h->curv.form = -1; return mpcx::capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed (" + std::to_string(lr) + ")"); }
+    note_curvature(h, s);
     return MPCX_OK;
 }
 
@@ -413,7 +424,8 @@ int mpcx_nlmpc_time_solve_batch(mpcx_nlmpc_t h, const mpcx_nlmpc_batch *b, void 
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (lr != 0) return capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed");
+    if (lr != 0) { h->solved_batch = 0; h->curv.form = -1; return capi_fail(MPCX_E_DEVICE, "NLMPC solve launch failed"); }
+    note_curvature(h, s);
     *ms_mean = ms / repeats;
     return MPCX_OK;
 }

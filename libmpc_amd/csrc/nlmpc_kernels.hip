@@ -40,7 +40,7 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // whole batch would (the only thing a batch changes is where the folded blocks live -- LDS when the batch is resident with them there -- and
 // that changes no arithmetic).  MPCX_NLMPC_FORM=wg|wave, MPCX_NLMPC_WAVES=1|2|4|8 and MPCX_NLMPC_BLOCKS=1|0 override; they are read when
 // the handle is created, never on the solve path.
-int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu);
+int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu, int minv, int carry);
 int nlmpc_wg_launch(const NlmpcDev *m, const NlmpcSolveDev *b, const engine::WgPlan *P, void *stream);
 
 static std::atomic<int> g_last_form{-1};
@@ -48,9 +48,10 @@ int nlmpc_last_form() { return g_last_form.load(std::memory_order_relaxed); }
 
 // per-handle state of the launcher: the overrides, the device's limits, the plans of the current (hard / soft, bounds) shape
 struct NlmpcZoo {
-    int env_form = -1, env_waves = 0, env_blocks = -1;          // -1 / 0: not set
+    int env_form = -1, env_waves = 0, env_blocks = -1, env_minv = -1, env_carry = -1;          // -1 / 0: not set
     int lds_per_cu = 160 * 1024, cus = 256;
     int last_form = -1;
+    NlmpcCurvLayout launched{};                               // where the last solve left its curvature estimate (form < 0: nowhere)
     // cache key and plans: throughput plan (most workgroups per CU; blocks where it puts them), the plan with the blocks in LDS, and the
     // plans of the second pass (full working-set capacity) for either
     int k_hard = -1, k_nbnd = -1, k_nbnd_state = -1, k_ws_total = -1;
@@ -61,10 +62,14 @@ struct NlmpcZoo {
 void *nlmpc_zoo_new()
 {
     NlmpcZoo *z = new NlmpcZoo;
-    const char *form = getenv("MPCX_NLMPC_FORM"), *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS");
+    z->launched.form = -1;
+    const char *form = getenv("MPCX_NLMPC_FORM"), *wv = getenv("MPCX_NLMPC_WAVES"), *bl = getenv("MPCX_NLMPC_BLOCKS"),
+               *mi = getenv("MPCX_NLMPC_MINV"), *ca = getenv("MPCX_NLMPC_CARRY");
     if (form) z->env_form = !strcmp(form, "wave") ? 0 : (!strcmp(form, "wg") ? 1 : -1);
     if (wv) z->env_waves = atoi(wv);
     if (bl) z->env_blocks = atoi(bl) ? 1 : 0;
+    if (mi) z->env_minv = atoi(mi) ? 1 : 0;
+    if (ca) z->env_carry = atoi(ca) ? 1 : 0;
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) z->lds_per_cu = v;
@@ -74,15 +79,47 @@ void *nlmpc_zoo_new()
 }
 void nlmpc_zoo_free(void *z) { delete static_cast<NlmpcZoo *>(z); }
 int nlmpc_zoo_last_form(void *z) { return z ? static_cast<NlmpcZoo *>(z)->last_form : -1; }
-// a signature of the layout the last solve left its curvature estimate in (form, wavefronts, where the packed matrix lies): carried curvature
-// is only valid for the same one
-long nlmpc_zoo_layout_signature(void *zp, const NlmpcDev *m, int hard)
+
+// the plans of the controller as it stands (hard / soft, bounds, workspace): made when one of those changed, not per solve
+static void zoo_refresh(NlmpcZoo *z, const NlmpcDev *m, int hard)
+{
+    if (z->k_hard == hard && z->k_nbnd == m->nbnd && z->k_nbnd_state == m->nbnd_state && z->k_ws_total == m->ws.total) return;
+    auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok, int waves = -1) {
+        return nlmpc_wg_plan(*m, hard, waves < 0 ? z->env_waves : waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu, z->env_minv, z->env_carry) == 0 && X.ws_total <= m->ws.total;
+    };
+    z->k_hard = hard; z->k_nbnd = m->nbnd; z->k_nbnd_state = m->nbnd_state; z->k_ws_total = m->ws.total;
+    z->fits = plan(z->P, z->env_blocks, true);
+    z->has_lds = z->fits && z->env_blocks < 0 && z->P.waves > 1 && !z->P.f_lds && plan(z->Q, 1, true) && z->Q.waves > 1;
+    // (the second pass: the same wavefronts per instance -- the same arithmetic -- with the working set's full capacity)
+    z->has_full = z->fits && plan(z->Pfull, z->P.f_lds, false, z->P.waves) && z->Pfull.kw > z->P.kw;
+    z->has_lds_full = z->has_lds && plan(z->Qfull, 1, false, z->Q.waves) && z->Qfull.kw > z->Q.kw;
+}
+// the plan a batch of this size takes (nullptr: the wavefront form)
+static const engine::WgPlan *zoo_pick(NlmpcZoo *z, int batch, bool &lds_plan)
+{
+    lds_plan = false;
+    if (z->env_form == 0 || !z->fits) return nullptr;
+    // the blocks in LDS where the whole batch is resident with them there (the latency form: config 3 at up to two instances per CU)
+    lds_plan = z->has_lds && (long)batch <= (long)z->cus * z->Q.per_cu;
+    return lds_plan ? &z->Q : &z->P;
+}
+static NlmpcCurvLayout layout_of(const engine::WgPlan *X, const NlmpcDev *m, int hard)
+{
+    NlmpcCurvLayout L{};
+    L.form = X ? 1 : 0; L.waves = X ? X->waves : 0; L.f_lds = X ? X->f_lds : 0; L.w_hinv = X ? X->w_hinv : m->ws.hinv;
+    L.hard = hard ? 1 : 0; L.nbnd_state = m->nbnd_state; L.nr = m->nr;
+    return L;
+}
+// Carried curvature is valid only for a solve that reads the estimate where the previous one left it: the layout the NEXT launch of this
+// batch will use (the plans are brought up to date first), and the one the LAST launch used
+void nlmpc_zoo_next_layout(void *zp, const NlmpcDev *m, int hard, int batch, NlmpcCurvLayout *out)
 {
     NlmpcZoo *z = static_cast<NlmpcZoo *>(zp);
-    if (!z || z->last_form < 0) return -1;
-    if (z->last_form == 0) return 0;
-    return 1 + z->P.w_hinv * 16L + z->P.waves + 1000003L * (z->k_nbnd_state + 1) + (hard ? 7 : 0);
+    zoo_refresh(z, m, hard);
+    bool lds_plan;
+    *out = layout_of(zoo_pick(z, batch, lds_plan), m, hard);
 }
+void nlmpc_zoo_last_layout(void *zp, NlmpcCurvLayout *out) { *out = static_cast<NlmpcZoo *>(zp)->launched; }
 
 int nlmpc_launch_solve(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream)
 {
@@ -90,41 +127,34 @@ int nlmpc_launch_solve(void *ctx, const NlmpcDev *m, const NlmpcSolveDev *b, voi
         using Mdl = decltype(mdl);
         NlmpcZoo local;
         NlmpcZoo *z = ctx ? static_cast<NlmpcZoo *>(ctx) : &local;
-        if (z->env_form != 0) {
-            if (z->k_hard != b->hard || z->k_nbnd != m->nbnd || z->k_nbnd_state != m->nbnd_state || z->k_ws_total != m->ws.total) {
-                auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok, int waves = -1) {
-                    return nlmpc_wg_plan(*m, b->hard, waves < 0 ? z->env_waves : waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu) == 0 && X.ws_total <= m->ws.total;
-                };
-                z->k_hard = b->hard; z->k_nbnd = m->nbnd; z->k_nbnd_state = m->nbnd_state; z->k_ws_total = m->ws.total;
-                z->fits = plan(z->P, z->env_blocks, true);
-                z->has_lds = z->fits && z->env_blocks < 0 && z->P.waves > 1 && !z->P.f_lds && plan(z->Q, 1, true) && z->Q.waves > 1;
-                // (the second pass: the same wavefronts per instance -- the same arithmetic -- with the working set's full capacity)
-                z->has_full = z->fits && plan(z->Pfull, z->P.f_lds, false, z->P.waves) && z->Pfull.kw > z->P.kw;
-                z->has_lds_full = z->has_lds && plan(z->Qfull, 1, false, z->Q.waves) && z->Qfull.kw > z->Q.kw;
-            }
-            if (z->fits) {
-                // the blocks in LDS where the whole batch is resident with them there (the latency form: config 3 at up to two instances per CU)
-                const bool lds_plan = z->has_lds && (long)b->batch <= (long)z->cus * z->Q.per_cu;
-                const engine::WgPlan &X = lds_plan ? z->Q : z->P;
-                int rc = nlmpc_wg_launch(m, b, &X, stream);
-                if (rc == 0) {
-                    // working sets that outgrew a capacity the plan had cut: those instances again, with the full one
-                    const bool again = lds_plan ? z->has_lds_full : z->has_full;
-                    if (again) {
-                        engine::WgPlan Y = lds_plan ? z->Qfull : z->Pfull;
-                        Y.only_overflowed = 1;
-                        NlmpcSolveDev b2 = *b;
-                        b2.keep_curvature = 0;                  // (the first pass left its own estimate where this layout does not look)
-                        rc = nlmpc_wg_launch(m, &b2, &Y, stream);
-                    }
-                    if (rc == 0) { z->last_form = X.waves; g_last_form.store(X.waves, std::memory_order_relaxed); return 0; }
+        z->launched.form = -1;
+        zoo_refresh(z, m, b->hard);
+        bool lds_plan;
+        if (const engine::WgPlan *Xp = zoo_pick(z, b->batch, lds_plan)) {
+            const engine::WgPlan &X = *Xp;
+            int rc = nlmpc_wg_launch(m, b, &X, stream);
+            if (rc == 0) {
+                // working sets that outgrew a capacity the plan had cut: those instances again, with the full one (the first pass has left their
+                // start and their curvature estimate alone: WgSqp::finish)
+                const bool again = lds_plan ? z->has_lds_full : z->has_full;
+                if (again) {
+                    engine::WgPlan Y = lds_plan ? z->Qfull : z->Pfull;
+                    Y.only_overflowed = 1;
+                    NlmpcSolveDev b2 = *b;
+                    if (Y.w_hinv != X.w_hinv) b2.keep_curvature = 0;
+                    rc = nlmpc_wg_launch(m, &b2, &Y, stream);
                 }
-                if (z->env_form == 1) return rc;                // forced: report
-                // otherwise (an attribute or launch error on this device): the wavefront form still runs
-            } else if (z->env_form == 1) return -2;
-        }
+                if (rc == 0) { z->last_form = X.waves; z->launched = layout_of(&X, m, b->hard); g_last_form.store(X.waves, std::memory_order_relaxed); return 0; }
+            }
+            if (z->env_form == 1) return rc;                // forced: report
+            // otherwise (an attribute or launch error on this device): the wavefront form still runs
+        } else if (z->env_form == 1) return -2;
         z->last_form = 0; g_last_form.store(0, std::memory_order_relaxed);
-        return engine::launch_solve<Mdl>(nullptr, m, b, stream);
+        NlmpcSolveDev bw = *b;
+        if (z->env_form != 0 && z->fits) bw.keep_curvature = 0;      // (the caller counted on the workgroup form's layout)
+        const int rc = engine::launch_solve<Mdl>(nullptr, m, &bw, stream);
+        if (rc == 0) z->launched = layout_of(nullptr, m, b->hard);
+        return rc;
     });
 }
 

@@ -72,13 +72,16 @@ class NlmpcC:
         self.lib.nlc_user_ineq(C.byref(self.m), _p(z), _p(self.x0), _p(g), _p(J))
         return g, J
 
-    def solve(self, x0, u0, max_iter=100, hard=True):
-        """NLOptimizer::run, cold start (NLOptimizer.hpp:412-638), with scipy's SLSQP"""
+    def solve(self, x0, u0, max_iter=100, hard=True, lb_u=None, ub_u=None):
+        """NLOptimizer::run, cold start (NLOptimizer.hpp:412-638), with scipy's SLSQP; lb_u / ub_u: NLMPC::setInputBounds on every
+        step of the control horizon (NLOptimizer.hpp:346-404: bounds on the decision vector)"""
         from scipy.optimize import minimize
         self.x0 = np.ascontiguousarray(x0, float)
         nx, nu, ph, ch = self.nx, self.nu, self.ph, self.ch
         z0 = np.concatenate([np.tile(self.x0, ph), np.tile(np.asarray(u0, float), ch), [0.0]])
         lo = np.full(self.nz, -np.inf); hi = np.full(self.nz, np.inf)
+        if lb_u is not None:
+            lo[ph * nx:ph * nx + ch * nu] = np.tile(lb_u, ch); hi[ph * nx:ph * nx + ch * nu] = np.tile(ub_u, ch)
         if hard:
             lo[-1] = hi[-1] = 0.0
         cons = [{"type": "eq", "fun": lambda z: self.state_eq(z, False)[0], "jac": lambda z: self.state_eq(z, True)[1]},

@@ -15,6 +15,9 @@
 
 #include "mpcx/nlmpc_engine.hpp"
 #ifdef HIPEMU_WITH_WG
+#ifdef HIPEMU_CHECK_CARRY
+#include "wg_probes.hpp"
+#endif
 #include "mpcx/nlmpc_sqp_wg.hpp"
 #endif
 
@@ -87,7 +90,8 @@ static int run(int argc, char **argv)
         int nsb = 0;
         for (int k = 0; k < M.nbnd; ++k) nsb += bidx[k] < nxs ? 1 : 0;
         const int waves = getenv("HIPEMU_WAVES") ? atoi(getenv("HIPEMU_WAVES")) : 0;
-        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, getenv("HIPEMU_BLOCKS") ? atoi(getenv("HIPEMU_BLOCKS")) : -1) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
+        auto envi = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : -1; };      // (as the launcher reads them when a handle is created)
+        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, envi("HIPEMU_BLOCKS"), true, 160 * 1024, envi("MPCX_NLMPC_MINV"), envi("MPCX_NLMPC_CARRY")) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
         if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles, inverse form %d carried %d (plan %d of %d doubles)\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total, P.minv, P.carry_m, P.ws_total, M.ws.scal);
     }
 #endif
@@ -138,7 +142,7 @@ static int run(int argc, char **argv)
             printf("], \"z\": [");
             for (int k = 0; k < nz; ++k) printf("%s%.17g", k ? ", " : "", zout[(size_t)b * nz + k]);
             auto stat = [&](int k) { const double x = ws[(size_t)b * ws_total + M.ws.scal + k]; return std::isfinite(x) ? x : -1.0; };       // (the one-wavefront form files fewer)
-            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"carried\": %g, \"mu\": [", stat(12), stat(1), stat(13), stat(15));
+            printf("], \"max_nw\": %g, \"dual_steps\": %g, \"shed\": %g, \"carried\": %g, \"attempts\": %d, \"left_inverse\": %d, \"mu\": [", stat(12), stat(1), stat(13), stat(15), form == "wg" ? 1 + (((int)stat(14) >> 1) & 1) : 1, form == "wg" ? ((int)stat(14) >> 2) & 1 : 0);
             for (int k = 0; k < mt; ++k) printf("%s%.17g", k ? ", " : "", mu[(size_t)b * mt + k]);
             printf("]}\n");
         }
