@@ -2134,13 +2134,16 @@ inline void nlmpc_plan(NlmpcDev &m)
     // by a few lanes, and a dependent load from L2 costs ~2.7k cycles on the loaded chip.  (A larger budget costs occupancy: config 3 at
     // six wavefronts per CU instead of eight lost more than it gained)
     int jl = (nx < 8 && !m.vector_hooks) ? ((ph * nx * (2 * nx + nu) + ph * nx * nx + 2 * ph * nx + m.nr + 1) & ~1) : 0;
-    if (const char *e = getenv("MPCX_DEBUG_LDS_BLOCKS")) { if (atoi(e) == 0) jl = 0; }      // testing aid: A/B against the workspace form
+    // (testing aids MPCX_DEBUG_LDS_BLOCKS = 0 | 2 and MPCX_DEBUG_LDS_CAP: read HERE, when a controller is created or its bounds change the plan -- never on a solve path)
+    const int dbg_blocks = [] { const char *e = getenv("MPCX_DEBUG_LDS_BLOCKS"); return e ? atoi(e) : -1; }();
+    const int dbg_cap = [] { const char *e = getenv("MPCX_DEBUG_LDS_CAP"); return e ? atoi(e) : -1; }();
+    if (dbg_blocks == 0) jl = 0;                                        // A/B against the workspace form
     // (MPCX_DEBUG_LDS_BLOCKS=2, testing aid: the blocks in LDS next to whatever the factor gets -- with a two-level factor the
     // combination of DESIGN.md section 9-2 that the plan itself never selects)
-    const bool force_blk = jl > 0 && getenv("MPCX_DEBUG_LDS_BLOCKS") && atoi(getenv("MPCX_DEBUG_LDS_BLOCKS")) == 2;
+    const bool force_blk = jl > 0 && dbg_blocks == 2;
     if (force_blk) cap = imax(fixed + tail_min, 2048 - jl);
     else if (jl > 0 && fixed + imax(tail_min, KW * (KW + 1) / 2) + jl <= 2048) cap = 2048 - jl; else jl = 0;
-    if (const char *e = getenv("MPCX_DEBUG_LDS_CAP")) cap = atoi(e);          // testing aid
+    if (dbg_cap >= 0) cap = dbg_cap;
     const int tail = imax(tail_min, imin(KW * (KW + 1) / 2, cap - fixed));
     m.nl = 0;
     while (m.nl < KW && (m.nl + 1) * (m.nl + 2) / 2 <= tail) ++m.nl;
@@ -2189,7 +2192,8 @@ int launch_solve(void *, const NlmpcDev *m, const NlmpcSolveDev *b, void *stream
     const bool blk = m->lds_blocks >= 0;                      // the dynamics blocks live in the LDS slice (nlmpc_plan; small built-in systems)
     if (blk && !kSqpLdsBlocks<Mdl>) return -2;
     auto go = [&](auto kern) {
-        if (getenv("MPCX_DEBUG_OCCUPANCY")) {                 // testing aid: resident blocks per CU as the runtime sees them
+        static const bool show = getenv("MPCX_DEBUG_OCCUPANCY") != nullptr;      // testing aid (read once): resident blocks per CU as the runtime sees them
+        if (show) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, wpb * 64, lds);
             fprintf(stderr, "nlmpc_sqp: %d blocks of %d wavefronts, %zu bytes of LDS each; resident per CU: %d; factor rows in LDS %d of %d; blocks in LDS %d\n",

@@ -87,6 +87,8 @@ struct LmpcBatchDev {
 // which entry of the model array instance b uses
 __host__ __device__ inline int lmpc_model_of(const LmpcBatchDev &Bt, int b) { return Bt.n_models <= 0 ? 0 : (Bt.model_index ? Bt.model_index[b] : b); }
 
+// LDS a workgroup of the current device may take (one CU's: gfx950 160 KB), asked of the runtime once per device -- implemented in lmpc_kernels.hip
+size_t lmpc_lds_limit();
 // implemented in lmpc_kernels.hip
 int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not covered
 // which: bit 0 = assemble, bit 1 = polish-only solve, bit 2 = ADMM fallback (7 = the normal path;

@@ -1020,8 +1020,10 @@ template <int CPZ, int CPG>
 int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream)
 {
     size_t ldsf = ((size_t)2 * 128 * CPZ + (size_t)kWavesPerBlock * m.fast_slice + (b.n_models > 0 ? (size_t)kWavesPerBlock * 2 * 128 * CPZ : 0)) * sizeof(double);
-    if (const char *pad = getenv("MPCX_DBG_LDS_PAD")) ldsf += (size_t)atoi(pad);
-    if (ldsf > 160 * 1024) return -2;
+    static const size_t dbg_pad = [] { const char *pad = getenv("MPCX_DBG_LDS_PAD"); return pad ? (size_t)atoi(pad) : (size_t)0; }();      // (occupancy experiments; read once)
+    ldsf += dbg_pad;
+    const size_t lds_max = lmpc_lds_limit();
+    if (ldsf > lds_max) return -2;
     auto k2 = lmpc_solve<CPZ, CPG>;
     auto k2h = lmpc_solve_hetero<CPZ, CPG>;
     // the fused forms serve the one-chunk variant only (fused_record: up to 384 rows of the composed map)
@@ -1047,10 +1049,10 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
             // assemble + solve in one workgroup of sixteen (two-chunk variant: eight) wavefronts, one per CU
             constexpr int NW = kGroupWavesOf<CPZ>;
             const size_t ldsg = lmpc_group_lds_bytes(m);
-            if (ldsg == 0 || ldsg > 160 * 1024) return -2;
+            if (ldsg == 0 || ldsg > lds_max) return -2;
             static std::atomic<int> gconf[64];
             if (!gconf[devid].load(std::memory_order_acquire)) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group<CPZ, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(lmpc_solve_group<CPZ, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) return -3;
                 gconf[devid].store(1, std::memory_order_release);
             }
             const int wgs = (b.batch + NW - 1) / NW;
@@ -1061,10 +1063,10 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
     // persistent form: the composed map, the box bounds and kPersistWaves slices must fit one CU's LDS, and the batch must be worth
     // the prologue of every workgroup (the composed map: 87 KB at N = 20)
     const size_t ldsp = ((size_t)m.rowsF * m.kin + 2 * (size_t)128 + kPersistWaves * (size_t)m.fast_slice) * sizeof(double);
-    if (fused && b.pcounter && ldsp <= 160 * 1024 && b.batch >= 1024) {
+    if (fused && b.pcounter && ldsp <= lds_max && b.batch >= 1024) {
         static std::atomic<int> pconf[64];
         if (!pconf[devid].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -3;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) return -3;
             pconf[devid].store(1, std::memory_order_release);
         }
         (void)hipMemsetAsync(b.pcounter, 0, 8 * sizeof(int), stream);

@@ -365,7 +365,7 @@ size_t lmpc_condense_lds(const LmpcDev &m, int *NP_out, int *NQ_out, size_t *big
     if (NQ_out) *NQ_out = NQ;
     const size_t rest = 2 * (size_t)m.nx * ld + (size_t)(m.ny > 1 ? m.ny : 1) * ld + ((m.ny + 3) & ~3) + 4 + NP + NQ + 8;
     const size_t pq = (size_t)NP * ld + (size_t)NQ * ld;
-    const bool big = NP > 96 || (pq + rest) * sizeof(double) > 160 * 1024 - 64;
+    const bool big = NP > 96 || (pq + rest) * sizeof(double) > lmpc_lds_limit() - 64;
     if (big_out) *big_out = big ? pq : 0;
     return ((big ? 0 : pq) + rest) * sizeof(double);
 }
@@ -375,7 +375,7 @@ int lmpc_condense_launch(LmpcDev *models_d, const LmpcDev &m0, int count, void *
     int NP = 0, NQ = 0;
     size_t big = 0;
     const size_t lds = lmpc_condense_lds(m0, &NP, &NQ, &big);
-    if (lds > 160 * 1024 - 64) return -2;
+    if (lds > lmpc_lds_limit() - 64) return -2;
     static std::atomic<size_t> conf[2][64];
     int devid = 0;
     (void)hipGetDevice(&devid);

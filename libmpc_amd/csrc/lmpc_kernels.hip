@@ -1477,7 +1477,7 @@ template <int CPZ, int CPG>
 int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, hipStream_t stream, int which, int fast)
 {
     const size_t lds = (size_t)kWavesPerBlock * m.lds_per_wave * sizeof(double);
-    if (lds > 160 * 1024) return -2;
+    if (lds > lmpc_lds_limit()) return -2;
     auto k1 = lmpc_assemble_generic<CPZ, CPG>;
     auto k3 = lmpc_solve_admm<CPZ, CPG>;
     // the attribute is per device: remember what each device was given (an atomic per device, so that two host threads or
@@ -1538,6 +1538,21 @@ int launch_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b
 }
 
 }  // namespace
+
+size_t lmpc_lds_limit()
+{
+    static std::atomic<size_t> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 160 * 1024;
+    dev &= 63;
+    size_t v = cached[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+        int a = 0;
+        v = (hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && a > 0) ? (size_t)a : (size_t)160 * 1024;
+        cached[dev].store(v, std::memory_order_release);
+    }
+    return v;
+}
 
 int lmpc_kernel_variant(int ldz, int ldg)
 {

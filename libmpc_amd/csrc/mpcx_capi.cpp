@@ -176,7 +176,7 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
     // there it is taken on request only (mpcx_lmpc_debug_use_fused(h, 2)): measured no faster than the two-kernel path
     const size_t ldsg = mpcx::lmpc_group_lds_bytes(D);
     const int cpv = mpcx::lmpc_kernel_variant(o.ldz, o.ldg);
-    D.group_ok = (h->use_fused != 0 && ldsg > 0 && ldsg <= 160 * 1024 && ((cpv == 1 && !D.cost_direct) || (cpv == 2 && h->use_fused == 2))) ? 1 : 0;
+    D.group_ok = (h->use_fused != 0 && ldsg > 0 && ldsg <= mpcx::lmpc_lds_limit() && ((cpv == 1 && !D.cost_direct) || (cpv == 2 && h->use_fused == 2))) ? 1 : 0;
     D.slo = U.up(o.slo, rc); D.shi = U.up(o.shi, rc);
 }
 
@@ -848,7 +848,7 @@ int mpcx_lmpc_hetero_create_ex(const mpcx_lmpc_t *controllers, int count, int de
     {
         mpcx::LmpcDev probe{};
         probe.nz = cond[0].nz; probe.mg = cond[0].mg; probe.nx = controllers[0]->ctl.d.nx; probe.ny = controllers[0]->ctl.d.ny;
-        if (mpcx::lmpc_condense_lds(probe, nullptr, nullptr) > 160 * 1024 - 64) on_device = false;
+        if (mpcx::lmpc_condense_lds(probe, nullptr, nullptr) > mpcx::lmpc_lds_limit() - 64) on_device = false;
     }
     const mpcx::Condensed *like = on_device ? &cond[0] : nullptr;
     {
