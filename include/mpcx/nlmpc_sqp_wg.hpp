@@ -44,6 +44,9 @@ struct WgPlan {
                                 // per instance and per attempt: an instance that fails in the inverse form is solved again, from the start, in the factor form (ST_MINV)
     int cut;                    // the working set's capacity was cut below what the problem can need: a second launch (only_overflowed) takes the instances that outgrow it
     int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
+    int curv0;                  // the curvature estimate is set to the condensed Gauss-Newton Hessian of the cost (init_curvature) ...
+    int curv_lds;               // init_curvature's two NX x nzu buffers fit the overlay behind Xs / Us (otherwise they are in the workspace: w_phi)
+    int curv0_it;               // ... before iteration curv0_it (0: the solve starts from it; k > 0: the first k iterations run from the identity, as NLopt's SLSQP does)
     int carry_m;                // (minv, every row a short list with constant entries) the inverse is carried from one sub-problem to the next: w_msave
     int lds_total;              // doubles
     // LDS offsets (doubles)
@@ -53,7 +56,7 @@ struct WgPlan {
     int o_Xs, o_Us, o_dXs, o_dUs, o_Jm, o_lam, o_dx;      // overlay, outside the sub-problem
     int o_L;                                              // overlay, inside the sub-problem: the packed factor
     // workspace offsets (doubles) of one instance
-    int w_scal, w_F, w_art, w_einv, w_gx, w_hinv, w_sp, w_msave;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
+    int w_scal, w_F, w_art, w_einv, w_gx, w_hinv, w_sp, w_msave, w_phi;   // (w_scal: the controller's NlmpcWsLayout::scal, 16 doubles: cost, dual steps, cycles per phase)
     int ws_total;
 };
 
@@ -1849,8 +1852,14 @@ struct WgSqp {
     static MPCX_WG_PHASE int ws_invert_m(int n)
     {
         const V v; const auto &P = v.A->P;
+        return invert_packed(v.at(P.o_L), v.at(P.o_mbuf), n);
+    }
+    // a symmetric positive definite matrix, packed by rows of its lower triangle in LDS, replaced by its inverse (the sweep operator, pivot by
+    // pivot); buf: n doubles of LDS.  0: a pivot fell below 1e-13 of the largest diagonal entry (the matrix is then garbage)
+    static MPCX_WG_CALL int invert_packed(double *Mp, double *buf, int n)
+    {
+        const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
-        double *Mp = v.at(P.o_L), *buf = v.at(P.o_mbuf);
         double dmax = 0.0;
         for (int r = tid; r < n; r += NT) dmax = fmax(dmax, Mp[r * (r + 1) / 2 + r]);
         Red<WAVES> R(v.at(P.o_red));
@@ -2522,6 +2531,147 @@ struct WgSqp {
         return vmax;
     }
 
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // The curvature estimate's START: the condensed Gauss-Newton Hessian of the cost at the first iterate, inverted.
+    //     B0 = Phi' Qx Phi + Ru,   Phi_{i+1} = Abar_i Phi_i + Bbar_i E_b(i)      (the sensitivities of the states to the blocked inputs),
+    // Qx_r / Ru_i the second derivatives of stage r's share of the cost in its own row of X / U (central second differences of Mdl::stage --
+    // exact for the quadratic costs of the reference's examples), the slack's entry from Mdl::slack_cost.  NLopt's SLSQP starts its BFGS matrix
+    // from the identity, and so did this kernel: a problem in 60 (120) reduced variables then spends 60 (120) iterations LEARNING a matrix that
+    // can be written down -- config 3 took 78 SQP iterations per solve, config 5 48.  What is left for the BFGS updates is the curvature of the
+    // dynamics and of the constraints.  The optimum is the same (the iteration's fixed points do not depend on B), the route to it is shorter.
+    // Phi_i' (Qx Phi_i) is the one GEMM-shaped product of the non-linear path ("the condensed Hessian" of BASELINE's config 5): sixteen-row tiles
+    // of B0 accumulate over the horizon in the f64 MFMA accumulators (v_mfma_f64_16x16x4_f64), each wavefront its own tiles.
+    // Runs once per solve, before the first iteration, with Xs / Us / the folded blocks of the first evaluation in place; scratch: the overlay
+    // behind Xs and Us, and the sub-problem's four vectors.  Not positive definite (a cost that is not convex): the identity, as before.
+    struct Pert2 {                                            // two perturbed entries of one row
+        const double *M; int n, row, c1, c2; double d1, d2;
+        __device__ __forceinline__ double operator()(int i, int j) const
+        {
+            double v = M[i * n + j];
+            if (i == row) { if (j == c1) v += d1; if (j == c2) v += d2; }
+            return v;
+        }
+    };
+    template <bool ISX> static __device__ __forceinline__ double stage_d2(const V &v, int r, int a, int b2)
+    {
+        const auto &P = v.A->P;
+        const double *Xs = v.at(P.o_Xs), *Us = v.at(P.o_Us), *prm = v.at(P.o_prm);
+        const double *Mx = ISX ? Xs : Us;
+        constexpr int N = ISX ? NX : NU;
+        const double ha = 1e-4 * fmax(1.0, fabs(Mx[r * N + a])), hb = 1e-4 * fmax(1.0, fabs(Mx[r * N + b2]));
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double da = (s & 1) ? -ha : ha, db = (s & 2) ? -hb : hb;
+            const Pert2 Pp{Mx, N, r, a, b2, da, db};
+            const Pert O{ISX ? Us : Xs, ISX ? NU : NX, -1, -1, -1, 0.0};
+            double f;
+            if constexpr (ISX) f = Mdl::stage(r, Pp, O, v.ph, prm); else f = Mdl::stage(r, O, Pp, v.ph, prm);
+            acc += ((s == 0 || s == 3) ? f : -f);
+        }
+        return acc / (4.0 * ha * hb);
+    }
+    static MPCX_WG_PHASE void init_curvature()
+    {
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int ph = v.ph, ch = v.ch, nzu = v.nzu, nq = v.nq;
+        const Scale sc = v.scale();
+        double *hinv = v.at(P.o_hinv), *st = v.at(P.o_st);
+        // (the two sensitivity buffers: LDS where the overlay has the room, the instance's workspace otherwise -- a plan that cut the working set's
+        // capacity has cut the overlay with it; once per solve either way)
+        double *phiA = P.curv_lds ? v.at(P.o_Us) + (((ph + 1) * NU + 1) & ~1) : v.w + P.w_phi, *phiB = phiA + NX * nzu, *Qb = v.at(P.o_xq);
+        typename FP::type F = FP::get(v);
+        const int nh = nq * (nq + 1) / 2;
+        for (int e = tid; e < nh; e += NT) hinv[e] = 0.0;
+        for (int e = tid; e < 2 * NX * nzu; e += NT) phiA[e] = 0.0;
+        T::sync();
+        // the inputs' own curvature: row i of U (row ph is the copy of row ph - 1) belongs to block min(i, ph - 1, ch - 1); one thread per entry of a
+        // block's NU x NU matrix, the rows of one block added up in their order
+        for (int e = tid; e < ch * NU * NU; e += NT) {
+            const int bq = e / (NU * NU), jj = e - bq * NU * NU, j1 = jj / NU, j2 = jj - j1 * NU;
+            if (j2 > j1) continue;
+            double acc = 0.0;
+            for (int i = 0; i <= ph; ++i) if (min(min(i, ph - 1), ch - 1) == bq) acc += stage_d2<false>(v, i, j1, j2);
+            const int p = bq * NU + j1, q = bq * NU + j2;
+            hinv[p * (p + 1) / 2 + q] = sc.by_su(sc.by_su(acc, j1), j2);
+        }
+        if (nq > nzu && tid == 0) {                             // the slack (soft constraints): its own second difference
+            const double e0 = v.at(P.o_z)[v.nz - 1], he = 1e-4 * fmax(1.0, fabs(e0));
+            const double *prm = v.at(P.o_prm);
+            hinv[nzu * (nzu + 1) / 2 + nzu] = (Mdl::slack_cost(e0 + he, prm) - 2.0 * Mdl::slack_cost(e0, prm) + Mdl::slack_cost(e0 - he, prm)) / (he * he);
+        }
+        // the horizon: Phi one step on, T = Qx Phi, B0 += Phi' T -- the last as 16 x 16 tiles in the MFMA accumulators (tile (tp, tq), tq <= tp, is
+        // tile number tp (tp + 1) / 2 + tq; wavefront w owns tiles w, w + WAVES, ..: up to kCurvTiles of them)
+        const int nt = (nzu + 15) >> 4, ntiles = nt * (nt + 1) / 2;
+        constexpr int kCurvTiles = 5;                           // 8 x 8 tiles' lower triangle over eight wavefronts; fewer wavefronts: several passes over the horizon
+        const int j = lane & 15, kq = lane >> 4;
+        for (int t0 = 0; t0 < ntiles; t0 += WAVES * kCurvTiles) {
+            wg_v4d acc[kCurvTiles];
+            int tp[kCurvTiles], tqq[kCurvTiles];
+#pragma unroll
+            for (int u = 0; u < kCurvTiles; ++u) {
+                acc[u] = wg_v4d{0.0, 0.0, 0.0, 0.0};
+                const int tn = t0 + wave + u * WAVES;
+                int r, c;
+                tri_index(tn < ntiles ? tn : 0, r, c);
+                tp[u] = tn < ntiles ? r : -1; tqq[u] = c;
+            }
+            if (t0 > 0) { for (int e = tid; e < 2 * NX * nzu; e += NT) phiA[e] = 0.0; T::sync(); }
+            double *cur = phiA, *nxt = phiB;
+            for (int i = 0; i < ph; ++i) {
+                const int bi = min(i, ch - 1), ncol = (bi + 1) * NU;        // the columns that are not zero yet
+                // Phi_{i+1} = Abar_i Phi_i + Bbar_i E_bi, one thread per entry; the second differences of stage i + 1 in its row of X next to it
+                for (int e = tid; e < NX * ncol; e += NT) {
+                    const int a = e / ncol, q = e - a * ncol;
+                    double s = q >= bi * NU ? F[(size_t)(i * NX + a) * FW + NX + (q - bi * NU)] : 0.0;
+#pragma unroll
+                    for (int b2 = 0; b2 < NX; ++b2) s = fma(F[(size_t)(i * NX + a) * FW + b2], cur[b2 * nzu + q], s);
+                    nxt[a * nzu + q] = s;
+                }
+                for (int e = tid; e < NX * NX; e += NT) { const int a = e / NX, b2 = e - a * NX; Qb[e] = b2 <= a ? stage_d2<true>(v, i + 1, a, b2) : 0.0; }
+                T::sync();
+                for (int e = tid; e < NX * ncol; e += NT) {     // T = Qx Phi_{i+1} (Qx by its lower triangle) into the other buffer: Phi_i is done with
+                    const int a = e / ncol, q = e - a * ncol;
+                    double s = 0.0;
+#pragma unroll
+                    for (int b2 = 0; b2 < NX; ++b2) s = fma(b2 <= a ? Qb[a * NX + b2] : Qb[b2 * NX + a], nxt[b2 * nzu + q], s);
+                    cur[a * nzu + q] = s;
+                }
+                T::sync();
+                // B0 tile (tp, tq) += Phi[:, 16 tp ..]' T[:, 16 tq ..]: k runs over the NX state entries, four per MFMA
+#pragma unroll
+                for (int u = 0; u < kCurvTiles; ++u) {
+                    if (tp[u] < 0 || 16 * tqq[u] >= ncol) continue;
+                    const int pc = 16 * tp[u] + j, qc = 16 * tqq[u] + j;
+                    for (int k0 = 0; k0 < NX; k0 += 4) {
+                        const int k = k0 + kq;
+                        const double av = (k < NX && pc < ncol) ? nxt[k * nzu + pc] : 0.0, bv = (k < NX && qc < ncol) ? cur[k * nzu + qc] : 0.0;
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
+                    }
+                }
+                T::sync();
+                double *sw = cur; cur = nxt; nxt = sw;          // (Phi_{i+1} is in nxt: it is the next step's Phi_i)
+            }
+            // the tiles into the packed matrix (element (4 r + kq, j) of a tile in register r): every entry has one owner
+#pragma unroll
+            for (int u = 0; u < kCurvTiles; ++u) {
+                if (tp[u] < 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * tp[u] + 4 * r + kq, q = 16 * tqq[u] + j;
+                    if (p < nzu && q <= p) hinv[p * (p + 1) / 2 + q] += acc[u][r];
+                }
+            }
+            T::sync();
+        }
+        const int ok = invert_packed(hinv, v.at(P.o_np), nq);
+        if (tid == 0) st[ST_CARRY] = 0.0;                       // (a saved inverse of the Schur complement belongs to the estimate that is gone)
+        if (!ok) { for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; } }
+        (void)M; (void)st;
+        T::sync();
+    }
+
     // from here on the sub-problems of this attempt keep the working set's factor (see the kernel's loop)
     static MPCX_WG_PHASE void leave_inverse()
     {
@@ -2666,6 +2816,13 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         }
         stepped = false;
         if (it >= S.max_iter) break;
+        if (P.curv0 && it == P.curv0_it && !S.keep_curvature && resets == 0) {
+            // the curvature estimate from the cost's own second derivatives at this iterate (trajectory and folded blocks are in place); the
+            // phase works in the overlay the cost's gradient lies in: that part of the evaluation again
+            K::init_curvature();
+            K::eval_cost(0);
+            have_old = false;
+        }
         if (P.needs_phi) K::condense_phi(); else K::condense_chain();
         lap(3);
         if (have_old) K::bfgs(a_prev, nw_keep);
@@ -2751,10 +2908,10 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 #if !defined(__HIPCC_RTC__)
 // the LDS / workspace plan of the workgroup form for controller m (dimensions, bounds) and the hard / soft flag; 0, or -2 if the
 // shape does not fit (the caller falls back to nlmpc_sqp)
-// (minv_wanted / carry_wanted: -1 the plan's own choice, 0 | 1 forced -- the launcher's MPCX_NLMPC_MINV / MPCX_NLMPC_CARRY, read when the handle is created)
+// (minv_wanted / carry_wanted / curv_wanted: -1 the plan's own choice, 0 | 1 forced -- the launcher's MPCX_NLMPC_MINV / MPCX_NLMPC_CARRY / MPCX_NLMPC_CURV0, read when the handle is created)
 template <class Mdl>
 inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1, bool cut_ok = true, int lds_per_cu = 160 * 1024,
-                   int minv_wanted = -1, int carry_wanted = -1)
+                   int minv_wanted = -1, int carry_wanted = -1, int curv_wanted = -1, int curv_it = -1)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
@@ -2868,6 +3025,11 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         place();
     }
     if (!placed) return -2;
+    // the curvature estimate set to the condensed Gauss-Newton Hessian (init_curvature): where the cost is a sum over the horizon's rows and the
+    // sub-problem's four vectors hold an NX x NX block
+    P.curv0_it = curv_it >= 0 ? curv_it : Mdl::CURV0_AFTER;
+    P.curv0 = (curv_wanted != 0 && Mdl::COST_STAGEWISE && NX * NX <= 4 * ((nr + 1) & ~1)) ? 1 : 0;
+    P.curv_lds = P.o_Us + (((ph + 1) * NU + 1) & ~1) + 2 * NX * m.nzu <= P.lds_total ? 1 : 0;
     {
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
@@ -2877,6 +3039,7 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);
         P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
+        P.w_phi = take((P.curv0 && !P.curv_lds) ? 2 * NX * m.nzu : 0);
         // the carried inverse (see ws_warm): where no row's entries change between sub-problems -- bounds on inputs, user rows affine in the inputs (Mdl::XFREE_ROWS_AFFINE) --
         // and the controller's workspace has the room
         const int carry_env = carry_wanted < 0 ? 1 : carry_wanted;

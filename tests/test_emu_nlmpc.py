@@ -58,12 +58,41 @@ def test_workgroup_form_with_bounds_equalities_and_dense_rows(runner, env):
              (["ugv", 12, 4, 0.1, 0, 150], np.hstack([np.c_[0.4 * X0[:3], np.zeros((3, 2))], np.zeros((3, 2))]), [])]
     for args, inst, extra in cases:
         a = runner(args + ["wave"] + extra, inst)
-        b = runner(args + ["wg"] + extra, inst, env)
+        # (the same route: both from the identity -- the workgroup form's Gauss-Newton start is the next test's subject)
+        b = runner(args + ["wg"] + extra, inst, dict(env, MPCX_NLMPC_CURV0="0"))
         for x, y in zip(a, b):
             assert x["status"] == y["status"] and x["solver_status"] == y["solver_status"], (args[0], x["b"])
             if x["status"] == 0:
                 np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-5, atol=1e-5)
                 assert abs(x["iterations"] - y["iterations"]) <= 3
+        c = runner(args + ["wg"] + extra, inst, env)            # ... and as the library runs it: the same statuses and optimum
+        for x, y in zip(a, c):
+            assert x["status"] == y["status"], (args[0], x["b"])
+            if x["status"] == 0:
+                np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPEMU_ORDER": "reverse"}])
+def test_gauss_newton_start_of_the_curvature_estimate(runner, env):
+    """WgSqp::init_curvature (the condensed Hessian of the cost, sixteen-row tiles in the MFMA accumulators, inverted in place): the same optimum as
+    from the identity in fewer iterations, the same bits in both thread orders (a missing barrier in the new phase would show), at the start of
+    the solve (oscillators, Van der Pol) and installed after ten iterations (the UGV: Ugv::CURV0_AFTER)"""
+    x6 = np.zeros((2, 18)); x6[:, 0] = 1.0; x6[1, 1:12] = np.linspace(-0.1, 0.1, 11)
+    cases = [(["vanderpol", 10, 5, 0.1, 1, 200], np.array([[0.0, 1.0, 0.0], [0.5, -0.4, 0.0]])),
+             (["ugv", 30, 30, 0.1, 0, 150], np.array([[0.1, -0.2, 0, 0, 0, 0], [-0.3, 0.4, 0, 0, 0, 0]], float)),
+             (["osc6", 20, 10, 0.1, 1, 200], x6)]
+    for args, inst in cases:
+        a = runner(args + ["wg"], inst, dict(env, MPCX_NLMPC_CURV0="0"))
+        b = runner(args + ["wg"], inst, env)
+        for x, y in zip(a, b):
+            assert x["status"] == 0 and y["status"] == 0
+            np.testing.assert_allclose(y["cmd"], x["cmd"], rtol=1e-5, atol=1e-5)
+            assert abs(y["cost"] - x["cost"]) <= 1e-8 * abs(x["cost"])
+            assert y["iterations"] < x["iterations"] or x["iterations"] <= 6, (args[0], x["iterations"], y["iterations"])
+        if env:
+            f = runner(args + ["wg"], inst, {})
+            for x, y in zip(f, b):
+                assert x["cmd"] == y["cmd"] and x["cost"] == y["cost"] and x["iterations"] == y["iterations"]
 
 
 def test_config3_golden_instances_through_the_interpreter(runner):
@@ -161,7 +190,8 @@ def test_carried_inverse_stays_the_inverse(tmp_path_factory):
     inp = " ".join(repr(float(x)) for x in np.hstack([X0, np.zeros((1, 6))])[0]) + "\n"
     out = {}
     for carry, order in (("0", "forward"), ("1", "forward"), ("1", "reverse")):
-        e = dict(os.environ); e.update({"MPCX_NLMPC_MINV": "1", "MPCX_NLMPC_CARRY": carry, "HIPEMU_ORDER": order})
+        # (from the identity: thirty sub-problems to carry the inverse through; from the Gauss-Newton start the solve takes nine)
+        e = dict(os.environ); e.update({"MPCX_NLMPC_MINV": "1", "MPCX_NLMPC_CARRY": carry, "HIPEMU_ORDER": order, "MPCX_NLMPC_CURV0": "0"})
         r = subprocess.run([exe, "osc6", "20", "10", "0.1", "1", "200", "wg"], input=inp, capture_output=True, text=True, env=e, timeout=900)
         assert r.returncode == 0, r.stderr[:2000]
         errs = [float(l.split("=")[-1]) for l in r.stderr.splitlines() if l.startswith("carry check")]

@@ -218,8 +218,11 @@ def test_working_sets_beyond_a_cut_capacity_are_solved_by_the_second_pass(monkey
         _set_form(monkeypatch, form, None)
         if form == "wg":
             monkeypatch.setenv("MPCX_NLMPC_BLOCKS", "1")
+            # (from the identity: on that route some working sets of this batch outgrow the cut capacity; from the Gauss-Newton start none does)
+            monkeypatch.setenv("MPCX_NLMPC_CURV0", "0")
         else:
             monkeypatch.delenv("MPCX_NLMPC_BLOCKS", raising=False)
+            monkeypatch.delenv("MPCX_NLMPC_CURV0", raising=False)
         c = NLMPC(OSCILLATORS6, 20, 10, 0.1)
         c.setOptimizerParameters(NLParameters(maximum_iteration=200))
         r = c.optimizeBatch(torch.from_numpy(X0), torch.zeros(B, 6, dtype=torch.float64)); torch.cuda.synchronize()
@@ -229,6 +232,54 @@ def test_working_sets_beyond_a_cut_capacity_are_solved_by_the_second_pass(monkey
             biggest = max(c.debug_workspace(i)["scal"][12] for i in range(0, B, 8))
             assert biggest > 53, biggest
     monkeypatch.delenv("MPCX_NLMPC_BLOCKS", raising=False)
+    monkeypatch.delenv("MPCX_NLMPC_CURV0", raising=False)
     a, b = out["wg"], out["wave"]
     assert (b["status"] == 0).all() and np.array_equal(a["status"], b["status"]), (a["solver_status"][a["status"] != 0], np.nonzero(a["status"] != 0)[0])
     assert (np.abs(a["cmd"] - b["cmd"]) / np.maximum(1.0, np.abs(b["cmd"]).max(axis=1, keepdims=True))).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name,ph,ch,hard,B,iters", [("vanderpol", 10, 5, True, 512, 200), ("osc6", 20, 10, True, 256, 200), ("osc8", 30, 15, True, 128, 200), ("ugv", 30, 30, False, 1024, 150)])
+def test_gauss_newton_start_reaches_the_identity_start_s_optimum_in_fewer_iterations(name, ph, ch, hard, B, iters, monkeypatch):
+    """WgSqp::init_curvature: the curvature estimate set to the condensed Hessian of the cost (Phi' Qx Phi + Ru on the f64 MFMA pipe) instead of
+    the identity NLopt's SLSQP starts from.  The fixed points of the iteration do not depend on the estimate: every instance solves, and on the
+    convex-cost systems every instance ends at the optimum the identity start ends at, in a fraction of the iterations.  On the UGV (non-convex:
+    the side an obstacle is passed on) the matrix is installed after ten iterations from the identity (Ugv::CURV0_AFTER) and the two routes
+    may end at different local optima: at least 96 % agree, and of the rest more end lower than higher (the golden comparison with the oracle
+    is test_ugv_config_matches_golden_oracle_solutions)."""
+    import torch
+    from libmpc_amd import _capi
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8
+    model = dict(vanderpol=VANDERPOL, ugv=UGV, osc6=OSCILLATORS6, osc8=OSCILLATORS8)[name]
+    rng = np.random.default_rng(5)
+    nx, nu = dict(vanderpol=(2, 1), ugv=(4, 2), osc6=(12, 6), osc8=(16, 8))[name]
+    if name == "vanderpol":
+        X0 = rng.uniform(-1.0, 1.0, size=(B, 2))
+    elif name == "ugv":
+        X0 = np.zeros((B, 4)); X0[:, :2] = rng.uniform(-0.5, 0.5, size=(B, 2))
+    else:
+        X0 = rng.uniform(-0.1, 0.1, size=(B, nx)); X0[:, 0] += 1.0
+    out = {}
+    for curv in ("0", None):
+        for k in ("MPCX_NLMPC_FORM", "MPCX_NLMPC_WAVES", "MPCX_NLMPC_BLOCKS", "MPCX_NLMPC_CURV0", "MPCX_NLMPC_CURV0_IT"):
+            monkeypatch.delenv(k, raising=False)
+        if curv is not None:
+            monkeypatch.setenv("MPCX_NLMPC_CURV0", curv)
+        c = NLMPC(model, ph, ch, 0.1)
+        c.setOptimizerParameters(NLParameters(maximum_iteration=iters, hard_constraints=int(hard)))
+        r = c.optimizeBatch(torch.from_numpy(X0), torch.zeros(B, nu, dtype=torch.float64)); torch.cuda.synchronize()
+        assert _capi.lib().mpcx_nlmpc_last_form(c._h) > 0
+        out[curv] = {k: v.cpu().numpy() for k, v in r.items() if k != "_keep"}
+    monkeypatch.delenv("MPCX_NLMPC_CURV0", raising=False)
+    a, b = out["0"], out[None]
+    assert (b["status"] == 0).all(), {int(k): int((b["solver_status"] == k).sum()) for k in np.unique(b["solver_status"])}
+    both = (a["status"] == 0) & (b["status"] == 0)
+    same = np.all(np.abs(a["cmd"] - b["cmd"]) <= 1e-5 * np.maximum(1.0, np.abs(a["cmd"])), axis=1) & both
+    lower = both & ~same & (b["cost"] < a["cost"]); higher = both & ~same & (b["cost"] > a["cost"])
+    print("%s: mean iterations %.1f from the identity, %.1f from the Gauss-Newton matrix; %d of %d instances at the same optimum, %d lower, %d higher"
+          % (name, a["iterations"].mean(), b["iterations"].mean(), same.sum(), both.sum(), lower.sum(), higher.sum()))
+    assert b["iterations"].mean() < (0.8 if name == "vanderpol" else 0.6) * a["iterations"].mean()      # (the small system needs a dozen iterations either way)
+    if name == "ugv":
+        assert same.sum() >= 0.96 * both.sum() and higher.sum() <= lower.sum()
+    else:
+        assert same.sum() == both.sum()
+        np.testing.assert_allclose(b["cost"][both], a["cost"][both], rtol=1e-8)
