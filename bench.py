@@ -268,6 +268,52 @@ def timed(step, steps, warmup, barrier, world, dev):
     return dt
 
 
+def multi_gpu_configs(world, rank, local, dev, gather, barrier):
+    """BASELINE.json's two multi-GPU configs in the line of the DEFAULT multi-GPU command (`bench.py --gpus N`, which weak-scales the headline
+    config 2): config 4 (quadrotor LMPC N = 50, 32768 instances per rank) and config 5 (eight oscillators, 1024 per rank), batch-sharded with the
+    RCCL all-gather of u* behind every solve, timed as the headline is (barrier, K steps, barrier, maximum over the ranks).  Every rank runs this;
+    rank 0 files the figures under `multi_gpu_configs` -- a scaling run of the default command then yields the curves north_star asks for."""
+    import ctypes as C
+    from libmpc_amd._capi import check
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    res = {}
+    s = torch.cuda.current_stream(local)
+    # config 4
+    B4, steps4 = 32768, 10
+    c4 = quadrotor_lmpc(50, device=local)
+    x0, u0, yref = quadrotor_batch(B4, first=rank * B4)
+    b4, r4, keep4 = c4.make_batch(x0, u0, yref=yref)
+    all4 = torch.empty((world * B4, 4), dtype=torch.float64, device=dev)
+
+    def step4():
+        c4.launch(b4, s)
+        gather.allgather(r4.cmd, out=all4, stream=s.cuda_stream)
+
+    dt4 = timed(step4, steps4, 2, barrier, world, dev)
+    assert torch.equal(all4[rank * B4:(rank + 1) * B4], r4.cmd)
+    res["config4_lmpc50_b32768_per_gpu"] = {"value": world * B4 * steps4 / dt4, "unit": "solves/s", "ms_per_step": dt4 / steps4 * 1e3, "steps": steps4,
+                                            "total_batch": world * B4, "solved_fraction": float((r4.status == 0).double().mean()),
+                                            "workload": "quadrotor LMPC nx=12 nu=4 ph=ch=50, %d instances per rank, RCCL all-gather of u* (%d x 4 doubles)" % (B4, world * B4)}
+    del c4, b4, r4, keep4, all4
+    # config 5
+    B5, steps5 = 1024, 3
+    c5, x5, u5 = nl_make("osc8", B5, first=rank * 7919, device=local)
+    b5, o5 = c5.make_batch(torch.from_numpy(x5), torch.from_numpy(u5))
+    all5 = torch.empty((world * B5, c5.nu), dtype=torch.float64, device=dev)
+
+    def step5():
+        check(c5._lib.mpcx_nlmpc_solve_batch(c5._h, C.byref(b5), s.cuda_stream))
+        gather.allgather(o5["cmd"], out=all5, stream=s.cuda_stream)
+
+    dt5 = timed(step5, steps5, 1, barrier, world, dev)
+    assert torch.equal(all5[rank * B5:(rank + 1) * B5], o5["cmd"])
+    st5 = o5["solver_status"].cpu().numpy()
+    res["config5_osc8_b1024_per_gpu"] = {"value": world * B5 * steps5 / dt5, "unit": "solves/s", "ms_per_step": dt5 / steps5 * 1e3, "steps": steps5,
+                                         "total_batch": world * B5, "solved_fraction": float(np.isin(st5, (3, 4)).mean()),
+                                         "workload": "networked oscillators NLMPC, 8 oscillators nx=16 nu=8 ph=30 ch=15, %d instances per rank, RCCL all-gather of u* (%d x 8 doubles)" % (B5, world * B5)}
+    return res
+
+
 def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrier):
     from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
 
@@ -329,6 +375,9 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
                                "note": "{solve k || all-gather k-1} captured as one HIP graph per buffer parity, one graph launch per step"}
         except Exception as e:      # (a runtime whose RCCL cannot be captured: the eager figures above stand)
             serial["graph"] = {"value": None, "note": "graph capture of the overlapped step failed: %s" % str(e)[:200]}
+
+    # the default multi-GPU command also times BASELINE's two multi-GPU configs (every rank takes part: collectives inside)
+    mgc = multi_gpu_configs(world, rank, local, dev, gather, barrier) if (gather and args.config is None and args.workload is None and not args.batch and not args.horizon) else None
 
     # extra leg: consecutive batches are independent, so a serving loop keeps several in flight -- the tail of one launch
     # (it lasts as long as its slowest instance) overlaps the start of the next.  Not `value`: reported beside it.
@@ -464,6 +513,8 @@ def run_lmpc(args, ph, B, steps, warmup, world, rank, local, dev, gather, barrie
            "allgather_overlapped": serial,
            "solved_fraction": float((status == 0).mean()),
            "roofline": roof, "cpu_baseline": cpu}
+    if mgc:
+        out["multi_gpu_configs"] = mgc
     if world == 1 and args.nlmpc_extra:
         out["nlmpc"] = nlmpc_extra(local)
     print(json.dumps(out))
@@ -575,7 +626,7 @@ def nl_make(name, B, first=0, device=0):
     return c, x0, np.zeros((B, c.nu))
 
 
-def nl_flops(c, name, it, nact):
+def nl_flops(c, name, it, nact, wg=True):
     """algorithmic flops of the SQP solves of one batch, for the path the kernel takes: per iteration
     the transcription's function evaluations, the condensing, the reduction, the BFGS update, the dual active-set steps
     the final active set needs, the state step and one line-search round.  Where no sub-problem row reads a state
@@ -608,7 +659,10 @@ def nl_flops(c, name, it, nact):
         qp = 2.0 * nq * nq + nact * (2.0 * nq * nq + 4.0 * nq * nact)
     bfgs = 8.0 * nq * nq
     ls = 8 * (f_cost + f_f * ph * (1 + ct) + f_ineq * c.nineq)
-    return float((it * (ev + cond + red + bfgs + step + ls) + it * qp).sum())
+    # once per solve (the workgroup form: WgSqp::init_curvature): the sensitivities one step on and Qx Phi (2 nx^2 nzu each per step), Phi' (Qx Phi) by its
+    # lower triangle (nx nzu^2 per step), the sweep that inverts the nq x nq matrix (nq^3)
+    curv = ph * (4.0 * nx * nx * nzu + 1.0 * nx * nzu * nzu) + float(nq) ** 3 if wg else 0.0
+    return float((it * (ev + cond + red + bfgs + step + ls) + it * qp + curv).sum())
 
 
 def nlmpc_extra(local):
@@ -674,7 +728,8 @@ def run_nlmpc(args, name, B, steps, warmup, world, rank, local, dev, gather, bar
     torch.cuda.synchronize()
     st = out["solver_status"].cpu().numpy(); it = out["iterations"].cpu().numpy().astype(np.float64)
     nact = (out["multipliers"].cpu().numpy() != 0).sum(axis=1).astype(np.float64)
-    flops = nl_flops(c, name, it, nact)
+    form = int(c._lib.mpcx_nlmpc_last_form(c._h))
+    flops = nl_flops(c, name, it, nact, wg=form > 0)
     bytes_alg = float(B) * 8.0 * (c.nx + c.nu + c.nu + 1 + 2)
     ach = flops / (kern_ms * 1e-3) / 1e12
     form = int(c._lib.mpcx_nlmpc_last_form(c._h))

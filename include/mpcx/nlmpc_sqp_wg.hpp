@@ -38,7 +38,8 @@ struct WgPlan {
     int nd, ndld, nd_user, nsb; // dense sub-problem rows (columns of art): user rows that read a state (or promise no sparsity), then bounds on states
     int nsx;                    // (user row, state row) pairs with a non-zero Jacobian block
     int art_total;              // doubles of the dense rows' storage (every row as long as the last input block it can depend on: wg_row_len)
-    int needs_phi;              // some sub-problem row reads a state
+    int needs_phi;              // some sub-problem row reads a state (otherwise the tables that say which -- xmask, jxoff -- and the LDS copy of the multipliers, which only
+                                // the multipliers of the dynamics need, do not exist: 7 KB at eight oscillators with input bounds, what lets that shape fit a CU's LDS)
     int f_lds;                  // the folded dynamics blocks live in LDS
     int minv;                   // the working set's Schur complement is kept as its inverse (large working sets), not as a Cholesky factor --
                                 // per instance and per attempt: an instance that fails in the inverse form is solved again, from the start, in the factor form (ST_MINV)
@@ -610,7 +611,8 @@ struct WgSqp {
         } else {
             for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; }
         }
-        for (int k = tid; k < mt; k += NT) { mu[k] = 0.0; flag[k] = 0; }
+        const bool lean = !P.needs_phi;                          // no row reads a state: no xmask / jxoff / mu in LDS
+        for (int k = tid; k < mt; k += NT) { if (!lean) mu[k] = 0.0; flag[k] = 0; }
         for (int k = tid; k < ST_TOTAL; k += NT) st[k] = (k == ST_MINV && P.minv && attempt == 0) ? 1.0 : 0.0;
         T::sync();
         // NLOptimizer::fixOptimalSolution (NLOptimizer.hpp:705-716): a start outside the bounds goes to (ub - lb) / 2 (sic)
@@ -619,7 +621,7 @@ struct WgSqp {
             if (z[k] < lo || z[k] > hi) z[k] = (hi - lo) / 2.0;
         }
         // which state rows a user row reads (bit i-1: X row i, i = 1 .. ph; row 0 is x0, not a variable)
-        for (int k = tid; k < m; k += NT) {
+        if (!lean) for (int k = tid; k < m; k += NT) {
             unsigned long long mk = 0;
             for (int i = 1; i <= ph; ++i)
                 if (k < mi ? Mdl::ineq_reads_x(k, i) : Mdl::eq_reads_x(k - mi, i)) mk |= 1ull << (i - 1);
@@ -630,21 +632,21 @@ struct WgSqp {
             int ns = 0, ndc = 0;
             int *drow = v.iat(P.o_drow);                        // the user row behind dense column dc
             for (int k = 0; k < m; ++k) {
-                jxoff[k] = ns;
-                unsigned long long mk = xmask[k];
+                if (!lean) jxoff[k] = ns;
+                unsigned long long mk = lean ? 0ull : xmask[k];
                 const bool dense = mk != 0ull || !Mdl::XFREE_ROWS_SPARSE;
                 dcol[k] = dense ? ndc : -1;
                 if (dense) drow[ndc++] = k;
                 while (mk) { const int i = (int)__builtin_ctzll(mk) + 1; mk &= mk - 1; slot[ns++] = (k << 8) | i; }
             }
-            jxoff[m] = ns;
+            if (!lean) jxoff[m] = ns;
             // the same pairs grouped by state row: what the sweep consumes as it passes state row i + 1 (entry: row << 12 | block slot;
             // bit 31: the pair is all there is to the row's reduced entries -- one state row, no input -- and is stored, not added)
             int *xrf = v.iat(P.o_xrf), *xre = v.iat(P.o_xre);
             int ne = 0;
             for (int i = 1; i <= ph; ++i) {
                 xrf[i - 1] = ne;
-                for (int k = 0; k < m; ++k)
+                if (!lean) for (int k = 0; k < m; ++k)
                     if ((xmask[k] >> (i - 1)) & 1ull)
                         xre[ne++] = (k << 12) | (jxoff[k] + __builtin_popcountll(xmask[k] & ((1ull << (i - 1)) - 1ull))) | (sole_state_row(k, xmask[k], mi, ph) ? (int)0x80000000 : 0);
             }
@@ -1852,14 +1854,17 @@ struct WgSqp {
     static MPCX_WG_PHASE int ws_invert_m(int n)
     {
         const V v; const auto &P = v.A->P;
-        return invert_packed(v.at(P.o_L), v.at(P.o_mbuf), n);
+        return invert_packed(P.o_L, P.o_mbuf, n);
     }
     // a symmetric positive definite matrix, packed by rows of its lower triangle in LDS, replaced by its inverse (the sweep operator, pivot by
     // pivot); buf: n doubles of LDS.  0: a pivot fell below 1e-13 of the largest diagonal entry (the matrix is then garbage)
-    static MPCX_WG_CALL int invert_packed(double *Mp, double *buf, int n)
+    // (the two arrays by their LDS offsets: a pointer handed through an out-of-line call is a generic one, and flat accesses wait on both memory
+    // counters and take the long way to LDS -- measured on this very function: 10.7 k cycles per pivot instead of 0.7 k)
+    static MPCX_WG_CALL int invert_packed(int mp_off, int buf_off, int n)
     {
         const V v; const auto &P = v.A->P;
         const int tid = threadIdx.x;
+        double *Mp = v.at(mp_off), *buf = v.at(buf_off);
         double dmax = 0.0;
         for (int r = tid; r < n; r += NT) dmax = fmax(dmax, Mp[r * (r + 1) / 2 + r]);
         Red<WAVES> R(v.at(P.o_red));
@@ -1872,11 +1877,41 @@ struct WgSqp {
             T::sync();
             ok = d > 1e-13 * dmax;
             const double id = 1.0 / d;
-            tri_rows(Mp, n, tid, [&](int r, int c, double &a) {
-                if (r == k) a = c == k ? -id : buf[c] * id;
-                else if (c == k) a = buf[r] * id;
-                else a = fma(-buf[r] * id, buf[c], a);
-            });
+            // (the pass over the triangle, rows r and n - 1 - r to a group of lanes as in tri_rows, written out: four elements' operands are requested
+            // before the first is used and the pivot's row and column are selects, not branches -- as a lambda per element the pass was a chain of
+            // dependent LDS round trips under exec masks, 8 k cycles per pivot at n = 121)
+            {
+                const int np = (n + 1) >> 1;
+                const int PL = np > 0 && NT / np > 0 ? NT / np : 1, groups = NT / PL, g = tid / PL, l = tid - g * PL;
+                for (int p0 = 0; p0 < np; p0 += groups) {
+                    const int p = p0 + g;
+                    if (p < np && g < groups) {
+                        const int ra = p, rb = n - 1 - p, len = ra == rb ? ra + 1 : n + 1;
+                        const double ba = buf[ra] * id, bb = buf[rb] * id;
+                        const int oa = ra * (ra + 1) / 2, ob = rb * (rb + 1) / 2 - ra - 1;
+                        for (int j0 = l; j0 < len; j0 += 4 * PL) {
+                            double a[4], bc[4];
+                            int ix[4], cc[4];
+                            bool fa[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = j0 + u * PL < len ? j0 + u * PL : l;
+                                fa[u] = j <= ra;
+                                cc[u] = fa[u] ? j : j - ra - 1;
+                                ix[u] = (fa[u] ? oa : ob) + j;
+                                a[u] = Mp[ix[u]]; bc[u] = buf[cc[u]];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int r = fa[u] ? ra : rb;
+                                const double br = fa[u] ? ba : bb;                  // buf[r] / d
+                                const double x = r == k ? (cc[u] == k ? -id : bc[u] * id) : (cc[u] == k ? br : fma(-br, bc[u], a[u]));
+                                if (j0 + u * PL < len) Mp[ix[u]] = x;
+                            }
+                        }
+                    }
+                }
+            }
             T::sync();
         }
         if (!ok) return 0;
@@ -2281,9 +2316,11 @@ struct WgSqp {
         MPCX_TRACE(" %d dual steps, %d rows at the end, fail %d\n", nsteps, nw, fail);
         if (tid == 0) { st[ST_R5] += (double)nsteps; st[ST_R5 + 1] = fmax(st[ST_R5 + 1], (double)nw); st[ST_QNW] = (double)nw; }
         if (fail) { T::sync(); return fail; }
-        for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
-        T::sync();
-        for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
+        if (P.needs_phi) {                                       // (the LDS copy of the multipliers: what merit's chain for the dynamics multipliers reads)
+            for (int k = tid; k < mt; k += NT) mu[k] = 0.0;
+            T::sync();
+            for (int t = tid; t < nw; t += NT) mu[wq[t]] = sgq[t] * uq[t];
+        }
         if (tid == 0 && nq < nr) xq[nq] = 0.0;                  // (p is xq: without a slack variable its last entry stays zero)
         if (P.carry_m && minv) {
             // the inverse of this working set's Schur complement is the next sub-problem's, up to the rank-two change of B^-1 in between
@@ -2543,6 +2580,11 @@ struct WgSqp {
     // of B0 accumulate over the horizon in the f64 MFMA accumulators (v_mfma_f64_16x16x4_f64), each wavefront its own tiles.
     // Runs once per solve, before the first iteration, with Xs / Us / the folded blocks of the first evaluation in place; scratch: the overlay
     // behind Xs and Us, and the sub-problem's four vectors.  Not positive definite (a cost that is not convex): the identity, as before.
+#ifdef MPCX_NL_STATS
+#define MPCX_CLAP(k) do { const long long now_ = __builtin_readcyclecounter(); ct_[k] += now_ - cl_; cl_ = now_; } while (0)
+#else
+#define MPCX_CLAP(k) do { } while (0)
+#endif
     struct Pert2 {                                            // two perturbed entries of one row
         const double *M; int n, row, c1, c2; double d1, d2;
         __device__ __forceinline__ double operator()(int i, int j) const
@@ -2571,36 +2613,23 @@ struct WgSqp {
         }
         return acc / (4.0 * ha * hb);
     }
-    static MPCX_WG_PHASE void init_curvature()
+    // the horizon of init_curvature.  PHI_LDS: the two sensitivity buffers lie in the overlay behind Xs / Us; otherwise in the instance's workspace (a
+    // plan that cut the working set's capacity has cut the overlay with it) -- the pointer typed either way, so that no access is a flat one
+    template <bool PHI_LDS>
+    static __device__ __forceinline__ void curv_horizon(const V &v)
     {
-        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
+        const auto &P = v.A->P;
         const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int ph = v.ph, ch = v.ch, nzu = v.nzu, nq = v.nq;
-        const Scale sc = v.scale();
-        double *hinv = v.at(P.o_hinv), *st = v.at(P.o_st);
-        // (the two sensitivity buffers: LDS where the overlay has the room, the instance's workspace otherwise -- a plan that cut the working set's
-        // capacity has cut the overlay with it; once per solve either way)
-        double *phiA = P.curv_lds ? v.at(P.o_Us) + (((ph + 1) * NU + 1) & ~1) : v.w + P.w_phi, *phiB = phiA + NX * nzu, *Qb = v.at(P.o_xq);
+        const int ph = v.ph, ch = v.ch, nzu = v.nzu;
+        double *hinv = v.at(P.o_hinv), *Qb = v.at(P.o_xq);
+        typedef typename BlockPtr<PHI_LDS>::type PhiPtr;
+        PhiPtr phiA = BlockPtr<PHI_LDS>::make(PHI_LDS ? v.at(P.o_Us) + (((ph + 1) * NU + 1) & ~1) : v.w + P.w_phi), phiB = phiA + NX * nzu;
         typename FP::type F = FP::get(v);
-        const int nh = nq * (nq + 1) / 2;
-        for (int e = tid; e < nh; e += NT) hinv[e] = 0.0;
+#ifdef MPCX_NL_STATS
+        long long ct_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_ = __builtin_readcyclecounter();
+#endif
         for (int e = tid; e < 2 * NX * nzu; e += NT) phiA[e] = 0.0;
         T::sync();
-        // the inputs' own curvature: row i of U (row ph is the copy of row ph - 1) belongs to block min(i, ph - 1, ch - 1); one thread per entry of a
-        // block's NU x NU matrix, the rows of one block added up in their order
-        for (int e = tid; e < ch * NU * NU; e += NT) {
-            const int bq = e / (NU * NU), jj = e - bq * NU * NU, j1 = jj / NU, j2 = jj - j1 * NU;
-            if (j2 > j1) continue;
-            double acc = 0.0;
-            for (int i = 0; i <= ph; ++i) if (min(min(i, ph - 1), ch - 1) == bq) acc += stage_d2<false>(v, i, j1, j2);
-            const int p = bq * NU + j1, q = bq * NU + j2;
-            hinv[p * (p + 1) / 2 + q] = sc.by_su(sc.by_su(acc, j1), j2);
-        }
-        if (nq > nzu && tid == 0) {                             // the slack (soft constraints): its own second difference
-            const double e0 = v.at(P.o_z)[v.nz - 1], he = 1e-4 * fmax(1.0, fabs(e0));
-            const double *prm = v.at(P.o_prm);
-            hinv[nzu * (nzu + 1) / 2 + nzu] = (Mdl::slack_cost(e0 + he, prm) - 2.0 * Mdl::slack_cost(e0, prm) + Mdl::slack_cost(e0 - he, prm)) / (he * he);
-        }
         // the horizon: Phi one step on, T = Qx Phi, B0 += Phi' T -- the last as 16 x 16 tiles in the MFMA accumulators (tile (tp, tq), tq <= tp, is
         // tile number tp (tp + 1) / 2 + tq; wavefront w owns tiles w, w + WAVES, ..: up to kCurvTiles of them)
         const int nt = (nzu + 15) >> 4, ntiles = nt * (nt + 1) / 2;
@@ -2618,7 +2647,7 @@ struct WgSqp {
                 tp[u] = tn < ntiles ? r : -1; tqq[u] = c;
             }
             if (t0 > 0) { for (int e = tid; e < 2 * NX * nzu; e += NT) phiA[e] = 0.0; T::sync(); }
-            double *cur = phiA, *nxt = phiB;
+            PhiPtr cur = phiA, nxt = phiB;
             for (int i = 0; i < ph; ++i) {
                 const int bi = min(i, ch - 1), ncol = (bi + 1) * NU;        // the columns that are not zero yet
                 // Phi_{i+1} = Abar_i Phi_i + Bbar_i E_bi, one thread per entry; the second differences of stage i + 1 in its row of X next to it
@@ -2629,8 +2658,10 @@ struct WgSqp {
                     for (int b2 = 0; b2 < NX; ++b2) s = fma(F[(size_t)(i * NX + a) * FW + b2], cur[b2 * nzu + q], s);
                     nxt[a * nzu + q] = s;
                 }
+                MPCX_CLAP(1);
                 for (int e = tid; e < NX * NX; e += NT) { const int a = e / NX, b2 = e - a * NX; Qb[e] = b2 <= a ? stage_d2<true>(v, i + 1, a, b2) : 0.0; }
                 T::sync();
+                MPCX_CLAP(2);
                 for (int e = tid; e < NX * ncol; e += NT) {     // T = Qx Phi_{i+1} (Qx by its lower triangle) into the other buffer: Phi_i is done with
                     const int a = e / ncol, q = e - a * ncol;
                     double s = 0.0;
@@ -2639,6 +2670,7 @@ struct WgSqp {
                     cur[a * nzu + q] = s;
                 }
                 T::sync();
+                MPCX_CLAP(3);
                 // B0 tile (tp, tq) += Phi[:, 16 tp ..]' T[:, 16 tq ..]: k runs over the NX state entries, four per MFMA
 #pragma unroll
                 for (int u = 0; u < kCurvTiles; ++u) {
@@ -2651,7 +2683,8 @@ struct WgSqp {
                     }
                 }
                 T::sync();
-                double *sw = cur; cur = nxt; nxt = sw;          // (Phi_{i+1} is in nxt: it is the next step's Phi_i)
+                MPCX_CLAP(4);
+                PhiPtr sw = cur; cur = nxt; nxt = sw;          // (Phi_{i+1} is in nxt: it is the next step's Phi_i)
             }
             // the tiles into the packed matrix (element (4 r + kq, j) of a tile in register r): every entry has one owner
 #pragma unroll
@@ -2665,7 +2698,53 @@ struct WgSqp {
             }
             T::sync();
         }
-        const int ok = invert_packed(hinv, v.at(P.o_np), nq);
+#ifdef MPCX_NL_STATS
+        if (tid == 0) for (int k = 0; k < 5; ++k) (v.w + P.w_scal)[32 + k] += (double)ct_[k];
+#endif
+    }
+    static MPCX_WG_PHASE void init_curvature()
+    {
+        const V v; const auto &M = v.A->M; const auto &P = v.A->P;
+        const int tid = threadIdx.x;
+        const int ph = v.ph, ch = v.ch, nzu = v.nzu, nq = v.nq;
+        const Scale sc = v.scale();
+        double *hinv = v.at(P.o_hinv), *st = v.at(P.o_st);
+        const int nh = nq * (nq + 1) / 2;
+#ifdef MPCX_NL_STATS
+        long long ct_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_ = __builtin_readcyclecounter();      // cycles of this phase's parts: scal[32 ..] (tools/nlmpc_phases.py)
+#endif
+        for (int e = tid; e < nh; e += NT) hinv[e] = 0.0;
+        T::sync();
+        // the inputs' own curvature: row i of U (row ph is the copy of row ph - 1) belongs to block min(i, ph - 1, ch - 1); one thread per entry of a
+        // block's NU x NU matrix, the rows of one block added up in their order
+        for (int e = tid; e < ch * NU * NU; e += NT) {
+            const int bq = e / (NU * NU), jj = e - bq * NU * NU, j1 = jj / NU, j2 = jj - j1 * NU;
+            if (j2 > j1) continue;
+            double acc = 0.0;
+            for (int i = 0; i <= ph; ++i) if (min(min(i, ph - 1), ch - 1) == bq) acc += stage_d2<false>(v, i, j1, j2);
+            const int p = bq * NU + j1, q = bq * NU + j2;
+            hinv[p * (p + 1) / 2 + q] = sc.by_su(sc.by_su(acc, j1), j2);
+        }
+        if (nq > nzu && tid == 0) {                             // the slack (soft constraints): its own second difference
+            const double e0 = v.at(P.o_z)[v.nz - 1], he = 1e-4 * fmax(1.0, fabs(e0));
+            const double *prm = v.at(P.o_prm);
+            hinv[nzu * (nzu + 1) / 2 + nzu] = (Mdl::slack_cost(e0 + he, prm) - 2.0 * Mdl::slack_cost(e0, prm) + Mdl::slack_cost(e0 - he, prm)) / (he * he);
+        }
+        MPCX_CLAP(0);
+#ifdef MPCX_NL_STATS
+        if (tid == 0) { for (int k = 0; k < 5; ++k) (v.w + P.w_scal)[32 + k] = 0.0; (v.w + P.w_scal)[32] = (double)ct_[0]; }
+        T::sync();
+#endif
+        if (P.curv_lds) curv_horizon<true>(v); else curv_horizon<false>(v);
+#ifdef MPCX_NL_STATS
+        cl_ = __builtin_readcyclecounter();
+#endif
+        MPCX_CLAP(5);
+        const int ok = invert_packed(P.o_hinv, P.o_np, nq);
+        MPCX_CLAP(6);
+#ifdef MPCX_NL_STATS
+        if (tid == 0) for (int k = 5; k < 8; ++k) (v.w + P.w_scal)[32 + k] = (double)ct_[k];
+#endif
         if (tid == 0) st[ST_CARRY] = 0.0;                       // (a saved inverse of the Schur complement belongs to the estimate that is gone)
         if (!ok) { for (int e = tid; e < nh; e += NT) { int r, c; tri_index(e, r, c); hinv[e] = r == c ? 1.0 : 0.0; } }
         (void)M; (void)st;
@@ -2726,7 +2805,15 @@ struct WgSqp {
         // overwritten here -- z_out may be the caller's z_warm, the estimate's place is the same in both plans)
         const bool again = P.cut && st[ST_OVER] != 0.0;
         if (o_z && !again) for (int k = tid; k < nz; k += NT) o_z[(size_t)b * nz + k] = z[k];
-        if (o_mu) for (int k = tid; k < mt; k += NT) o_mu[(size_t)b * mt + k] = mu[k];
+        // the multipliers of the last sub-problem (0 = not in its working set; zeros after a failed solve): from the working set's lists
+        if (o_mu) {
+            const int nw = failed ? 0 : (int)st[ST_QNW];
+            const int *wq = v.iat(P.o_wq);
+            const double *sgq = v.at(P.o_sgq), *uq = v.at(P.o_uq);
+            for (int k = tid; k < mt; k += NT) o_mu[(size_t)b * mt + k] = 0.0;
+            T::sync();
+            for (int t = tid; t < nw; t += NT) o_mu[(size_t)b * mt + wq[t]] = sgq[t] * uq[t];
+        }
         if (o_sx) for (int k = tid; k < (ph + 1) * NX; k += NT) o_sx[(size_t)b * (ph + 1) * NX + k] = failed ? 0.0 : Xs[k];
         if (o_su) for (int k = tid; k < (ph + 1) * NU; k += NT) o_su[(size_t)b * (ph + 1) * NU + k] = failed ? 0.0 : Us[k];
         if (o_sy)                                           // Model::getOutput (Model.hpp:72-96): row i = out(x_i, u_i), zeros without one
@@ -2819,9 +2906,11 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
         if (P.curv0 && it == P.curv0_it && !S.keep_curvature && resets == 0) {
             // the curvature estimate from the cost's own second derivatives at this iterate (trajectory and folded blocks are in place); the
             // phase works in the overlay the cost's gradient lies in: that part of the evaluation again
+            lap(3);
             K::init_curvature();
             K::eval_cost(0);
             have_old = false;
+            lap(9);                                           // (counted with "update + start": once per solve)
         }
         if (P.needs_phi) K::condense_phi(); else K::condense_chain();
         lap(3);
@@ -2964,8 +3053,8 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.o_red = take(kWgRedDoubles); P.o_st = take(ST_TOTAL);
         P.o_z = take(nz); P.o_c = take(nxs); P.o_gin = take(mu_); P.o_gu = take(nr); P.o_gr = take(nr);
         P.o_glold = take(nr); P.o_sv = take(nr); P.o_hinv = take(nr * (nr + 1) / 2);
-        P.o_mu = take(mt); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
-        P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(mu_); P.o_jxoff = take((mu_ + 2) / 2); P.o_slot = take((nsx + 1) / 2);
+        P.o_mu = take(P.needs_phi ? mt : 0); P.o_flag = take((mt + 1) / 2); P.o_br = take(mt); P.o_s1v = take(mt); P.o_s1m = take((mt + 1) / 2);
+        P.o_dcol = take((mt + 1) / 2); P.o_xmask = take(P.needs_phi ? mu_ : 0); P.o_jxoff = take(P.needs_phi ? (mu_ + 2) / 2 : 0); P.o_slot = take((nsx + 1) / 2);
         P.o_sbf = take((ph + 2) / 2); P.o_jx = take(nsx * NX); P.o_art = f_lds ? take(P.art_total) : 0;
         P.o_wq = take((kw + 1) / 2); P.o_sgq = take(kw); P.o_uq = take(kw); P.o_tq = take(kw); P.o_invd = take(kw);
         P.o_xq = take(nr); P.o_p = P.o_xq;        // (the sub-problem's iterate is the step when it ends)

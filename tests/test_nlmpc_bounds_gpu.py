@@ -66,9 +66,9 @@ def _bound_rows(s, ub):
     return [(nxs + k, sg) for k in range(s["ch"] * s["N"]) for sg in (1.0, -1.0)]
 
 
-# the workgroup form does not hold eight oscillators WITH 240 bound rows (its LDS block is 151 KB without them): that shape runs in the
-# one-wavefront form whatever is asked for; forcing "wg" there is an error by design (MPCX_NLMPC_FORM=wg reports instead of falling back)
-@pytest.mark.parametrize("shape,variant", [("osc6", v) for v in VARIANTS] + [("osc8", "default"), ("osc8", "wave")])
+# (eight oscillators WITH their 240 bound rows fit the workgroup form's LDS block since round 6 -- 157.8 of 160 KB: plans in which no row reads a
+# state keep neither the tables that say which nor an LDS copy of the multipliers -- so every variant runs for both shapes)
+@pytest.mark.parametrize("shape,variant", [(sh, v) for sh in ("osc6", "osc8") for v in VARIANTS])
 def test_bound_active_oscillators_match_the_golden_oracle_solutions(shape, variant, monkeypatch):
     s = SHAPES[shape]
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nlmpc_oracle_solutions.json")))[s["key"]]
@@ -136,7 +136,7 @@ def _kkt_at_point(m, z, x0, s, ub):
 
 
 @pytest.mark.parametrize("shape,ub,B,variant", [("osc6", 0.05, 1024, "default"), ("osc6", 0.15, 1024, "default"), ("osc6", 0.05, 256, "wg-inverse-not-carried"),
-                                                 ("osc6", 0.05, 256, "wg-factor"), ("osc6", 0.05, 256, "wave"), ("osc8", 0.05, 256, "default"), ("osc8", 0.15, 256, "default")])
+                                                 ("osc6", 0.05, 256, "wg-factor"), ("osc6", 0.05, 256, "wave"), ("osc8", 0.05, 256, "default"), ("osc8", 0.15, 256, "default"), ("osc8", 0.05, 128, "wg-factor"), ("osc8", 0.05, 128, "wave")])
 def test_every_bound_active_instance_solves_to_the_oracle_optimum(shape, ub, B, variant, monkeypatch):
     import torch
     s = SHAPES[shape]
@@ -154,7 +154,7 @@ def test_every_bound_active_instance_solves_to_the_oracle_optimum(shape, ub, B, 
     on_bound = (np.abs(np.abs(r["z"][:, s["ph"] * 2 * N:-1]) - ub) <= 1e-9).sum(axis=1)
     left = _attempts(c, B) if c._lib.mpcx_nlmpc_last_form(c._h) > 0 else (np.ones(B, int), np.zeros(B, int))
     # against the oracle's SLSQP run here: six oscillators ~1 s per instance (the first 256 of the batch), eight ~10 s (a sample of 24)
-    idx = list(range(min(B, 256))) if N == 6 else list(range(0, B, B // 24))
+    idx = list(range(min(B, 256))) if N == 6 else list(range(0, B, max(1, B // 24)))
     orc = _oracle_batch(shape, X0, ub, idx)
     worst = worst_cost = 0.0
     compared = 0

@@ -41,6 +41,15 @@ if wg and "stats" in os.environ.get("MPCX_LIBRARY", ""):
     print("sub-problem, cycles per SQP iteration: " + "; ".join("%s %.0f" % (n, v) for n, v in zip(qn, raw)))
     if raw[11:15].any():     # the dual part of a step, its four stretches (they are counted inside "solve" above too)
         print("   dual part: gather + zero %.0f; S^-1 t (the inverse's product / the factor's two substitutions) %.0f; z'n and ratio test %.0f; multipliers, scatter, the row's place %.0f" % tuple(raw[11:15]))
+if wg and "stats" in os.environ.get("MPCX_LIBRARY", ""):
+    # the Gauss-Newton start of the curvature estimate (WgSqp::init_curvature), once per solve: cycles of its parts
+    ic = np.zeros(8)
+    for i in range(0, B, max(1, B // 16)):
+        ws = c.debug_workspace(i)
+        ic += np.concatenate([ws["scal"], ws["lamw"]])[32:40]
+    ic /= len(range(0, B, max(1, B // 16)))
+    print("curvature start, cycles per solve: zero + the inputs' part %.0f; over the horizon: sensitivities one step on %.0f, the stage's second differences %.0f, Qx Phi %.0f, Phi' T on MFMA %.0f; "
+          "tiles to the packed matrix %.0f; inversion %.0f" % tuple(ic[:7]))
 if wg:
     print("dual steps per SQP iteration: %.2f" % (dual / len(range(0, B, max(1, B // 16)))))
 print("iterations mean", it.mean(), " cycles per iteration (mean over sampled instances): %.0f" % (tot / len(range(0, B, max(1, B // 16))) / it.mean()))
