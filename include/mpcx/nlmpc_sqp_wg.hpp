@@ -46,6 +46,8 @@ struct WgPlan {
     int cut;                    // the working set's capacity was cut below what the problem can need: a second launch (only_overflowed) takes the instances that outgrow it
     int only_overflowed;        // a second pass with the full working-set capacity: only the instances whose working set outgrew the first pass's
     int curv0;                  // the curvature estimate is set to the condensed Gauss-Newton Hessian of the cost (init_curvature) ...
+    int inv_nb, inv_lds;        // init_curvature inverts its matrix in blocks of inv_nb pivots (16 from 97 variables on, 8 below; 0: pivot by pivot -- a debug choice), the panel
+                                // buffers in the overlay behind Xs / Us where it has the room (inv_lds), in the workspace otherwise (w_phi)
     int curv_lds;               // init_curvature's two NX x nzu buffers fit the overlay behind Xs / Us (otherwise they are in the workspace: w_phi)
     int curv0_it;               // ... before iteration curv0_it (0: the solve starts from it; k > 0: the first k iterations run from the identity, as NLopt's SLSQP does)
     int carry_m;                // (minv, every row a short list with constant entries) the inverse is carried from one sub-problem to the next: w_msave
@@ -1871,42 +1873,78 @@ struct WgSqp {
         dmax = R.max(dmax);
         T::sync();
         bool ok = true;
+        // Which elements of the triangle a thread owns does not depend on the pivot (rows r and n - 1 - r to a group of PL lanes, as in tri_rows):
+        // where they are, and which column they belong to, is worked out ONCE, before the sweep -- the pass over the triangle is bound by the
+        // instructions it issues (a wave64 instruction takes four cycles, two wavefronts share a SIMD: 800 instructions per pivot were 6.5 k
+        // cycles), and most of them were this arithmetic.  Up to kOwn elements per thread in registers; a matrix too large for that many
+        // (n = 121 on four wavefronts) takes the pass that recomputes them.
+        constexpr int kOwn = 16;
+        const int np = (n + 1) >> 1;
+        const int PL = np > 0 && NT / np > 0 ? NT / np : 1, groups = NT / PL, g = tid / PL, l = tid - g * PL;
+        const bool fits = np <= groups && (n + 1 + PL - 1) / PL <= kOwn;
+        const bool mine = g < np && g < groups;
+        const int ra = mine ? g : 0, rb = n - 1 - ra, len = !mine ? 0 : (ra == rb ? ra + 1 : n + 1);
+        const int oa = ra * (ra + 1) / 2, ob = rb * (rb + 1) / 2 - ra - 1;
+        int ix[kOwn], cc[kOwn];
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) {
+            const int j = l + u * PL;
+            const bool live = j < len, fa = j <= ra;
+            ix[u] = live ? (fa ? oa : ob) + j : -1;
+            cc[u] = (fa ? j : j - ra - 1) | (fa ? 0 : 1 << 30);      // bit 30: the element lies in row rb
+        }
         for (int k = 0; k < n && ok; ++k) {                       // the sweep operator on pivot k: afterwards Mp = -(S^-1) on the swept part
             for (int t = tid; t < n; t += NT) buf[t] = hsym(Mp, t, k);
             const double d = Mp[k * (k + 1) / 2 + k];
             T::sync();
             ok = d > 1e-13 * dmax;
             const double id = 1.0 / d;
-            // (the pass over the triangle, rows r and n - 1 - r to a group of lanes as in tri_rows, written out: four elements' operands are requested
-            // before the first is used and the pivot's row and column are selects, not branches -- as a lambda per element the pass was a chain of
-            // dependent LDS round trips under exec masks, 8 k cycles per pivot at n = 121)
-            {
-                const int np = (n + 1) >> 1;
-                const int PL = np > 0 && NT / np > 0 ? NT / np : 1, groups = NT / PL, g = tid / PL, l = tid - g * PL;
+            if (fits) {
+                const double ba = buf[ra] * id, bb = buf[rb] * id;      // buf[r] / d of this thread's two rows
+                const bool ka = ra == k, kb = rb == k;
+#pragma unroll
+                for (int u0 = 0; u0 < kOwn; u0 += 4) {
+                    double a[4], bc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = ix[u0 + u] >= 0 ? ix[u0 + u] : 0;
+                        a[u] = Mp[e]; bc[u] = buf[cc[u0 + u] & 0xffff];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool inb = (cc[u0 + u] >> 30) != 0;
+                        const int c = cc[u0 + u] & 0xffff;
+                        const double br = inb ? bb : ba;
+                        const bool rk = inb ? kb : ka;
+                        const double x = rk ? (c == k ? -id : bc[u] * id) : (c == k ? br : fma(-br, bc[u], a[u]));
+                        if (ix[u0 + u] >= 0) Mp[ix[u0 + u]] = x;
+                    }
+                }
+            } else {
                 for (int p0 = 0; p0 < np; p0 += groups) {
                     const int p = p0 + g;
                     if (p < np && g < groups) {
-                        const int ra = p, rb = n - 1 - p, len = ra == rb ? ra + 1 : n + 1;
-                        const double ba = buf[ra] * id, bb = buf[rb] * id;
-                        const int oa = ra * (ra + 1) / 2, ob = rb * (rb + 1) / 2 - ra - 1;
-                        for (int j0 = l; j0 < len; j0 += 4 * PL) {
+                        const int qa = p, qb = n - 1 - p, qlen = qa == qb ? qa + 1 : n + 1;
+                        const double ba = buf[qa] * id, bb = buf[qb] * id;
+                        const int pa = qa * (qa + 1) / 2, pb = qb * (qb + 1) / 2 - qa - 1;
+                        for (int j0 = l; j0 < qlen; j0 += 4 * PL) {
                             double a[4], bc[4];
-                            int ix[4], cc[4];
+                            int jx[4], jc[4];
                             bool fa[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const int j = j0 + u * PL < len ? j0 + u * PL : l;
-                                fa[u] = j <= ra;
-                                cc[u] = fa[u] ? j : j - ra - 1;
-                                ix[u] = (fa[u] ? oa : ob) + j;
-                                a[u] = Mp[ix[u]]; bc[u] = buf[cc[u]];
+                                const int j = j0 + u * PL < qlen ? j0 + u * PL : l;
+                                fa[u] = j <= qa;
+                                jc[u] = fa[u] ? j : j - qa - 1;
+                                jx[u] = (fa[u] ? pa : pb) + j;
+                                a[u] = Mp[jx[u]]; bc[u] = buf[jc[u]];
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const int r = fa[u] ? ra : rb;
-                                const double br = fa[u] ? ba : bb;                  // buf[r] / d
-                                const double x = r == k ? (cc[u] == k ? -id : bc[u] * id) : (cc[u] == k ? br : fma(-br, bc[u], a[u]));
-                                if (j0 + u * PL < len) Mp[ix[u]] = x;
+                                const int r = fa[u] ? qa : qb;
+                                const double br = fa[u] ? ba : bb;
+                                const double x = r == k ? (jc[u] == k ? -id : bc[u] * id) : (jc[u] == k ? br : fma(-br, bc[u], a[u]));
+                                if (j0 + u * PL < qlen) Mp[jx[u]] = x;
                             }
                         }
                     }
@@ -1915,6 +1953,118 @@ struct WgSqp {
             T::sync();
         }
         if (!ok) return 0;
+        tri_rows(Mp, n, tid, [&](int, int, double &a) { a = -a; });
+        T::sync();
+        return 1;
+    }
+    // The same inversion BLOCKED, for init_curvature's nq x nq matrix (n = 61 .. 121: the pivot-by-pivot sweep issues ~600 instructions per pivot and
+    // wavefront, and a phase like that is bound by exactly that -- four cycles per wave64 instruction, the SIMD's wavefronts taking turns).  NB pivots
+    // at a time (16, or 8 where the scratch is short): the sweep operator on a block K of pivots is
+    //     A_KK <- -D,  D = A_KK^-1;     A_iK <- W_i = A_iK D;     A_ij <- A_ij - W_i A_jK'        (i, j outside K)
+    // -- the panel product W = P D and the rank-NB update of the whole triangle as 16 x 16 tiles on the matrix pipe (v_mfma_f64_16x16x4_f64), the
+    // NB x NB block inverted by wavefront 0 with the scalar sweep.  Scratch (LDS, by offset): NB^2 + 2 NB N16 doubles, N16 = n rounded up to 16.
+    // Rows and pivots beyond n are identity / zero padding and are never stored.
+    // (SLDS: the scratch lies in LDS at that offset; otherwise in the instance's workspace at that offset -- the same arithmetic either way: which
+    // block size a controller takes depends on its size alone, never on a plan's LDS layout, so that every plan of a handle returns the same bits)
+    template <int NB, bool SLDS>
+    static MPCX_WG_CALL int invert_packed_blocked(int mp_off, int scratch_off, int n)
+    {
+        const V v; const auto &P = v.A->P;
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int j = lane & 15, kq = lane >> 4;
+        double *Mp = v.at(mp_off);
+        typedef typename BlockPtr<SLDS>::type ScrPtr;
+        ScrPtr Sb = BlockPtr<SLDS>::make(SLDS ? v.at(scratch_off) : v.w + scratch_off);
+        const int nt = (n + 15) >> 4, N16 = 16 * nt;
+        ScrPtr Pn = Sb + NB * NB, Wn = Pn + NB * N16;
+        double *flagslot = v.at(P.o_red) + 48;                  // (one word: the block's pivots were all positive)
+        double dmax = 0.0;
+        for (int r = tid; r < n; r += NT) dmax = fmax(dmax, Mp[r * (r + 1) / 2 + r]);
+        Red<WAVES> R(v.at(P.o_red));
+        dmax = R.max(dmax);
+        T::sync();
+        for (int k0 = 0; k0 < n; k0 += NB) {
+            // the panel A[:, K] (rows beyond n: zero) and the block A_KK (pivots beyond n: identity)
+            for (int e = tid; e < N16 * NB; e += NT) {
+                const int t = e / NB, c = e - t * NB, k = k0 + c;
+                Pn[e] = (t < n && k < n) ? hsym(Mp, t, k) : 0.0;
+            }
+            for (int e = tid; e < NB * NB; e += NT) {
+                const int c1 = e / NB, c2 = e - c1 * NB;
+                Sb[e] = (k0 + c1 < n && k0 + c2 < n) ? hsym(Mp, k0 + c1, k0 + c2) : (c1 == c2 ? 1.0 : 0.0);
+            }
+            if (tid == 0) flagslot[0] = 1.0;
+            T::sync();
+            // D = A_KK^-1 in place: the scalar sweep by wavefront 0 (afterwards Sb = -D)
+            if (wave == 0) {
+                bool okb = true;
+                for (int c = 0; c < NB; ++c) {
+                    const double d = Sb[c * NB + c];
+                    double col[(NB * NB + 63) / 64], row[(NB * NB + 63) / 64], a[(NB * NB + 63) / 64];
+#pragma unroll
+                    for (int u = 0; u < (NB * NB + 63) / 64; ++u) {
+                        const int e = lane + 64 * u, r1 = e / NB, c1 = e - r1 * NB;
+                        const bool live = e < NB * NB;
+                        col[u] = live ? Sb[r1 * NB + c] : 0.0; row[u] = live ? Sb[c * NB + c1] : 0.0; a[u] = live ? Sb[e] : 0.0;
+                    }
+                    okb = okb && (d > 1e-13 * dmax || k0 + c >= n);
+                    const double id = 1.0 / d;
+                    nl_wave_sync();
+#pragma unroll
+                    for (int u = 0; u < (NB * NB + 63) / 64; ++u) {
+                        const int e = lane + 64 * u, r1 = e / NB, c1 = e - r1 * NB;
+                        if (e < NB * NB) Sb[e] = r1 == c ? (c1 == c ? -id : row[u] * id) : (c1 == c ? col[u] * id : fma(-col[u] * id, row[u], a[u]));
+                    }
+                    nl_wave_sync();
+                }
+                if (lane == 0 && !okb) flagslot[0] = 0.0;
+            }
+            T::sync();
+            if (flagslot[0] == 0.0) return 0;
+            // W = P D (D = -Sb): sixteen rows of the panel to a wavefront at a time
+            for (int ti = wave; ti < nt; ti += WAVES) {
+                wg_v4d w = {0.0, 0.0, 0.0, 0.0};
+                for (int q0 = 0; q0 < NB; q0 += 4) {
+                    const double av = Pn[(16 * ti + j) * NB + q0 + kq], bv = j < NB ? -Sb[(q0 + kq) * NB + j] : 0.0;
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, w, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (j < NB) Wn[(16 * ti + 4 * r + kq) * NB + j] = w[r];
+            }
+            T::sync();
+            // the whole triangle: A_tile -= W_ti P_tj' (the rows and columns of K get garbage here and their values below)
+            const int ntl = nt * (nt + 1) / 2;
+            for (int tn = wave; tn < ntl; tn += WAVES) {
+                int ti, tj;
+                tri_index(tn, ti, tj);
+                wg_v4d c4;
+                int ex[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + kq, col = 16 * tj + j;
+                    ex[r] = (row < n && col <= row) ? row * (row + 1) / 2 + col : -1;
+                    c4[r] = ex[r] >= 0 ? Mp[ex[r]] : 0.0;
+                }
+                for (int q0 = 0; q0 < NB; q0 += 4) {
+                    const double av = -Wn[(16 * ti + j) * NB + q0 + kq], bv = Pn[(16 * tj + j) * NB + q0 + kq];
+                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ex[r] >= 0) Mp[ex[r]] = c4[r];
+            }
+            T::sync();
+            // the rows and columns of K: A_iK = W_i, A_KK = -D
+            for (int e = tid; e < n * NB; e += NT) {
+                const int t = e / NB, c = e - t * NB, k = k0 + c;
+                if (k >= n) continue;
+                const bool tk = t >= k0 && t < k0 + NB;
+                const double x = tk ? Sb[(t - k0) * NB + c] : Wn[t * NB + c];
+                if (tk && t < k) continue;                      // (both in K: the pair (t, k) with t >= k writes it)
+                const int r1 = t > k ? t : k, c1 = t > k ? k : t;
+                Mp[r1 * (r1 + 1) / 2 + c1] = x;
+            }
+            T::sync();
+        }
         tri_rows(Mp, n, tid, [&](int, int, double &a) { a = -a; });
         T::sync();
         return 1;
@@ -2650,41 +2800,50 @@ struct WgSqp {
             PhiPtr cur = phiA, nxt = phiB;
             for (int i = 0; i < ph; ++i) {
                 const int bi = min(i, ch - 1), ncol = (bi + 1) * NU;        // the columns that are not zero yet
-                // Phi_{i+1} = Abar_i Phi_i + Bbar_i E_bi, one thread per entry; the second differences of stage i + 1 in its row of X next to it
-                for (int e = tid; e < NX * ncol; e += NT) {
-                    const int a = e / ncol, q = e - a * ncol;
-                    double s = q >= bi * NU ? F[(size_t)(i * NX + a) * FW + NX + (q - bi * NU)] : 0.0;
-#pragma unroll
-                    for (int b2 = 0; b2 < NX; ++b2) s = fma(F[(size_t)(i * NX + a) * FW + b2], cur[b2 * nzu + q], s);
-                    nxt[a * nzu + q] = s;
-                }
-                MPCX_CLAP(1);
-                for (int e = tid; e < NX * NX; e += NT) { const int a = e / NX, b2 = e - a * NX; Qb[e] = b2 <= a ? stage_d2<true>(v, i + 1, a, b2) : 0.0; }
-                T::sync();
-                MPCX_CLAP(2);
-                for (int e = tid; e < NX * ncol; e += NT) {     // T = Qx Phi_{i+1} (Qx by its lower triangle) into the other buffer: Phi_i is done with
-                    const int a = e / ncol, q = e - a * ncol;
-                    double s = 0.0;
-#pragma unroll
-                    for (int b2 = 0; b2 < NX; ++b2) s = fma(b2 <= a ? Qb[a * NX + b2] : Qb[b2 * NX + a], nxt[b2 * nzu + q], s);
-                    cur[a * nzu + q] = s;
-                }
-                T::sync();
-                MPCX_CLAP(3);
-                // B0 tile (tp, tq) += Phi[:, 16 tp ..]' T[:, 16 tq ..]: k runs over the NX state entries, four per MFMA
-#pragma unroll
-                for (int u = 0; u < kCurvTiles; ++u) {
-                    if (tp[u] < 0 || 16 * tqq[u] >= ncol) continue;
-                    const int pc = 16 * tp[u] + j, qc = 16 * tqq[u] + j;
+                // Phi_{i+1} = Abar_i Phi_i + Bbar_i E_bi, sixteen columns to a wavefront at a time on the matrix pipe (A operand: row j of Abar_i, B operand:
+                // Phi_i's rows); the second differences of stage i + 1 in its row of X by the lanes next to it
+                const int nct = (ncol + 15) >> 4;
+                for (int t = wave; t < nct; t += WAVES) {
+                    const int q = 16 * t + j;
+                    wg_v4d pa = {0.0, 0.0, 0.0, 0.0};
                     for (int k0 = 0; k0 < NX; k0 += 4) {
                         const int k = k0 + kq;
-                        const double av = (k < NX && pc < ncol) ? nxt[k * nzu + pc] : 0.0, bv = (k < NX && qc < ncol) ? cur[k * nzu + qc] : 0.0;
-                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
+                        const double av = (j < NX && k < NX) ? F[(size_t)(i * NX + j) * FW + k] : 0.0, bv = (k < NX && q < ncol) ? cur[k * nzu + q] : 0.0;
+                        pa = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, pa, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = 4 * r + kq;
+                        if (a < NX && q < ncol) nxt[a * nzu + q] = pa[r] + (q >= bi * NU ? F[(size_t)(i * NX + a) * FW + NX + (q - bi * NU)] : 0.0);
+                    }
+                }
+                MPCX_CLAP(1);
+                for (int e = tid; e < NX * NX; e += NT) { const int a = e / NX, b2 = e - a * NX; Qb[e] = stage_d2<true>(v, i + 1, max(a, b2), min(a, b2)); }
+                T::sync();
+                MPCX_CLAP(2);
+                // B0 tile (tp, tq) += Phi[:, 16 tp ..]' (Qx Phi[:, 16 tq ..]): T = Qx Phi's tile first -- its accumulator registers ARE the B operands of the
+                // second product (register r holds rows 4 r .. 4 r + 3 in the layout a k-step wants), so T never leaves the registers
+#pragma unroll
+                for (int u = 0; u < kCurvTiles; ++u) {
+                    if (tp[u] < 0 || 16 * tqq[u] >= ncol || 16 * tp[u] >= ncol) continue;
+                    const int pc = 16 * tp[u] + j, qc = 16 * tqq[u] + j;
+                    wg_v4d ta = {0.0, 0.0, 0.0, 0.0};
+                    for (int k0 = 0; k0 < NX; k0 += 4) {
+                        const int k = k0 + kq;
+                        const double av = (j < NX && k < NX) ? Qb[j * NX + k] : 0.0, bv = (k < NX && qc < ncol) ? nxt[k * nzu + qc] : 0.0;
+                        ta = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, ta, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (4 * r >= NX) continue;
+                        const int k = 4 * r + kq;
+                        const double av = (k < NX && pc < ncol) ? nxt[k * nzu + pc] : 0.0;
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, ta[r], acc[u], 0, 0, 0);
                     }
                 }
                 T::sync();
                 MPCX_CLAP(4);
-                PhiPtr sw = cur; cur = nxt; nxt = sw;          // (Phi_{i+1} is in nxt: it is the next step's Phi_i)
+                PhiPtr sw = cur; cur = nxt; nxt = sw;          // (Phi_{i+1} is the next step's Phi_i)
             }
             // the tiles into the packed matrix (element (4 r + kq, j) of a tile in register r): every entry has one owner
 #pragma unroll
@@ -2740,7 +2899,11 @@ struct WgSqp {
         cl_ = __builtin_readcyclecounter();
 #endif
         MPCX_CLAP(5);
-        const int ok = invert_packed(P.o_hinv, P.o_np, nq);
+        // (blocked, on the matrix pipe, where the overlay behind Xs / Us holds the panel buffers: the plan says with which block size)
+        const int so = P.inv_lds ? P.o_Us + (((ph + 1) * NU + 1) & ~1) : P.w_phi;
+        const int ok = P.inv_nb == 16 ? (P.inv_lds ? invert_packed_blocked<16, true>(P.o_hinv, so, nq) : invert_packed_blocked<16, false>(P.o_hinv, so, nq))
+                     : P.inv_nb == 8 ? (P.inv_lds ? invert_packed_blocked<8, true>(P.o_hinv, so, nq) : invert_packed_blocked<8, false>(P.o_hinv, so, nq))
+                                     : invert_packed(P.o_hinv, P.o_np, nq);
         MPCX_CLAP(6);
 #ifdef MPCX_NL_STATS
         if (tid == 0) for (int k = 5; k < 8; ++k) (v.w + P.w_scal)[32 + k] = (double)ct_[k];
@@ -3000,7 +3163,7 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 // (minv_wanted / carry_wanted / curv_wanted: -1 the plan's own choice, 0 | 1 forced -- the launcher's MPCX_NLMPC_MINV / MPCX_NLMPC_CARRY / MPCX_NLMPC_CURV0, read when the handle is created)
 template <class Mdl>
 inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_bounds, WgPlan &P, int blocks_wanted = -1, bool cut_ok = true, int lds_per_cu = 160 * 1024,
-                   int minv_wanted = -1, int carry_wanted = -1, int curv_wanted = -1, int curv_it = -1)
+                   int minv_wanted = -1, int carry_wanted = -1, int curv_wanted = -1, int curv_it = -1, int inv_wanted = -1)
 {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, FW = NX + NU + 1;
     const int ph = m.ph, nxs = ph * NX, nr = m.nr, nz = m.nz, mi = m.nineq, mu_ = mi + m.nue, mt = mu_ + m.nbnd;
@@ -3119,6 +3282,9 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
     P.curv0_it = curv_it >= 0 ? curv_it : Mdl::CURV0_AFTER;
     P.curv0 = (curv_wanted != 0 && Mdl::COST_STAGEWISE && NX * NX <= 4 * ((nr + 1) & ~1)) ? 1 : 0;
     P.curv_lds = P.o_Us + (((ph + 1) * NU + 1) & ~1) + 2 * NX * m.nzu <= P.lds_total ? 1 : 0;
+    const int n16 = (P.nq + 15) & ~15;
+    P.inv_nb = inv_wanted >= 0 ? (inv_wanted >= 16 ? 16 : inv_wanted >= 8 ? 8 : 0) : (P.nq > 96 ? 16 : 8);      // (by the problem's size alone: see invert_packed_blocked)
+    P.inv_lds = P.lds_total - (P.o_Us + (((ph + 1) * NU + 1) & ~1)) >= P.inv_nb * P.inv_nb + 2 * P.inv_nb * n16 ? 1 : 0;
     {
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
@@ -3128,7 +3294,10 @@ inline int wg_plan(const NlmpcDev &m, int hard, int waves_wanted, int state_boun
         P.w_gx = take(nxs);
         P.w_hinv = take(nr * (nr + 1) / 2);
         P.w_sp = take(mt * kNlSparse + (mt * kNlSparse + 1) / 2);
-        P.w_phi = take((P.curv0 && !P.curv_lds) ? 2 * NX * m.nzu : 0);
+        {
+            const int phi = (P.curv0 && !P.curv_lds) ? 2 * NX * m.nzu : 0, inv = (P.curv0 && P.inv_nb && !P.inv_lds) ? P.inv_nb * P.inv_nb + 2 * P.inv_nb * n16 : 0;
+            P.w_phi = take(phi > inv ? phi : inv);              // (one after the other: the sensitivities' buffers, then the inversion's)
+        }
         // the carried inverse (see ws_warm): where no row's entries change between sub-problems -- bounds on inputs, user rows affine in the inputs (Mdl::XFREE_ROWS_AFFINE) --
         // and the controller's workspace has the room
         const int carry_env = carry_wanted < 0 ? 1 : carry_wanted;

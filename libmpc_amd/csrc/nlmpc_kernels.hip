@@ -40,7 +40,7 @@ int nlmpc_launch(void *, const NlmpcDev *m, const NlmpcBatchDev *b, void *stream
 // whole batch would (the only thing a batch changes is where the folded blocks live -- LDS when the batch is resident with them there -- and
 // that changes no arithmetic).  MPCX_NLMPC_FORM=wg|wave, MPCX_NLMPC_WAVES=1|2|4|8 and MPCX_NLMPC_BLOCKS=1|0 override; they are read when
 // the handle is created, never on the solve path.
-int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu, int minv, int carry, int curv0, int curv_it);
+int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu, int minv, int carry, int curv0, int curv_it, int inv_nb);
 int nlmpc_wg_launch(const NlmpcDev *m, const NlmpcSolveDev *b, const engine::WgPlan *P, void *stream);
 
 static std::atomic<int> g_last_form{-1};
@@ -48,7 +48,7 @@ int nlmpc_last_form() { return g_last_form.load(std::memory_order_relaxed); }
 
 // per-handle state of the launcher: the overrides, the device's limits, the plans of the current (hard / soft, bounds) shape
 struct NlmpcZoo {
-    int env_form = -1, env_waves = 0, env_blocks = -1, env_minv = -1, env_carry = -1, env_curv0 = -1, env_curv_it = -1;          // -1 / 0: not set
+    int env_form = -1, env_waves = 0, env_blocks = -1, env_minv = -1, env_carry = -1, env_curv0 = -1, env_curv_it = -1, env_inv_nb = -1;          // -1 / 0: not set
     int lds_per_cu = 160 * 1024, cus = 256;
     int last_form = -1;
     NlmpcCurvLayout launched{};                               // where the last solve left its curvature estimate (form < 0: nowhere)
@@ -67,6 +67,7 @@ void *nlmpc_zoo_new()
                *mi = getenv("MPCX_NLMPC_MINV"), *ca = getenv("MPCX_NLMPC_CARRY"), *cv = getenv("MPCX_NLMPC_CURV0");
     if (cv) z->env_curv0 = atoi(cv) ? 1 : 0;
     if (const char *ci = getenv("MPCX_NLMPC_CURV0_IT")) z->env_curv_it = atoi(ci);
+    if (const char *ib = getenv("MPCX_NLMPC_INV_NB")) z->env_inv_nb = atoi(ib);
     if (form) z->env_form = !strcmp(form, "wave") ? 0 : (!strcmp(form, "wg") ? 1 : -1);
     if (wv) z->env_waves = atoi(wv);
     if (bl) z->env_blocks = atoi(bl) ? 1 : 0;
@@ -87,7 +88,7 @@ static void zoo_refresh(NlmpcZoo *z, const NlmpcDev *m, int hard)
 {
     if (z->k_hard == hard && z->k_nbnd == m->nbnd && z->k_nbnd_state == m->nbnd_state && z->k_ws_total == m->ws.total) return;
     auto plan = [&](engine::WgPlan &X, int blocks, bool cut_ok, int waves = -1) {
-        return nlmpc_wg_plan(*m, hard, waves < 0 ? z->env_waves : waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu, z->env_minv, z->env_carry, z->env_curv0, z->env_curv_it) == 0 && X.ws_total <= m->ws.total;
+        return nlmpc_wg_plan(*m, hard, waves < 0 ? z->env_waves : waves, m->nbnd_state, X, blocks, cut_ok, z->lds_per_cu, z->env_minv, z->env_carry, z->env_curv0, z->env_curv_it, z->env_inv_nb) == 0 && X.ws_total <= m->ws.total;
     };
     z->k_hard = hard; z->k_nbnd = m->nbnd; z->k_nbnd_state = m->nbnd_state; z->k_ws_total = m->ws.total;
     z->fits = plan(z->P, z->env_blocks, true);

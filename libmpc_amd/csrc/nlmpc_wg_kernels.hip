@@ -9,9 +9,9 @@
 
 namespace mpcx {
 
-int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu, int minv, int carry, int curv0, int curv_it)
+int nlmpc_wg_plan(const NlmpcDev &m, int hard, int waves, int state_bounds, engine::WgPlan &P, int blocks, bool cut_ok, int lds_per_cu, int minv, int carry, int curv0, int curv_it, int inv_nb)
 {
-    return dispatch_model(m.model_id, [&](auto mdl) { return engine::wg_plan<decltype(mdl)>(m, hard, waves, state_bounds, P, blocks, cut_ok, lds_per_cu, minv, carry, curv0, curv_it); });
+    return dispatch_model(m.model_id, [&](auto mdl) { return engine::wg_plan<decltype(mdl)>(m, hard, waves, state_bounds, P, blocks, cut_ok, lds_per_cu, minv, carry, curv0, curv_it, inv_nb); });
 }
 
 int nlmpc_wg_launch(const NlmpcDev *m, const NlmpcSolveDev *b, const engine::WgPlan *P, void *stream)

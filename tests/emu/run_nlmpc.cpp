@@ -91,7 +91,7 @@ static int run(int argc, char **argv)
         for (int k = 0; k < M.nbnd; ++k) nsb += bidx[k] < nxs ? 1 : 0;
         const int waves = getenv("HIPEMU_WAVES") ? atoi(getenv("HIPEMU_WAVES")) : 0;
         auto envi = [](const char *k) { const char *e = getenv(k); return e ? atoi(e) : -1; };      // (as the launcher reads them when a handle is created)
-        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, envi("HIPEMU_BLOCKS"), true, 160 * 1024, envi("MPCX_NLMPC_MINV"), envi("MPCX_NLMPC_CARRY"), envi("MPCX_NLMPC_CURV0"), envi("MPCX_NLMPC_CURV0_IT")) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
+        if (engine::wg_plan<Mdl>(M, hard, waves, nsb, P, envi("HIPEMU_BLOCKS"), true, 160 * 1024, envi("MPCX_NLMPC_MINV"), envi("MPCX_NLMPC_CARRY"), envi("MPCX_NLMPC_CURV0"), envi("MPCX_NLMPC_CURV0_IT"), envi("MPCX_NLMPC_INV_NB")) != 0) { fprintf(stderr, "the workgroup form does not take this shape\n"); return 3; }
         if (getenv("HIPEMU_VERBOSE")) fprintf(stderr, "wg plan: waves %d, lds %d doubles (%.1f KB), kw %d, nd %d, nsx %d, ws %zu doubles, inverse form %d carried %d (plan %d of %d doubles)\n", P.waves, P.lds_total, P.lds_total / 128.0, P.kw, P.nd, P.nsx, ws_total, P.minv, P.carry_m, P.ws_total, M.ws.scal);
     }
 #endif
