@@ -225,26 +225,6 @@ template <int WAVES> MPCX_WG_CALL WgArgmax wg_red_argmax(double v, int idx, doub
 // the entering row of the dual method, which follow each other with their results in registers, have a set each and no barrier behind them --
 // a set is written again only after every thread has passed a later barrier of the step.
 constexpr int kWgRedDoubles = 64;     // set 0: two parities of sixteen; sets 1 and 2: one reduction per use, sixteen each
-// a sum and an argmax with one barrier (the dual ratio test next to the curvature along the step)
-struct WgSumArgmax { double sum, v; int idx; };
-template <int WAVES> MPCX_WG_CALL WgSumArgmax wg_red_sum_argmax(double a, double v, int idx, double *s)
-{
-    a = wave_sum(a);
-    wave_argmax(v, idx);
-    if constexpr (WAVES > 1) {
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { s[w] = a; s[8 + w] = v; s[16 + w] = (double)idx; }
-        __syncthreads();
-        a = s[0]; v = s[8]; idx = (int)s[16];
-#pragma unroll
-        for (int i = 1; i < WAVES; ++i) {
-            a += s[i];
-            const double ov = s[8 + i]; const int oi = (int)s[16 + i];
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-    }
-    return WgSumArgmax{a, v, idx};
-}
 template <int WAVES> struct Red {
     double *buf;
     int par;
@@ -824,21 +804,22 @@ struct WgSqp {
                 const int ii = live ? i : ph - 1;
                 double col[NX];
                 {
-                    // two passes of two evaluations of the vector field, the same call sites for every kind of column:
-                    // pass 0 at x_i (E: at x_{i+1}), pass 1 at x_{i+1} (used by the input columns and the defect only).
+                    // TWO evaluations of the vector field per lane, the same call sites for every kind of column (round 6; four until then, half of them
+                    // discarded): E and A columns the central difference at x_{i+1} / x_i; the defect column f(x_i, u_i) and f(x_{i+1}, u_i); an input column
+                    // needs the central difference at BOTH points -- the one at x_i on its own lane, the one at x_{i+1} on the identity column's lane of
+                    // the same number (idle otherwise), handed over by a lane exchange and added in the order the two passes added them.
                     // The point is read from LDS where it is needed: a column keeps one perturbed copy and two results at a time.
+                    static_assert(NU <= NX, "the identity columns' lanes lend themselves to the input columns");
                     const double *xr = Xs + ii * NX, *ur = Us + ii * NU;
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) col[a] = 0.0;
-#pragma unroll
-                    for (int pass = 0; pass < 2; ++pass) {
-                        const bool at_next = pass == 1 || kind == 0;
+                    {
+                        const bool helper = kind == 4 && vv < NU;
+                        const bool isu = kind == 2 || kind == 4, pert = kind <= 2 || helper;
+                        const bool n1 = kind == 0 || kind == 4, n2 = n1 || kind == 3;         // the first / second evaluation's point is x_{i+1}
                         double xp[NX], up[NU], o1[NX], o2[NX];
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) xp[a] = xr[(at_next ? NX : 0) + a];
+                        for (int a = 0; a < NX; ++a) xp[a] = xr[(n1 ? NX : 0) + a];
 #pragma unroll
                         for (int a = 0; a < NU; ++a) up[a] = ur[a];
-                        const bool isu = kind == 2, pert = kind <= 2;
                         double bs = 0.0;
 #pragma unroll
                         for (int a = 0; a < NX; ++a) if (!isu && a == vv) bs = xp[a];
@@ -851,15 +832,19 @@ struct WgSqp {
                         for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs + d;
                         Mdl::f(o1, xp, up, prm);
 #pragma unroll
+                        for (int a = 0; a < NX; ++a) xp[a] = xr[(n2 ? NX : 0) + a];
+#pragma unroll
                         for (int a = 0; a < NX; ++a) if (pert && !isu && a == vv) xp[a] = bs - d;
 #pragma unroll
                         for (int a = 0; a < NU; ++a) if (pert && isu && a == vv) up[a] = bs - d;
                         Mdl::f(o2, xp, up, prm);
-                        // derivative columns: the central difference; the defect: f(x_i, u_i) on pass 0, f(x_{i+1}, u_i) on pass 1
-                        const bool use = pass == 0 || kind >= 2;
                         const double i2d = 1.0 / (2 * d);                 // (one division per column; the quotient's last bit is below the differences' noise)
 #pragma unroll
-                        for (int a = 0; a < NX; ++a) col[a] += !use ? 0.0 : (kind == 3 ? o1[a] : (o1[a] - o2[a]) * i2d);
+                        for (int a = 0; a < NX; ++a) col[a] = kind == 3 ? o1[a] + o2[a] : (o1[a] - o2[a]) * i2d;
+                        // the input columns take their second half from the lane that computed it
+                        const int src = base + 2 * NX + NU + 1 + (kind == 2 ? vv : 0);
+#pragma unroll
+                        for (int a = 0; a < NX; ++a) { const double t = __shfl(col[a], src); if (kind == 2) col[a] += t; }
                     }
                     if (!M.scaled) {
                         // (no scalings -- the rule: the five kinds of column by selects, the same arithmetic; as branches on the lane's kind the

@@ -393,9 +393,16 @@ int lmpc_condense_launch(LmpcDev *models_d, const LmpcDev &m0, int count, void *
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     // the BIG form: a scratch block per workgroup, two workgroups per CU's worth of them; released when the kernel has finished
-    const int blocks = count < 512 ? count : 512;
+    // (a set-up path: the bank is being created, the caller synchronises right behind this call.  On a device short of memory the scratch shrinks --
+    // fewer workgroups walk the bank -- before the launch gives up)
+    int blocks = count < 512 ? count : 512;
     double *scratch = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&scratch), (size_t)blocks * big * sizeof(double)) != hipSuccess) return -4;
+    while (hipMalloc(reinterpret_cast<void **>(&scratch), (size_t)blocks * big * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        scratch = nullptr;
+        if (blocks == 1) return -4;
+        blocks = (blocks + 1) / 2;
+    }
     hipLaunchKernelGGL(lmpc_condense_models<true>, dim3(blocks), dim3(kCondWaves * 64), lds, s, models_d, count, NP, NQ, scratch, big);
     const bool ok = hipGetLastError() == hipSuccess;
     const hipError_t es = hipStreamSynchronize(s);
