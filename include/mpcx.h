@@ -235,7 +235,9 @@ enum { MPCX_MODEL_VANDERPOL = 1,   /* examples/vanderpol_ex.cpp: nx=2 nu=1, cont
        MPCX_MODEL_UGV = 2,         /* examples/ugv_ex.cpp: nx=4 nu=2, discrete, two circular obstacles           */
        MPCX_MODEL_OSCILLATORS6 = 3,/* examples/networked_oscillators_ex.cpp: 6 coupled oscillators, nx=12 nu=6   */
        MPCX_MODEL_OSCILLATORS8 = 4,/* the same network with 8 oscillators (BASELINE config 5), nx=16 nu=8        */
-       MPCX_MODEL_VANDERPOL_TERMINAL = 5 };/* Van der Pol + the user equality x(ph) = 0 (setEqConFunction path)  */
+       MPCX_MODEL_VANDERPOL_TERMINAL = 5,/* Van der Pol + the user equality x(ph) = 0 (setEqConFunction path)    */
+       MPCX_MODEL_VANDERPOL_RATE = 6 };/* Van der Pol + a rate limit |u_i - u_{i-1}| <= params[0] (default 0.1): inequality rows
+                                          with two entries, several rows on one input (no reference example has them)  */
 typedef struct mpcx_nlmpc_dims {
     int nx, nu, ph, ch;
     int nz;      /* decision variables  ph*nx + ch*nu + 1 (Objective.hpp:45)                         */

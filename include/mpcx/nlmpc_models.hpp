@@ -81,6 +81,10 @@ struct NoUserEq {
     __device__ static double slack_cost(double, const double *) { return 0.0; }      // the cost's term in the slack variable alone
     static constexpr bool XFREE_ROWS_SPARSE = false;                    // true: a user row that reads no state has at most kNlSparse non-zero entries in the
                                                                         // move-blocked inputs (+ slack); the workgroup form then keeps it as an (index, value) list
+    static constexpr bool SPARSE_ROWS_ONE_ENTRY = false;                // true: every short-list row (XFREE_ROWS_SPARSE) has ONE entry.  Two such rows on one variable are
+                                                                        // parallel and the dual method never holds two parallel rows, so at most one working row touches a
+                                                                        // variable: the workgroup form then scatters N_W' r by LDS atomic adds that cannot meet; without the
+                                                                        // promise it sums every variable's contributions in the working set's order (the same bits every run)
     static constexpr int CURV0_AFTER = 0;                               // the workgroup form sets its curvature estimate to the condensed Gauss-Newton Hessian of the cost before
                                                                         // iteration CURV0_AFTER (0: the solve starts from it).  A model whose constraints make the problem non-convex
                                                                         // in a way that matters -- which side an obstacle is passed on -- lets the first iterations run from the
@@ -126,6 +130,7 @@ struct VanDerPol : NoUserEq, NoOutput {      // reference examples/vanderpol_ex.
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     static constexpr bool XFREE_ROWS_SPARSE = true;
     static constexpr bool XFREE_ROWS_AFFINE = true;                     // u <= 0.5
+    static constexpr bool SPARSE_ROWS_ONE_ENTRY = true;
     __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
     __host__ __device__ static bool ineq_reads_u(int k, int i) { return k == i; }
     __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }
@@ -138,6 +143,28 @@ struct VanDerPolTerminal : VanDerPol {
     __host__ __device__ static int neq_user(int) { return 2; }
     template <class XA, class UA>
     __device__ static double eq(int k, const XA &X, const UA &, int ph, const double *) { return X(ph, k); }
+};
+
+// The same system with a rate limit on the input, |u_i - u_{i-1}| <= params[0], next to u_i <= 0.5: short-list rows with TWO entries, and up to five
+// rows that touch one input (its own bound, the two rate rows of its step and of the next) -- what the reference's examples do not have and the
+// sub-problem's (index, value) lists are built for.  Rows are grouped by step, [u_i <= 0.5 | u_i - u_{i-1} <= r | u_{i-1} - u_i <= r] (the rate
+// rows of step 0 compare u_0 with itself: constant -r), so that the rows reading U row i are the contiguous range ineq_rows_of_u wants.
+// (A limit on the SECOND difference -- three entries, three working rows on one input at most optima -- was tried as the test vehicle and dropped:
+// with a = 0.02 the problem is degenerate enough that scipy's SLSQP gives up on two starts of three and the kernel's line search stalls on some.)
+struct VanDerPolRate : VanDerPol {
+    __host__ __device__ static int nineq(int ph) { return 3 * (ph + 1); }
+    template <class XA, class UA>
+    __device__ static double ineq(int k, const XA &, const UA &U, double, int, const double *p)
+    {
+        const int i = k / 3, t = k - 3 * i, im = i > 0 ? i - 1 : 0;
+        if (t == 0) return U(i, 0) - 0.5;
+        const double du = U(i, 0) - U(im, 0);
+        return (t == 1 ? du : -du) - p[0];
+    }
+    static constexpr bool INEQ_U_ROWS_DISJOINT = false;
+    static constexpr bool SPARSE_ROWS_ONE_ENTRY = false;
+    __host__ __device__ static bool ineq_reads_u(int k, int i) { const int s = k / 3, t = k - 3 * s; return i == s || (t > 0 && s > 0 && i == s - 1); }
+    __host__ __device__ static void ineq_rows_of_u(int i, int &first, int &count) { first = 3 * i; count = 6; }      // (rows 3 i .. 3 i + 5; asked for i < ph only: within nineq)
 };
 
 struct Ugv : NoUserEq {            // reference examples/ugv_ex.cpp:32-124 (zero-order hold of a planar double integrator)
@@ -245,6 +272,7 @@ struct Oscillators : NoUserEq, NoOutput {    // reference examples/networked_osc
     static constexpr bool INEQ_U_ROWS_DISJOINT = true;
     static constexpr bool XFREE_ROWS_SPARSE = true;
     static constexpr bool XFREE_ROWS_AFFINE = true;                     // u_j <= 0.5
+    static constexpr bool SPARSE_ROWS_ONE_ENTRY = true;
     __host__ __device__ static bool ineq_reads_x(int, int) { return false; }
     __host__ __device__ static bool ineq_reads_u(int k, int i) { return k / N == i; }
     __host__ __device__ static void ineq_rows_of_x(int, int &first, int &count) { first = 0; count = 0; }

@@ -1410,9 +1410,28 @@ struct WgSqp {
         __device__ __forceinline__ explicit Ws(const V &v)
             : wq(v.iat(v.A->P.o_wq)), dcol(v.iat(v.A->P.o_dcol)), sgq(v.at(v.A->P.o_sgq)), cd(v.at(v.A->P.o_cd)), yd(v.at(v.A->P.o_yd)), nd(v.A->P.nd) {}
     };
-    // out[q] = sum_t coef[t] * (oriented normal of working row t)[q] for q < nq: the sparse rows scatter their few entries (an LDS atomic
-    // add each: two rows on one variable add up in either order to the same bits), the dense rows go through art.  Arrays by their LDS
-    // offsets; every thread calls; synchronised on return.  (Out of line, like everything the sub-problem uses more than once.)
+    // N_W' r over the SPARSE working rows, two ways (kOneEntry, a property of the model):
+    //   * every short-list row has one entry (bounds, the examples' u_j <= 0.5): two such rows on one variable are parallel, the dual method never
+    //     holds two parallel rows, so at most one working row touches a variable -- the rows' owners scatter by LDS atomic adds that cannot meet;
+    //   * otherwise (rows with several entries, several rows on one variable): every variable gathers its contributions in the working set's
+    //     order, ml[t] the rows' oriented coefficients in LDS -- the same bits on every run, whatever the scheduling.
+    static constexpr bool kOneEntry = Mdl::SPARSE_ROWS_ONE_ENTRY || !Mdl::XFREE_ROWS_SPARSE;
+    // (gather form) out[q] = sum over the sparse working rows t, in order, of ml[t] * (row t's entry on q), q = id, id + nth, ..
+    static __device__ __forceinline__ void sparse_gather(const V &v, const Sp &sp, const Ws &W, int nw, const double *ml, double *out, int id, int nth)
+    {
+        for (int q = id; q < v.nq; q += nth) {
+            double acc = 0.0;
+            for (int t = 0; t < nw; ++t) {
+                const int k = W.wq[t];
+                if (W.dcol[k] >= 0) continue;
+                const int cn = sp.count(k);
+                for (int e = 0; e < cn; ++e) if (sp.index(k, e) == q) acc = fma(sp.value(k, e), ml[t], acc);
+            }
+            out[q] = acc;
+        }
+    }
+    // out[q] = sum_t coef[t] * (oriented normal of working row t)[q] for q < nq: the sparse rows as above, the dense rows go through art.  Arrays
+    // by their LDS offsets; every thread calls; synchronised on return.  (Out of line, like everything the sub-problem uses more than once.)
     static MPCX_WG_CALL void ws_nt_mul(int nw, int coef_off, int out_off)
     {
         const V v; const Sp sp(v); const Ws W(v);
@@ -1422,14 +1441,25 @@ struct WgSqp {
         for (int q = tid; q < nq; q += NT) out[q] = 0.0;
         for (int dc = tid; dc < W.nd; dc += NT) W.cd[dc] = 0.0;
         T::sync();
-        for (int t = tid; t < nw; t += NT) {
-            const int k = W.wq[t], dc = W.dcol[k];
-            const double ml = W.sgq[t] * coef[t];
-            if (dc >= 0) W.cd[dc] = ml;
-            else {
-                const int cn = sp.count(k);
-                for (int j = 0; j < cn; ++j) atomicAdd(out + sp.index(k, j), sp.value(k, j) * ml);
+        if constexpr (kOneEntry) {
+            for (int t = tid; t < nw; t += NT) {
+                const int k = W.wq[t], dc = W.dcol[k];
+                const double ml = W.sgq[t] * coef[t];
+                if (dc >= 0) W.cd[dc] = ml;
+                else {
+                    const int cn = sp.count(k);
+                    for (int j = 0; j < cn; ++j) atomicAdd(out + sp.index(k, j), sp.value(k, j) * ml);
+                }
             }
+        } else {
+            double *ml = v.at(v.A->P.o_tq);                      // (the dual step's scratch: free between steps)
+            for (int t = tid; t < nw; t += NT) {
+                const int dc = W.dcol[W.wq[t]];
+                ml[t] = W.sgq[t] * coef[t];
+                if (dc >= 0) W.cd[dc] = ml[t];
+            }
+            T::sync();
+            sparse_gather(v, sp, W, nw, ml, out, tid, NT);
         }
         T::sync();
         if (W.nd > 0) { art_ws_mul(v, nw, W.cd, out, tid); T::sync(); }
@@ -1658,13 +1688,21 @@ struct WgSqp {
                 if (h1) uq[lane + 64] = u1 - tt * t1;
                 if (can_move) {
                     nl_wave_sync();                                  // (the zeros above are in place)
-                    auto scatter = [&](bool h, int k, int dc, double ml) {
-                        if (!h) return;
-                        if (dc >= 0) cd[dc] = ml;
-                        else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
-                    };
-                    scatter(h0, k0, d0, s0 * t0);
-                    scatter(h1, k1, d1, s1 * t1);
+                    if constexpr (kOneEntry) {
+                        auto scatter = [&](bool h, int k, int dc, double ml) {
+                            if (!h) return;
+                            if (dc >= 0) cd[dc] = ml;
+                            else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                        };
+                        scatter(h0, k0, d0, s0 * t0);
+                        scatter(h1, k1, d1, s1 * t1);
+                    } else {
+                        const Ws W(v);
+                        if (h0) { tq[lane] = s0 * t0; if (d0 >= 0) cd[d0] = s0 * t0; }
+                        if (h1) { tq[lane + 64] = s1 * t1; if (d1 >= 0) cd[d1] = s1 * t1; }
+                        nl_wave_sync();
+                        sparse_gather(v, sp, W, nw, tq, wv, lane, 64);
+                    }
                 }
             }
             if (what == 1) {                                     // row nw of the factor: y and the square root of z'n (chol_append's guard)
@@ -1798,13 +1836,22 @@ struct WgSqp {
                 for (int q = lane; q < nq; q += 64) wv[q] = 0.0;
                 for (int dc = lane; dc < nd; dc += 64) cd[dc] = 0.0;
                 nl_wave_sync();
-                auto scatter = [&](bool h, int k, int dc, double ml) {
-                    if (!h) return;
-                    if (dc >= 0) cd[dc] = ml;
-                    else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
-                };
-                scatter(h0, k0, d0, s0 * t0);
-                scatter(h1, k1, d1, s1 * t1);
+                if constexpr (kOneEntry) {
+                    auto scatter = [&](bool h, int k, int dc, double ml) {
+                        if (!h) return;
+                        if (dc >= 0) cd[dc] = ml;
+                        else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                    };
+                    scatter(h0, k0, d0, s0 * t0);
+                    scatter(h1, k1, d1, s1 * t1);
+                } else {
+                    const Ws W(v);
+                    double *ml = v.at(P.o_tq);
+                    if (h0) { ml[lane] = s0 * t0; if (d0 >= 0) cd[d0] = s0 * t0; }
+                    if (h1) { ml[lane + 64] = s1 * t1; if (d1 >= 0) cd[d1] = s1 * t1; }
+                    nl_wave_sync();
+                    sparse_gather(v, sp, W, nw, ml, wv, lane, 64);
+                }
             }
             if (lane == 0) { unsigned long long *shw = reinterpret_cast<unsigned long long *>(st + ST_SHED); shw[0] = b0; shw[1] = b1; }
         }
@@ -2127,8 +2174,10 @@ struct WgSqp {
                 const double u = rq[t], ml = sgq[t] * u;
                 uq[t] = u;
                 if (dc >= 0) cd[dc] = ml;
-                else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                else if constexpr (kOneEntry) { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                else tq[t] = ml;
             }
+            if constexpr (!kOneEntry) { const Ws W(v); T::sync(); sparse_gather(v, sp, W, nw, tq, wv, tid, NT); }
             T::sync();
         }
     }
@@ -2191,9 +2240,11 @@ struct WgSqp {
                     const int k = wq[t], dc = dcol[k];
                     const double ml = sgq[t] * r;
                     if (dc >= 0) cd[dc] = ml;
-                    else { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                    else if constexpr (kOneEntry) { const int cn = sp.count(k); for (int e = 0; e < cn; ++e) atomicAdd(wv + sp.index(k, e), sp.value(k, e) * ml); }
+                    else tq[t] = ml;
                 }
             }
+            if constexpr (!kOneEntry) { if (can_move) { const Ws W(v); T::sync(); sparse_gather(v, sp, W, nw, tq, wv, tid, NT); } }
             if (what == 1) {                                     // M <- [M + r r'/d, -r/d; -r'/d, 1/d] with d = z'n (guarded as the factor's pivot is)
                 const double d = zn > 1e-13 * snn ? zn : 1e-13 * snn + 1e-300, id = 1.0 / d;
                 tri_rows(Mp, nw, tid, [&](int r, int c, double &a) { a = fma(rq[r] * id, rq[c], a); });

@@ -148,6 +148,7 @@ int mpcx_nlmpc_create(int model_id, int ph, int ch, double Ts, const double *par
     int want = 0;
     if (model_id == MPCX_MODEL_UGV) { prm = {0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, Ts}; want = 9; }
     else if (model_id == MPCX_MODEL_OSCILLATORS6 || model_id == MPCX_MODEL_OSCILLATORS8) { prm = {1.0, 0.1}; want = 2; }
+    else if (model_id == MPCX_MODEL_VANDERPOL_RATE) { prm = {0.1}; want = 1; }
     else prm = {0.0};
     if (params && n_params > 0) {
         if (n_params != want) return capi_fail(MPCX_E_INVALID, "this model takes " + std::to_string(want) + " parameters");

@@ -17,6 +17,7 @@ int dispatch_model(int model_id, F &&fn)
     case 3: return fn(Oscillators<6>{});
     case 4: return fn(Oscillators<8>{});
     case 5: return fn(VanDerPolTerminal{});
+    case 6: return fn(VanDerPolRate{});
     default: return -1;
     }
 }

@@ -22,7 +22,7 @@ import numpy as np
 from . import _capi
 from ._capi import check
 
-VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8, VANDERPOL_TERMINAL = 1, 2, 3, 4, 5
+VANDERPOL, UGV, OSCILLATORS6, OSCILLATORS8, VANDERPOL_TERMINAL, VANDERPOL_RATE = 1, 2, 3, 4, 5, 6
 
 
 def NLParameters(**kw) -> _capi.NLParams:

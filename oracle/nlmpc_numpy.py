@@ -265,6 +265,21 @@ def vanderpol(ph=10, ch=5, Ts=0.1):
     return m
 
 
+def vanderpol_rate(ph=10, ch=5, Ts=0.1, rate=0.1):
+    """the Van der Pol example with a rate limit |u_i - u_{i-1}| <= rate next to u_i <= 0.5 -- rows with two entries, several rows on one input
+    (no reference example has them; mpcx::models::VanDerPolRate).  Rows grouped by step: [u_i - 0.5, u_i - u_{i-1} - rate, u_{i-1} - u_i - rate],
+    step 0 comparing u_0 with itself"""
+    m = vanderpol(ph, ch, Ts)
+    m.ineq = 3 * (ph + 1)
+
+    def ineq(X, Y, U, e):
+        u = U[:, 0]
+        du = u - np.concatenate([[u[0]], u[:-1]])
+        return np.stack([u - 0.5, du - rate, -du - rate], axis=1).reshape(-1)
+    m.ineq_fun = ineq
+    return m
+
+
 def vanderpol_terminal(ph=10, ch=5, Ts=0.1):
     """the Van der Pol example with a terminal equality x(ph) = 0 -- the textbook use of NLMPC::setEqConFunction
     (NLMPC.hpp:246-262); no reference example sets one"""

@@ -54,6 +54,7 @@ static int run(int argc, char **argv)
     std::vector<double> prm;
     if (std::string(argv[1]) == "ugv") prm = {0.7071067811865476, 0.7071067811865476, 2.0, 1.0, 0.3, 1.0, 1.0, 0.3, Ts};
     else if (std::string(argv[1]).substr(0, 3) == "osc") prm = {1.0, 0.1};
+    else if (std::string(argv[1]) == "vanderpol_rate") prm = {0.1};
     else prm = {0.0};
     M.params = prm.data();
     std::vector<double> su(NU, suv), ss(NX, ssv), iss(NX, 1.0 / ssv);
@@ -158,6 +159,7 @@ int main(int argc, char **argv)
     using namespace mpcx::models;
     if (m == "vanderpol") return run<VanDerPol>(argc, argv);
     if (m == "vanderpol_terminal") return run<VanDerPolTerminal>(argc, argv);
+    if (m == "vanderpol_rate") return run<VanDerPolRate>(argc, argv);
     if (m == "ugv") return run<Ugv>(argc, argv);
     if (m == "osc6") return run<Oscillators<6>>(argc, argv);
     if (m == "osc8") return run<Oscillators<8>>(argc, argv);

@@ -205,3 +205,18 @@ def test_carried_inverse_stays_the_inverse(tmp_path_factory):
         assert abs(y["cost"] - plain["cost"]) <= 1e-12 * max(1.0, abs(plain["cost"]))
         np.testing.assert_allclose(y["cmd"], plain["cmd"], rtol=1e-6, atol=1e-7)
     assert out[("1", "forward")][0]["cmd"] == out[("1", "reverse")][0]["cmd"]           # (no exchange through LDS without its barrier)
+
+
+@pytest.mark.parametrize("env", [{}, {"HIPEMU_ORDER": "reverse"}, {"MPCX_NLMPC_MINV": "1"}])
+def test_rows_with_two_entries_and_several_rows_on_one_input(runner, env):
+    """mpcx::models::VanDerPolRate (|u_i - u_{i-1}| <= 0.1 next to u_i <= 0.5): short-list rows with two entries, several of them on one input -- N_W' r as
+    the fixed-order gather (WgSqp::sparse_gather) in the factor form and, forced, in the inverse form; both thread orders; against the oracle"""
+    rng = np.random.default_rng(3)
+    X0 = rng.uniform(-1.0, 1.0, size=(4, 2)); X0[0] = [0.0, 1.0]
+    r = runner(["vanderpol_rate", 10, 10, 0.1, 1, 200, "wg"], np.hstack([X0, np.zeros((4, 1))]), env)
+    m = ref.vanderpol_rate(ph=10, ch=10, Ts=0.1, rate=0.1)
+    for b, y in enumerate(r):
+        o = m.solve(X0[b], np.zeros(1), max_iter=1000)
+        assert o["success"] and y["status"] == 0
+        np.testing.assert_allclose(y["cmd"], o["cmd"], rtol=1e-5, atol=1e-5)
+        assert abs(y["cost"] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"]))

@@ -283,3 +283,67 @@ def test_gauss_newton_start_reaches_the_identity_start_s_optimum_in_fewer_iterat
     else:
         assert same.sum() == both.sum()
         np.testing.assert_allclose(b["cost"][both], a["cost"][both], rtol=1e-8)
+
+
+def _rate_rows_on_one_input(mu, ph, ch):
+    """the largest number of active rows (non-zero multiplier) of the rate-limited Van der Pol problem that touch one blocked input: its bound row
+    u_i <= 0.5 (one entry) and the rate rows of its step and of the next (two entries each)"""
+    touch = np.zeros(ch, int)
+    for k in np.nonzero(mu[:3 * (ph + 1)])[0]:
+        i, t = divmod(int(k), 3)
+        cols = {min(i, ch - 1)} if t == 0 else {min(i, ch - 1), min(max(i - 1, 0), ch - 1)}
+        if t > 0 and len(cols) == 1:
+            continue                                         # (both entries on one block: they cancel, the row has no entry)
+        for c in cols:
+            touch[c] += 1
+    return touch.max()
+
+
+@pytest.mark.parametrize("variant", ["default", "wg-inverse"])
+def test_rows_with_several_entries_on_one_input_are_summed_in_a_fixed_order(variant, monkeypatch):
+    """mpcx::models::VanDerPolRate -- the Van der Pol example with |u_i - u_{i-1}| <= 0.1 next to u_i <= 0.5: short-list rows with TWO entries, up to
+    five rows on one input.  For such a model N_W' r gathers every variable's contributions in the working set's order (WgSqp::sparse_gather; the
+    examples' one-entry rows scatter by atomic adds that cannot meet): the oracle's optimum, several active rows on one input at the optimum (two at
+    most there -- a peak that touches the bound for one step would make it three and does not occur among these starts; the working sets on the way
+    hold more), and the same bits over twenty launches."""
+    import torch
+    from libmpc_amd import _capi
+    from libmpc_amd.nlmpc import NLMPC, NLParameters, VANDERPOL_RATE
+    for k in ("MPCX_NLMPC_FORM", "MPCX_NLMPC_WAVES", "MPCX_NLMPC_BLOCKS", "MPCX_NLMPC_MINV", "MPCX_NLMPC_CARRY", "MPCX_NLMPC_CURV0"):
+        monkeypatch.delenv(k, raising=False)
+    if variant == "wave":
+        monkeypatch.setenv("MPCX_NLMPC_FORM", "wave")
+    elif variant == "wg-inverse":
+        monkeypatch.setenv("MPCX_NLMPC_FORM", "wg"); monkeypatch.setenv("MPCX_NLMPC_MINV", "1")
+    ph, ch, B = 10, 10, 256
+    c = NLMPC(VANDERPOL_RATE, ph, ch, 0.1, params=[0.1])
+    c.setOptimizerParameters(NLParameters(maximum_iteration=200))
+    rng = np.random.default_rng(3)
+    X0 = rng.uniform(-1.0, 1.0, size=(B, 2)); X0[0] = [0.0, 1.0]
+    x0t, u0t = torch.from_numpy(X0), torch.zeros(B, 1, dtype=torch.float64)
+    r = c.optimizeBatch(x0t, u0t, multipliers=True); torch.cuda.synchronize()
+    assert (_capi.lib().mpcx_nlmpc_last_form(c._h) > 0) == (variant != "wave")
+    first = {k: v.clone() for k, v in r.items() if k != "_keep"}
+    st = first["status"].cpu().numpy()
+    assert (st == 0).mean() >= 0.95, {int(k): int((first["solver_status"].cpu().numpy() == k).sum()) for k in np.unique(first["solver_status"].cpu().numpy())}
+    m = ref.vanderpol_rate(ph=ph, ch=ch, Ts=0.1, rate=0.1)
+    cmd, cost, mu = first["cmd"].cpu().numpy(), first["cost"].cpu().numpy(), first["multipliers"].cpu().numpy()
+    worst, compared = 0.0, 0
+    for b in range(0, B, 8):
+        if st[b] != 0:
+            continue
+        o = m.solve(X0[b], [0.0], max_iter=1000)
+        if not o["success"]:
+            continue
+        compared += 1
+        np.testing.assert_allclose(cmd[b], o["cmd"], rtol=1e-5, atol=1e-5)
+        assert abs(cost[b] - o["cost"]) <= 1e-8 * max(1.0, abs(o["cost"]))
+        worst = max(worst, np.abs(cmd[b] - o["cmd"]).max() / max(1.0, np.abs(o["cmd"]).max()))
+    assert compared >= 24
+    most = max(_rate_rows_on_one_input(mu[b], ph, ch) for b in range(B) if st[b] == 0)
+    print("rate-limited Van der Pol, %s: max |cmd - oracle| / max(1, |cmd|) = %.2e over %d instances; up to %d active rows on one input" % (variant, worst, compared, most))
+    assert most >= 2
+    for _ in range(20):
+        r2 = c.optimizeBatch(x0t, u0t, multipliers=True); torch.cuda.synchronize()
+        for key in ("cmd", "cost", "z", "iterations", "solver_status", "multipliers"):
+            assert torch.equal(r2[key], first[key]), key
