@@ -54,6 +54,9 @@ struct LmpcDev {
     // stacked maps of the MFMA assemble kernel (see Condensed in lmpc_model.hpp)
     int kin, nxp, nup, nyp, ione, nz16, mg16, ns, ns16, kq16, rowsA, ldy16;
     const double *MA0, *MA1, *Ym, *slo, *shi;
+    // the same maps as lmpc_solve_group takes them (lmpc_pack_mfma_tiles): a lane's A operands of four consecutive k-steps side by side, a wavefront's of
+    // one row tile and k-step group 2 KB in a row -- the phase is bound by the vector memory pipe's instruction rate, not by bytes
+    const double *MA0p, *MA1p, *Ymp;
     // composed maps of the fused solve kernel: rows [t0; gt0 (ldy) | goff (ldg) | f (ldz) | feasibility rows (nsp) | Qc vin (kin)]
     int rowsF, nsp, fused_ok, group_ok;
     const double *MF0, *MF1;
@@ -97,6 +100,10 @@ int lmpc_kernel_variant(int ldz, int ldg);     // -1 if the dimensions are not c
 int lmpc_launch(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream,
                 int which = 7, int fast_variant = -1);
 int lmpc_lds_per_wave(const LmpcDev &m, int *stage_len, int *arena_len);
+// src: rows x K column-major (rows a multiple of 16, K of 4) -> out[((t G + g) 64 + lane) 4 + e] = src[(4 (4 g + e) + kq) rows + 16 t + j] with lane = 16 kq + j,
+// G = ceil(K / 16) k-step groups per row tile t (zero beyond K): what one wavefront's MFMA A operands of four k-steps look like in registers
+void lmpc_pack_mfma_tiles(const double *src, int rows, int K, double *out);
+inline size_t lmpc_packed_len(int rows, int K) { return (size_t)(rows / 16) * ((K + 15) / 16) * 256; }
 int lmpc_fast_slice(const LmpcDev &m);          // needs wsld, kin, nx
 size_t lmpc_group_lds_bytes(const LmpcDev &m);  // LDS block of lmpc_solve_group (0: no group form for the variant); needs fast_slice, kin, nz16, nu
 // implemented in lmpc_fast.hip: the lean polish kernel (b.fused: the fused / persistent forms) on `stream`

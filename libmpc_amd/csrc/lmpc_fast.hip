@@ -229,8 +229,9 @@ template <int CPZ, int CPG> constexpr int fast_slice_fixed() { return 2 * 128 * 
 // with the composed maps), 2 already in the slice (lmpc_solve_group: the workgroup's MFMA assemble phase put it there)
 template <int CPZ, int CPG, int SRC = 0>
 __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b, const int lane,
-                           double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr, double *outs = nullptr)
+                           double *slice, const double *lwuw, gdw ws, const double *mf_lds = nullptr, double *outs = nullptr, const int eqbits = 0)
 {
+    // eqbits (SRC = 2, lmpc_solve_group): bit s = this lane's general row s is an equality (lg0 == ug0), looked up by the caller with its other loads
     // outs (lmpc_solve_group): the instance's scalar results and its command go to this LDS record [cost, status, solver status,
     // feasible, iterations, rounds, active rows, done | cmd (nu)] instead of to HBM; the workgroup writes sixteen of them coalesced
     constexpr int NZS = 2 * CPZ, NGS = 2 * CPG, ZP = 128 * CPZ, GPD = 128 * CPG;
@@ -320,11 +321,15 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
             const int r = 128 * c + 2 * lane;
             const double2 l = *reinterpret_cast<const double2 *>(lgs + r), u = *reinterpret_cast<const double2 *>(ugs + r);
             const double2 t = *reinterpret_cast<const double2 *>(gt0s + r);
-            const d2 l0 = ld2(GP(lg0) + (offg[c] - ldz)), u0 = ld2(GP(ug0) + (offg[c] - ldz));
-            const bool ok = r < ldg;
             vg[2 * c] = viol(t.x, l.x, u.x); vg[2 * c + 1] = viol(t.y, l.y, u.y);
             lowg[2 * c] = t.x < l.x; lowg[2 * c + 1] = t.y < l.y;
-            actg[2 * c] = (ok && l0.x == u0.x) ? 2 : 0; actg[2 * c + 1] = (ok && l0.y == u0.y) ? 2 : 0;
+            if constexpr (SRC == 2) {
+                actg[2 * c] = ((eqbits >> (2 * c)) & 1) ? 2 : 0; actg[2 * c + 1] = ((eqbits >> (2 * c + 1)) & 1) ? 2 : 0;
+            } else {
+                const d2 l0 = ld2(GP(lg0) + (offg[c] - ldz)), u0 = ld2(GP(ug0) + (offg[c] - ldz));
+                const bool ok = r < ldg;
+                actg[2 * c] = (ok && l0.x == u0.x) ? 2 : 0; actg[2 * c + 1] = (ok && l0.y == u0.y) ? 2 : 0;
+            }
             vinit = fmax(vinit, fmax(vg[2 * c], vg[2 * c + 1]));
         }
         const double thr0 = MPCX_INIT_THETA * wave_max_dpp(vinit);
@@ -848,14 +853,47 @@ __global__ __launch_bounds__(kPersistWaves * 64) void lmpc_solve_persistent(cons
 // Round 5: the two-chunk variant too (CPZ = CPG = 2: up to 256 condensed variables -- config 4's N = 50).  Its slices are 10.9 KB, so a workgroup
 // holds EIGHT instances on eight wavefronts (eight of the sixteen MFMA columns carry an instance, the others repeat the last one and store
 // nothing); such a controller's cost comes from its definition, one product with H per instance inside solve_fast (SRC = 2 is a fused form).
+// The kernel arguments are a kilobyte here (the model struct by value) and the compiler fetches each field where it is first used: a dozen scalar
+// loads on different cache lines, each a miss, one after the other.  Touch every 64-byte line of the segment at once instead (one dword each, all
+// requested before the one wait), after which the compiler's own loads hit the scalar cache.
+template <size_t BYTES>
+__device__ __forceinline__ void kernarg_touch()
+{
+    static_assert(BYTES <= 16 * 64, "kernarg_touch covers sixteen lines");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    int t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
+    asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x40\n\ts_load_dword %2, %16, 0x80\n\ts_load_dword %3, %16, 0xc0\n\t"
+                 "s_load_dword %4, %16, 0x100\n\ts_load_dword %5, %16, 0x140\n\ts_load_dword %6, %16, 0x180\n\ts_load_dword %7, %16, 0x1c0\n\t"
+                 "s_load_dword %8, %16, 0x200\n\ts_load_dword %9, %16, 0x240\n\ts_load_dword %10, %16, 0x280\n\ts_load_dword %11, %16, 0x2c0\n\t"
+                 "s_load_dword %12, %16, 0x300\n\ts_load_dword %13, %16, 0x340\n\ts_load_dword %14, %16, 0x380\n\ts_load_dword %15, %16, 0x3c0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10), "=&s"(t11),
+                   "=&s"(t12), "=&s"(t13), "=&s"(t14), "=&s"(t15)
+                 : "s"(ka)
+                 : "memory");
+}
 template <int CPZ> constexpr int kGroupWavesOf = CPZ == 1 ? 16 : 8;
-constexpr int kGroupKU = 20;              // MFMA k-steps whose A operands are in flight together (the whole of N = 20's second product)
+constexpr int kGroupG2 = 5;               // groups of four MFMA k-steps of the second product whose A operands are in flight together (the whole of N = 20's)
+constexpr int kGroupG1 = 2;               // ... of the first product (kin = 32: the whole of it for up to 12 states, 4 inputs and 12 outputs)
+// Round 6: the phase's trips to memory side by side.  A launch starts with cold caches (the controller's factors come from the memory side once per
+// XCD and launch) and the phase used to chain its first-touch loads: the model struct, the box bounds, the inputs, the first product's operands,
+// the row bounds of its epilogue, the second product's operands, the bounds again at the head of the solve -- seven dependent trips of 1.5-2 us
+// each before the first round.  Now the model struct travels in the kernel arguments and every wavefront requests ALL of what the phase will
+// touch before it waits for any of it: one trip.  The products take their operands in the old order (the same bits), from copies of the maps laid
+// out as the MFMA wants them (LmpcDev::MA0p / MA1p / Ymp: a lane's operands of four k-steps are 32 contiguous bytes, a wavefront's 2 KB): the phase
+// was bound by the instruction rate of the vector memory pipe -- forty-odd 8-byte loads per lane, 64 lanes on four rows each -- not by its bytes.
+// Measured by cutting the kernel short (tools/group_cut.py; quadrotor N = 20, 4096 instances, us per step with the idle fallback launch): empty
+// 6.9, inputs staged 7.6, first product 10.6, second product 15.3, whole 49.0 before the packed copies.
 template <int CPZ, int CPG>
-__global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase, const int variant)
+__global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(const LmpcDev Mv, const LmpcBatchDev Bt, double *wsbase, const int variant)
 {
     constexpr int kGroupWaves = kGroupWavesOf<CPZ>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
+#if defined(MPCX_GROUP_CUT) && MPCX_GROUP_CUT == 0
+    { if (threadIdx.x < kGroupWavesOf<CPZ> && blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x < Bt.batch) Bt.done[blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x] = 2; return; }                                   // (timing experiment, tools/group_cut.sh: what a launch costs up to here)
+#endif
+    kernarg_touch<sizeof(LmpcDev) + sizeof(LmpcBatchDev) + sizeof(double *) + sizeof(int)>();
+    const LmpcDev &M = Mv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int nx = M.nx, nu = M.nu, ny = M.ny;
@@ -870,51 +908,107 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + kGroupWaves * 16);   // [16]
     const int outld = 8 + ((nu + 1) & ~1);
     double *outs = c0s + kGroupWaves * 16 + 16;                             // [16][8 + nu]: results of the sixteen instances
-    fast_load_box<CPZ>(M, lwuw);
     double *mine = slices + (size_t)wave * M.fast_slice;
-    const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
+    const gdp MAp = gl(variant ? M.MA1p : M.MA0p), Ymp = GP(Ymp);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
+    const int ntile2 = M.ldy16 >> 4;
+    const int G1 = (kin4 + 3) >> 2, G2 = (nz4 + 3) >> 2;          // k-step groups per row tile of the packed maps
+    auto ld4 = [](gdp p) -> v4d { return *reinterpret_cast<const v4d MPCX_GAS *>(p); };
     // the slice of instance j (this lane's MFMA column; a column beyond the workgroup's instances computes a copy and stores nothing)
     const bool jlive = j < kGroupWaves;
     double *sj = slices + (size_t)(jlive ? j : 0) * M.fast_slice;
     double *t0j = sj, *gt0j = sj + ZP, *lgj = gt0j + GPD, *ugj = lgj + GPD, *fj = ugj + GPD;
 
-    {
-        const int b0 = blockIdx.x * kGroupWaves;    // one batch of sixteen (eight) per workgroup, no loop (see lmpc_solve)
-        const int bj = b0 + (jlive ? j : kGroupWaves - 1);
-        const int bc = bj < Bt.batch ? bj : Bt.batch - 1;
-        // profiling aid: when the wavefront started its batch, when the first product was done, when the records were complete
-        auto gstamp = [&](int k) { if (Bt.dbg_cycles && lane == 0 && b0 + wave < Bt.batch) Bt.dbg_cycles[(size_t)(b0 + wave) * 8 + k] = (long long)__builtin_readcyclecounter(); };
-        gstamp(4);
-        fast_init_pads<CPZ, CPG>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
-        // vin operands: k-step kb holds rows 4kb + kq of instance j
-        for (int kb = wave; kb < kin4; kb += kGroupWaves) {
-            const int k = 4 * kb + kq;
-            double v = 0.0;
-            if (k < M.nxp) { if (k < nx) v = gl(Bt.x0)[(size_t)bc * nx + k]; }
-            else if (k < M.nxp + M.nup) { const int c = k - M.nxp; if (c < nu) v = gl(Bt.u0)[(size_t)bc * nu + c]; }
-            else if (k < M.ione) { const int c = k - M.nxp - M.nup; if (variant && c < ny) v = gl(Bt.yref)[(size_t)bc * Bt.yref_bs + c]; }
-            else if (k == M.ione) v = 1.0;
-            Bv[kb * 64 + lane] = v;
-        }
-        if (threadIdx.x < 16) bad[threadIdx.x] = 0u;
-        __syncthreads();
+    const int b0 = blockIdx.x * kGroupWaves;    // one batch of sixteen (eight) per workgroup, no loop (see lmpc_solve)
+    const int bj = b0 + (jlive ? j : kGroupWaves - 1);
+    const int bc = bj < Bt.batch ? bj : Bt.batch - 1;
+    // profiling aid: when the wavefront started, when the first product was done, when the records were complete
+    auto gstamp = [&](int k) { if (Bt.dbg_cycles && lane == 0 && b0 + wave < Bt.batch) Bt.dbg_cycles[(size_t)(b0 + wave) * 8 + k] = (long long)__builtin_readcyclecounter(); };
+    gstamp(4);
 
+    // ---- every first-touch load of the phase, requested before anything waits
+    // vin operands: k-step kb holds rows 4 kb + kq of instance j (one predicated load per lane: the branches only choose the address)
+    auto vin_at = [&](int kb) -> double {
+        const int k = 4 * kb + kq;
+        gdp src = gl(Bt.x0);
+        bool ld = false;
+        if (k < M.nxp) { ld = k < nx; src = gl(Bt.x0) + ((size_t)bc * nx + k); }
+        else if (k < M.nxp + M.nup) { const int c = k - M.nxp; ld = c < nu; src = gl(Bt.u0) + ((size_t)bc * nu + c); }
+        else if (k < M.ione) { const int c = k - M.nxp - M.nup; ld = variant && c < ny; src = gl(Bt.yref) + ((size_t)bc * Bt.yref_bs + c); }
+        double v = k == M.ione ? 1.0 : 0.0;
+        if (ld) v = *src;
+        return v;
+    };
+    const double vin0 = wave < kin4 ? vin_at(wave) : 0.0;
+    // the box bounds (the workgroup's copy: the first ZP / 2 threads hold a pair each)
+    const int ebx = 2 * (int)threadIdx.x;
+    const bool boxok = ebx < ldz;
+    d2 bxl = {0.0, 0.0}, bxu = {0.0, 0.0};
+    if (ebx < ZP) { bxl = ld2(GP(lw) + (boxok ? ebx : 0)); bxu = ld2(GP(uw) + (boxok ? ebx : 0)); }
+    // first product: the operands of this wavefront's first tile (a wavefront without one requests the last tile's: no divergence, nothing used)
+    const int t1 = wave < ntile1 ? wave : ntile1 - 1;
+    v4d a1[kGroupG1];
+#pragma unroll
+    for (int g = 0; g < kGroupG1; ++g) a1[g] = ld4(MAp + (((size_t)t1 * G1 + (g < G1 ? g : 0)) * 64 + lane) * 4);
+    // ... and what its epilogue compares with or subtracts from: four rows of (lg0, ug0) or of (slo, shi)
+    double eblo[4], ebhi[4];
+    {
+        const bool ing = t1 >= tg && t1 < ts, ins = t1 >= ts && t1 < tq;
+        const gdp plo = ing ? GP(lg0) + 16 * (t1 - tg) : GP(slo) + 16 * (ins ? t1 - ts : 0);
+        const gdp phi = ing ? GP(ug0) + 16 * (t1 - tg) : GP(shi) + 16 * (ins ? t1 - ts : 0);
+        const int lim = ing ? ldg - 16 * (t1 - tg) : (ins ? M.ns - 16 * (t1 - ts) : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + kq;
+            eblo[r] = 0.0; ebhi[r] = 0.0;
+            if (row < lim) { eblo[r] = plo[row]; ebhi[r] = phi[row]; }
+        }
+    }
+    // second product: the operands of this wavefront's first tile
+    const int t2 = wave < ntile2 ? wave : ntile2 - 1;
+    v4d a2[kGroupG2];
+#pragma unroll
+    for (int g = 0; g < kGroupG2; ++g) a2[g] = ld4(Ymp + (((size_t)t2 * G2 + (g < G2 ? g : 0)) * 64 + lane) * 4);
+    // the solve's first look at the general rows -- which are equalities (lg0 == ug0) -- is the same for every instance: the last wavefront looks
+    d2 eql[CPG], equ[CPG];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const int r = 128 * c + 2 * lane;
+        eql[c] = d2{0.0, 0.0}; equ[c] = d2{1.0, 1.0};
+        if (wave == kGroupWaves - 1) { eql[c] = ld2(GP(lg0) + (r < ldg ? r : 0)); equ[c] = ld2(GP(ug0) + (r < ldg ? r : 0)); }
+    }
+
+    fast_init_pads<CPZ, CPG>(mine, ldz, ldg, lane);      // (the previous instance's active-set bitmaps may have run over them)
+    if (wave < kin4) Bv[wave * 64 + lane] = vin0;
+    for (int kb = wave + kGroupWaves; kb < kin4; kb += kGroupWaves) Bv[kb * 64 + lane] = vin_at(kb);
+    if (ebx < ZP) {
+        const double INF = __builtin_huge_val();
+        *reinterpret_cast<double2 *>(lwuw + ebx) = boxok ? make_double2(bxl.x, bxl.y) : make_double2(-INF, -INF);
+        *reinterpret_cast<double2 *>(lwuw + ZP + ebx) = boxok ? make_double2(bxu.x, bxu.y) : make_double2(INF, INF);
+    }
+    if (threadIdx.x < 16) bad[threadIdx.x] = 0u;
+    __syncthreads();
+    gstamp(7);
+#if defined(MPCX_GROUP_CUT) && MPCX_GROUP_CUT == 1
+    { if (threadIdx.x < kGroupWavesOf<CPZ> && blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x < Bt.batch) Bt.done[blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x] = 2; return; }
+#endif
+
+    {
         double c0p = 0.0;
         bool badl = false;
-        for (int t = wave; t < ntile1; t += kGroupWaves) {
+        auto tile1 = [&]<bool PRE>(const int t) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const gdp Mt = MA + 16 * t + j;
-            // every A operand of the tile requested at once: nothing else is resident on this CU to hide a chain of L2 round trips
-            for (int kb = 0; kb < kin4; kb += kGroupKU) {
-                double a[kGroupKU];
+            for (int g0 = 0; g0 < G1; g0 += kGroupG1) {
+                v4d a[kGroupG1];
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) a[u] = Mt[(size_t)(4 * (kb + u < kin4 ? kb + u : kb) + kq) * M.rowsA];
+                for (int g = 0; g < kGroupG1; ++g) a[g] = (PRE && g0 == 0) ? a1[g] : ld4(MAp + (((size_t)t * G1 + (g0 + g < G1 ? g0 + g : g0)) * 64 + lane) * 4);
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) {
-                    const double bq = kb + u < kin4 ? Bv[(kb + u < kin4 ? kb + u : kb) * 64 + lane] : 0.0;      // (LDS: no need to hold them all)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq, acc, 0, 0, 0);
-                }
+                for (int g = 0; g < kGroupG1; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kb = 4 * (g0 + g) + e;
+                        if (kb < kin4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], Bv[kb * 64 + lane], acc, 0, 0, 0);      // (kb is wave-uniform)
+                    }
             }
             if (t < tg) {
                 // linear term: operand of the second product, and the instance's f
@@ -928,13 +1022,16 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * (t - tg) + 4 * r + kq;
-                    if (jlive && row < ldg) { lgj[row] = GP(lg0)[row] - acc[r]; ugj[row] = GP(ug0)[row] - acc[r]; }
+                    if (jlive && row < ldg) {
+                        const double l0 = PRE ? eblo[r] : GP(lg0)[row], u0 = PRE ? ebhi[r] : GP(ug0)[row];
+                        lgj[row] = l0 - acc[r]; ugj[row] = u0 - acc[r];
+                    }
                 }
             } else if (t < tq) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * (t - ts) + 4 * r + kq;
-                    if (row < M.ns) badl |= violates(acc[r], GP(slo)[row], GP(shi)[row], M.eps_abs, M.eps_rel);
+                    if (row < M.ns) badl |= violates(acc[r], PRE ? eblo[r] : GP(slo)[row], PRE ? ebhi[r] : GP(shi)[row], M.eps_abs, M.eps_rel);
                 }
             } else {
 #pragma unroll
@@ -943,7 +1040,10 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
                     if (kb2 < kin4) c0p = fma(0.5 * Bv[kb2 * 64 + lane], acc[r], c0p);
                 }
             }
-        }
+        };
+        int *eqb = reinterpret_cast<int *>(outs + kGroupWaves * outld);      // [64] the equality flags of the general rows, for every wavefront's solve
+        if (wave < ntile1) tile1.template operator()<true>(wave);
+        for (int t = wave + kGroupWaves; t < ntile1; t += kGroupWaves) tile1.template operator()<false>(t);
         if (badl && jlive) atomicOr(&bad[j], 1u);
         // this wavefront's share of the cost constant of instance j (no atomics: the sum must not depend on arrival order)
         c0p += __shfl_xor(c0p, 16, 64);
@@ -951,20 +1051,23 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
         if (kq == 0) c0s[wave * 16 + j] = c0p;
         __syncthreads();
         gstamp(5);
+#if defined(MPCX_GROUP_CUT) && MPCX_GROUP_CUT == 2
+        { if (threadIdx.x < kGroupWavesOf<CPZ> && blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x < Bt.batch) Bt.done[blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x] = 2; return; }
+#endif
 
-        const int ntile2 = M.ldy16 >> 4;
-        for (int t = wave; t < ntile2; t += kGroupWaves) {
+        auto tile2 = [&]<bool PRE>(const int t) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const gdp Yt = Ym + 16 * t + j;
-            for (int kb = 0; kb < nz4; kb += kGroupKU) {
-                double a[kGroupKU];
+            for (int g0 = 0; g0 < G2; g0 += kGroupG2) {
+                v4d a[kGroupG2];
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) a[u] = Yt[(size_t)(4 * (kb + u < nz4 ? kb + u : kb) + kq) * M.ldy16];
+                for (int g = 0; g < kGroupG2; ++g) a[g] = (PRE && g0 == 0) ? a2[g] : ld4(Ymp + (((size_t)t * G2 + (g0 + g < G2 ? g0 + g : g0)) * 64 + lane) * 4);
 #pragma unroll
-                for (int u = 0; u < kGroupKU; ++u) {
-                    const double bq = kb + u < nz4 ? Bf[(kb + u < nz4 ? kb + u : kb) * 64 + lane] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq, acc, 0, 0, 0);
-                }
+                for (int g = 0; g < kGroupG2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kb = 4 * (g0 + g) + e;
+                        if (kb < nz4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], Bf[kb * 64 + lane], acc, 0, 0, 0);
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -973,6 +1076,17 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
                 if (row < ldz) t0j[row] = acc[r];
                 else if (row < ldy) gt0j[row - ldz] = acc[r];
             }
+        };
+        if (wave < ntile2) tile2.template operator()<true>(wave);
+        for (int t = wave + kGroupWaves; t < ntile2; t += kGroupWaves) tile2.template operator()<false>(t);
+        if (wave == kGroupWaves - 1) {                          // (a wavefront without a tile of the second product at the benchmark's sizes)
+            int bits = 0;
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const bool ok = 128 * c + 2 * lane < ldg;
+                bits |= ((ok && eql[c].x == equ[c].x) ? 1 : 0) << (2 * c) | ((ok && eql[c].y == equ[c].y) ? 1 : 0) << (2 * c + 1);
+            }
+            eqb[lane] = bits;
         }
         if (threadIdx.x < kGroupWaves) {
             double *tl = slices + (size_t)threadIdx.x * M.fast_slice + 2 * ZP + 3 * GPD;
@@ -982,9 +1096,13 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
             tl[1] = bad[threadIdx.x] ? 1.0 : 0.0;
         }
         __syncthreads();
+        const int eqbits = eqb[lane];
         const int b = b0 + wave;
         gstamp(6);
-        if (b < Bt.batch) solve_fast<CPZ, CPG, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld);
+#if defined(MPCX_GROUP_CUT) && MPCX_GROUP_CUT == 3
+        { if (threadIdx.x < kGroupWavesOf<CPZ> && blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x < Bt.batch) Bt.done[blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x] = 2; return; }
+#endif
+        if (b < Bt.batch) solve_fast<CPZ, CPG, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld, eqbits);
         __syncthreads();
         // the sixteen instances' results, written by neighbouring lanes: one transaction per array and workgroup instead of sixteen
         {
@@ -1056,7 +1174,7 @@ int launch_fast_variant(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchD
                 gconf[devid].store(1, std::memory_order_release);
             }
             const int wgs = (b.batch + NW - 1) / NW;
-            hipLaunchKernelGGL((lmpc_solve_group<CPZ, CPG>), dim3(wgs), dim3(NW * 64), ldsg, stream, m_dev, b, ws, b.fused - 3);
+            hipLaunchKernelGGL((lmpc_solve_group<CPZ, CPG>), dim3(wgs), dim3(NW * 64), ldsg, stream, m, b, ws, b.fused - 3);      // (the model struct by value: see the kernel)
             return hipGetLastError() == hipSuccess ? 0 : -3;
         }
     }
@@ -1093,13 +1211,13 @@ int lmpc_fast_slice(const LmpcDev &m)
 }
 
 // LDS block of lmpc_solve_group for this controller (0: no group form for its variant): two box-bound vectors, a slice per instance, the staged
-// MFMA operands, the cost constants and flags, the result records
+// MFMA operands, the cost constants and flags, the result records, the equality flags of the general rows
 size_t lmpc_group_lds_bytes(const LmpcDev &m)
 {
     const int cp = lmpc_kernel_variant(m.ldz, m.ldg);
     if (cp != 1 && cp != 2) return 0;
     const int nw = cp == 1 ? 16 : 8;
-    return ((size_t)2 * 128 * cp + (size_t)nw * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + (size_t)nw * 16 + 16 + (size_t)nw * (8 + ((m.nu + 1) & ~1))) * sizeof(double);
+    return ((size_t)2 * 128 * cp + (size_t)nw * m.fast_slice + (size_t)(m.kin / 4 + m.nz16 / 4) * 64 + (size_t)nw * 16 + 16 + (size_t)nw * (8 + ((m.nu + 1) & ~1)) + 32) * sizeof(double);
 }
 
 int lmpc_launch_fast(const LmpcDev &m, const LmpcDev *m_dev, const LmpcBatchDev &b, double *ws, void *stream)

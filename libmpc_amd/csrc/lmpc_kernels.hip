@@ -1374,12 +1374,21 @@ template <int CPZ, int CPG>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void lmpc_solve_admm(const LmpcDev *__restrict__ Mp, const LmpcBatchDev Bt, double *wsbase)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const LmpcDev &M = *Mp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    // the usual launch finds nothing to do: with the flags in an array of their own (lmpc_solve_group's), a wavefront whose first chunk is the only one it
+    // has and is all done leaves before it has looked at the model struct at all -- one trip to memory instead of three in a row
+    if (Bt.chunked && Bt.done) {
+        const int c0 = (blockIdx.x * wpb + wave) * kFallbackChunk;
+        if (c0 + (int)(gridDim.x * wpb * kFallbackChunk) >= Bt.batch) {
+            const int bi = c0 + lane;
+            if (__ballot(lane < kFallbackChunk && bi < Bt.batch && gl(Bt.done)[bi] == 0) == 0ull) return;
+        }
+    }
+    const LmpcDev &M = *Mp;
     double *stage = smem + (size_t)wave * M.lds_per_wave;
     double *nt0 = stage + M.stage_len;
     double *arena = nt0 + M.ldy;
-    const int wpb = blockDim.x >> 6;
     if (Bt.chunked) {
         // after the polish-only kernel almost nothing is left: a wavefront looks at the flags of kFallbackChunk instances at
         // once (one load each, side by side) and only enters the solver for those still open -- an eighth of the wavefronts

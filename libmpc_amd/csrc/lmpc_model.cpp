@@ -1,5 +1,6 @@
 // Host-side controller state and condensing.  See lmpc_model.hpp.
 #include "lmpc_model.hpp"
+#include "lmpc_device.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -688,6 +689,18 @@ void LmpcController::refresh_fast_maps(Condensed &o) const
         }
     }
     compose_fused_maps(o);
+}
+
+void lmpc_pack_mfma_tiles(const double *src, int rows, int K, double *out)
+{
+    const int T = rows / 16, G = (K + 15) / 16;
+    for (int t = 0; t < T; t++)
+        for (int g = 0; g < G; g++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 4; e++) {
+                    const int k = 4 * (4 * g + e) + (lane >> 4);
+                    out[(((size_t)t * G + g) * 64 + lane) * 4 + e] = k < K ? src[(size_t)k * rows + 16 * t + (lane & 15)] : 0.0;
+                }
 }
 
 }  // namespace mpcx

@@ -165,6 +165,15 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
     D.nz16 = o.nz16; D.mg16 = o.mg16; D.ns = o.ns; D.ns16 = o.ns16; D.kq16 = o.kq16; D.rowsA = o.rowsA; D.ldy16 = o.ldy16;
     D.fast_slice = mpcx::lmpc_fast_slice(D);
     D.MA0 = U.up(o.MA[0], rc); D.MA1 = U.up(o.MA[1], rc); D.Ym = U.up(o.Ym, rc);
+    {
+        std::vector<double> pk;
+        auto packed = [&](const std::vector<double> &v, int rows, int K) -> const std::vector<double> & {
+            pk.clear();
+            if (!v.empty()) { pk.resize(mpcx::lmpc_packed_len(rows, K)); mpcx::lmpc_pack_mfma_tiles(v.data(), rows, K, pk.data()); }
+            return pk;
+        };
+        D.MA0p = U.up(packed(o.MA[0], o.rowsA, o.kin), rc); D.MA1p = U.up(packed(o.MA[1], o.rowsA, o.kin), rc); D.Ymp = U.up(packed(o.Ym, o.ldy16, o.nz16), rc);
+    }
     D.MF0 = U.up(o.MF[0], rc); D.MF1 = U.up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
     // (and the cost comes from the multipliers: otherwise the two-kernel path's batched cost kernel is the better one)
@@ -249,7 +258,7 @@ static void rebase_dev(mpcx::LmpcDev &D, const char *base, const char *base_dev)
     fix(D.g_kind); fix(D.g_step); fix(D.g_comp); fix(D.g_refrow);
     fix(D.f_kind); fix(D.f_step); fix(D.f_comp); fix(D.f_lo); fix(D.f_hi);
     fix(D.boxrow_ptr); fix(D.boxrow_ref); fix(D.boxrow_lo); fix(D.boxrow_hi); fix(D.blk);
-    fix(D.MA0); fix(D.MA1); fix(D.Ym); fix(D.slo); fix(D.shi); fix(D.MF0); fix(D.MF1);
+    fix(D.MA0); fix(D.MA1); fix(D.Ym); fix(D.MA0p); fix(D.MA1p); fix(D.Ymp); fix(D.slo); fix(D.shi); fix(D.MF0); fix(D.MF1);
 }
 
 extern "C" {
@@ -553,6 +562,13 @@ static int refresh_references(mpcx_lmpc_t h)
     const bool ok = h->reup(D.yref_s, c.yRef.a) && h->reup(D.uref_s, c.uRef.a) && h->reup(D.duref_s, c.duRef.a) &&
                     h->reup(D.dmeas_s, c.dMeas.a) && h->reup(D.MA0, h->cond.MA[0]) && h->reup(D.MA1, h->cond.MA[1]) &&
                     h->reup(D.MF0, h->cond.MF[0]) && h->reup(D.MF1, h->cond.MF[1]);
+    if (ok && !h->cond.MA[0].empty()) {          // ... and their packed copies (lmpc_solve_group's)
+        std::vector<double> pk(mpcx::lmpc_packed_len(h->cond.rowsA, h->cond.kin));
+        for (int v = 0; v < 2; ++v) {
+            mpcx::lmpc_pack_mfma_tiles(h->cond.MA[v].data(), h->cond.rowsA, h->cond.kin, pk.data());
+            if (!h->reup(v ? D.MA1p : D.MA0p, pk)) return fail(MPCX_E_DEVICE, "device upload failed");
+        }
+    }
     return ok ? MPCX_OK : fail(MPCX_E_DEVICE, "device upload failed");
 }
 

@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 t = buf.cpu().numpy().astype(np.float64)
 # the cycle counter (s_memtime) is per XCD: stamps compare within a workgroup, not across workgroups
 print("N=%d batch %d (cycles over instances)" % (ph, B))
-for name, v in (("vin + first product", t[:, 5] - t[:, 4]), ("second product + tails", t[:, 6] - t[:, 5]),
+for name, v in (("kernel entry -> inputs staged", t[:, 7] - t[:, 4]), ("first product", t[:, 5] - t[:, 7]), ("second product + tails", t[:, 6] - t[:, 5]),
                 ("solve: slice -> first working set", t[:, 1] - t[:, 0]), ("solve: rounds", t[:, 2] - t[:, 1]), ("solve: unpack", t[:, 3] - t[:, 2]),
                 ("wavefront start -> end of its instance", t[:, 3] - t[:, 4])):
     print("  %-44s min %9.0f p10 %9.0f median %9.0f max %9.0f" % (name, v.min(), np.percentile(v, 10), np.median(v), v.max()))
