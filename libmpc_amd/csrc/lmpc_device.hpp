@@ -57,6 +57,7 @@ struct LmpcDev {
     // the same maps as lmpc_solve_group takes them (lmpc_pack_mfma_tiles): a lane's A operands of four consecutive k-steps side by side, a wavefront's of
     // one row tile and k-step group 2 KB in a row -- the phase is bound by the vector memory pipe's instruction rate, not by bytes
     const double *MA0p, *MA1p, *Ymp;
+    const double *Hp;                            // H the same way, nz16 x nz16 zero padded (lmpc_cost_mfma's operand; null unless cost_direct)
     // composed maps of the fused solve kernel: rows [t0; gt0 (ldy) | goff (ldg) | f (ldz) | feasibility rows (nsp) | Qc vin (kin)]
     int rowsF, nsp, fused_ok, group_ok;
     const double *MF0, *MF1;

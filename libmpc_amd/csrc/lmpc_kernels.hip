@@ -400,8 +400,11 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
     double *Bf = Bv + (size_t)kin4 * 64;             // [nz4][64]    f as MFMA B operands
     double *c0s = Bf + (size_t)nz4 * 64;             // [4][16]: one slot per wavefront and instance, added up in wave order
     unsigned *bad = reinterpret_cast<unsigned *>(c0s + 64);   // [16]
-    const gdp MA = gl(variant ? M.MA1 : M.MA0), Ym = GP(Ym);
+    const gdp MAp = gl(variant ? M.MA1p : M.MA0p), Ymp = GP(Ymp);
     const int ntile1 = M.rowsA >> 4, tg = M.nz16 >> 4, ts = tg + (M.mg16 >> 4), tq = ts + (M.ns16 >> 4);
+    const int G1 = (kin4 + 3) >> 2, G2 = (nz4 + 3) >> 2;          // k-step groups per row tile of the packed maps
+    constexpr int kAsmGB = 4;                                      // groups in flight per wavefront: sixteen k-steps
+    auto ld4 = [](gdp p) -> v4d { return *reinterpret_cast<const v4d MPCX_GAS *>(p); };
 
     for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
         const int bj = b0 + j;
@@ -425,19 +428,19 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
         bool badl = false;
         for (int t = wave; t < ntile1; t += 4) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const gdp Mt = MA + 16 * t + j;
-            int kb = 0;
-            for (; kb + 4 <= kin4; kb += 4) {
-                double a[4], bq[4];
+            // (operands from the packed copy of the map: 32 contiguous bytes per lane and load, four k-steps each -- lmpc_pack_mfma_tiles)
+            for (int g0 = 0; g0 < G1; g0 += kAsmGB) {
+                v4d a[kAsmGB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = Mt[(size_t)(4 * (kb + u) + kq) * M.rowsA];
+                for (int g = 0; g < kAsmGB; ++g) if (g0 + g < G1) a[g] = ld4(MAp + (((size_t)t * G1 + g0 + g) * 64 + lane) * 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = Bv[(kb + u) * 64 + lane];
+                for (int g = 0; g < kAsmGB; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const int kb = 4 * (g0 + g) + e;
+                        if (kb < kin4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], Bv[kb * 64 + lane], acc, 0, 0, 0);
+                    }
             }
-            for (; kb < kin4; ++kb)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(size_t)(4 * kb + kq) * M.rowsA], Bv[kb * 64 + lane], acc, 0, 0, 0);
             if (t < tg) {
                 // linear term: keep as operand for the second product, and file it
 #pragma unroll
@@ -476,19 +479,18 @@ __global__ __launch_bounds__(256) void lmpc_assemble_mfma(const LmpcDev *__restr
         const int ntile2 = M.ldy16 >> 4;
         for (int t = wave; t < ntile2; t += 4) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const gdp Yt = Ym + 16 * t + j;
-            int kb = 0;
-            for (; kb + 4 <= nz4; kb += 4) {
-                double a[4], bq[4];
+            for (int g0 = 0; g0 < G2; g0 += kAsmGB) {
+                v4d a[kAsmGB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = Yt[(size_t)(4 * (kb + u) + kq) * M.ldy16];
+                for (int g = 0; g < kAsmGB; ++g) if (g0 + g < G2) a[g] = ld4(Ymp + (((size_t)t * G2 + g0 + g) * 64 + lane) * 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = Bf[(kb + u) * 64 + lane];
+                for (int g = 0; g < kAsmGB; ++g)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const int kb = 4 * (g0 + g) + e;
+                        if (kb < nz4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], Bf[kb * 64 + lane], acc, 0, 0, 0);
+                    }
             }
-            for (; kb < nz4; ++kb)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(size_t)(4 * kb + kq) * M.ldy16], Bf[kb * 64 + lane], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
@@ -1421,7 +1423,9 @@ __global__ __launch_bounds__(256) void lmpc_cost_mfma(const LmpcDev *__restrict_
     const int ldz = M.ldz, ldy = M.ldy, ldg = M.ldg, nz4 = M.nz16 >> 2, ntile = M.nz16 >> 4;
     double *Bw = smem;                              // [nz4][64]
     double *cs = Bw + (size_t)nz4 * 64;             // [4 wavefronts][16 instances]
-    const gdp H = GP(H);
+    const gdp H = GP(H), Hp = GP(Hp);
+    const int G = (nz4 + 3) >> 2;
+    constexpr int kCostGB = 4;
     for (int b0 = blockIdx.x * 16; b0 < Bt.batch; b0 += gridDim.x * 16) {
         const int bj = b0 + j;
         const bool live = bj < Bt.batch;
@@ -1436,25 +1440,41 @@ __global__ __launch_bounds__(256) void lmpc_cost_mfma(const LmpcDev *__restrict_
         double part = 0.0;
         for (int tl = wave; tl < ntile; tl += 4) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const int rowa = 16 * tl + j;
-            const gdp Ht = H + (rowa < ldz ? rowa : 0);
-            int kb = 0;
-            for (; kb + 4 <= nz4; kb += 4) {
-                double a[4], bq[4];
+            if (Hp) {
+                // operands from the packed, zero-padded copy of H: 32 contiguous bytes per lane and load, four k-steps each (the same products in the same order)
+                for (int g0 = 0; g0 < G; g0 += kCostGB) {
+                    v4d a[kCostGB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int col = 4 * (kb + u) + kq;
-                    a[u] = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
+                    for (int g = 0; g < kCostGB; ++g) if (g0 + g < G) a[g] = *reinterpret_cast<const v4d MPCX_GAS *>(Hp + (((size_t)tl * G + g0 + g) * 64 + lane) * 4);
+#pragma unroll
+                    for (int g = 0; g < kCostGB; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kb = 4 * (g0 + g) + e;
+                            if (kb < nz4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][e], Bw[kb * 64 + lane], acc, 0, 0, 0);
+                        }
                 }
+            } else {
+                const int rowa = 16 * tl + j;
+                const gdp Ht = H + (rowa < ldz ? rowa : 0);
+                int kb = 0;
+                for (; kb + 4 <= nz4; kb += 4) {
+                    double a[4], bq[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = Bw[(kb + u) * 64 + lane];
+                    for (int u = 0; u < 4; ++u) {
+                        const int col = 4 * (kb + u) + kq;
+                        a[u] = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
-            }
-            for (; kb < nz4; ++kb) {
-                const int col = 4 * kb + kq;
-                const double a = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bw[kb * 64 + lane], acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) bq[u] = Bw[(kb + u) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+                }
+                for (; kb < nz4; ++kb) {
+                    const int col = 4 * kb + kq;
+                    const double a = (col < M.nz && rowa < ldz) ? Ht[(size_t)col * ldz] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bw[kb * 64 + lane], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

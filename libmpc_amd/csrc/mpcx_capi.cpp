@@ -173,6 +173,13 @@ static void fill_dev_arrays(const mpcx_lmpc *h, const mpcx::LmpcController &c, c
             return pk;
         };
         D.MA0p = U.up(packed(o.MA[0], o.rowsA, o.kin), rc); D.MA1p = U.up(packed(o.MA[1], o.rowsA, o.kin), rc); D.Ymp = U.up(packed(o.Ym, o.ldy16, o.nz16), rc);
+        std::vector<double> hpad;
+        if (D.cost_direct && !o.MA[0].empty() && !o.H.empty()) {          // (a controller that takes lmpc_cost_mfma: the shared-model path with the cost from its definition)
+            hpad.assign((size_t)o.nz16 * o.nz16, 0.0);
+            for (int c = 0; c < o.nz; ++c)
+                for (int r = 0; r < o.nz; ++r) hpad[(size_t)c * o.nz16 + r] = o.H[(size_t)c * o.ldz + r];
+        }
+        D.Hp = hpad.empty() ? nullptr : U.up(packed(hpad, o.nz16, o.nz16), rc);
     }
     D.MF0 = U.up(o.MF[0], rc); D.MF1 = U.up(o.MF[1], rc); D.rowsF = o.rowsF; D.nsp = o.nsp;
     // the fused kernel serves the one-chunk variant while the composed map stays small enough to stream from L2 per instance
@@ -258,7 +265,7 @@ static void rebase_dev(mpcx::LmpcDev &D, const char *base, const char *base_dev)
     fix(D.g_kind); fix(D.g_step); fix(D.g_comp); fix(D.g_refrow);
     fix(D.f_kind); fix(D.f_step); fix(D.f_comp); fix(D.f_lo); fix(D.f_hi);
     fix(D.boxrow_ptr); fix(D.boxrow_ref); fix(D.boxrow_lo); fix(D.boxrow_hi); fix(D.blk);
-    fix(D.MA0); fix(D.MA1); fix(D.Ym); fix(D.MA0p); fix(D.MA1p); fix(D.Ymp); fix(D.slo); fix(D.shi); fix(D.MF0); fix(D.MF1);
+    fix(D.MA0); fix(D.MA1); fix(D.Ym); fix(D.MA0p); fix(D.MA1p); fix(D.Ymp); fix(D.Hp); fix(D.slo); fix(D.shi); fix(D.MF0); fix(D.MF1);
 }
 
 extern "C" {
