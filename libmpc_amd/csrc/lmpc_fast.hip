@@ -728,7 +728,10 @@ __device__ void solve_fast(const LmpcDev &M, const LmpcBatchDev &Bt, const int b
 #ifndef MPCX_FAST_WAVES1
 #define MPCX_FAST_WAVES1 4
 #endif
-template <int CPZ> constexpr int fast_waves() { return CPZ == 1 ? MPCX_FAST_WAVES1 : 2; }     // (CPZ = 2 at three per SIMD: 7 % faster at config 4, but 20 spilled VGPRs = 74 MB of scratch writes per 32 768)
+#ifndef MPCX_FAST_WAVES2
+#define MPCX_FAST_WAVES2 2
+#endif
+template <int CPZ> constexpr int fast_waves() { return CPZ == 1 ? MPCX_FAST_WAVES1 : (CPZ == 2 ? MPCX_FAST_WAVES2 : 2); }     // (CPZ = 2 at three per SIMD: 7 % faster at config 4, but 20 spilled VGPRs = 74 MB of scratch writes per 32 768)
 
 // LDS of the lean kernels: [lw | uw] of the workgroup (padded to whole lane pairs), then one slice per wavefront (M.fast_slice doubles)
 template <int CPZ>

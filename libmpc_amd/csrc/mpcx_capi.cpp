@@ -1190,8 +1190,13 @@ int mpcx_lmpc_debug_get(mpcx_lmpc_t h, const char *name, double *out, int cap)
                (double)o.n_ref, (double)o.m_ref, (double)o.neq_ref, (double)o.fixed_rows.size(),
                (double)h->dev.lds_per_wave, (double)(o.h_regularised ? 1 : 0)};
         v = &tmp;
-    } else if (n == "MA0") v = &o.MA[0]; else if (n == "MA1") v = &o.MA[1];
-    else if (n == "flags") {           // which forms of the solve this controller can take: cost from its definition (lmpc_cost_mfma follows lmpc_solve), one-workgroup form, fused mat-vec form
+    } else if (n == "MA0") v = &o.MA[0]; else if (n == "MA1") v = &o.MA[1]; else if (n == "Ym") v = &o.Ym;
+    else if (n == "MA0p" || n == "MA1p" || n == "Ymp") {      // the packed copies lmpc_solve_group / lmpc_assemble_mfma read (computed here as at upload)
+        const std::vector<double> &src = n == "Ymp" ? o.Ym : o.MA[n == "MA1p" ? 1 : 0];
+        const int rows = n == "Ymp" ? o.ldy16 : o.rowsA, K = n == "Ymp" ? o.nz16 : o.kin;
+        if (!src.empty()) { tmp.resize(mpcx::lmpc_packed_len(rows, K)); mpcx::lmpc_pack_mfma_tiles(src.data(), rows, K, tmp.data()); }
+        v = &tmp;
+    } else if (n == "flags") {           // which forms of the solve this controller can take: cost from its definition (lmpc_cost_mfma follows lmpc_solve), one-workgroup form, fused mat-vec form
         tmp = {(double)h->dev.cost_direct, (double)h->dev.group_ok, (double)h->dev.fused_ok};
         v = &tmp;
     } else if (n == "dims_maps") {

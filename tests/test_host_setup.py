@@ -242,3 +242,23 @@ def test_reference_setters_do_not_rebuild_the_controller():
     c.info()
     lib.mpcx_lmpc_debug_setup_counts(c._h, C.byref(full), C.byref(refs))
     assert full.value == 2
+
+
+@pytest.mark.parametrize("ph", [10, 20, 50])
+def test_packed_mfma_operands_are_the_maps_rearranged(ph):
+    """lmpc_pack_mfma_tiles (what lmpc_solve_group, lmpc_assemble_mfma and lmpc_cost_mfma read their A operands from): entry ((t G + g) 64 + lane) 4 + e of
+    the packed copy is entry (row 16 t + lane % 16, column 4 (4 g + e) + lane // 16) of the map, zero beyond its columns -- every entry of the map exactly once"""
+    from libmpc_amd.workloads import quadrotor_lmpc
+    c = quadrotor_lmpc(ph, device=-1)
+    kin, _, _, _, _, nz16, _, _, _, _, rowsA, ldy16 = c.debug_get("dims_maps").astype(int)
+    for name, rows, K in (("MA0", rowsA, kin), ("MA1", rowsA, kin), ("Ym", ldy16, nz16)):
+        src = c.debug_get(name).reshape(K, rows)            # column-major rows x K: [k][row]
+        G = (K + 15) // 16
+        p = c.debug_get(name + "p").reshape(rows // 16, G, 64, 4)
+        lane = np.arange(64)
+        for g in range(G):
+            for e in range(4):
+                k = 4 * (4 * g + e) + lane // 16
+                want = np.where((k < K)[None, :], np.stack([src[np.minimum(k, K - 1), 16 * t + lane % 16] for t in range(rows // 16)]), 0.0)
+                assert np.array_equal(p[:, g, :, e], want), (name, g, e)
+        assert np.isclose(np.abs(p).sum(), np.abs(src).sum(), rtol=1e-12)
