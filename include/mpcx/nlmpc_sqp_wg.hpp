@@ -3062,8 +3062,13 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 #ifdef MPCX_EMU_TRACE
     auto lap = [&](int k) { const long long now = hipemu::st().n_block_syncs; cyc[k] += now - tstamp; tstamp = now; };    // (the interpreter: barriers per phase)
     tstamp = hipemu::st().n_block_syncs;
-#else
+#elif defined(MPCX_NL_STATS)
     auto lap = [&](int k) { const long long now = __builtin_readcyclecounter(); cyc[k] += now - tstamp; tstamp = now; };
+#else
+    // (the product build keeps no phase clock: ten counters live across every out-of-line phase are ten stack slots -- scratch, i.e. memory -- read and
+    // written a dozen times per iteration by every lane, on the dependent chain of a kernel that is bound by exactly that)
+    auto lap = [](int) {};
+    (void)cyc; (void)tstamp;
 #endif
     const bool tol_on = S.ftol_abs > 0 || S.ftol_rel > 0 || S.xtol_abs > 0 || S.xtol_rel > 0;
     int it = 0, code = 5, attempt = 0;                   // nlopt codes: 3 FTOL_REACHED, 4 XTOL_REACHED, 5 MAXEVAL_REACHED, -1 FAILURE, -3 OUT_OF_MEMORY, -4 ROUNDOFF_LIMITED
@@ -3187,7 +3192,9 @@ __global__ __launch_bounds__(64 * WAVES, (kWgWavesPerSimd<Mdl, WAVES, FL>)) void
 #ifdef MPCX_NL_STATS
         for (int k = 0; k < 16; ++k) scal[16 + k] = st[ST_QSTAT + k];  // (beyond the statistics block: a part of the workspace this form does not use)
 #endif
+#if defined(MPCX_NL_STATS) || defined(MPCX_EMU_TRACE)
         for (int k = 0; k < 10; ++k) scal[2 + k] = (double)cyc[k];
+#endif
     }
     (void)NT;
 }

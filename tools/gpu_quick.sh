@@ -10,4 +10,4 @@ T=${1:-r02}
 for w in vanderpol ugv osc6 osc8; do
   ( timeout 400 python bench.py --workload $w --cpu-seconds 0 ) > $O/${T}_bench_$w.json 2> $O/${T}_bench_$w.err; cut -c1-200 $O/${T}_bench_$w.json; tail -2 $O/${T}_bench_$w.err | grep -v amdgpu.ids
 done
-for w in osc8 ugv; do ( timeout 300 python tools/nlmpc_phases.py $w 256 ) > $O/${T}_phases_$w.txt 2>&1; cat $O/${T}_phases_$w.txt | grep -v amdgpu.ids; done
+for w in osc8 ugv; do ( MPCX_LIBRARY=$PWD/libmpc_amd/libmpcx_stats.so timeout 300 python tools/nlmpc_phases.py $w 256 ) > $O/${T}_phases_$w.txt 2>&1; cat $O/${T}_phases_$w.txt | grep -v amdgpu.ids; done
