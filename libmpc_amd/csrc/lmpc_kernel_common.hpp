@@ -26,6 +26,10 @@ constexpr int kFallbackChunk = 64;      // instances one wavefront of the fallba
 #define MPCX_ADD_THETA 0.3
 #endif
 // lean solve (solve_fast): thresholds of the first working set and of the rows that enter later, as fractions of the largest violation
+// (round 6 tried 0.5: tools/activeset_sim.py over five batches of 4096 at N = 20 and one each at N = 10 / 50 has the mean number of rounds fall by 2 % at every
+// horizon -- 3.512 -> 3.440, 3.548 -> 3.464, 3.579 -> 3.504; N = 50: 3.557 -> 3.485 -- and the GPU reports those counts; side by side on one box the benchmark
+// batch is 1 % SLOWER with it (0.0459 vs 0.0463 ms: its time is its slowest instance's, whose later working sets are larger), 32768 instances 0.8 % faster,
+// config 4's shard within the noise: kept at 0.3)
 #ifndef MPCX_INIT_THETA
 #define MPCX_INIT_THETA 0.3
 #endif

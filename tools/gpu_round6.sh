@@ -34,6 +34,12 @@ done
 for wb in "ugv 256" "osc8 256"; do set -- $wb
   ( timeout 300 python bench.py --workload $1 --batch $2 --cpu-seconds 0 --steps 5 --warmup 1 ) > $O/${T}_bench_$1_b$2.json 2> $O/${T}_bench_$1_b$2.err; cut -c1-200 $O/${T}_bench_$1_b$2.json
 done
+# lmpc_solve_group cut short (tools/group_cut.sh built libmpcx_cut{0..3}.so before this call): what each part of its assemble phase costs a launch
+if [ -f libmpc_amd/libmpcx_cut0.so ]; then
+  ( for k in 0 1 2 3; do echo -n "kernel returns after part $k (0 entry, 1 inputs staged, 2 first product, 3 second product): "; MPCX_LIBRARY=$PWD/libmpc_amd/libmpcx_cut$k.so timeout 120 python tools/group_cut.py 2>&1 | grep "step ms"; done
+    echo -n "the whole kernel: "; timeout 120 python tools/group_cut.py 2>&1 | grep "step ms" ) > $O/${T}_group_cut.txt 2>&1; cat $O/${T}_group_cut.txt
+fi
+( timeout 200 python tools/group_phases.py 20 4096 2>&1 | grep -v "amdgpu.ids\|Warn" ) > $O/${T}_group_phases_lmpc20_b4096.txt; tail -12 $O/${T}_group_phases_lmpc20_b4096.txt
 for wb in "osc8 256" "osc8 1024" "ugv 256" "ugv 4096" "osc6 1024"; do set -- $wb
   ( MPCX_LIBRARY=$PWD/libmpc_amd/libmpcx_stats.so timeout 300 python tools/nlmpc_phases.py $1 $2 ) > $O/${T}_phases_wg_$1_b$2.txt 2>&1; grep -v "amdgpu.ids\|Warn" $O/${T}_phases_wg_$1_b$2.txt | tail -14
 done

@@ -12,5 +12,4 @@ batch, res, keep = c.make_batch(x0, u0, yref=yref)
 for _ in range(3):
     c.launch(batch)
 torch.cuda.synchronize()
-ks = None
-print("step ms %.4f  kernels %s" % (c.time_launches(batch, 200), ks))
+print("step ms %.4f (lmpc_solve_group + the idle fallback launch, HIP events over 200 steps)" % c.time_launches(batch, 200))
