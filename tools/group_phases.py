@@ -32,3 +32,15 @@ g = t[: B // 16 * 16, 4].reshape(-1, 16)
 print("  spread of the 16 start stamps in a workgroup: median %.0f max %.0f" % (np.median(g.max(axis=1) - g.min(axis=1)), (g.max(axis=1) - g.min(axis=1)).max()))
 ms = c.time_launches(batch, 50)
 print("step ms %.4f" % ms)
+# the instances that set the launch time: rounds and final working-set size of the ten slowest solves
+try:
+    rr = res.polish_rounds.cpu().numpy(); ac = res.active_count.cpu().numpy()
+    dur = t[:, 3] - t[:, 0]
+    order = np.argsort(-dur)[:10]
+    print("slowest solves (instance: cycles, rounds, final working rows): " + "; ".join("%d: %.0f, %d, %d" % (i, dur[i], rr[i], ac[i]) for i in order))
+    for k in range(1, int(rr.max()) + 1):
+        m = rr == k
+        if m.any():
+            print("  %d rounds: %5d instances, solve cycles median %7.0f max %7.0f" % (k, m.sum(), np.median(dur[m]), dur[m].max()))
+except Exception as e:      # (a result object without these arrays)
+    print("no per-instance round counts:", e)
