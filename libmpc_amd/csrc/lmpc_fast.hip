@@ -875,6 +875,10 @@ __device__ __forceinline__ void kernarg_touch()
                  : "s"(ka)
                  : "memory");
 }
+#ifndef MPCX_GROUP_BALANCE
+#define MPCX_GROUP_BALANCE 1
+#endif
+
 template <int CPZ> constexpr int kGroupWavesOf = CPZ == 1 ? 16 : 8;
 constexpr int kGroupG2 = 5;               // groups of four MFMA k-steps of the second product whose A operands are in flight together (the whole of N = 20's)
 constexpr int kGroupG1 = 2;               // ... of the first product (kin = 32: the whole of it for up to 12 states, 4 inputs and 12 outputs)
@@ -1100,12 +1104,55 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
         }
         __syncthreads();
         const int eqbits = eqb[lane];
-        const int b = b0 + wave;
+        // ---- which wavefront solves which instance.  A launch of the benchmark batch holds every instance at once, four wavefronts on every SIMD, and it
+        // ends when the busiest SIMD has issued the rounds of its four: the time of the launch is that SIMD's work (tools/group_phases.py: solves of six
+        // rounds took 45 k cycles at the median and 78 k where the three neighbours were long ones too -- 25 rounds on the worst SIMD of the batch against
+        // 14 on average; asking the arbiter for precedence changes nothing, measured).  How many rounds an instance will need is not known, but how far its
+        // unconstrained optimum lies outside the bounds says a good deal about it (the sum of the violations correlates 0.83 with the rounds over the
+        // benchmark batch, their number 0.76: tools/activeset_sim.py), and the slices are in LDS: the instances are dealt to the wavefronts in the order of
+        // that sum, back and forth over the four SIMDs (wavefront w runs on SIMD w mod 4) -- the worst SIMD's rounds 25 -> 22 in the simulation (19 with the
+        // rounds known beforehand, 18.2 = a quarter of the worst workgroup's), the step 0.0460 -> 0.0408 ms on the GPU (dealt by the number: 0.0425).
+        int inst = wave;
+#if MPCX_GROUP_BALANCE
+        if (b0 + kGroupWaves <= Bt.batch) {
+            const double *t0m = mine, *gt0m = mine + ZP, *lgm = gt0m + GPD, *ugm = lgm + GPD;
+            auto over = [](double v, double lo, double hi) { return fmax(fmax(lo - v, v - hi), 0.0); };
+            double sv = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPZ; ++c) {
+                const int e = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lwuw + e), u = *reinterpret_cast<const double2 *>(lwuw + ZP + e), t = *reinterpret_cast<const double2 *>(t0m + e);
+                sv += over(t.x, l.x, u.x) + over(t.y, l.y, u.y);
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const int r = 128 * c + 2 * lane;
+                const double2 l = *reinterpret_cast<const double2 *>(lgm + r), u = *reinterpret_cast<const double2 *>(ugm + r), t = *reinterpret_cast<const double2 *>(gt0m + r);
+                sv += over(t.x, l.x, u.x) + over(t.y, l.y, u.y);
+            }
+            sv = wave_sum(sv);
+            double *keys = reinterpret_cast<double *>(bad);      // (the flags were read before the barrier above; sixteen doubles are theirs)
+            if (lane == 0) keys[wave] = sv;
+            __syncthreads();
+            const int me = lane & (kGroupWaves - 1);
+            const double ki = keys[me];
+            int rank = 0;
+#pragma unroll
+            for (int jj = 0; jj < kGroupWaves; ++jj) {
+                const double kj = readlane_d(ki, jj);
+                rank += (kj > ki || (kj == ki && jj < me)) ? 1 : 0;
+            }
+            const int q = rank >> 2, sd = (q & 1) ? 3 - (rank & 3) : (rank & 3);
+            inst = (int)__builtin_ctzll(__ballot(lane < kGroupWaves && 4 * q + sd == wave));      // (a permutation: exactly one lane answers)
+        }
+#endif
+        double *const slice_i = slices + (size_t)inst * M.fast_slice;
+        const int b = b0 + inst;
         gstamp(6);
 #if defined(MPCX_GROUP_CUT) && MPCX_GROUP_CUT == 3
         { if (threadIdx.x < kGroupWavesOf<CPZ> && blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x < Bt.batch) Bt.done[blockIdx.x * kGroupWavesOf<CPZ> + threadIdx.x] = 2; return; }
 #endif
-        if (b < Bt.batch) solve_fast<CPZ, CPG, 2>(M, Bt, b, lane, mine, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + wave * outld, eqbits);
+        if (b < Bt.batch) solve_fast<CPZ, CPG, 2>(M, Bt, b, lane, slice_i, lwuw, glw(wsbase) + (size_t)b * M.wsld, nullptr, outs + inst * outld, eqbits);
         __syncthreads();
         // the sixteen instances' results, written by neighbouring lanes: one transaction per array and workgroup instead of sixteen
         {
