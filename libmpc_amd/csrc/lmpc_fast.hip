@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kPersistWaves * 64) void lmpc_solve_persistent(cons
 template <size_t BYTES>
 __device__ __forceinline__ void kernarg_touch()
 {
-    static_assert(BYTES <= 16 * 64, "kernarg_touch covers sixteen lines");
+    static_assert(BYTES <= 16 * 64 && BYTES > 15 * 64, "kernarg_touch covers sixteen lines, the sixteenth must exist");
     const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     int t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
     asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x40\n\ts_load_dword %2, %16, 0x80\n\ts_load_dword %3, %16, 0xc0\n\t"

@@ -379,6 +379,32 @@ def test_one_handle_large_then_small_batch_every_path():
         np.testing.assert_allclose(small.cost.cpu().numpy(), want.cost.cpu().numpy(), rtol=1e-8, atol=1e-6)      # (the composed maps of the mat-vec form round differently)
 
 
+@pytest.mark.parametrize("ph", [20, 50])
+def test_instances_dealt_to_the_wavefronts_are_solved_as_in_place(ph):
+    """lmpc_solve_group deals the sixteen (N = 50: eight) instances of a workgroup to its wavefronts by how far their unconstrained optimum lies outside
+    the bounds (the launch is its busiest SIMD's work); which wavefront solves an instance must not show: whole workgroups, a partial last
+    one (kept in place) and a batch below one workgroup against the two-kernel path, where every instance is solved by the wavefront of its index --
+    commands, costs, statuses, rounds and active sets bit for bit."""
+    import torch
+    from libmpc_amd.workloads import quadrotor_batch, quadrotor_lmpc
+    for B, first in ((5, 0), (16, 100), (31, 200), (1024 + 7, 300)):
+        x0, u0, yref = quadrotor_batch(B, first=first)
+        got = {}
+        for mode in (2, 0):
+            c = quadrotor_lmpc(ph, device=0)
+            c.debug_use_fused(mode)
+            r = c.optimizeBatch(x0, u0, yref=yref, want_active=True); torch.cuda.synchronize()
+            assert (r.status == 0).all()
+            got[mode] = r
+        a, b = got[2], got[0]
+        for name in ("cmd", "status", "solver_status", "polish_rounds", "active_count", "active_lower", "active_upper"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (name, B)
+        if ph == 20:
+            assert torch.equal(a.cost, b.cost), B                # (N = 50: the group form takes the cost from its definition inside the solve, the other from lmpc_cost_mfma)
+        else:
+            np.testing.assert_allclose(a.cost.cpu().numpy(), b.cost.cpu().numpy(), rtol=1e-9)
+
+
 def test_shards_equal_rows_of_the_unsharded_solve():
     """Multi-GPU readiness on one device: the batch of 8 x 512 instances solved as eight shards (what eight ranks would do,
     quadrotor_batch(B, first = r B)) gives, bit for bit, the rows of the unsharded solve."""
