@@ -1134,14 +1134,19 @@ __global__ __launch_bounds__(kGroupWavesOf<CPZ> * 64) void lmpc_solve_group(cons
             double *keys = reinterpret_cast<double *>(bad);      // (the flags were read before the barrier above; sixteen doubles are theirs)
             if (lane == 0) keys[wave] = sv;
             __syncthreads();
-            const int me = lane & (kGroupWaves - 1);
+            // (the rank of instance `me`: the sixteen comparisons as four per lane, lane (me, part) against keys 4 part .. 4 part + 3, the parts added up by two
+            // lane exchanges -- a quarter of the vector instructions of sixteen broadcasts per lane, in a kernel that is bound by them)
+            const int me = lane & (kGroupWaves - 1), part = lane >> 4;
             const double ki = keys[me];
             int rank = 0;
 #pragma unroll
-            for (int jj = 0; jj < kGroupWaves; ++jj) {
-                const double kj = readlane_d(ki, jj);
+            for (int q = 0; q < kGroupWaves / 4; ++q) {
+                const int jj = (kGroupWaves / 4) * part + q;
+                const double kj = keys[jj];
                 rank += (kj > ki || (kj == ki && jj < me)) ? 1 : 0;
             }
+            rank += __shfl_xor(rank, 16, 64);
+            rank += __shfl_xor(rank, 32, 64);
             const int q = rank >> 2, sd = (q & 1) ? 3 - (rank & 3) : (rank & 3);
             inst = (int)__builtin_ctzll(__ballot(lane < kGroupWaves && 4 * q + sd == wave));      // (a permutation: exactly one lane answers)
         }
