@@ -22,6 +22,8 @@ timeout 900 tools/profile_sq.sh $T osc8_b1024 --workload osc8 --steps 2 --warmup
 timeout 600 tools/profile_sq.sh $T vanderpol_b4096 --workload vanderpol --steps 30 --warmup 3 > $O/${T}_sq_vdp.log 2>&1
 timeout 600 tools/profile_sq.sh $T lmpc50_b32768 --config 4 --steps 6 --warmup 2 --nlmpc-extra 0 > $O/${T}_sq_lmpc50.log 2>&1
 timeout 600 tools/profile_sq.sh $T lmpchetero20_b4096 --workload lmpc-hetero --steps 20 --warmup 3 > $O/${T}_sq_lmpchetero.log 2>&1
+timeout 600 tools/profile_sq.sh $T ugv_b256 --workload ugv --batch 256 --steps 3 --warmup 1 > $O/${T}_sq_ugv256.log 2>&1
+timeout 600 tools/profile_sq.sh $T osc8_b256 --workload osc8 --batch 256 --steps 3 --warmup 1 > $O/${T}_sq_osc8256.log 2>&1
 cp $O/${T}_pmc_traffic_*.json $O/${T}_sq_*.json $O/${T}_kernel_trace_stats_*.txt profiles/ 2>/dev/null
 ( timeout 300 python bench.py --steps 200 --warmup 20 ) > $O/${T}_bench_lmpc20.json 2> $O/${T}_bench_lmpc20.err; cut -c1-300 $O/${T}_bench_lmpc20.json
 ( MPCX_FORCE_DIST=1 timeout 400 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --pipeline-streams 0 --nlmpc-extra 0 ) 2> $O/${T}_bench_lmpc20_rccl1.err | grep "^{" > $O/${T}_bench_lmpc20_rccl1.json; cut -c1-200 $O/${T}_bench_lmpc20_rccl1.json
